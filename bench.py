@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- NLL evaluations per second of the sxmc hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: one full NLL evaluation
+at a new parameter vector = zero + histogram fill of ALL signals' MC samples with the systematics
+applied per sample + PDF lookup at the data events + event log-sum + reduction + nll_total, followed
+by the fused Metropolis accept/reject and next proposal (so the parameters really change every
+step), i.e. one MCMC step of the reference (mcmc.cpp:261-348).
+
+Default workload (N=1): BASELINE.json configs[2] = "C3": 1e8 samples, 3 observables, 12 signals,
+shift+scale+resolution_scale floated, 20^3 bins, 1e5 data events.  Inputs are synthetic, generated on
+the GPU and resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: fake experiments shard over the GPUs (sxmc.cpp:59 is an independent-iteration loop); every rank
+holds a replica of the MC tables and walks its own chain with its own seed -- no data-path
+collective; the per-rank intervals are gathered with one RCCL all_gather at the end.  value = steps of
+all ranks / max-over-ranks time ("weak" scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+
+def make_c3_on_gpu(torch, dev, scale, seed, nevents):
+    """C3 tables generated with torch on the GPU (same distributions as workloads.config3)."""
+    from sxmc_amd import workloads
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    counts = workloads.split_counts(int(1e8 * scale), 12)
+    tensors, signals = [], []
+    per = max(1, nevents // 12)
+    ev_rows = []
+    for j, n in enumerate(counts):
+        e_true = torch.empty(n, device=dev).normal_(2.0 + 0.5 * j, 1.2, generator=g)
+        e = e_true + torch.empty(n, device=dev).normal_(0.0, 0.3, generator=g)
+        r = 6.0 * torch.empty(n, device=dev).uniform_(0.0, 1.0, generator=g) ** (1.0 / 3.0)
+        c = torch.empty(n, device=dev).uniform_(-1.0, 1.0, generator=g)
+        tab = torch.stack([e, r, c, e_true, torch.zeros(n, device=dev)], dim=1).contiguous()
+        del e_true, e, r, c
+        tensors.append(tab)
+        ev_rows.append(tab[:per, :3].cpu().numpy())
+        signals.append(workloads.Signal(_Shape(n, 5), 5, nexpected=80.0 + 5 * j, source_id=j))
+    ev = np.concatenate(ev_rows, axis=0)[:nevents]
+    events = np.zeros((ev.shape[0], 4), dtype=np.float32)
+    events[:, :3] = ev
+    w = workloads.Workload("C3", 3, [0.0, 0.0, -1.0], [10.0, 6.0, 1.0], [20, 20, 20], signals,
+                           workloads.C3_SYSTS, workloads.C3_SIGMAS, events,
+                           "S=12, N=%d, D=3, 20^3 bins, shift+scale+resolution_scale" % sum(counts))
+    return w, tensors
+
+
+class _Shape:
+    """Stands in for a host table when the samples live only on the GPU."""
+
+    def __init__(self, n, f):
+        self.shape = (n, f)
+
+
+def make_workload(args, torch, dev, seed):
+    from sxmc_amd import workloads
+    name = args.workload.lower()
+    if name == "c3":
+        return make_c3_on_gpu(torch, dev, args.scale, seed, args.events)
+    makers = {"c1": workloads.config1, "c2": workloads.config2, "c5": workloads.config5,
+              "bench_pdfz": workloads.bench_pdfz}
+    w = makers[name](args.scale, seed=seed) if name == "c1" else makers[name](args.scale, seed=seed,
+                                                                             nevents=args.events)
+    tensors = [torch.from_numpy(s.samples).to(dev) for s in w.signals]
+    return w, tensors
+
+
+def cpu_baseline(w, host_tables, vector, nevals, nthreads):
+    """The oracle (CPU restatement of the reference loop) timed on this box's host cores, same
+    workload, same inputs.  Returns (seconds per evaluation, bins, norms, nll)."""
+    from oracle import oracle
+    geom = oracle.HistGeometry(w.lower, w.upper, w.nbins)
+    ne = w.events.shape[0]
+    rbs = [oracle.set_eval_points(geom, w.events, s.dataset) for s in w.signals]
+    best = None
+    for _ in range(nevals):
+        t0 = time.perf_counter()
+        lut = np.zeros((w.nsignals, ne), np.float32)
+        norms = np.zeros(w.nsignals, np.uint32)
+        all_bins = []
+        for j, s in enumerate(w.signals):
+            bins, norm = oracle.bin_samples(geom, host_tables[j], s.nfields, w.systematics,
+                                            vector[w.nsources:], nthreads=nthreads)
+            oracle.eval_pdf(rbs[j], bins, norm, geom.bin_volume, out=lut[j])
+            norms[j] = norm
+            all_bins.append(bins)
+        val, _ = oracle.full_nll(lut, vector, ne, w.nsignals, w.nsources, w.parameter_means(),
+                                 w.parameter_sigmas(), [s.nexpected for s in w.signals],
+                                 [s.n_mc for s in w.signals], [s.source_id for s in w.signals], norms)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best, all_bins, norms, val
+
+
+def chain_intervals(chain, nparameters):
+    """Per-parameter (point_estimate, lower, upper, coverage) from a chain: the payload of the
+    RCCL gather (interval.h:22-27).  Central 90% of the samples (projection-style)."""
+    out = np.zeros((nparameters, 4), dtype=np.float32)
+    for i in range(nparameters):
+        col = chain[:, i]
+        out[i] = (np.mean(col), np.quantile(col, 0.05), np.quantile(col, 0.95), 0.9)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", help="c3 (default, the metric's config), c1, c2, c5, bench_pdfz")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the sample counts (testing only)")
+    ap.add_argument("--events", type=int, default=100000)
+    ap.add_argument("--form", default="fused", choices=["fused", "reference"])
+    ap.add_argument("--launch", default="0,0", help="bin_threads,bin_blocks_per_cu (0 = default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-evals", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+
+    from sxmc_amd import capi, dist
+    from sxmc_amd.mcmc import MCMC
+
+    rank, local_rank, world = dist.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    capi.call("sxmc_set_device", local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init()
+    info = capi.device_info(local_rank)
+
+    # ---- inputs: same MC tables on every rank (replica), own data events + chain seed per rank
+    w, tensors = make_workload(args, torch, dev, args.seed)
+    exp_seed = dist.experiment_seed(args.seed, rank)
+    rng = np.random.default_rng(exp_seed)
+    w.events = w.events[rng.permutation(w.events.shape[0])]
+
+    want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1
+    host_tables = [t.cpu().numpy() for t in tensors] if want_cpu else None
+
+    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=(args.form == "fused"), samples_on_device=tensors)
+    del tensors
+    torch.cuda.empty_cache()
+    threads, bpc = (int(x) for x in args.launch.split(","))
+    m.group.SetLaunchConfig(threads, bpc)
+    m.setup(sync_interval=max(args.steps, args.warmup, 1))
+
+    for _ in range(args.warmup):
+        m.step()
+    m.flush()
+
+    # ---- timed region: exactly K steps between barrier + synchronize on both sides
+    m.group.Profile(True, args.steps)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    fill_ms_total, nfill = m.group.ProfileRead()
+    m.group.Profile(False, 0)
+
+    chain, accepted = m.flush()
+    intervals = dist.gather_intervals(chain_intervals(chain, w.nparameters)[None], world, w.nparameters)
+
+    total_steps = args.steps * world
+    value = total_steps / elapsed
+    ab = m.group.AlgorithmicBytes()
+    fill_bytes = ab["fill_read"] + ab["hist"]
+    fill_ms = fill_ms_total / max(nfill, 1)
+    achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
+
+    result = {
+        "metric": "NLL evals/sec (10^8 samples, 3 obs, 12 signals)",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %s" % (w.name, w.description),
+            "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
+            "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
+            "step_form": args.form, "launch": args.launch, "scale": args.scale,
+            "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
+            "samples_per_sec": value * w.nsamples_total,
+            "experiments_per_sec_at_1e5_steps": value / 1e5,
+            "accepted_fraction_rank0": accepted / max(args.steps, 1),
+            "device": info["name"], "compute_units": info["compute_units"],
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "fill_kernel (histogram fill, all signals batched)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": fill_ms, "launches_timed": nfill,
+            "whole_step_algorithmic_bytes": fill_bytes + ab["event"],
+            "whole_step_frac": (fill_bytes + ab["event"]) * value / world / 1e9 / HBM_PEAK_GBS,
+        },
+        "cpu_baseline": None,
+        "intervals_gathered": [int(x) for x in intervals.shape],
+    }
+
+    if want_cpu:
+        # same inputs, same parameter vector: time the oracle and assert parity in the same run
+        vector = m.proposed_vector.get()
+        m.group.EvalAsync(True, None)
+        m.nll(m.proposed_vector, m.proposed_nll)
+        capi.synchronize()
+        gpu_nll = float(m.proposed_nll.get()[0])
+        gpu_bins = [p.GetBins() for p in m.pdfs]
+        gpu_norms = m.normalizations.get()
+        sec1, bins, norms, cpu_nll = cpu_baseline(w, host_tables, vector, args.cpu_evals, 1)
+        ncores = os.cpu_count() or 1
+        secn, bins_n, norms_n, _ = cpu_baseline(w, host_tables, vector, 1, ncores)
+        exact = all(np.array_equal(a, b) for a, b in zip(gpu_bins, bins)) and np.array_equal(gpu_norms, norms)
+        rel = abs(gpu_nll - cpu_nll) / abs(cpu_nll)
+        result["cpu_baseline"] = {
+            "value": 1.0 / sec1, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": "%d full NLL evaluations of the same workload (all %d samples, %d events), best of %d, "
+                      "oracle/libsxmc_oracle.so single thread (the reference's CPU mode is a serial loop)"
+                      % (args.cpu_evals, w.nsamples_total, w.events.shape[0], args.cpu_evals),
+            "all_cores": {"value": 1.0 / secn, "cores": ncores,
+                          "note": "same oracle, pthreads over sample chunks with private histograms"},
+        }
+        result["parity"] = {"bins_and_norms_bit_exact": bool(exact), "nll_gpu": gpu_nll, "nll_cpu": cpu_nll,
+                            "nll_rel_diff": rel, "nll_tolerance": 1e-6}
+        if not exact or not rel <= 1e-6:
+            print(json.dumps(result))
+            raise SystemExit("PARITY FAILURE: GPU result differs from the CPU oracle")
+
+    if rank == 0:
+        print(json.dumps(result))
+    dist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,225 @@
+/*
+ * sxmc_hip.h -- C ABI of libsxmc_hip.so: the MI355X (gfx950) implementation of sxmc's per-step
+ * NLL evaluation (pdfz::EvalHist histogram fill with per-sample systematics + the nll_kernels
+ * event log-sum, reduction and fused MCMC step).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, `int` status returns, no exceptions,
+ * no torch or C++ types.  Each entry point names the reference interface it replaces
+ * (file:line relative to /root/reference).  The C++ mirror of the reference's own classes
+ * (pdfz::Eval, pdfz::EvalHist, the device-mirror array and the kernel launch points mcmc.cpp
+ * uses) lives in sxmc_amd/include/sxmc/ and is a header-only layer over this ABI.
+ *
+ * Unless stated otherwise pointers named `d_*` or documented "device" are HIP device pointers
+ * (hipMalloc'd, or any pointer valid on the current device such as a torch tensor's data_ptr),
+ * and everything else is host memory.  All functions return SXMC_OK (0) or an error code;
+ * sxmc_last_error() returns the message of the last failure on the calling thread.
+ */
+#ifndef SXMC_HIP_H
+#define SXMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SXMC_OK 0
+#define SXMC_ERR_INVALID 1 /* argument validation failed: where the reference throws pdfz::Error */
+#define SXMC_ERR_HIP 2     /* a HIP runtime call failed (reference: checkCuda) */
+#define SXMC_ERR_STATE 3   /* call sequence error, e.g. eval before the buffers are bound */
+
+#define SXMC_MAX_NFIELDS 10   /* pdfz.cpp:17 MAX_NFIELDS */
+#define SXMC_MAX_SYST 16      /* systematics per evaluator (reference: unbounded array, pdfz.cpp:126-132) */
+#define SXMC_MAX_SYST_PARS 8  /* polynomial coefficients per systematic */
+
+/* pdfz.h:111-116 Systematic::Type */
+#define SXMC_SYST_SHIFT 0
+#define SXMC_SYST_SCALE 1
+#define SXMC_SYST_RESOLUTION_SCALE 2
+#define SXMC_SYST_CTSCALE 3
+
+typedef struct sxmc_hist* sxmc_hist_t;   /* one pdfz::EvalHist (pdfz.h:402-574) */
+typedef struct sxmc_group* sxmc_group_t; /* the set of evaluators MCMC steps together (mcmc.cpp:264-271) */
+typedef void* sxmc_stream_t;             /* hipStream_t; NULL = the legacy default stream */
+typedef void* sxmc_event_t;              /* hipEvent_t */
+
+/* Counter-based generator state, one per parameter.  Replaces curandStateXORWOW
+ * (nll_kernels.h:25-29 RNGState).  Philox4x32-10 keyed by `seed`, stream `subsequence`. */
+typedef struct {
+  uint64_t seed;
+  uint64_t subsequence;
+  uint64_t offset; /* draws consumed so far */
+  uint64_t reserved;
+} sxmc_rng_state;
+
+/* ---------------------------------------------------------------- runtime / memory ---------- */
+/* Replaces hemi's checkCuda error reporting. */
+const char* sxmc_last_error(void);
+const char* sxmc_version(void);
+
+int sxmc_device_count(int* count);
+int sxmc_set_device(int device);
+/* name: at least 256 bytes. */
+int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes,
+                     int* lds_bytes_per_cu, int* clock_khz);
+int sxmc_device_synchronize(void);
+
+/* Device side of hemi::Array<T>: allocation and the two copy directions
+ * its accessors perform implicitly. */
+int sxmc_malloc(void** d_ptr, size_t bytes);
+int sxmc_free(void* d_ptr);
+int sxmc_host_alloc(void** h_ptr, size_t bytes); /* pinned; hemi::Array(n, pinned=true) */
+int sxmc_host_free(void* h_ptr);
+int sxmc_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int sxmc_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int sxmc_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
+int sxmc_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, sxmc_stream_t s);
+int sxmc_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, sxmc_stream_t s);
+int sxmc_memset(void* d_dst, int value, size_t bytes);
+
+/* cudaStreamCreate / cudaStreamSynchronize (pdfz.cpp:91, 493) */
+int sxmc_stream_create(sxmc_stream_t* s);
+int sxmc_stream_destroy(sxmc_stream_t s);
+int sxmc_stream_synchronize(sxmc_stream_t s);
+
+int sxmc_event_create(sxmc_event_t* e);
+int sxmc_event_destroy(sxmc_event_t e);
+int sxmc_event_record(sxmc_event_t e, sxmc_stream_t s);
+int sxmc_event_synchronize(sxmc_event_t e);
+int sxmc_event_elapsed_ms(sxmc_event_t start, sxmc_event_t stop, float* ms);
+
+/* ---------------------------------------------------------------- pdfz::EvalHist ------------ */
+/* EvalHist::EvalHist + Eval::Eval (pdfz.cpp:57-97, 179-236).
+ * samples: row-major [nsamples_floats / nfields][nfields] float32; host memory, or device
+ * memory when samples_on_device != 0.  The evaluator keeps its own column-major copy
+ * (the reference also copies, pdfz.cpp:197).  n_lower/n_upper/n_nbins are the lengths of the
+ * three arrays so that the reference's size validation can be reproduced:
+ * SXMC_ERR_INVALID for every condition under which the reference throws pdfz::Error
+ * (pdfz.cpp:64-82, 189-195, 217-219) and additionally for upper[i] <= lower[i], nbins[i] < 0. */
+int sxmc_hist_create(const float* samples, size_t nsamples_floats, int samples_on_device,
+                     int nfields, int nobservables,
+                     const double* lower, size_t n_lower,
+                     const double* upper, size_t n_upper,
+                     const int* nbins, size_t n_nbins,
+                     unsigned dataset, sxmc_hist_t* out);
+/* EvalHist::~EvalHist (pdfz.cpp:239-242); also destroys the evaluator's stream, which the
+ * reference leaks (pdfz.cpp:100-103). */
+int sxmc_hist_destroy(sxmc_hist_t h);
+
+/* Eval::AddSystematic (pdfz.cpp:126-174).  `pars` are indices into the parameter buffer
+ * (npars of them, host memory, copied).  extra_field is used by RESOLUTION_SCALE only. */
+int sxmc_hist_add_systematic(sxmc_hist_t h, int type, int obs, int extra_field,
+                             int npars, const short* pars);
+
+/* EvalHist::SetEvalPoints (pdfz.cpp:245-302).  points: host, rows of nobservables+1 floats
+ * (last = dataset id).  SXMC_ERR_INVALID if npoints_floats % (nobservables+1) != 0. */
+int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints_floats);
+
+/* Eval::SetPDFValueBuffer / SetNormalizationBuffer / SetParameterBuffer (pdfz.cpp:106-124).
+ * Device pointers, borrowed: they must outlive every evaluation that uses them. */
+int sxmc_hist_set_pdf_value_buffer(sxmc_hist_t h, float* d_output, int offset, int stride);
+int sxmc_hist_set_normalization_buffer(sxmc_hist_t h, unsigned* d_norm, int offset);
+int sxmc_hist_set_parameter_buffer(sxmc_hist_t h, const double* d_params, int offset, int stride);
+
+/* EvalHist::EvalAsync / EvalFinished (pdfz.cpp:441-495): zero, fill, (evaluate) on the
+ * evaluator's own stream; returns before completion. */
+int sxmc_hist_eval_async(sxmc_hist_t h, int do_eval_pdf);
+int sxmc_hist_eval_finished(sxmc_hist_t h);
+
+/* Introspection used by CreateHistogram / GetSamples / tests (pdfz.cpp:498-594, pdfz.h:542-556). */
+int sxmc_hist_total_nbins(sxmc_hist_t h, int* total_nbins);
+int sxmc_hist_bin_volume(sxmc_hist_t h, double* bin_volume);
+int sxmc_hist_nsamples(sxmc_hist_t h, size_t* nsamples);
+int sxmc_hist_npoints(sxmc_hist_t h, size_t* npoints);
+int sxmc_hist_get_bins(sxmc_hist_t h, unsigned* h_bins, size_t n);       /* after eval_finished */
+int sxmc_hist_get_read_bins(sxmc_hist_t h, int* h_read_bins, size_t n);
+/* GetSamples: rows of nobservables+1 floats (observables, dataset id); n = nsamples*(nobs+1). */
+int sxmc_hist_get_samples(sxmc_hist_t h, float* h_out, size_t n);
+int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s);
+
+/* Replaces EvalHist::Optimize/OptimizeBin/OptimizeEval (pdfz.cpp:622-814): the launch shape
+ * is sized analytically from the device; 0 keeps the default.  threads: 256, 512 or 1024. */
+int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_per_cu);
+
+/* ---------------------------------------------------------------- evaluator group ----------- */
+/* The "EvalAsync on all signals, then EvalFinished on all" of mcmc.cpp:264-271 and
+ * bench_sxmc.cpp:193-200 as ONE batched launch sequence (zero, fill, evaluate) over all
+ * members.  Members are borrowed; their bindings are re-read whenever they change. */
+int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* out);
+int sxmc_group_destroy(sxmc_group_t g);
+int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks_per_cu);
+int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s);
+/* As sxmc_group_eval_async(g, 1, s) followed by nll_event_chunks (nll_kernels.cpp:89-116) over
+ * the members' lookup table, with the table lookup and the event sum fused in one kernel: the
+ * lut is still written (it is the API contract, mcmc.cpp:232-236) but not re-read.  Requires
+ * all members to share the same number of evaluation points.  Writes one partial sum per
+ * block: d_sums[0 .. *npartial_out).  d_sums must hold at least 1024 doubles. */
+int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s,
+                              const double* d_pars, const double* d_nexpected,
+                              const unsigned* d_n_mc, const short* d_source_id,
+                              const unsigned* d_norms, double* d_sums, int* npartial_out);
+int sxmc_group_synchronize(sxmc_group_t g);
+/* Live timing of the dominant kernel (the histogram fill) with HIP events on the stream it is
+ * launched on.  enable!=0 starts recording (at most `capacity` launches are kept). */
+int sxmc_group_profile(sxmc_group_t g, int enable, int capacity);
+int sxmc_group_profile_read(sxmc_group_t g, double* fill_ms_total, int* nlaunches);
+/* Algorithmic bytes of one group evaluation, SURVEY 8(d):
+ * sum_j 4*N_j*U_j  (fill_read) ; sum_j 4*B_j*w (hist) ; 16*E*S (event) */
+int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist, double* event);
+
+/* ---------------------------------------------------------------- NLL / MCMC step kernels --- */
+/* Launch points with the argument lists of nll_kernels.h:60-207, preceded by the
+ * (grid, block, stream) triple the caller passes to HEMI_KERNEL_LAUNCH (mcmc.cpp:252, 314,
+ * 326, 396, 404, 409).  All array arguments are device pointers. */
+
+/* init_device_rngs (nll_kernels.cpp:18-27): state[i] = (seed, subsequence i, offset 0) */
+int sxmc_launch_init_device_rngs(int grid, int block, sxmc_stream_t s, int nthreads,
+                                 unsigned long long seed, sxmc_rng_state* d_state);
+/* pick_new_vector (nll_kernels.cpp:191-197) */
+int sxmc_launch_pick_new_vector(int grid, int block, sxmc_stream_t s, int nthreads,
+                                sxmc_rng_state* d_rng, const float* d_jump_width,
+                                const double* d_current_vector, double* d_proposed_vector);
+/* jump_decider (nll_kernels.cpp:200-206) */
+int sxmc_launch_jump_decider(int grid, int block, sxmc_stream_t s, sxmc_rng_state* d_rng,
+                             double* d_nll_current, const double* d_nll_proposed,
+                             double* d_v_current, const double* d_v_proposed,
+                             unsigned nparameters, int* d_accepted, int* d_counter,
+                             float* d_jump_buffer);
+/* nll_event_chunks (nll_kernels.cpp:89-116): thread t of grid*block writes d_sums[t] */
+int sxmc_launch_nll_event_chunks(int grid, int block, sxmc_stream_t s, const float* d_lut,
+                                 const double* d_pars, size_t ne, size_t ns,
+                                 const double* d_nexpected, const unsigned* d_n_mc,
+                                 const short* d_source_id, const unsigned* d_norms,
+                                 double* d_sums);
+/* nll_event_reduce (nll_kernels.cpp:209-212); grid must be 1 */
+int sxmc_launch_nll_event_reduce(int grid, int block, sxmc_stream_t s, size_t nthreads,
+                                 const double* d_sums, double* d_total_sum);
+/* nll_total (nll_kernels.cpp:215-227) */
+int sxmc_launch_nll_total(int grid, int block, sxmc_stream_t s, size_t nparameters,
+                          const double* d_pars, size_t nsignals, size_t nsources,
+                          const double* d_means, const double* d_sigmas,
+                          const double* d_events_total, const double* d_nexpected,
+                          const unsigned* d_n_mc, const short* d_source_id,
+                          const unsigned* d_norms, double* d_nll);
+/* finish_nll_jump_pick_combo (nll_kernels.cpp:230-271); grid must be 1 */
+int sxmc_launch_finish_nll_jump_pick_combo(int grid, int block, sxmc_stream_t s,
+                                           size_t npartial_sums, const double* d_sums,
+                                           size_t nsignals, size_t nsources,
+                                           const double* d_means, const double* d_sigmas,
+                                           sxmc_rng_state* d_rng, double* d_nll_current,
+                                           double* d_nll_proposed, double* d_v_current,
+                                           double* d_v_proposed, int* d_accepted,
+                                           int* d_counter, float* d_jump_buffer,
+                                           int nparameters, const float* d_jump_width,
+                                           const double* d_nexpected, const unsigned* d_n_mc,
+                                           const short* d_source_id, const unsigned* d_norms,
+                                           int debug_mode);
+
+/* Test hook: raw Philox4x32-10 output of d_state[0], 4 words per draw; advances the state. */
+int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SXMC_HIP_H */

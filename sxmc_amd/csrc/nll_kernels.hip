@@ -1,0 +1,314 @@
+// nll_kernels.hip -- gfx950 kernels for the NLL half of the MCMC step (wave64 only).
+//
+// What is computed is fixed by the reference (file:line relative to /root/reference):
+//   init_device_rngs            src/nll_kernels.cpp:18-27
+//   pick_new_vector(_device)    src/nll_kernels.cpp:30-53, 191-197
+//   jump_decider(_device)       src/nll_kernels.cpp:56-86, 200-206
+//   nll_event_chunks            src/nll_kernels.cpp:89-116
+//   nll_event_reduce(_device)   src/nll_kernels.cpp:119-146, 209-212
+//   nll_total(_device)          src/nll_kernels.cpp:149-188, 215-227
+//   finish_nll_jump_pick_combo  src/nll_kernels.cpp:230-271
+// The reduction is a wave64 shuffle tree followed by one LDS hop across waves (the reference's
+// shared-memory tree has its barrier outside the loop, nll_kernels.cpp:139-143).  Random numbers
+// come from a counter-based Philox4x32-10 stream per parameter instead of cuRAND XORWOW: chains
+// are statistically, not bitwise, comparable with the reference (whose CPU and GPU targets do
+// not agree with each other either).
+#include "sxmc_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------ RNG
+struct Philox4 {
+  unsigned x, y, z, w;
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long counter_lo,
+                                                 unsigned long long counter_hi,
+                                                 unsigned long long key) {
+  unsigned c0 = (unsigned)counter_lo, c1 = (unsigned)(counter_lo >> 32);
+  unsigned c2 = (unsigned)counter_hi, c3 = (unsigned)(counter_hi >> 32);
+  unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ Philox4 rng_next(sxmc_rng_state* st) {
+  const Philox4 r = philox4x32_10(st->offset, st->subsequence, st->seed);
+  st->offset += 1;
+  return r;
+}
+
+// (0, 1], like curand_uniform
+__device__ __forceinline__ double rng_uniform(sxmc_rng_state* st) {
+  const Philox4 r = rng_next(st);
+  return ((double)r.x + 1.0) * 2.3283064365386963e-10;
+}
+
+// unit normal (Box-Muller in double precision)
+__device__ __forceinline__ double rng_normal(sxmc_rng_state* st) {
+  const Philox4 r = rng_next(st);
+  const double u1 = ((double)r.x + 1.0) * 2.3283064365386963e-10;  // (0,1]
+  const double u2 = (double)r.y * 2.3283064365386963e-10;          // [0,1)
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+__global__ void init_rngs_kernel(int n, unsigned long long seed, sxmc_rng_state* state) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  state[idx].seed = seed;
+  state[idx].subsequence = (unsigned long long)idx;
+  state[idx].offset = 0;
+  state[idx].reserved = 0;
+}
+
+// Raw generator output for tests: out[4*i..4*i+3] = draw i of state[0]
+__global__ void philox_dump_kernel(sxmc_rng_state* state, unsigned* out, int ndraws) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int i = 0; i < ndraws; i++) {
+    const Philox4 r = rng_next(&state[0]);
+    out[4 * i + 0] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+  }
+}
+
+// ------------------------------------------------------------------------------------ device parts
+__device__ __forceinline__ void pick_new_vector_device(int n, sxmc_rng_state* rng,
+                                                       const float* jump_width,
+                                                       const double* current_vector,
+                                                       double* proposed_vector) {
+  const int offset = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = offset; i < n; i += stride) {
+    if (jump_width[i] > 0) {  // fixed parameters carry width -1 (mcmc.cpp:204-207)
+      const double u = rng_normal(&rng[i]);
+      proposed_vector[i] = current_vector[i] + jump_width[i] * u;
+    } else {
+      proposed_vector[i] = current_vector[i];
+    }
+  }
+}
+
+__device__ __forceinline__ void jump_decider_device(sxmc_rng_state* rng, double* nll_current,
+                                                    const double* nll_proposed, double* v_current,
+                                                    const double* v_proposed, unsigned nparameters,
+                                                    int* accepted, int* counter, float* jump_buffer,
+                                                    bool debug_mode) {
+  const double u = rng_uniform(&rng[0]);
+  const double np = nll_proposed[0];
+  const double nc = nll_current[0];
+  if (debug_mode || (np < nc || u <= exp(nc - np))) {  // Metropolis, nll_kernels.cpp:69-77
+    nll_current[0] = np;
+    for (unsigned i = 0; i < nparameters; i++) v_current[i] = v_proposed[i];
+    accepted[0] += 1;
+  }
+  const int count = counter[0];
+  for (unsigned i = 0; i < nparameters; i++) {
+    jump_buffer[count * (nparameters + 1) + i] = (float)v_current[i];
+  }
+  jump_buffer[count * (nparameters + 1) + nparameters] = (float)nll_current[0];
+  counter[0] = count + 1;
+}
+
+__device__ __forceinline__ void nll_total_device(size_t nparameters, size_t nsignals, size_t nsources,
+                                                 const double* pars, const double* means,
+                                                 const double* sigmas, const double* events_total,
+                                                 const double* nexpected, const unsigned* n_mc,
+                                                 const short* source_id, const unsigned* norms,
+                                                 double* nll) {
+  double sum = -events_total[0];
+  if (isnan(sum)) {
+    nll[0] = 1e18;
+    return;
+  }
+  for (unsigned i = 0; i < nsignals; i++) {
+    const short sid = source_id[i];
+    sum += pars[sid] * nexpected[i] * norms[i] / n_mc[i];
+  }
+  for (unsigned i = 0; i < nparameters; i++) {
+    if (i < nsources && pars[i] < 0) {  // steep penalty for negative rates
+      nll[0] = 1e18;
+      return;
+    }
+    if (sigmas[i] > 0) {
+      const double x = (pars[i] - means[i]) / sigmas[i];
+      sum += 0.5 * x * x;
+    }
+  }
+  nll[0] = sum;
+}
+
+// Sum of sums[0..n) over the workgroup; the total is returned to every thread.
+__device__ __forceinline__ double block_sum(size_t n, const double* sums, double* s_wave /*[17]*/) {
+  double t = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) t += sums[i];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off, kWave);
+  const int wave = threadIdx.x / kWave;
+  const int nwaves = (blockDim.x + kWave - 1) / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) s_wave[wave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < nwaves; w++) tot += s_wave[w];
+    s_wave[16] = tot;
+  }
+  __syncthreads();
+  return s_wave[16];
+}
+
+// ------------------------------------------------------------------------------------ kernels
+__global__ void pick_new_vector_kernel(int nthreads, sxmc_rng_state* rng, const float* jump_width,
+                                       const double* current_vector, double* proposed_vector) {
+  pick_new_vector_device(nthreads, rng, jump_width, current_vector, proposed_vector);
+}
+
+__global__ void jump_decider_kernel(sxmc_rng_state* rng, double* nll_current, const double* nll_proposed,
+                                    double* v_current, const double* v_proposed, unsigned nparameters,
+                                    int* accepted, int* counter, float* jump_buffer) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    jump_decider_device(rng, nll_current, nll_proposed, v_current, v_proposed, nparameters, accepted,
+                        counter, jump_buffer, false);
+  }
+}
+
+__global__ void nll_event_chunks_kernel(const float* __restrict__ lut, const double* __restrict__ pars,
+                                        size_t ne, size_t ns, const double* __restrict__ nexpected,
+                                        const unsigned* __restrict__ n_mc,
+                                        const short* __restrict__ source_id,
+                                        const unsigned* __restrict__ norms, double* sums) {
+  extern __shared__ double s_coef[];  // [ns]: pars[sid] * nexpected * eff, the event-independent factor
+  for (size_t j = threadIdx.x; j < ns; j += blockDim.x) {
+    const float eff = (float)(1.0 * norms[j] / n_mc[j]);
+    s_coef[j] = pars[source_id[j]] * nexpected[j] * eff;
+  }
+  __syncthreads();
+  const size_t offset = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double sum = 0;
+  for (size_t i = offset; i < ne; i += stride) {
+    double s = 0;
+    for (size_t j = 0; j < ns; j++) {
+      const float v = lut[j * ne + i];
+      s = s + s_coef[j] * (double)(!isnan(v) ? v : 0.0f);  // NaNs come from empty histograms
+    }
+    if (s > 0) sum += log(s);
+  }
+  if (!isnan(sum)) sums[offset] = sum;
+}
+
+__global__ void nll_event_reduce_kernel(size_t nthreads, const double* sums, double* total_sum) {
+  __shared__ double s_wave[17];
+  const double t = block_sum(nthreads, sums, s_wave);
+  if (threadIdx.x == 0) total_sum[0] = t;
+}
+
+__global__ void nll_total_kernel(size_t npars, const double* pars, size_t nsignals, size_t nsources,
+                                 const double* means, const double* sigmas, const double* events_total,
+                                 const double* nexpected, const unsigned* n_mc, const short* source_id,
+                                 const unsigned* norms, double* nll) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    nll_total_device(npars, nsignals, nsources, pars, means, sigmas, events_total, nexpected, n_mc,
+                     source_id, norms, nll);
+  }
+}
+
+__global__ void finish_nll_jump_pick_combo_kernel(size_t npartial_sums, const double* sums, size_t nsignals,
+                                                  size_t nsources, const double* means, const double* sigmas,
+                                                  sxmc_rng_state* rng, double* nll_current,
+                                                  double* nll_proposed, double* v_current, double* v_proposed,
+                                                  int* accepted, int* counter, float* jump_buffer,
+                                                  int nparameters, const float* jump_width,
+                                                  const double* nexpected, const unsigned* n_mc,
+                                                  const short* source_id, const unsigned* norms,
+                                                  bool debug_mode) {
+  __shared__ double s_wave[17];
+  double total_sum = block_sum(npartial_sums, sums, s_wave);
+
+  if (threadIdx.x == 0) {
+    nll_total_device(nparameters, nsignals, nsources, v_proposed, means, sigmas, &total_sum, nexpected, n_mc,
+                     source_id, norms, nll_proposed);
+    jump_decider_device(rng, nll_current, nll_proposed, v_current, v_proposed, nparameters, accepted, counter,
+                        jump_buffer, debug_mode);
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  pick_new_vector_device(nparameters, rng, jump_width, v_current, v_proposed);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ launchers
+extern "C" {
+
+hipError_t sx_nll_init_rngs(int grid, int block, hipStream_t s, int n, unsigned long long seed,
+                            sxmc_rng_state* st) {
+  hipLaunchKernelGGL(init_rngs_kernel, dim3(grid), dim3(block), 0, s, n, seed, st);
+  return hipGetLastError();
+}
+
+hipError_t sx_nll_philox_dump(hipStream_t s, sxmc_rng_state* st, unsigned* out, int ndraws) {
+  hipLaunchKernelGGL(philox_dump_kernel, dim3(1), dim3(64), 0, s, st, out, ndraws);
+  return hipGetLastError();
+}
+
+hipError_t sx_nll_pick_new_vector(int grid, int block, hipStream_t s, int n, sxmc_rng_state* rng,
+                                  const float* jw, const double* cur, double* prop) {
+  hipLaunchKernelGGL(pick_new_vector_kernel, dim3(grid), dim3(block), 0, s, n, rng, jw, cur, prop);
+  return hipGetLastError();
+}
+
+hipError_t sx_nll_jump_decider(int grid, int block, hipStream_t s, sxmc_rng_state* rng, double* nc,
+                               const double* np, double* vc, const double* vp, unsigned n, int* acc,
+                               int* cnt, float* jb) {
+  hipLaunchKernelGGL(jump_decider_kernel, dim3(grid), dim3(block), 0, s, rng, nc, np, vc, vp, n, acc, cnt, jb);
+  return hipGetLastError();
+}
+
+hipError_t sx_nll_event_chunks(int grid, int block, hipStream_t s, const float* lut, const double* pars,
+                               size_t ne, size_t ns, const double* nexpected, const unsigned* n_mc,
+                               const short* source_id, const unsigned* norms, double* sums) {
+  hipLaunchKernelGGL(nll_event_chunks_kernel, dim3(grid), dim3(block), ns * sizeof(double), s, lut, pars, ne,
+                     ns, nexpected, n_mc, source_id, norms, sums);
+  return hipGetLastError();
+}
+
+hipError_t sx_nll_event_reduce(int block, hipStream_t s, size_t n, const double* sums, double* total) {
+  hipLaunchKernelGGL(nll_event_reduce_kernel, dim3(1), dim3(block), 0, s, n, sums, total);
+  return hipGetLastError();
+}
+
+hipError_t sx_nll_total(hipStream_t s, size_t npars, const double* pars, size_t nsignals, size_t nsources,
+                        const double* means, const double* sigmas, const double* events_total,
+                        const double* nexpected, const unsigned* n_mc, const short* source_id,
+                        const unsigned* norms, double* nll) {
+  hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(64), 0, s, npars, pars, nsignals, nsources, means, sigmas,
+                     events_total, nexpected, n_mc, source_id, norms, nll);
+  return hipGetLastError();
+}
+
+hipError_t sx_nll_finish_combo(int block, hipStream_t s, size_t npartial, const double* sums, size_t nsignals,
+                               size_t nsources, const double* means, const double* sigmas, sxmc_rng_state* rng,
+                               double* nll_current, double* nll_proposed, double* v_current, double* v_proposed,
+                               int* accepted, int* counter, float* jump_buffer, int nparameters,
+                               const float* jump_width, const double* nexpected, const unsigned* n_mc,
+                               const short* source_id, const unsigned* norms, bool debug_mode) {
+  hipLaunchKernelGGL(finish_nll_jump_pick_combo_kernel, dim3(1), dim3(block), 0, s, npartial, sums, nsignals,
+                     nsources, means, sigmas, rng, nll_current, nll_proposed, v_current, v_proposed, accepted,
+                     counter, jump_buffer, nparameters, jump_width, nexpected, n_mc, source_id, norms,
+                     debug_mode);
+  return hipGetLastError();
+}
+
+}  // extern "C"

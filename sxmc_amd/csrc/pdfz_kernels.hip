@@ -1,0 +1,627 @@
+// pdfz_kernels.hip -- gfx950 kernels for the pdfz::EvalHist half of the NLL evaluation:
+// zero, histogram fill with per-sample systematics, PDF lookup.  Written for CDNA4 only
+// (wave64, 160 KiB LDS per CU, 256 CUs); no other target is supported.
+//
+// What is computed is fixed by the reference (file:line relative to /root/reference):
+//   zero_hist    src/pdfz.cpp:334-346
+//   bin_samples  src/pdfz.cpp:349-408  (+ apply_systematic 306-331)
+//   eval_pdf     src/pdfz.cpp:411-436
+// How it is computed is not: the samples are stored column-major and read with one 16-byte
+// load per lane per column, each workgroup owns a contiguous slice of the concatenated sample
+// index space of ALL signals, accumulates into an LDS-private uint32 histogram with ds_add_u32
+// and flushes only its non-zero bins with one global atomic each; in-domain counts are kept in
+// a register per lane and reduced once per workgroup.
+//
+// Exactness: double arithmetic is IEEE add/sub/mul with NO contraction (compile flag
+// -ffp-contract=off plus the pragma below), in the reference's operation order, so bin
+// indices are bit-identical to the reference CPU loop.  x^i is formed by repeated
+// multiplication (exact for i <= 1, correctly rounded for i == 2).
+#include "sxmc_device.h"
+
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kWave = 64;
+
+// Pointers read out of a descriptor are generic (flat) to the compiler; every buffer they name is
+// HBM, so say so: global_* instructions keep vmcnt in order (flat_* would force vmcnt(0)
+// lgkmcnt(0) before every use and defeat the load pipelining below).
+template <typename T>
+using gptr = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ gptr<T> to_global(T* p) {
+  return (gptr<T>)p;
+}
+
+__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ double uniform_d(double x) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------ zero
+// bins <- 0, norm <- 0 for every member (blockIdx.y = member).
+__global__ __launch_bounds__(256) void zero_kernel(const SxSignalDesc* __restrict__ descs) {
+  const SxSignalDesc& d = descs[blockIdx.y];
+  unsigned* bins = d.bins;
+  const unsigned n = (unsigned)d.total_nbins;
+  const unsigned n4 = n >> 2;
+  uint4* b4 = reinterpret_cast<uint4*>(bins);  // hipMalloc'd: 256-byte aligned
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    b4[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *d.norm = 0u;
+  }
+}
+
+// ------------------------------------------------------------------------------------ fill
+// Compile-time slot dispatch: the slot index is wave-uniform (it comes from the descriptor),
+// so this is a scalar branch to code that addresses the slot's registers directly.
+template <int NSLOT, typename Fn>
+__device__ __forceinline__ void with_slot(int slot, Fn&& fn) {
+  switch (slot) {
+    case 0: fn(std::integral_constant<int, 0>{}); break;
+    case 1: if constexpr (NSLOT > 1) fn(std::integral_constant<int, 1>{}); break;
+    case 2: if constexpr (NSLOT > 2) fn(std::integral_constant<int, 2>{}); break;
+    case 3: if constexpr (NSLOT > 3) fn(std::integral_constant<int, 3>{}); break;
+    case 4: if constexpr (NSLOT > 4) fn(std::integral_constant<int, 4>{}); break;
+    case 5: if constexpr (NSLOT > 5) fn(std::integral_constant<int, 5>{}); break;
+    case 6: if constexpr (NSLOT > 6) fn(std::integral_constant<int, 6>{}); break;
+    default: break;
+  }
+}
+
+// apply_systematic (pdfz.cpp:316-330) on SXMC_VEC samples of one slot, p already formed.
+template <int NSLOT>
+__device__ __forceinline__ void apply_transform(double (&f)[NSLOT][SXMC_VEC], int type,
+                                                double (&x)[SXMC_VEC], int extra_slot,
+                                                const double (&p)[SXMC_VEC]) {
+  switch (type) {
+    case SXMC_SYST_SHIFT:
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) x[q] = x[q] + p[q];
+      break;
+    case SXMC_SYST_SCALE:
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) x[q] = x[q] * (1 + p[q]);
+      break;
+    case SXMC_SYST_CTSCALE:
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) x[q] = 1 + (x[q] - 1) * (1 + p[q]);
+      break;
+    case SXMC_SYST_RESOLUTION_SCALE:
+      with_slot<NSLOT>(extra_slot, [&](auto E) {
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) x[q] = x[q] + (p[q] * (x[q] - f[E][q]));
+      });
+      break;
+    default:
+      break;
+  }
+}
+
+// One systematic whose p is a wave-uniform constant (npars == 1: p = 0 + c0 * x^0).
+template <int NSLOT>
+__device__ __forceinline__ void apply_op_const(double (&f)[NSLOT][SXMC_VEC], int type,
+                                               int obs_slot, int extra_slot, double pc) {
+  if (type < 0) return;
+  with_slot<NSLOT>(obs_slot, [&](auto K) {
+    const double p[SXMC_VEC] = {pc, pc, pc, pc};
+    apply_transform<NSLOT>(f, type, f[K], extra_slot, p);
+  });
+}
+
+// General systematic: p = sum_i c_i * x^i at the current x (pdfz.cpp:310-314).
+template <int NSLOT>
+__device__ __forceinline__ void apply_op_poly(double (&f)[NSLOT][SXMC_VEC], const SxSystOp& op,
+                                              gptr<const double> params, int param_stride) {
+  const int type = uniform_i(op.type);
+  const int npars = uniform_i(op.npars);
+  const int extra_slot = uniform_i(op.extra_slot);
+  with_slot<NSLOT>(uniform_i(op.obs_slot), [&](auto K) {
+    double p[SXMC_VEC] = {0.0, 0.0, 0.0, 0.0};
+    double pw[SXMC_VEC] = {1.0, 1.0, 1.0, 1.0};
+    for (int i = 0; i < npars; i++) {
+      const double c = uniform_d(params[(long)op.pars[i] * param_stride]);
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        p[q] = p[q] + c * pw[q];
+        pw[q] = pw[q] * f[K][q];
+      }
+    }
+    apply_transform<NSLOT>(f, type, f[K], extra_slot, p);
+  });
+}
+
+typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load per lane
+
+template <int NSLOT>
+struct Columns {
+  vfloat4 v[NSLOT];
+};
+
+template <int NSLOT>
+__device__ __forceinline__ void load_columns(Columns<NSLOT>& c, const gptr<const vfloat4> (&col)[NSLOT],
+                                             unsigned long long v) {
+#pragma unroll
+  for (int k = 0; k < NSLOT; k++) {
+    c.v[k] = col[k][v];
+  }
+}
+
+// The histogram fill.  grid = a few workgroups per CU; workgroup b owns the slice
+// [total_vec*b/G, total_vec*(b+1)/G) of the concatenated (over members) 4-sample units and
+// walks the members that intersect it.
+template <int NOBS, int NSLOT, bool LDS_HIST>
+__global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restrict__ descs,
+                                                    int nsig, unsigned long long total_vec,
+                                                    unsigned hist_words) {
+  extern __shared__ unsigned lds[];  // LDS_HIST: [hist_words] histogram, then 1 word norm
+  const unsigned tid = threadIdx.x;
+  const unsigned nthreads = blockDim.x;
+
+  const unsigned long long G = gridDim.x;
+  unsigned long long r0 = total_vec * blockIdx.x / G;
+  const unsigned long long r1 = total_vec * (blockIdx.x + 1ull) / G;
+
+  // LDS layout: word 0 = workgroup norm counter, histogram from word 4 (16-byte aligned)
+  unsigned* s_norm = lds;
+  unsigned* hist = lds + 4;
+
+  int j = 0;
+  while (j + 1 < nsig && descs[j + 1].vec_start <= r0) j++;
+
+  bool lds_clean = false;
+
+  for (; j < nsig && r0 < r1; ++j) {
+    const SxSignalDesc& d = descs[j];
+    const unsigned long long s0 = d.vec_start;
+    const unsigned long long s1 = s0 + d.nvec;
+    if (s1 <= r0) continue;
+    const unsigned long long v0 = r0 - s0;
+    const unsigned long long v1 = (r1 < s1 ? r1 : s1) - s0;
+    r0 = (r1 < s1 ? r1 : s1);
+
+    const unsigned B = (unsigned)d.total_nbins;
+    gptr<unsigned> gbins = to_global(d.bins);
+
+    if (!lds_clean) {
+      // whole LDS histogram (sized for the largest member), once per workgroup
+      if (LDS_HIST) {
+        for (unsigned b = tid; b < hist_words; b += nthreads) hist[b] = 0u;
+      }
+      if (tid == 0) *s_norm = 0u;
+      __syncthreads();
+    }
+
+    // ---- wave-uniform geometry and systematics into scalar registers
+    double lo[NOBS], hi[NOBS], sc[NOBS];
+    int st[NOBS];
+#pragma unroll
+    for (int k = 0; k < NOBS; k++) {
+      lo[k] = d.lower[k];
+      hi[k] = d.upper[k];
+      sc[k] = d.scale[k];
+      st[k] = d.bin_stride[k];
+    }
+    gptr<const vfloat4> col[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
+    }
+
+    const int nsyst = d.nsyst;
+    const bool fast = d.fast_syst != 0;
+    gptr<const double> params = to_global(d.params);
+    const int pstride = d.param_stride;
+    int op_type[SXMC_FAST_SYST], op_obs[SXMC_FAST_SYST], op_extra[SXMC_FAST_SYST];
+    double op_p[SXMC_FAST_SYST];
+#pragma unroll
+    for (int s = 0; s < SXMC_FAST_SYST; s++) {
+      const bool on = fast && s < nsyst;
+      op_type[s] = on ? (int)d.syst[s].type : SXMC_OP_NOP;
+      op_obs[s] = on ? (int)d.syst[s].obs_slot : 0;
+      op_extra[s] = on ? (int)d.syst[s].extra_slot : 0;
+      // p = 0 + c0 * pow(x, 0) = 0 + c0 * 1 (pdfz.cpp:310-314 with npars == 1)
+      const double c0 = on ? uniform_d(params[(long)d.syst[s].pars[0] * pstride]) : 0.0;
+      op_p[s] = 0.0 + c0 * 1.0;
+    }
+
+    unsigned cnt = 0;
+
+    unsigned long long v = v0 + tid;
+    Columns<NSLOT> cur, nxt;
+    if (v < v1) load_columns<NSLOT>(cur, col, v);
+    while (v < v1) {
+      // Next unit's loads are issued unconditionally (index clamped into the slice) so that the
+      // wait counters stay exact: a branch around them makes the compiler wait for them at once.
+      const unsigned long long vn = v + nthreads;
+      load_columns<NSLOT>(nxt, col, vn < v1 ? vn : v1 - 1);
+
+      double f[NSLOT][SXMC_VEC];
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+        f[k][0] = (double)cur.v[k].x;
+        f[k][1] = (double)cur.v[k].y;
+        f[k][2] = (double)cur.v[k].z;
+        f[k][3] = (double)cur.v[k].w;
+      }
+
+      if (fast) {
+#pragma unroll
+        for (int s = 0; s < SXMC_FAST_SYST; s++) {
+          apply_op_const<NSLOT>(f, op_type[s], op_obs[s], op_extra[s], op_p[s]);
+        }
+      } else {
+        for (int s = 0; s < nsyst; s++) {
+          apply_op_poly<NSLOT>(f, d.syst[s], params, pstride);
+        }
+      }
+
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        bool ok = true;
+        int bin = 0;
+#pragma unroll
+        for (int k = 0; k < NOBS; k++) {
+          const double x = f[k][q];
+          // in-domain test of pdfz.cpp:391 written so that NaN is outside
+          ok = ok && (x >= lo[k]) && (x < hi[k]);
+          bin += (int)((x - lo[k]) * sc[k]) * st[k];
+        }
+        if (ok) {
+          cnt += 1u;
+          if ((unsigned)bin < B) {
+            if (LDS_HIST) {
+              __hip_atomic_fetch_add(&hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+      }
+
+      cur = nxt;
+      v = vn;
+    }
+
+    // ---- in-domain count: lane registers -> wave -> workgroup -> one global atomic
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
+    if ((tid & (kWave - 1)) == 0 && cnt != 0u) {
+      __hip_atomic_fetch_add(s_norm, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+
+    // ---- flush: only non-zero bins reach HBM; leave the LDS histogram zeroed for the next member
+    if (LDS_HIST) {
+      for (unsigned b = tid; b < B; b += nthreads) {
+        const unsigned c = hist[b];
+        if (c != 0u) {
+          __hip_atomic_fetch_add(&gbins[b], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hist[b] = 0u;
+        }
+      }
+    }
+    if (tid == 0) {
+      const unsigned c = *s_norm;
+      if (c != 0u) __hip_atomic_fetch_add(to_global(d.norm), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_norm = 0u;
+    }
+    __syncthreads();
+    lds_clean = true;
+  }
+}
+
+// Shape-agnostic fallback (any nobs/nslot up to SXMC_MAX_NFIELDS): one sample per lane per
+// iteration, fields in a dynamically indexed array.  Correctness path for shapes without a
+// specialization; same arithmetic.
+template <bool LDS_HIST>
+__global__ __launch_bounds__(1024) void fill_kernel_generic(const SxSignalDesc* __restrict__ descs,
+                                                            int nsig, unsigned long long total_vec,
+                                                            unsigned hist_words) {
+  extern __shared__ unsigned lds[];
+  const unsigned tid = threadIdx.x;
+  const unsigned nthreads = blockDim.x;
+  const unsigned long long G = gridDim.x;
+  unsigned long long r0 = total_vec * blockIdx.x / G;
+  const unsigned long long r1 = total_vec * (blockIdx.x + 1ull) / G;
+  unsigned* s_norm = lds;
+  unsigned* hist = lds + 4;
+
+  int j = 0;
+  while (j + 1 < nsig && descs[j + 1].vec_start <= r0) j++;
+  bool lds_clean = false;
+
+  for (; j < nsig && r0 < r1; ++j) {
+    const SxSignalDesc& d = descs[j];
+    const unsigned long long s0 = d.vec_start;
+    const unsigned long long s1 = s0 + d.nvec;
+    if (s1 <= r0) continue;
+    const unsigned long long v0 = r0 - s0;
+    const unsigned long long v1 = (r1 < s1 ? r1 : s1) - s0;
+    r0 = (r1 < s1 ? r1 : s1);
+    const unsigned B = (unsigned)d.total_nbins;
+    gptr<unsigned> gbins = to_global(d.bins);
+    if (!lds_clean) {
+      // whole LDS histogram (sized for the largest member), once per workgroup
+      if (LDS_HIST) {
+        for (unsigned b = tid; b < hist_words; b += nthreads) hist[b] = 0u;
+      }
+      if (tid == 0) *s_norm = 0u;
+      __syncthreads();
+    }
+    const int nobs = d.nobs, nslot = d.nslot, nsyst = d.nsyst;
+    gptr<const double> params = to_global(d.params);
+    const int pstride = d.param_stride;
+    unsigned cnt = 0;
+    // sample units: v counts 4-sample units, so samples [4*v0, 4*v1)
+    for (unsigned long long i = v0 * SXMC_VEC + tid; i < v1 * SXMC_VEC; i += nthreads) {
+      double f[SXMC_MAX_NFIELDS];
+      for (int k = 0; k < nslot; k++) {
+        f[k] = (double)to_global(d.cols)[(unsigned long long)d.slot_col[k] * d.col_pitch + i];
+      }
+      for (int s = 0; s < nsyst; s++) {
+        const SxSystOp& op = d.syst[s];
+        double x = f[op.obs_slot];
+        double p = 0.0, pw = 1.0;
+        for (int t = 0; t < op.npars; t++) {
+          p = p + params[(long)op.pars[t] * pstride] * pw;
+          pw = pw * x;
+        }
+        switch (op.type) {
+          case SXMC_SYST_SHIFT: x = x + p; break;
+          case SXMC_SYST_SCALE: x = x * (1 + p); break;
+          case SXMC_SYST_CTSCALE: x = 1 + (x - 1) * (1 + p); break;
+          case SXMC_SYST_RESOLUTION_SCALE: x = x + (p * (x - f[op.extra_slot])); break;
+          default: break;
+        }
+        f[op.obs_slot] = x;
+      }
+      bool ok = true;
+      int bin = 0;
+      for (int k = 0; k < nobs && ok; k++) {
+        const double x = f[k];
+        ok = (x >= d.lower[k]) && (x < d.upper[k]);
+        if (ok) bin += (int)((x - d.lower[k]) * d.scale[k]) * d.bin_stride[k];
+      }
+      if (ok) {
+        cnt += 1u;
+        if ((unsigned)bin < B) {
+          if (LDS_HIST) {
+            __hip_atomic_fetch_add(&hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
+    if ((tid & (kWave - 1)) == 0 && cnt != 0u) {
+      __hip_atomic_fetch_add(s_norm, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    if (LDS_HIST) {
+      for (unsigned b = tid; b < B; b += nthreads) {
+        const unsigned c = hist[b];
+        if (c != 0u) {
+          __hip_atomic_fetch_add(&gbins[b], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hist[b] = 0u;
+        }
+      }
+    }
+    if (tid == 0) {
+      const unsigned c = *s_norm;
+      if (c != 0u) __hip_atomic_fetch_add(to_global(d.norm), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_norm = 0u;
+    }
+    __syncthreads();
+    lds_clean = true;
+  }
+}
+
+// ------------------------------------------------------------------------------------ eval
+__device__ __forceinline__ float pdf_value(int rb, gptr<const unsigned> bins, double bin_norm) {
+  // pdfz.cpp:423-434: -2 -> 0, other negatives -> NaN, else (float)(bins / (norm * volume))
+  if (rb == -2) return 0.0f;
+  if (rb < 0) return __int_as_float(0x7fc00000);
+  return (float)((double)bins[rb] / bin_norm);
+}
+
+__global__ __launch_bounds__(256) void eval_pdf_kernel(const SxSignalDesc* __restrict__ descs) {
+  const SxSignalDesc& d = descs[blockIdx.y];
+  if (d.read_bins == nullptr) return;
+  gptr<const int> rbs = to_global(d.read_bins);
+  gptr<const unsigned> bins = to_global((const unsigned*)d.bins);
+  const unsigned long long n = d.npoints;
+  const double bin_norm = (double)(*to_global((const unsigned*)d.norm)) * d.bin_volume;
+  gptr<float> out = to_global(d.pdf_out);
+  const long stride = d.pdf_stride;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    out[stride * (long)i] = pdf_value(rbs[i], bins, bin_norm);
+  }
+}
+
+// eval_pdf for all members fused with nll_event_chunks (nll_kernels.cpp:89-116): per event the
+// lookup-table values are produced, stored (the lut is the API contract) and consumed in
+// registers.  One partial sum per workgroup.
+__global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                       unsigned long long npoints,
+                                                       const double* __restrict__ pars,
+                                                       const double* __restrict__ nexpected,
+                                                       const unsigned* __restrict__ n_mc,
+                                                       const short* __restrict__ source_id,
+                                                       const unsigned* __restrict__ norms,
+                                                       double* __restrict__ sums) {
+  extern __shared__ double sh[];  // [nsig] bin_norm, [nsig] rate coefficient, [4] wave sums
+  double* s_binnorm = sh;
+  double* s_coef = sh + nsig;
+  double* s_wave = sh + 2 * nsig;
+  for (int j = threadIdx.x; j < nsig; j += blockDim.x) {
+    s_binnorm[j] = (double)(*to_global((const unsigned*)descs[j].norm)) * descs[j].bin_volume;
+    const float eff = (float)(1.0 * norms[j] / n_mc[j]);       // nll_kernels.cpp:105
+    s_coef[j] = pars[source_id[j]] * nexpected[j] * eff;       // left-to-right, :107
+  }
+  __syncthreads();
+
+  double sum = 0.0;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < npoints; i += step) {
+    double s = 0.0;
+    for (int j = 0; j < nsig; j++) {
+      const SxSignalDesc& d = descs[j];
+      const float v = pdf_value(to_global(d.read_bins)[i], to_global((const unsigned*)d.bins), s_binnorm[j]);
+      to_global(d.pdf_out)[(long)d.pdf_stride * (long)i] = v;
+      s = s + s_coef[j] * (double)(!isnan(v) ? v : 0.0f);
+    }
+    if (s > 0) sum += log(s);
+  }
+
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) sum += __shfl_down(sum, off, kWave);
+  const int wave = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) s_wave[wave] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x / kWave); w++) t += s_wave[w];
+    if (!isnan(t)) sums[blockIdx.x] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------ layout
+// Row-major [n][F] -> column-major with pitch; pads [n, nvec*4) with NaN in every column.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ aos, float* __restrict__ cols,
+                                                        unsigned long long n, int F,
+                                                        unsigned long long pitch) {
+  const unsigned long long npad = (n + SXMC_VEC - 1) / SXMC_VEC * SXMC_VEC;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += step) {
+    for (int k = 0; k < F; k++) {
+      cols[(unsigned long long)k * pitch + i] = (i < n) ? aos[i * F + k] : __int_as_float(0x7fc00000);
+    }
+  }
+}
+
+// GetSamples (pdfz.h:542-556): rows of nobs observables + the dataset id.
+__global__ __launch_bounds__(256) void untranspose_obs_kernel(const float* __restrict__ cols, float* __restrict__ out,
+                                                              unsigned long long n, int nobs,
+                                                              unsigned long long pitch, float dataset) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    for (int k = 0; k < nobs; k++) out[i * (nobs + 1) + k] = cols[(unsigned long long)k * pitch + i];
+    out[i * (nobs + 1) + nobs] = dataset;
+  }
+}
+
+template <int NOBS, int NSLOT>
+hipError_t launch_fill_t(const SxLaunchShape& sh, const SxSignalDesc* descs, int nsig,
+                         unsigned long long total_vec, hipStream_t s) {
+  hipError_t e = hipSuccess;
+  if (sh.lds_hist) {
+    auto k = fill_kernel<NOBS, NSLOT, true>;
+    if (sh.lds_bytes > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sh.lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, nsig, total_vec,
+                       (unsigned)(sh.lds_bytes / 4 - 4));
+  } else {
+    hipLaunchKernelGGL((fill_kernel<NOBS, NSLOT, false>), dim3(sh.grid), dim3(sh.threads), 64, s, descs,
+                       nsig, total_vec, 0u);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool sx_fill_has_specialization(int nobs, int nslot) {
+  return nobs >= 1 && nobs <= 5 && nslot >= nobs && nslot <= nobs + 2;
+}
+
+hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, int nsig,
+                          unsigned long long total_vec, hipStream_t s) {
+  if (total_vec == 0 || nsig == 0) return hipSuccess;
+#define SX_CASE(NO, NS) \
+  if (sh.nobs == NO && sh.nslot == NS) return launch_fill_t<NO, NS>(sh, descs, nsig, total_vec, s);
+  SX_CASE(1, 1) SX_CASE(1, 2) SX_CASE(1, 3)
+  SX_CASE(2, 2) SX_CASE(2, 3) SX_CASE(2, 4)
+  SX_CASE(3, 3) SX_CASE(3, 4) SX_CASE(3, 5)
+  SX_CASE(4, 4) SX_CASE(4, 5) SX_CASE(4, 6)
+  SX_CASE(5, 5) SX_CASE(5, 6) SX_CASE(5, 7)
+#undef SX_CASE
+  if (sh.lds_hist) {
+    auto k = fill_kernel_generic<true>;
+    if (sh.lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, nsig, total_vec,
+                       (unsigned)(sh.lds_bytes / 4 - 4));
+  } else {
+    hipLaunchKernelGGL(fill_kernel_generic<false>, dim3(sh.grid), dim3(sh.threads), 64, s, descs, nsig,
+                       total_vec, 0u);
+  }
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, hipStream_t s) {
+  if (nsig == 0) return hipSuccess;
+  int bx = (max_bins / 4 + 255) / 256;
+  if (bx < 1) bx = 1;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(zero_kernel, dim3(bx, nsig), dim3(256), 0, s, d_descs);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,
+                              hipStream_t s) {
+  if (nsig == 0 || max_points == 0) return hipSuccess;
+  unsigned long long bx = (max_points + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(eval_pdf_kernel, dim3((unsigned)bx, nsig), dim3(256), 0, s, d_descs);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
+                              const double* pars, const double* nexpected, const unsigned* n_mc,
+                              const short* source_id, const unsigned* norms, double* sums,
+                              int grid, int block, hipStream_t s) {
+  const size_t shmem = (2 * (size_t)nsig + 16) * sizeof(double);
+  hipLaunchKernelGGL(eval_nll_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, pars,
+                     nexpected, n_mc, source_id, norms, sums);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_transpose(const float* aos, float* cols, unsigned long long nsamples, int nfields,
+                               unsigned long long col_pitch, hipStream_t s) {
+  unsigned long long npad = (nsamples + SXMC_VEC - 1) / SXMC_VEC * SXMC_VEC;
+  if (npad == 0) return hipSuccess;
+  unsigned long long bx = (npad + 255) / 256;
+  if (bx > 8192) bx = 8192;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)bx), dim3(256), 0, s, aos, cols, nsamples, nfields,
+                     col_pitch);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_untranspose_obs(const float* cols, float* out, unsigned long long nsamples, int nobs,
+                                     unsigned long long col_pitch, float dataset, hipStream_t s) {
+  if (nsamples == 0) return hipSuccess;
+  unsigned long long bx = (nsamples + 255) / 256;
+  if (bx > 8192) bx = 8192;
+  hipLaunchKernelGGL(untranspose_obs_kernel, dim3((unsigned)bx), dim3(256), 0, s, cols, out, nsamples, nobs,
+                     col_pitch, dataset);
+  return hipGetLastError();
+}

@@ -1,0 +1,84 @@
+// sxmc_device.h -- structures shared between the host side of libsxmc_hip.so and its gfx950
+// kernels.  Internal: the public boundary is include/sxmc_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sxmc_hip.h"
+
+#define SXMC_FAST_SYST 4   // systematics whose operands are hoisted into scalar registers
+#define SXMC_VEC 4         // samples per lane per iteration (one 16-byte load per column)
+#define SXMC_OP_NOP (-1)
+
+// One systematic, addressed by SLOT (position among the columns a launch loads), not by field.
+// Restates SystematicDescriptor (pdfz.cpp:48-54) with the parameter indices inlined.
+struct SxSystOp {
+  short type;
+  short obs_slot;
+  short extra_slot;
+  short npars;
+  short pars[SXMC_MAX_SYST_PARS];
+};
+
+// Everything the kernels need to know about one evaluator (one signal's PDF).
+// Lives in device memory as an array, one entry per group member; every field is read with
+// wave-uniform addresses (scalar loads).
+struct SxSignalDesc {
+  // --- samples: column-major, column k at cols + k*col_pitch, padded with NaN to a multiple
+  //     of SXMC_VEC samples (NaN is outside every domain, so padding needs no masking)
+  const float* cols;
+  unsigned long long col_pitch;  // floats, multiple of 64
+  unsigned long long nsamples;
+  unsigned long long nvec;       // ceil(nsamples / SXMC_VEC)
+  unsigned long long vec_start;  // prefix sum of nvec over the launch's members
+  // --- histogram
+  unsigned* bins;
+  unsigned* norm;                // norm_buffer + norm_offset
+  int total_nbins;
+  int nobs;
+  int nslot;                     // columns loaded: nobs observables + referenced extra fields
+  int nsyst;
+  int fast_syst;                 // nsyst <= SXMC_FAST_SYST and every npars == 1
+  int param_stride;
+  const double* params;          // param_buffer + param_offset
+  int slot_col[SXMC_MAX_NFIELDS];
+  int bin_stride[SXMC_MAX_NFIELDS];
+  double lower[SXMC_MAX_NFIELDS];
+  double upper[SXMC_MAX_NFIELDS];
+  double scale[SXMC_MAX_NFIELDS];  // nbins / (upper - lower), computed on the host in double
+  SxSystOp syst[SXMC_MAX_SYST];
+  // --- evaluation at the data events
+  const int* read_bins;
+  unsigned long long npoints;
+  float* pdf_out;                // pdf_buffer + pdf_offset
+  int pdf_stride;
+  int pad0;
+  double bin_volume;
+};
+
+// Host-callable launchers implemented in the .hip files -------------------------------------
+struct SxLaunchShape {
+  int nobs;
+  int nslot;
+  int lds_hist;     // 1: LDS-privatized sub-histograms, 0: global atomics into the HBM histogram
+  int threads;      // 256 / 512 / 1024
+  int grid;
+  size_t lds_bytes;
+};
+
+hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, hipStream_t s);
+hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, int nsig,
+                          unsigned long long total_vec, hipStream_t s);
+bool sx_fill_has_specialization(int nobs, int nslot);
+hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,
+                              hipStream_t s);
+hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
+                              const double* pars, const double* nexpected, const unsigned* n_mc,
+                              const short* source_id, const unsigned* norms, double* sums,
+                              int grid, int block, hipStream_t s);
+hipError_t sx_launch_transpose(const float* aos, float* cols, unsigned long long nsamples,
+                               int nfields, unsigned long long col_pitch, hipStream_t s);
+hipError_t sx_launch_untranspose_obs(const float* cols, float* out, unsigned long long nsamples,
+                                     int nobs, unsigned long long col_pitch, float dataset,
+                                     hipStream_t s);

@@ -1,0 +1,948 @@
+// sxmc_hip.cpp -- host side of libsxmc_hip.so: the C ABI declared in include/sxmc_hip.h.
+// Handles, validation, device-resident layout, launch sizing.  The arithmetic lives in
+// pdfz_kernels.hip / nll_kernels.hip.  There is no CPU fallback: every evaluation entry point
+// launches gfx950 kernels or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sxmc_device.h"
+
+extern "C" {
+hipError_t sx_nll_init_rngs(int, int, hipStream_t, int, unsigned long long, sxmc_rng_state*);
+hipError_t sx_nll_philox_dump(hipStream_t, sxmc_rng_state*, unsigned*, int);
+hipError_t sx_nll_pick_new_vector(int, int, hipStream_t, int, sxmc_rng_state*, const float*, const double*,
+                                  double*);
+hipError_t sx_nll_jump_decider(int, int, hipStream_t, sxmc_rng_state*, double*, const double*, double*,
+                               const double*, unsigned, int*, int*, float*);
+hipError_t sx_nll_event_chunks(int, int, hipStream_t, const float*, const double*, size_t, size_t,
+                               const double*, const unsigned*, const short*, const unsigned*, double*);
+hipError_t sx_nll_event_reduce(int, hipStream_t, size_t, const double*, double*);
+hipError_t sx_nll_total(hipStream_t, size_t, const double*, size_t, size_t, const double*, const double*,
+                        const double*, const double*, const unsigned*, const short*, const unsigned*, double*);
+hipError_t sx_nll_finish_combo(int, hipStream_t, size_t, const double*, size_t, size_t, const double*,
+                               const double*, sxmc_rng_state*, double*, double*, double*, double*, int*, int*,
+                               float*, int, const float*, const double*, const unsigned*, const short*,
+                               const unsigned*, bool);
+}
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define SX_HIP(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      return fail(SXMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    }                                                                                       \
+  } while (0)
+
+#define SX_REQUIRE(cond, msg) \
+  do {                        \
+    if (!(cond)) return fail(SXMC_ERR_INVALID, msg); \
+  } while (0)
+
+constexpr int kLdsMaxBins = 40960 - 64;  // 160 KiB of LDS per workgroup minus the counter words
+
+struct HostSyst {
+  int type, obs, extra_field;
+  std::vector<short> pars;
+};
+
+struct DeviceProps {
+  int cus = 0;
+  int lds_per_cu = 0;
+  bool valid = false;
+};
+
+int get_props(DeviceProps& p) {
+  static thread_local DeviceProps cache;
+  static thread_local int cache_dev = -1;
+  int dev = 0;
+  SX_HIP(hipGetDevice(&dev));
+  if (!cache.valid || cache_dev != dev) {
+    hipDeviceProp_t prop;
+    SX_HIP(hipGetDeviceProperties(&prop, dev));
+    cache.cus = prop.multiProcessorCount;
+    cache.lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (cache.lds_per_cu <= 0) cache.lds_per_cu = 160 * 1024;
+    cache.valid = true;
+    cache_dev = dev;
+  }
+  p = cache;
+  return SXMC_OK;
+}
+
+}  // namespace
+
+struct sxmc_hist {
+  int nfields = 0, nobs = 0;
+  size_t nsamples = 0, nvec = 0, pitch = 0;
+  unsigned dataset = 0;
+  std::vector<double> lower, upper, scale;
+  std::vector<int> nbins, stride;
+  int total_nbins = 0;
+  double bin_volume = 0;
+  float* d_cols = nullptr;
+  unsigned* d_bins = nullptr;
+  int* d_read_bins = nullptr;
+  bool has_points = false;
+  size_t npoints = 0;
+  float* pdf = nullptr;
+  int pdf_off = 0, pdf_stride = 1;
+  unsigned* norm = nullptr;
+  int norm_off = 0;
+  const double* params = nullptr;
+  int par_off = 0, par_stride = 1;
+  std::vector<HostSyst> systs;
+  hipStream_t stream = nullptr;
+  unsigned long long version = 1;
+  sxmc_group* self = nullptr;
+  int cfg_threads = 0, cfg_bpc = 0;
+};
+
+namespace {
+struct LaunchClass {
+  SxLaunchShape shape;
+  std::vector<int> member_idx;
+  SxSignalDesc* d_descs = nullptr;
+  unsigned long long total_vec = 0;
+};
+}  // namespace
+
+struct sxmc_group {
+  std::vector<sxmc_hist*> members;
+  std::vector<unsigned long long> seen;
+  std::vector<SxSignalDesc> h_descs;
+  SxSignalDesc* d_descs = nullptr;  // member order: zero / eval kernels
+  std::vector<LaunchClass> classes;
+  int cfg_threads = 0, cfg_bpc = 0;
+  int cfg_seen_threads = -1, cfg_seen_bpc = -1;
+  int max_bins = 0;
+  unsigned long long max_points = 0;
+  bool same_points = false;
+  hipStream_t last_stream = nullptr;
+  bool built = false;
+  // profiling of the fill kernel
+  bool prof = false;
+  std::vector<hipEvent_t> ev0, ev1;
+  int prof_n = 0;
+};
+
+namespace {
+
+// Slot assignment: observables first (slot k = field k), then every other field a systematic
+// references, ascending.
+void member_slots(const sxmc_hist* h, std::vector<int>& slot_col) {
+  slot_col.clear();
+  for (int k = 0; k < h->nobs; k++) slot_col.push_back(k);
+  std::vector<int> extra;
+  for (const HostSyst& s : h->systs) {
+    if (s.obs >= h->nobs) extra.push_back(s.obs);
+    if (s.type == SXMC_SYST_RESOLUTION_SCALE && s.extra_field >= h->nobs) extra.push_back(s.extra_field);
+  }
+  std::sort(extra.begin(), extra.end());
+  extra.erase(std::unique(extra.begin(), extra.end()), extra.end());
+  for (int c : extra) slot_col.push_back(c);
+}
+
+int slot_of(const std::vector<int>& slot_col, int field) {
+  for (size_t k = 0; k < slot_col.size(); k++)
+    if (slot_col[k] == field) return (int)k;
+  return 0;
+}
+
+int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
+  std::memset(&d, 0, sizeof(d));
+  std::vector<int> slot_col;
+  member_slots(h, slot_col);
+  d.cols = h->d_cols;
+  d.col_pitch = h->pitch;
+  d.nsamples = h->nsamples;
+  d.nvec = h->nvec;
+  d.bins = h->d_bins;
+  d.norm = h->norm ? h->norm + h->norm_off : nullptr;
+  d.total_nbins = h->total_nbins;
+  d.nobs = h->nobs;
+  d.nslot = (int)slot_col.size();
+  d.nsyst = (int)h->systs.size();
+  d.param_stride = h->par_stride;
+  d.params = h->params ? h->params + h->par_off : nullptr;
+  for (int k = 0; k < d.nslot; k++) d.slot_col[k] = slot_col[k];
+  for (int k = 0; k < h->nobs; k++) {
+    d.bin_stride[k] = h->stride[k];
+    d.lower[k] = h->lower[k];
+    d.upper[k] = h->upper[k];
+    d.scale[k] = h->scale[k];
+  }
+  bool fast = d.nsyst <= SXMC_FAST_SYST;
+  for (int s = 0; s < d.nsyst; s++) {
+    const HostSyst& hs = h->systs[s];
+    SxSystOp& op = d.syst[s];
+    op.type = (short)hs.type;
+    op.obs_slot = (short)slot_of(slot_col, hs.obs);
+    op.extra_slot = (short)(hs.type == SXMC_SYST_RESOLUTION_SCALE ? slot_of(slot_col, hs.extra_field) : 0);
+    op.npars = (short)hs.pars.size();
+    for (size_t i = 0; i < hs.pars.size(); i++) op.pars[i] = hs.pars[i];
+    if (hs.pars.size() != 1) fast = false;
+  }
+  d.fast_syst = fast ? 1 : 0;
+  d.read_bins = h->has_points ? h->d_read_bins : nullptr;
+  d.npoints = h->has_points ? h->npoints : 0;
+  d.pdf_out = h->pdf ? h->pdf + h->pdf_off : nullptr;
+  d.pdf_stride = h->pdf_stride;
+  d.bin_volume = h->bin_volume;
+  return SXMC_OK;
+}
+
+int group_rebuild(sxmc_group* g) {
+  // Descriptors may still be read by kernels in flight on another stream: rebuilds are rare
+  // (bindings change only during setup), so a device-wide sync is the simple safe choice.
+  SX_HIP(hipDeviceSynchronize());
+  DeviceProps props;
+  int rc = get_props(props);
+  if (rc) return rc;
+
+  const int n = (int)g->members.size();
+  g->h_descs.assign((size_t)n, SxSignalDesc{});
+  for (LaunchClass& c : g->classes) {
+    if (c.d_descs) (void)hipFree(c.d_descs);
+  }
+  g->classes.clear();
+  g->max_bins = 0;
+  g->max_points = 0;
+  g->same_points = n > 0;
+
+  int threads = g->cfg_threads > 0 ? g->cfg_threads : 512;
+  if (threads != 256 && threads != 512 && threads != 1024) threads = 512;
+
+  for (int i = 0; i < n; i++) {
+    sxmc_hist* h = g->members[i];
+    SxSignalDesc& d = g->h_descs[i];
+    fill_desc(h, d);
+    g->max_bins = std::max(g->max_bins, h->total_nbins);
+    g->max_points = std::max<unsigned long long>(g->max_points, d.npoints);
+    if (!h->has_points || h->npoints != g->members[0]->npoints) g->same_points = false;
+
+    const int lds_hist = h->total_nbins <= kLdsMaxBins ? 1 : 0;
+    const bool spec = sx_fill_has_specialization(d.nobs, d.nslot);
+    const int key_nobs = spec ? d.nobs : 0, key_nslot = spec ? d.nslot : 0;
+    LaunchClass* cls = nullptr;
+    for (LaunchClass& c : g->classes) {
+      if (c.shape.nobs == key_nobs && c.shape.nslot == key_nslot && c.shape.lds_hist == lds_hist) cls = &c;
+    }
+    if (!cls) {
+      g->classes.push_back(LaunchClass{});
+      cls = &g->classes.back();
+      cls->shape.nobs = key_nobs;
+      cls->shape.nslot = key_nslot;
+      cls->shape.lds_hist = lds_hist;
+      cls->shape.threads = threads;
+    }
+    cls->member_idx.push_back(i);
+  }
+
+  if (!g->d_descs) SX_HIP(hipMalloc((void**)&g->d_descs, sizeof(SxSignalDesc) * std::max(n, 1)));
+  if (n) SX_HIP(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
+
+  for (LaunchClass& c : g->classes) {
+    std::vector<SxSignalDesc> descs;
+    unsigned long long prefix = 0;
+    int cls_max_bins = 0;
+    for (int idx : c.member_idx) {
+      SxSignalDesc d = g->h_descs[idx];
+      d.vec_start = prefix;
+      prefix += d.nvec;
+      cls_max_bins = std::max(cls_max_bins, d.total_nbins);
+      descs.push_back(d);
+    }
+    c.total_vec = prefix;
+    c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4) * 4 : 64;
+    int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, 1024 / threads);
+    const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
+    bpc = std::min(bpc, lds_limit);
+    unsigned long long grid = (unsigned long long)props.cus * bpc;
+    const unsigned long long want = (c.total_vec + threads - 1) / threads;  // >= 1 unit per lane
+    grid = std::max<unsigned long long>(1, std::min(grid, want));
+    c.shape.grid = (int)grid;
+    SX_HIP(hipMalloc((void**)&c.d_descs, sizeof(SxSignalDesc) * descs.size()));
+    SX_HIP(hipMemcpy(c.d_descs, descs.data(), sizeof(SxSignalDesc) * descs.size(), hipMemcpyHostToDevice));
+  }
+
+  g->seen.resize((size_t)n);
+  for (int i = 0; i < n; i++) g->seen[i] = g->members[i]->version;
+  g->cfg_seen_threads = g->cfg_threads;
+  g->cfg_seen_bpc = g->cfg_bpc;
+  g->built = true;
+  return SXMC_OK;
+}
+
+int group_refresh(sxmc_group* g) {
+  bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc;
+  for (size_t i = 0; !stale && i < g->members.size(); i++) {
+    if (g->seen[i] != g->members[i]->version) stale = true;
+  }
+  return stale ? group_rebuild(g) : SXMC_OK;
+}
+
+int group_check_bound(sxmc_group* g, bool need_pdf) {
+  for (sxmc_hist* h : g->members) {
+    if (!h->norm) return fail(SXMC_ERR_STATE, "evaluation before SetNormalizationBuffer");
+    if (!h->systs.empty() && !h->params) return fail(SXMC_ERR_STATE, "evaluation before SetParameterBuffer");
+    if (need_pdf && h->has_points && !h->pdf) return fail(SXMC_ERR_STATE, "evaluation before SetPDFValueBuffer");
+  }
+  return SXMC_OK;
+}
+
+int group_fill(sxmc_group* g, hipStream_t s) {
+  SX_HIP(sx_launch_zero(g->d_descs, (int)g->members.size(), g->max_bins, s));
+  for (LaunchClass& c : g->classes) {
+    const bool rec = g->prof && g->prof_n < (int)g->ev0.size();
+    if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
+    SX_HIP(sx_launch_fill(c.shape, c.d_descs, (int)c.member_idx.size(), c.total_vec, s));
+    if (rec) {
+      SX_HIP(hipEventRecord(g->ev1[g->prof_n], s));
+      g->prof_n++;
+    }
+  }
+  return SXMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sxmc_last_error(void) { return g_last_error.c_str(); }
+const char* sxmc_version(void) { return "sxmc_hip 0.1 (gfx950)"; }
+
+int sxmc_device_count(int* count) {
+  SX_REQUIRE(count, "null argument");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(SXMC_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  return SXMC_OK;
+}
+
+int sxmc_set_device(int device) {
+  SX_HIP(hipSetDevice(device));
+  return SXMC_OK;
+}
+
+int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes, int* lds_bytes_per_cu,
+                     int* clock_khz) {
+  hipDeviceProp_t prop;
+  SX_HIP(hipGetDeviceProperties(&prop, device));
+  if (name) {
+    std::snprintf(name, 256, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  return SXMC_OK;
+}
+
+int sxmc_device_synchronize(void) {
+  SX_HIP(hipDeviceSynchronize());
+  return SXMC_OK;
+}
+
+int sxmc_malloc(void** d_ptr, size_t bytes) {
+  SX_REQUIRE(d_ptr, "null argument");
+  SX_HIP(hipMalloc(d_ptr, bytes ? bytes : 4));
+  return SXMC_OK;
+}
+int sxmc_free(void* d_ptr) {
+  if (d_ptr) SX_HIP(hipFree(d_ptr));
+  return SXMC_OK;
+}
+int sxmc_host_alloc(void** h_ptr, size_t bytes) {
+  SX_REQUIRE(h_ptr, "null argument");
+  SX_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 4, hipHostMallocDefault));
+  return SXMC_OK;
+}
+int sxmc_host_free(void* h_ptr) {
+  if (h_ptr) SX_HIP(hipHostFree(h_ptr));
+  return SXMC_OK;
+}
+int sxmc_memcpy_h2d(void* d, const void* h, size_t n) {
+  if (n) SX_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+  return SXMC_OK;
+}
+int sxmc_memcpy_d2h(void* h, const void* d, size_t n) {
+  if (n) SX_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+  return SXMC_OK;
+}
+int sxmc_memcpy_d2d(void* d, const void* s, size_t n) {
+  if (n) SX_HIP(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice));
+  return SXMC_OK;
+}
+int sxmc_memcpy_h2d_async(void* d, const void* h, size_t n, sxmc_stream_t s) {
+  if (n) SX_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+  return SXMC_OK;
+}
+int sxmc_memcpy_d2h_async(void* h, const void* d, size_t n, sxmc_stream_t s) {
+  if (n) SX_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+  return SXMC_OK;
+}
+int sxmc_memset(void* d, int v, size_t n) {
+  if (n) SX_HIP(hipMemset(d, v, n));
+  return SXMC_OK;
+}
+
+int sxmc_stream_create(sxmc_stream_t* s) {
+  SX_REQUIRE(s, "null argument");
+  hipStream_t st;
+  SX_HIP(hipStreamCreate(&st));
+  *s = st;
+  return SXMC_OK;
+}
+int sxmc_stream_destroy(sxmc_stream_t s) {
+  if (s) SX_HIP(hipStreamDestroy((hipStream_t)s));
+  return SXMC_OK;
+}
+int sxmc_stream_synchronize(sxmc_stream_t s) {
+  SX_HIP(hipStreamSynchronize((hipStream_t)s));
+  return SXMC_OK;
+}
+int sxmc_event_create(sxmc_event_t* e) {
+  SX_REQUIRE(e, "null argument");
+  hipEvent_t ev;
+  SX_HIP(hipEventCreate(&ev));
+  *e = ev;
+  return SXMC_OK;
+}
+int sxmc_event_destroy(sxmc_event_t e) {
+  if (e) SX_HIP(hipEventDestroy((hipEvent_t)e));
+  return SXMC_OK;
+}
+int sxmc_event_record(sxmc_event_t e, sxmc_stream_t s) {
+  SX_HIP(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+  return SXMC_OK;
+}
+int sxmc_event_synchronize(sxmc_event_t e) {
+  SX_HIP(hipEventSynchronize((hipEvent_t)e));
+  return SXMC_OK;
+}
+int sxmc_event_elapsed_ms(sxmc_event_t a, sxmc_event_t b, float* ms) {
+  SX_REQUIRE(ms, "null argument");
+  SX_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return SXMC_OK;
+}
+
+// ------------------------------------------------------------------------------ evaluator
+int sxmc_hist_create(const float* samples, size_t nsamples_floats, int samples_on_device, int nfields,
+                     int nobservables, const double* lower, size_t n_lower, const double* upper,
+                     size_t n_upper, const int* nbins, size_t n_nbins, unsigned dataset, sxmc_hist_t* out) {
+  SX_REQUIRE(out, "null argument");
+  *out = nullptr;
+  // Eval::Eval validation, pdfz.cpp:64-82 (same order, same messages)
+  SX_REQUIRE(nfields > 0 && nsamples_floats % (size_t)nfields == 0,
+             "Length of samples array is not divisible by number of fields.");
+  SX_REQUIRE(nobservables != 0, "Number of observables in PDF is zero.");
+  SX_REQUIRE(nobservables > 0 && nobservables <= nfields,
+             "Number of observables cannot be greater than number of fields.");
+  SX_REQUIRE((int)n_upper == nobservables, "Number of upper bounds must be same as number of observables.");
+  SX_REQUIRE((int)n_lower == nobservables, "Number of lower bounds must be same as number of observables.");
+  // EvalHist::EvalHist validation, pdfz.cpp:189-195
+  SX_REQUIRE((int)n_nbins == nobservables, "Size of nbins array must be same as number of observables.");
+  SX_REQUIRE(nfields <= SXMC_MAX_NFIELDS,
+             "Exceeded maximum number of fields per sample. Edit MAX_NFIELDS in pdfz.cpp to fix this!");
+  SX_REQUIRE(nsamples_floats == 0 || samples, "null samples");
+  SX_REQUIRE(lower && upper && nbins, "null argument");
+
+  sxmc_hist* h = new sxmc_hist;
+  h->nfields = nfields;
+  h->nobs = nobservables;
+  h->dataset = dataset;
+  h->nsamples = nsamples_floats / (size_t)nfields;
+  h->lower.assign(lower, lower + nobservables);
+  h->upper.assign(upper, upper + nobservables);
+  h->nbins.assign(nbins, nbins + nobservables);
+  h->stride.assign((size_t)nobservables, 0);
+  h->scale.assign((size_t)nobservables, 0.0);
+
+  // bin volume, row-major strides, total bins: pdfz.cpp:200-219
+  double vol = 1.0f;
+  bool bad = false;
+  for (int i = 0; i < nobservables; i++) {
+    if (nbins[i] < 0) bad = true;
+    vol *= (upper[i] - lower[i]) / nbins[i];
+  }
+  long long total = 1;
+  h->stride[(size_t)nobservables - 1] = 1;
+  for (int i = nobservables - 2; i >= 0; i--) {
+    long long st = (long long)nbins[i + 1] * h->stride[(size_t)i + 1];
+    if (st > INT_MAX) bad = true;
+    h->stride[(size_t)i] = (int)std::min<long long>(st, INT_MAX);
+  }
+  total = (long long)h->stride[0] * nbins[0];
+  if (bad || total > INT_MAX) {
+    delete h;
+    return fail(SXMC_ERR_INVALID, "Histogram too large or negative bin count (total bins must fit in int).");
+  }
+  if (total == 0) {
+    delete h;
+    return fail(SXMC_ERR_INVALID, "Cannot make histogram with zero bins.");
+  }
+  for (int i = 0; i < nobservables; i++) {
+    if (!(upper[i] > lower[i])) {
+      delete h;
+      return fail(SXMC_ERR_INVALID, "Upper bound must be greater than lower bound.");
+    }
+    h->scale[(size_t)i] = nbins[i] / (upper[i] - lower[i]);  // pdfz.cpp:366-368, in host double
+  }
+  h->total_nbins = (int)total;
+  h->bin_volume = vol;
+
+  h->nvec = (h->nsamples + SXMC_VEC - 1) / SXMC_VEC;
+  h->pitch = std::max<size_t>(64, (h->nvec * SXMC_VEC + 63) / 64 * 64);
+
+  auto cleanup = [&](int code) {
+    if (h->d_cols) (void)hipFree(h->d_cols);
+    if (h->d_bins) (void)hipFree(h->d_bins);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return code;
+  };
+#define SX_HIP_H(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return cleanup(fail(SXMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)));        \
+  } while (0)
+
+  SX_HIP_H(hipStreamCreate(&h->stream));
+  SX_HIP_H(hipMalloc((void**)&h->d_cols, sizeof(float) * h->pitch * (size_t)nfields));
+  SX_HIP_H(hipMalloc((void**)&h->d_bins, sizeof(unsigned) * (size_t)h->total_nbins));
+  SX_HIP_H(hipMemset(h->d_bins, 0, sizeof(unsigned) * (size_t)h->total_nbins));
+  if (h->nsamples) {
+    const float* d_aos = samples;
+    float* staging = nullptr;
+    if (!samples_on_device) {
+      SX_HIP_H(hipMalloc((void**)&staging, sizeof(float) * nsamples_floats));
+      hipError_t e = hipMemcpy(staging, samples, sizeof(float) * nsamples_floats, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        (void)hipFree(staging);
+        return cleanup(fail(SXMC_ERR_HIP, std::string("hipMemcpy samples: ") + hipGetErrorString(e)));
+      }
+      d_aos = staging;
+    }
+    hipError_t e = sx_launch_transpose(d_aos, h->d_cols, h->nsamples, nfields, h->pitch, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (staging) (void)hipFree(staging);
+    if (e != hipSuccess) return cleanup(fail(SXMC_ERR_HIP, std::string("transpose: ") + hipGetErrorString(e)));
+  }
+#undef SX_HIP_H
+  *out = h;
+  return SXMC_OK;
+}
+
+int sxmc_hist_destroy(sxmc_hist_t h) {
+  if (!h) return SXMC_OK;
+  (void)hipStreamSynchronize(h->stream);
+  if (h->self) sxmc_group_destroy(h->self);
+  if (h->d_cols) (void)hipFree(h->d_cols);
+  if (h->d_bins) (void)hipFree(h->d_bins);
+  if (h->d_read_bins) (void)hipFree(h->d_read_bins);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return SXMC_OK;
+}
+
+int sxmc_hist_add_systematic(sxmc_hist_t h, int type, int obs, int extra_field, int npars, const short* pars) {
+  SX_REQUIRE(h, "null evaluator");
+  SX_REQUIRE(type == SXMC_SYST_SHIFT || type == SXMC_SYST_SCALE || type == SXMC_SYST_RESOLUTION_SCALE ||
+                 type == SXMC_SYST_CTSCALE,
+             "Unknown systematic type");  // pdfz.cpp:169-171
+  SX_REQUIRE(obs >= 0 && obs < h->nfields, "Systematic observable index out of range");
+  if (type == SXMC_SYST_RESOLUTION_SCALE) {
+    SX_REQUIRE(extra_field >= 0 && extra_field < h->nfields, "Systematic truth field index out of range");
+  }
+  SX_REQUIRE(npars >= 0 && npars <= SXMC_MAX_SYST_PARS, "Too many parameters for one systematic");
+  SX_REQUIRE(npars == 0 || pars, "null parameter index list");
+  SX_REQUIRE((int)h->systs.size() < SXMC_MAX_SYST, "Too many systematics on one evaluator");
+  HostSyst s;
+  s.type = type;
+  s.obs = obs;
+  s.extra_field = type == SXMC_SYST_RESOLUTION_SCALE ? extra_field : 0;
+  s.pars.assign(pars, pars + npars);
+  // check the slot budget (observables + distinct referenced extra fields)
+  h->systs.push_back(s);
+  std::vector<int> slots;
+  member_slots(h, slots);
+  if ((int)slots.size() > SXMC_MAX_NFIELDS) {
+    h->systs.pop_back();
+    return fail(SXMC_ERR_INVALID, "Too many fields referenced");
+  }
+  h->version++;
+  return SXMC_OK;
+}
+
+int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints_floats) {
+  SX_REQUIRE(h, "null evaluator");
+  const size_t row = (size_t)h->nobs + 1;
+  SX_REQUIRE(npoints_floats % row == 0,
+             "Number of entries in evaluation points array not divisible by number of observables.");
+  SX_REQUIRE(npoints_floats == 0 || points, "null points");
+  const size_t n = npoints_floats / row;
+  SX_REQUIRE(n <= (size_t)INT_MAX, "too many evaluation points");
+  // pdfz.cpp:264-301: the bin of each point never changes between evaluations, so it is
+  // resolved once on the host (NaN coordinates count as outside the domain).
+  std::vector<int> rb(n);
+  const int D = h->nobs;
+  for (size_t ip = 0; ip < n; ip++) {
+    bool in_domain = true;
+    int bin_id = 0;
+    for (int k = 0; k < D; k++) {
+      const double element = points[row * ip + (size_t)k];
+      if (!(element >= h->lower[(size_t)k] && element < h->upper[(size_t)k])) {
+        in_domain = false;
+        break;
+      }
+      bin_id += (int)((element - h->lower[(size_t)k]) * h->scale[(size_t)k]) * h->stride[(size_t)k];
+    }
+    if (points[row * ip + (size_t)D] != (float)h->dataset) bin_id = -2;  // pdfz.cpp:289-293
+    rb[ip] = in_domain ? bin_id : -1;
+  }
+  // in-flight evaluations may still read the old table
+  SX_HIP(hipDeviceSynchronize());
+  if (h->d_read_bins) {
+    SX_HIP(hipFree(h->d_read_bins));
+    h->d_read_bins = nullptr;
+  }
+  SX_HIP(hipMalloc((void**)&h->d_read_bins, sizeof(int) * std::max<size_t>(n, 1)));
+  if (n) SX_HIP(hipMemcpy(h->d_read_bins, rb.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  h->npoints = n;
+  h->has_points = true;
+  h->version++;
+  return SXMC_OK;
+}
+
+int sxmc_hist_set_pdf_value_buffer(sxmc_hist_t h, float* d_output, int offset, int stride) {
+  SX_REQUIRE(h, "null evaluator");
+  h->pdf = d_output;
+  h->pdf_off = offset;
+  h->pdf_stride = stride;
+  h->version++;
+  return SXMC_OK;
+}
+int sxmc_hist_set_normalization_buffer(sxmc_hist_t h, unsigned* d_norm, int offset) {
+  SX_REQUIRE(h, "null evaluator");
+  h->norm = d_norm;
+  h->norm_off = offset;
+  h->version++;
+  return SXMC_OK;
+}
+int sxmc_hist_set_parameter_buffer(sxmc_hist_t h, const double* d_params, int offset, int stride) {
+  SX_REQUIRE(h, "null evaluator");
+  h->params = d_params;
+  h->par_off = offset;
+  h->par_stride = stride;
+  h->version++;
+  return SXMC_OK;
+}
+
+int sxmc_hist_eval_async(sxmc_hist_t h, int do_eval_pdf) {
+  SX_REQUIRE(h, "null evaluator");
+  if (!h->self) {
+    int rc = sxmc_group_create(&h, 1, &h->self);
+    if (rc) return rc;
+  }
+  h->self->cfg_threads = h->cfg_threads;
+  h->self->cfg_bpc = h->cfg_bpc;
+  return sxmc_group_eval_async(h->self, do_eval_pdf, h->stream);
+}
+
+int sxmc_hist_eval_finished(sxmc_hist_t h) {
+  SX_REQUIRE(h, "null evaluator");
+  SX_HIP(hipStreamSynchronize(h->stream));
+  return SXMC_OK;
+}
+
+int sxmc_hist_total_nbins(sxmc_hist_t h, int* v) {
+  SX_REQUIRE(h && v, "null argument");
+  *v = h->total_nbins;
+  return SXMC_OK;
+}
+int sxmc_hist_bin_volume(sxmc_hist_t h, double* v) {
+  SX_REQUIRE(h && v, "null argument");
+  *v = h->bin_volume;
+  return SXMC_OK;
+}
+int sxmc_hist_nsamples(sxmc_hist_t h, size_t* v) {
+  SX_REQUIRE(h && v, "null argument");
+  *v = h->nsamples;
+  return SXMC_OK;
+}
+int sxmc_hist_npoints(sxmc_hist_t h, size_t* v) {
+  SX_REQUIRE(h && v, "null argument");
+  *v = h->has_points ? h->npoints : 0;
+  return SXMC_OK;
+}
+int sxmc_hist_get_bins(sxmc_hist_t h, unsigned* out, size_t n) {
+  SX_REQUIRE(h && out, "null argument");
+  SX_REQUIRE(n == (size_t)h->total_nbins, "bins buffer size mismatch");
+  SX_HIP(hipMemcpy(out, h->d_bins, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+  return SXMC_OK;
+}
+int sxmc_hist_get_read_bins(sxmc_hist_t h, int* out, size_t n) {
+  SX_REQUIRE(h && (out || n == 0), "null argument");
+  SX_REQUIRE(h->has_points && n == h->npoints, "read_bins buffer size mismatch");
+  if (n) SX_HIP(hipMemcpy(out, h->d_read_bins, sizeof(int) * n, hipMemcpyDeviceToHost));
+  return SXMC_OK;
+}
+int sxmc_hist_get_samples(sxmc_hist_t h, float* out, size_t n) {
+  SX_REQUIRE(h && (out || n == 0), "null argument");
+  SX_REQUIRE(n == h->nsamples * ((size_t)h->nobs + 1), "samples buffer size mismatch");
+  if (!n) return SXMC_OK;
+  float* tmp = nullptr;
+  SX_HIP(hipMalloc((void**)&tmp, sizeof(float) * n));
+  hipError_t e = sx_launch_untranspose_obs(h->d_cols, tmp, h->nsamples, h->nobs, h->pitch, (float)h->dataset,
+                                           h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, tmp, sizeof(float) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(SXMC_ERR_HIP, std::string("get_samples: ") + hipGetErrorString(e));
+  return SXMC_OK;
+}
+int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s) {
+  SX_REQUIRE(h && s, "null argument");
+  *s = h->stream;
+  return SXMC_OK;
+}
+int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_per_cu) {
+  SX_REQUIRE(h, "null evaluator");
+  SX_REQUIRE(bin_threads == 0 || bin_threads == 256 || bin_threads == 512 || bin_threads == 1024,
+             "bin_threads must be 0, 256, 512 or 1024");
+  SX_REQUIRE(bin_blocks_per_cu >= 0 && bin_blocks_per_cu <= 16, "bin_blocks_per_cu out of range");
+  h->cfg_threads = bin_threads;
+  h->cfg_bpc = bin_blocks_per_cu;
+  return SXMC_OK;
+}
+
+// ------------------------------------------------------------------------------ group
+int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* out) {
+  SX_REQUIRE(out && nmembers >= 0 && (members || nmembers == 0), "bad arguments");
+  for (int i = 0; i < nmembers; i++) SX_REQUIRE(members[i], "null member");
+  sxmc_group* g = new sxmc_group;
+  g->members.assign(members, members + nmembers);
+  *out = g;
+  return SXMC_OK;
+}
+
+int sxmc_group_destroy(sxmc_group_t g) {
+  if (!g) return SXMC_OK;
+  (void)hipDeviceSynchronize();
+  for (LaunchClass& c : g->classes)
+    if (c.d_descs) (void)hipFree(c.d_descs);
+  if (g->d_descs) (void)hipFree(g->d_descs);
+  for (hipEvent_t e : g->ev0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : g->ev1) (void)hipEventDestroy(e);
+  delete g;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks_per_cu) {
+  SX_REQUIRE(g, "null group");
+  SX_REQUIRE(bin_threads == 0 || bin_threads == 256 || bin_threads == 512 || bin_threads == 1024,
+             "bin_threads must be 0, 256, 512 or 1024");
+  SX_REQUIRE(bin_blocks_per_cu >= 0 && bin_blocks_per_cu <= 16, "bin_blocks_per_cu out of range");
+  g->cfg_threads = bin_threads;
+  g->cfg_bpc = bin_blocks_per_cu;
+  return SXMC_OK;
+}
+
+int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s) {
+  SX_REQUIRE(g, "null group");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  rc = group_check_bound(g, do_eval_pdf != 0);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)s;
+  g->last_stream = st;
+  rc = group_fill(g, st);
+  if (rc) return rc;
+  // pdfz.cpp:474-476: no lookup without evaluation points or when do_eval_pdf is false
+  if (do_eval_pdf && g->max_points > 0) {
+    SX_HIP(sx_launch_eval_pdf(g->d_descs, (int)g->members.size(), g->max_points, st));
+  }
+  return SXMC_OK;
+}
+
+int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s, const double* d_pars, const double* d_nexpected,
+                              const unsigned* d_n_mc, const short* d_source_id, const unsigned* d_norms,
+                              double* d_sums, int* npartial_out) {
+  SX_REQUIRE(g && d_pars && d_nexpected && d_n_mc && d_source_id && d_norms && d_sums && npartial_out,
+             "null argument");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  rc = group_check_bound(g, true);
+  if (rc) return rc;
+  if (!g->same_points) return fail(SXMC_ERR_STATE, "members do not share one set of evaluation points");
+  hipStream_t st = (hipStream_t)s;
+  g->last_stream = st;
+  rc = group_fill(g, st);
+  if (rc) return rc;
+  const unsigned long long ne = g->members[0]->npoints;
+  int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + 255) / 256));
+  SX_HIP(sx_launch_eval_nll(g->d_descs, (int)g->members.size(), ne, d_pars, d_nexpected, d_n_mc, d_source_id,
+                            d_norms, d_sums, grid, 256, st));
+  *npartial_out = grid;
+  return SXMC_OK;
+}
+
+int sxmc_group_synchronize(sxmc_group_t g) {
+  SX_REQUIRE(g, "null group");
+  SX_HIP(hipStreamSynchronize(g->last_stream));
+  return SXMC_OK;
+}
+
+int sxmc_group_profile(sxmc_group_t g, int enable, int capacity) {
+  SX_REQUIRE(g, "null group");
+  g->prof = enable != 0;
+  g->prof_n = 0;
+  if (g->prof) {
+    if (capacity < 1) capacity = 1;
+    while ((int)g->ev0.size() < capacity) {
+      hipEvent_t a, b;
+      SX_HIP(hipEventCreate(&a));
+      SX_HIP(hipEventCreate(&b));
+      g->ev0.push_back(a);
+      g->ev1.push_back(b);
+    }
+  }
+  return SXMC_OK;
+}
+
+int sxmc_group_profile_read(sxmc_group_t g, double* fill_ms_total, int* nlaunches) {
+  SX_REQUIRE(g && fill_ms_total && nlaunches, "null argument");
+  double tot = 0;
+  for (int i = 0; i < g->prof_n; i++) {
+    SX_HIP(hipEventSynchronize(g->ev1[i]));
+    float ms = 0;
+    SX_HIP(hipEventElapsedTime(&ms, g->ev0[i], g->ev1[i]));
+    tot += ms;
+  }
+  *fill_ms_total = tot;
+  *nlaunches = g->prof_n;
+  return SXMC_OK;
+}
+
+int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist, double* event) {
+  SX_REQUIRE(g && fill_read && hist && event, "null argument");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  double fr = 0, hb = 0, ev = 0;
+  for (size_t i = 0; i < g->members.size(); i++) {
+    const sxmc_hist* h = g->members[i];
+    const SxSignalDesc& d = g->h_descs[i];
+    fr += 4.0 * (double)h->nsamples * d.nslot;
+    hb += 4.0 * (double)h->total_nbins * (h->total_nbins <= kLdsMaxBins ? 1.0 : 2.0);
+    ev += 16.0 * (double)d.npoints;
+  }
+  *fill_read = fr;
+  *hist = hb;
+  *event = ev;
+  return SXMC_OK;
+}
+
+// ------------------------------------------------------------------------------ NLL launch points
+static int check_launch(int grid, int block) {
+  if (grid < 1 || block < 1 || block > 1024) return fail(SXMC_ERR_INVALID, "bad launch shape");
+  return SXMC_OK;
+}
+
+int sxmc_launch_init_device_rngs(int grid, int block, sxmc_stream_t s, int nthreads, unsigned long long seed,
+                                 sxmc_rng_state* d_state) {
+  if (int rc = check_launch(grid, block)) return rc;
+  SX_REQUIRE(d_state && (long long)grid * block >= nthreads, "init_device_rngs: grid*block < nthreads");
+  SX_HIP(sx_nll_init_rngs(grid, block, (hipStream_t)s, nthreads, seed, d_state));
+  return SXMC_OK;
+}
+
+int sxmc_launch_pick_new_vector(int grid, int block, sxmc_stream_t s, int nthreads, sxmc_rng_state* d_rng,
+                                const float* d_jump_width, const double* d_current_vector,
+                                double* d_proposed_vector) {
+  if (int rc = check_launch(grid, block)) return rc;
+  SX_HIP(sx_nll_pick_new_vector(grid, block, (hipStream_t)s, nthreads, d_rng, d_jump_width, d_current_vector,
+                                d_proposed_vector));
+  return SXMC_OK;
+}
+
+int sxmc_launch_jump_decider(int grid, int block, sxmc_stream_t s, sxmc_rng_state* d_rng, double* d_nll_current,
+                             const double* d_nll_proposed, double* d_v_current, const double* d_v_proposed,
+                             unsigned nparameters, int* d_accepted, int* d_counter, float* d_jump_buffer) {
+  if (int rc = check_launch(grid, block)) return rc;
+  SX_HIP(sx_nll_jump_decider(grid, block, (hipStream_t)s, d_rng, d_nll_current, d_nll_proposed, d_v_current,
+                             d_v_proposed, nparameters, d_accepted, d_counter, d_jump_buffer));
+  return SXMC_OK;
+}
+
+int sxmc_launch_nll_event_chunks(int grid, int block, sxmc_stream_t s, const float* d_lut, const double* d_pars,
+                                 size_t ne, size_t ns, const double* d_nexpected, const unsigned* d_n_mc,
+                                 const short* d_source_id, const unsigned* d_norms, double* d_sums) {
+  if (int rc = check_launch(grid, block)) return rc;
+  SX_REQUIRE(ns <= 4096, "too many signals");
+  SX_HIP(sx_nll_event_chunks(grid, block, (hipStream_t)s, d_lut, d_pars, ne, ns, d_nexpected, d_n_mc, d_source_id,
+                             d_norms, d_sums));
+  return SXMC_OK;
+}
+
+int sxmc_launch_nll_event_reduce(int grid, int block, sxmc_stream_t s, size_t nthreads, const double* d_sums,
+                                 double* d_total_sum) {
+  if (int rc = check_launch(grid, block)) return rc;
+  SX_REQUIRE(grid == 1, "nll_event_reduce runs in one workgroup");
+  SX_HIP(sx_nll_event_reduce(block, (hipStream_t)s, nthreads, d_sums, d_total_sum));
+  return SXMC_OK;
+}
+
+int sxmc_launch_nll_total(int grid, int block, sxmc_stream_t s, size_t nparameters, const double* d_pars,
+                          size_t nsignals, size_t nsources, const double* d_means, const double* d_sigmas,
+                          const double* d_events_total, const double* d_nexpected, const unsigned* d_n_mc,
+                          const short* d_source_id, const unsigned* d_norms, double* d_nll) {
+  if (int rc = check_launch(grid, block)) return rc;
+  SX_HIP(sx_nll_total((hipStream_t)s, nparameters, d_pars, nsignals, nsources, d_means, d_sigmas, d_events_total,
+                      d_nexpected, d_n_mc, d_source_id, d_norms, d_nll));
+  return SXMC_OK;
+}
+
+int sxmc_launch_finish_nll_jump_pick_combo(int grid, int block, sxmc_stream_t s, size_t npartial_sums,
+                                           const double* d_sums, size_t nsignals, size_t nsources,
+                                           const double* d_means, const double* d_sigmas, sxmc_rng_state* d_rng,
+                                           double* d_nll_current, double* d_nll_proposed, double* d_v_current,
+                                           double* d_v_proposed, int* d_accepted, int* d_counter,
+                                           float* d_jump_buffer, int nparameters, const float* d_jump_width,
+                                           const double* d_nexpected, const unsigned* d_n_mc,
+                                           const short* d_source_id, const unsigned* d_norms, int debug_mode) {
+  if (int rc = check_launch(grid, block)) return rc;
+  SX_REQUIRE(grid == 1, "finish_nll_jump_pick_combo runs in one workgroup");
+  SX_HIP(sx_nll_finish_combo(block, (hipStream_t)s, npartial_sums, d_sums, nsignals, nsources, d_means, d_sigmas,
+                             d_rng, d_nll_current, d_nll_proposed, d_v_current, d_v_proposed, d_accepted,
+                             d_counter, d_jump_buffer, nparameters, d_jump_width, d_nexpected, d_n_mc, d_source_id,
+                             d_norms, debug_mode != 0));
+  return SXMC_OK;
+}
+
+// test hook: raw Philox output of state[0] (advances it by ndraws)
+int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws) {
+  SX_HIP(sx_nll_philox_dump(nullptr, d_state, d_out, ndraws));
+  SX_HIP(hipDeviceSynchronize());
+  return SXMC_OK;
+}
+
+}  // extern "C"

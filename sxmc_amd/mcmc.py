@@ -1,0 +1,174 @@
+"""The caller of the hot path, in the shape of the reference's MCMC driver (src/mcmc.cpp).
+
+ROOT-free: the chain goes to a numpy array instead of a TNtuple.  Buffer set-up follows
+mcmc.cpp:159-242, the step sequence mcmc.cpp:261-348 and MCMC::nll mcmc.cpp:390-415.  Two step
+forms are offered:
+  * reference form   -- group.EvalAsync (zero, fill, lookup) ; nll_event_chunks ;
+                        finish_nll_jump_pick_combo      (4 kernels, lut written and re-read)
+  * fused form       -- group.EvalNllAsync (zero, fill, lookup+event sum) ;
+                        finish_nll_jump_pick_combo      (3 kernels)
+Both produce the same numbers up to the order of the partial sums.
+"""
+import numpy as np
+
+from . import capi, nll, pdfz
+from .capi import DeviceArray
+
+NLL_BLOCKS, NLL_BLOCK_SIZE, REDUCE_THREADS = 64, 256, 128    # mcmc.cpp:37-45
+
+
+def make_systematic(desc):
+    t = desc["type"]
+    if t == "shift":
+        return pdfz.ShiftSystematic(desc["obs"], desc["pars"])
+    if t == "scale":
+        return pdfz.ScaleSystematic(desc["obs"], desc["pars"])
+    if t == "ctscale":
+        return pdfz.CosThetaScaleSystematic(desc["obs"], desc["pars"])
+    if t == "resolution_scale":
+        return pdfz.ResolutionScaleSystematic(desc["obs"], desc["true_obs"], desc["pars"])
+    raise ValueError(t)
+
+
+class MCMC:
+    def __init__(self, workload, seed=1234, stream=None, fused=True, samples_on_device=None):
+        w = workload
+        self.w = w
+        self.stream = stream
+        self.fused = fused
+        self.nsources, self.nsignals = w.nsources, w.nsignals
+        self.nparameters = w.nparameters
+        self.nnllthreads = NLL_BLOCKS * NLL_BLOCK_SIZE
+
+        # evaluators (signal.cpp:112-133 build_pdfz + AddSystematic)
+        self.pdfs = []
+        for j, s in enumerate(w.signals):
+            src = samples_on_device[j] if samples_on_device is not None else s.samples
+            ev = pdfz.EvalHist(src, s.nfields, w.nobs, w.lower, w.upper, w.nbins, dataset=s.dataset)
+            for d in w.systematics:
+                ev.AddSystematic(make_systematic(d))
+            self.pdfs.append(ev)
+        self.group = nll.EvalGroup(self.pdfs)
+
+        # mcmc.cpp:53-98
+        self.parameter_means = DeviceArray(w.parameter_means().astype(np.float64))
+        self.parameter_sigma = DeviceArray(w.parameter_sigmas().astype(np.float64))
+        self.nexpected = DeviceArray(np.array([s.nexpected for s in w.signals], dtype=np.float64))
+        self.n_mc = DeviceArray(np.array([s.n_mc for s in w.signals], dtype=np.uint32))
+        self.source_id = DeviceArray(np.array([s.source_id for s in w.signals], dtype=np.int16))
+        self.rngs = nll.make_rngs(self.nparameters, seed, stream)
+
+        # mcmc.cpp:159-198
+        self.current_vector = DeviceArray(w.parameter_means().astype(np.float64))
+        self.proposed_vector = DeviceArray(w.parameter_means().astype(np.float64))
+        self.normalizations = DeviceArray.zeros(self.nsignals, np.uint32)
+        self.event_partial_sums = DeviceArray.zeros(self.nnllthreads, np.float64)
+        self.event_total_sum = DeviceArray.zeros(1, np.float64)
+        self.jump_counter = DeviceArray.zeros(1, np.int32)
+        self.accept_counter = DeviceArray.zeros(1, np.int32)
+        self.current_nll = DeviceArray.zeros(1, np.float64)
+        self.proposed_nll = DeviceArray.zeros(1, np.float64)
+        self.jump_width = None
+        self.jump_buffer = None
+        self.lut = None
+        self.nevents = 0
+
+    # mcmc.cpp:198-228 (keeps the reference's `i < nsignals` test at :217)
+    def initial_jump_widths(self, fixed=None):
+        w = self.w
+        means = w.parameter_means().astype(np.float32)
+        sigmas = w.parameter_sigmas().astype(np.float32)
+        fixed = [False] * self.nparameters if fixed is None else fixed
+        nfloat = sum(1 for f in fixed if not f)
+        scale_factor = np.float32(2.4 * 2.4 / nfloat)
+        out = np.zeros(self.nparameters, dtype=np.float32)
+        for i in range(self.nparameters):
+            if fixed[i]:
+                out[i] = -1
+                continue
+            if sigmas[i] > 0:
+                width = sigmas[i]
+            elif i < self.nsignals:
+                m = max(means[i], np.float32(10))
+                width = np.sqrt(m) / m
+            else:
+                width = np.sqrt(max(means[i], np.float32(1)))
+            out[i] = np.float32(0.1 * width * scale_factor)
+        return out
+
+    def setup(self, data=None, sync_interval=10000, jump_width=None):
+        """mcmc.cpp:186, 230-256: bind buffers, first evaluation at the current vector, NLL of it,
+        first proposal."""
+        w = self.w
+        data = w.events if data is None else data
+        data = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        self.nevents = data.size // (w.nobs + 1)
+        self.sync_interval = sync_interval
+        self.jump_buffer = DeviceArray.zeros(sync_interval * (self.nparameters + 1), np.float32)
+        jw = self.initial_jump_widths() if jump_width is None else np.asarray(jump_width, np.float32)
+        self.jump_width = DeviceArray(jw)
+        self.lut = DeviceArray.zeros(self.nevents * self.nsignals, np.float32)
+        for i, p in enumerate(self.pdfs):
+            p.SetEvalPoints(data)
+            p.SetPDFValueBuffer(self.lut, i * self.nevents, 1)
+            p.SetNormalizationBuffer(self.normalizations, i)
+            p.SetParameterBuffer(self.current_vector, self.nsources)
+        self.group.EvalAsync(True, self.stream)
+        self.group.EvalFinished()
+        for p in self.pdfs:
+            p.SetParameterBuffer(self.proposed_vector, self.nsources)
+        self.nll(self.current_vector, self.current_nll)
+        nll.pick_new_vector(1, 64, self.stream, self.nparameters, self.rngs, self.jump_width,
+                            self.current_vector, self.proposed_vector)
+
+    def nll(self, v, out):
+        """MCMC::nll (mcmc.cpp:390-415): three launches over an already evaluated lut."""
+        nll.nll_event_chunks(NLL_BLOCKS, NLL_BLOCK_SIZE, self.stream, self.lut, v, self.nevents, self.nsignals,
+                             self.nexpected, self.n_mc, self.source_id, self.normalizations,
+                             self.event_partial_sums)
+        nll.nll_event_reduce(1, REDUCE_THREADS, self.stream, self.nnllthreads, self.event_partial_sums,
+                             self.event_total_sum)
+        nll.nll_total(1, 1, self.stream, self.nparameters, v, self.nsignals, self.nsources,
+                      self.parameter_means, self.parameter_sigma, self.event_total_sum, self.nexpected,
+                      self.n_mc, self.source_id, self.normalizations, out)
+
+    def step(self, debug_mode=False):
+        """One pass of the hot path = one NLL evaluation at the proposed vector + the fused
+        accept/reject/propose (mcmc.cpp:264-271, 314-348).  Asynchronous."""
+        if self.fused:
+            npartial = self.group.EvalNllAsync(self.stream, self.proposed_vector, self.nexpected, self.n_mc,
+                                               self.source_id, self.normalizations, self.event_partial_sums)
+        else:
+            self.group.EvalAsync(True, self.stream)
+            nll.nll_event_chunks(NLL_BLOCKS, NLL_BLOCK_SIZE, self.stream, self.lut, self.proposed_vector,
+                                 self.nevents, self.nsignals, self.nexpected, self.n_mc, self.source_id,
+                                 self.normalizations, self.event_partial_sums)
+            npartial = self.nnllthreads
+        nll.finish_nll_jump_pick_combo(1, REDUCE_THREADS, self.stream, npartial, self.event_partial_sums,
+                                       self.nsignals, self.nsources, self.parameter_means,
+                                       self.parameter_sigma, self.rngs, self.current_nll, self.proposed_nll,
+                                       self.current_vector, self.proposed_vector, self.accept_counter,
+                                       self.jump_counter, self.jump_buffer, self.nparameters, self.jump_width,
+                                       self.nexpected, self.n_mc, self.source_id, self.normalizations,
+                                       debug_mode)
+
+    def flush(self):
+        """mcmc.cpp:351-377: read back and reset the jump buffer.  Returns (rows, naccepted)."""
+        capi.synchronize()
+        njumps = int(self.jump_counter.get()[0])
+        nacc = int(self.accept_counter.get()[0])
+        rows = self.jump_buffer.get()[: njumps * (self.nparameters + 1)].reshape(njumps, self.nparameters + 1)
+        self.jump_counter.set(np.zeros(1, np.int32))
+        self.accept_counter.set(np.zeros(1, np.int32))
+        return rows.copy(), nacc
+
+    def run(self, nsteps, debug_mode=False):
+        """The step loop without burn-in re-tuning: returns the chain [nsteps, P+1] (float32)."""
+        chunks, accepted = [], 0
+        for i in range(nsteps):
+            self.step(debug_mode)
+            if (i + 1) % self.sync_interval == 0 or i == nsteps - 1:
+                rows, nacc = self.flush()
+                chunks.append(rows)
+                accepted += nacc
+        return np.concatenate(chunks, axis=0), accepted

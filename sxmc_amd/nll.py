@@ -1,0 +1,112 @@
+"""Python spelling of the reference's NLL / MCMC-step kernel launch points (src/nll_kernels.h)
+and of the batched evaluator group, over the C ABI.
+
+Each function takes the (grid, block, stream) triple mcmc.cpp passes to HEMI_KERNEL_LAUNCH
+followed by the reference's argument list (nll_kernels.h:60-207).  Arrays are device buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import ptr
+
+
+def make_rngs(nparameters, seed, stream=None):
+    """hemi::Array<RNGState>(nparameters) + init_device_rngs (mcmc.cpp:116-126)."""
+    rng = capi.DeviceArray.empty(nparameters * 4, np.uint64)
+    block = 128
+    grid = nparameters // block + 1
+    capi.call("sxmc_launch_init_device_rngs", grid, block, ptr(stream), nparameters, int(seed), ptr(rng))
+    return rng
+
+
+def pick_new_vector(grid, block, stream, nthreads, rng, jump_width, current_vector, proposed_vector):
+    capi.call("sxmc_launch_pick_new_vector", grid, block, ptr(stream), int(nthreads), ptr(rng),
+              ptr(jump_width), ptr(current_vector), ptr(proposed_vector))
+
+
+def jump_decider(grid, block, stream, rng, nll_current, nll_proposed, v_current, v_proposed, nparameters,
+                 accepted, counter, jump_buffer):
+    capi.call("sxmc_launch_jump_decider", grid, block, ptr(stream), ptr(rng), ptr(nll_current),
+              ptr(nll_proposed), ptr(v_current), ptr(v_proposed), int(nparameters), ptr(accepted),
+              ptr(counter), ptr(jump_buffer))
+
+
+def nll_event_chunks(grid, block, stream, lut, pars, ne, ns, nexpected, n_mc, source_id, norms, sums):
+    capi.call("sxmc_launch_nll_event_chunks", grid, block, ptr(stream), ptr(lut), ptr(pars), int(ne), int(ns),
+              ptr(nexpected), ptr(n_mc), ptr(source_id), ptr(norms), ptr(sums))
+
+
+def nll_event_reduce(grid, block, stream, nthreads, sums, total_sum):
+    capi.call("sxmc_launch_nll_event_reduce", grid, block, ptr(stream), int(nthreads), ptr(sums), ptr(total_sum))
+
+
+def nll_total(grid, block, stream, nparameters, pars, nsignals, nsources, means, sigmas, events_total,
+              nexpected, n_mc, source_id, norms, nll):
+    capi.call("sxmc_launch_nll_total", grid, block, ptr(stream), int(nparameters), ptr(pars), int(nsignals),
+              int(nsources), ptr(means), ptr(sigmas), ptr(events_total), ptr(nexpected), ptr(n_mc),
+              ptr(source_id), ptr(norms), ptr(nll))
+
+
+def finish_nll_jump_pick_combo(grid, block, stream, npartial_sums, sums, nsignals, nsources, means, sigmas,
+                               rng, nll_current, nll_proposed, v_current, v_proposed, accepted, counter,
+                               jump_buffer, nparameters, jump_width, nexpected, n_mc, source_id, norms,
+                               debug_mode=False):
+    capi.call("sxmc_launch_finish_nll_jump_pick_combo", grid, block, ptr(stream), int(npartial_sums),
+              ptr(sums), int(nsignals), int(nsources), ptr(means), ptr(sigmas), ptr(rng), ptr(nll_current),
+              ptr(nll_proposed), ptr(v_current), ptr(v_proposed), ptr(accepted), ptr(counter),
+              ptr(jump_buffer), int(nparameters), ptr(jump_width), ptr(nexpected), ptr(n_mc), ptr(source_id),
+              ptr(norms), int(bool(debug_mode)))
+
+
+class EvalGroup:
+    """All signals' evaluators stepped together: the batched form of the
+    `EvalAsync on all, then EvalFinished on all` loop of mcmc.cpp:264-271."""
+
+    def __init__(self, evaluators):
+        self.evaluators = list(evaluators)
+        arr = (C.c_void_p * max(1, len(self.evaluators)))(*[e.handle for e in self.evaluators])
+        g = C.c_void_p(0)
+        capi.call("sxmc_group_create", arr, len(self.evaluators), C.byref(g))
+        self._g = g
+
+    def SetLaunchConfig(self, bin_threads=0, bin_blocks_per_cu=0):
+        capi.call("sxmc_group_set_launch_config", self._g, int(bin_threads), int(bin_blocks_per_cu))
+
+    def EvalAsync(self, do_eval_pdf=True, stream=None):
+        capi.call("sxmc_group_eval_async", self._g, int(bool(do_eval_pdf)), ptr(stream))
+
+    def EvalNllAsync(self, stream, pars, nexpected, n_mc, source_id, norms, sums):
+        """Fill + lookup + nll_event_chunks fused; returns the number of partial sums written."""
+        n = C.c_int(0)
+        capi.call("sxmc_group_eval_nll_async", self._g, ptr(stream), ptr(pars), ptr(nexpected), ptr(n_mc),
+                  ptr(source_id), ptr(norms), ptr(sums), C.byref(n))
+        return n.value
+
+    def EvalFinished(self):
+        capi.call("sxmc_group_synchronize", self._g)
+
+    def Profile(self, enable=True, capacity=4096):
+        capi.call("sxmc_group_profile", self._g, int(bool(enable)), int(capacity))
+
+    def ProfileRead(self):
+        ms, n = C.c_double(0), C.c_int(0)
+        capi.call("sxmc_group_profile_read", self._g, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def AlgorithmicBytes(self):
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        capi.call("sxmc_group_algorithmic_bytes", self._g, C.byref(a), C.byref(b), C.byref(c))
+        return dict(fill_read=a.value, hist=b.value, event=c.value)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            capi.load().sxmc_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -36,3 +36,15 @@ def eval_points_with_dataset(case, dataset=0.0):
     d = case["nobs"]
     pts = np.asarray(case["eval_points"], dtype=np.float32).reshape(-1, d)
     return np.concatenate([pts, np.full((pts.shape[0], 1), dataset, np.float32)], axis=1)
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11) on Python ints: ctr = 4 words, key = 2 words."""
+    M0, M1, W0, W1, MASK = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & MASK, p1 & MASK, ((p0 >> 32) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return (c0, c1, c2, c3)

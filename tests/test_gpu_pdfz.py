@@ -1,0 +1,337 @@
+"""GPU parity tests of the pdfz::EvalHist half of the path: the HIP kernels (through the C ABI)
+against the CPU oracle and the reference's own known answers.  Bit-exact: bins, norm, read_bins,
+lut.  Mirrors the structure of the reference's test/test_pdfz*.cpp."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sxmc_amd import capi, nll, pdfz
+from sxmc_amd.capi import DeviceArray
+from sxmc_amd.mcmc import make_systematic
+from tests.helpers import check_case_values, eval_points_with_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_eval(samples, nfields, lower, upper, nbins, systs, params, points=None, dataset=0,
+             param_offset=0, param_stride=1, pdf_offset=0, pdf_stride=1, pdf_size=None,
+             norm_offset=0, norm_init=None, launch=None, do_eval_pdf=True):
+    """One evaluator, the reference call sequence (test_pdfz_fixtures.h + test_pdfz.cpp:79-96)."""
+    nobs = len(nbins)
+    ev = pdfz.EvalHist(samples, nfields, nobs, lower, upper, nbins, dataset=dataset)
+    for s in systs:
+        ev.AddSystematic(make_systematic(s))
+    npoints = 0
+    if points is not None:
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        npoints = points.size // (nobs + 1)
+        ev.SetEvalPoints(points)
+    if pdf_size is None:
+        pdf_size = pdf_offset + max(npoints, 1) * pdf_stride
+    pdf_values = DeviceArray(np.full(pdf_size, 12345.0, dtype=np.float32))
+    norm = DeviceArray(np.array(norm_init if norm_init is not None else [0, 0, 0], dtype=np.uint32))
+    pbuf = DeviceArray(np.ascontiguousarray(params, dtype=np.float64))
+    ev.SetPDFValueBuffer(pdf_values, pdf_offset, pdf_stride)
+    ev.SetNormalizationBuffer(norm, norm_offset)
+    ev.SetParameterBuffer(pbuf, param_offset, param_stride)
+    if launch:
+        ev.SetLaunchConfig(*launch)
+    ev.EvalAsync(do_eval_pdf)
+    ev.EvalFinished()
+    res = dict(bins=ev.GetBins(), norm=norm.get(), out=pdf_values.get(),
+               read_bins=ev.GetReadBins() if points is not None else None, ev=ev)
+    return res
+
+
+def oracle_eval(samples, nfields, lower, upper, nbins, systs, params, points=None, dataset=0,
+                param_offset=0, param_stride=1, pdf_offset=0, pdf_stride=1, pdf_size=None):
+    geom = oracle.HistGeometry(lower, upper, nbins)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    bins, norm = oracle.bin_samples(geom, samples, nfields, systs, params[param_offset:], param_stride)
+    res = dict(bins=bins, norm=norm, geom=geom)
+    if points is not None:
+        rb = oracle.set_eval_points(geom, points, dataset)
+        n = rb.size
+        if pdf_size is None:
+            pdf_size = pdf_offset + max(n, 1) * pdf_stride
+        out = np.full(pdf_size, 12345.0, dtype=np.float32)
+        oracle.eval_pdf(rb, bins, norm, geom.bin_volume, out=out, offset=pdf_offset, stride=pdf_stride)
+        res.update(read_bins=rb, out=out)
+    return res
+
+
+def assert_same_bits(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def compare(kw, norm_offset=0, **gpu_kw):
+    g = gpu_eval(norm_offset=norm_offset, **kw, **gpu_kw)
+    o = oracle_eval(**kw)
+    assert np.array_equal(g["bins"], o["bins"])
+    assert int(g["norm"][norm_offset]) == o["norm"]
+    if kw.get("points") is not None:
+        assert np.array_equal(g["read_bins"], o["read_bins"])
+        assert_same_bits(g["out"], o["out"])
+    return g, o
+
+
+# ---------------------------------------------------------------- the reference's known answers
+def test_reference_known_answers_on_gpu(golden):
+    """Every EvalHist case of test/test_pdfz.cpp, test_pdfz_2d.cpp, test_pdfz_syst.cpp."""
+    for case in golden["cases"]:
+        kw = dict(samples=np.asarray(case["samples"], np.float32), nfields=case["nfields"],
+                  lower=case["lower"], upper=case["upper"], nbins=case["nbins"],
+                  systs=case["systematics"], params=case["params"],
+                  points=eval_points_with_dataset(case), pdf_offset=case["pdf_offset"],
+                  pdf_stride=case["pdf_stride"], pdf_size=case["pdf_size"])
+        g = gpu_eval(norm_offset=case["norm_offset"], norm_init=case["norm_init"], **kw)
+        check_case_values(case, g["out"], g["norm"])
+        o = oracle_eval(**kw)
+        assert np.array_equal(g["bins"], o["bins"]), case["name"]
+        assert_same_bits(g["out"], o["out"])          # untouched slots keep the sentinel too
+        g["ev"].close()
+
+
+def test_histogram_without_eval_points():
+    # pdfz.cpp:472-476: EvalAsync(false) / no SetEvalPoints only fills (CreateHistogram path)
+    rng = np.random.default_rng(0)
+    samples = rng.normal(0.5, 0.3, size=(5000, 1)).astype(np.float32)
+    kw = dict(samples=samples, nfields=1, lower=[0.0], upper=[1.0], nbins=[16], systs=[], params=[0.0])
+    g = gpu_eval(**kw, do_eval_pdf=False)
+    o = oracle_eval(**kw)
+    assert np.array_equal(g["bins"], o["bins"]) and g["norm"][0] == o["norm"]
+    assert g["bins"].sum() == o["norm"]
+
+
+# ---------------------------------------------------------------- seeded parity, all systematic kinds
+def table(rng, n, ncols, lo=-0.5, hi=1.5):
+    return rng.uniform(lo, hi, size=(n, ncols)).astype(np.float32)
+
+
+SYST_CASES = {
+    "none": ([], [0.0]),
+    "shift": ([dict(type="shift", obs=0, pars=[0])], [0.07]),
+    "scale": ([dict(type="scale", obs=0, pars=[0])], [-0.03]),
+    "ctscale": ([dict(type="ctscale", obs=0, pars=[0])], [0.11]),
+    "resolution": ([dict(type="resolution_scale", obs=0, true_obs=-1, pars=[0])], [0.21]),
+    "chain3": ([dict(type="shift", obs=-2, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+                dict(type="resolution_scale", obs=0, true_obs=-1, pars=[2])], [0.05, -0.01, 0.08]),
+    "poly2": ([dict(type="shift", obs=0, pars=[0, 1])], [0.02, 0.03]),
+    "poly3_scale": ([dict(type="scale", obs=0, pars=[2, 0, 1])], [0.01, -0.02, 0.03]),
+    "five_ops": ([dict(type="shift", obs=0, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+                  dict(type="ctscale", obs=0, pars=[2]), dict(type="shift", obs=0, pars=[1]),
+                  dict(type="resolution_scale", obs=0, true_obs=-1, pars=[0])], [0.01, 0.02, -0.03]),
+}
+
+
+def resolve(systs, nobs, nfields):
+    """-1 -> last field (a truth column), -2 -> last observable."""
+    out = []
+    for s in systs:
+        s = dict(s)
+        if s.get("true_obs") == -1:
+            s["true_obs"] = nfields - 1
+        if s["obs"] == -2:
+            s["obs"] = nobs - 1
+        out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("nobs,nbins", [(1, [37]), (2, [13, 7]), (3, [6, 5, 4]), (4, [3, 4, 2, 3]),
+                                        (5, [2, 3, 2, 2, 3])])
+@pytest.mark.parametrize("syst", sorted(SYST_CASES))
+def test_parity_all_systematics(nobs, nbins, syst):
+    rng = np.random.default_rng(100 * nobs + len(syst))
+    nfields = nobs + 2                       # observables, one unused column, one truth column
+    n = 20011                                # not a multiple of 4: exercises the NaN padding
+    samples = table(rng, n, nfields)
+    systs, params = SYST_CASES[syst]
+    systs = resolve(systs, nobs, nfields)
+    pts = np.concatenate([table(rng, 257, nobs), rng.integers(0, 2, size=(257, 1)).astype(np.float32)], axis=1)
+    kw = dict(samples=samples, nfields=nfields, lower=[0.0] * nobs, upper=[1.0] * nobs, nbins=nbins,
+              systs=systs, params=params, points=pts, dataset=1)
+    compare(kw)
+
+
+def test_parameter_offset_stride_and_output_offset_stride():
+    rng = np.random.default_rng(5)
+    samples = table(rng, 9001, 3)
+    systs = [dict(type="shift", obs=0, pars=[1]), dict(type="resolution_scale", obs=1, true_obs=2, pars=[0])]
+    params = [9.0, 9.0, 0.3, 9.0, -0.04, 9.0]          # offset 2 stride 2 -> p0 = 0.3, p1 = -0.04
+    pts = np.concatenate([table(rng, 100, 2), np.zeros((100, 1), np.float32)], axis=1)
+    kw = dict(samples=samples, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=[8, 9], systs=systs,
+              params=params, param_offset=2, param_stride=2, points=pts, pdf_offset=5, pdf_stride=3)
+    g, o = compare(kw, norm_offset=2, norm_init=[77, 88, 99])
+    assert list(g["norm"][:2]) == [77, 88]
+
+
+def test_systematic_on_a_non_observable_field():
+    # a shift on the truth column changes what the later resolution systematic sees
+    rng = np.random.default_rng(6)
+    samples = table(rng, 5000, 3)
+    systs = [dict(type="shift", obs=2, pars=[0]), dict(type="resolution_scale", obs=0, true_obs=2, pars=[1])]
+    compare(dict(samples=samples, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=[5, 5], systs=systs,
+                 params=[0.2, 0.5]))
+
+
+def test_shapes_without_specialization_use_the_generic_kernel():
+    rng = np.random.default_rng(7)
+    # 6 observables (no specialization) and 3 extra referenced fields (nslot = nobs + 3)
+    samples = table(rng, 7001, 7)
+    compare(dict(samples=samples, nfields=7, lower=[0.0] * 6, upper=[1.0] * 6, nbins=[2, 3, 2, 2, 2, 2],
+                 systs=[dict(type="scale", obs=1, pars=[0]),
+                        dict(type="resolution_scale", obs=0, true_obs=6, pars=[1])], params=[0.05, 0.1]))
+    samples = table(rng, 7001, 6)
+    systs = [dict(type="resolution_scale", obs=0, true_obs=3, pars=[0]),
+             dict(type="resolution_scale", obs=1, true_obs=4, pars=[0]),
+             dict(type="resolution_scale", obs=1, true_obs=5, pars=[1, 0])]
+    compare(dict(samples=samples, nfields=6, lower=[0.0] * 2, upper=[1.0] * 2, nbins=[9, 9], systs=systs,
+                 params=[0.05, 0.1]))
+
+
+def test_large_histogram_uses_global_atomics():
+    rng = np.random.default_rng(8)
+    samples = table(rng, 200003, 3, lo=-0.1, hi=1.1)
+    nb = [300, 300]                                    # 90000 bins > LDS capacity
+    pts = np.concatenate([table(rng, 1000, 2), np.zeros((1000, 1), np.float32)], axis=1)
+    compare(dict(samples=samples, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=nb,
+                 systs=[dict(type="shift", obs=0, pars=[0])], params=[0.01], points=pts))
+
+
+@pytest.mark.parametrize("launch", [(256, 1), (256, 4), (512, 2), (1024, 1), (1024, 2)])
+def test_launch_shapes_give_identical_counts(launch):
+    rng = np.random.default_rng(9)
+    samples = table(rng, 300007, 4)
+    systs = resolve(SYST_CASES["chain3"][0], 3, 4)
+    compare(dict(samples=samples, nfields=4, lower=[0.0] * 3, upper=[1.0] * 3, nbins=[20, 20, 20], systs=systs,
+                 params=SYST_CASES["chain3"][1]), launch=launch)
+
+
+def test_edge_inputs():
+    # empty sample table; single sample; NaN and +-inf samples; samples exactly on the edges
+    compare(dict(samples=np.zeros((0, 1), np.float32), nfields=1, lower=[0.0], upper=[1.0], nbins=[4],
+                 systs=[], params=[0.0], points=np.array([[0.5, 0.0]], np.float32)))
+    compare(dict(samples=np.array([[0.25]], np.float32), nfields=1, lower=[0.0], upper=[1.0], nbins=[4],
+                 systs=[], params=[0.0]))
+    edge = np.array([[np.nan], [np.inf], [-np.inf], [0.0], [1.0], [np.nextafter(np.float32(1), np.float32(0))],
+                     [-0.0], [0.5]], np.float32)
+    g, o = compare(dict(samples=edge, nfields=1, lower=[0.0], upper=[1.0], nbins=[4], systs=[], params=[0.0]))
+    assert o["norm"] == 4
+    # empty evaluation point list
+    g = gpu_eval(np.array([[0.25]], np.float32), 1, [0.0], [1.0], [4], [], [0.0],
+                 points=np.zeros((0, 2), np.float32))
+    assert g["norm"][0] == 1 and g["read_bins"].size == 0
+
+
+def test_determinism_and_reevaluation():
+    # integer accumulation is order independent: two evaluations are bitwise identical, and the
+    # histogram is re-zeroed on every evaluation (pdfz.cpp:454-458)
+    rng = np.random.default_rng(10)
+    samples = table(rng, 100003, 2)
+    ev = pdfz.EvalHist(samples, 2, 2, [0.0, 0.0], [1.0, 1.0], [30, 30])
+    ev.AddSystematic(pdfz.ShiftSystematic(0, 0))
+    norm = DeviceArray.zeros(1, np.uint32)
+    par = DeviceArray(np.array([0.05]))
+    ev.SetNormalizationBuffer(norm)
+    ev.SetParameterBuffer(par)
+    runs = []
+    for _ in range(3):
+        ev.EvalAsync(False)
+        ev.EvalFinished()
+        runs.append((ev.GetBins(), norm.get()[0]))
+    assert all(np.array_equal(r[0], runs[0][0]) and r[1] == runs[0][1] for r in runs)
+    par.set(np.array([-0.05]))                       # parameter buffer is re-read each evaluation
+    ev.EvalAsync(False)
+    ev.EvalFinished()
+    geom = oracle.HistGeometry([0.0, 0.0], [1.0, 1.0], [30, 30])
+    ob, on = oracle.bin_samples(geom, samples, 2, [dict(type="shift", obs=0, pars=[0])], np.array([-0.05]))
+    assert np.array_equal(ev.GetBins(), ob) and norm.get()[0] == on
+
+
+def test_get_samples_roundtrip():
+    rng = np.random.default_rng(11)
+    samples = table(rng, 1003, 4)
+    ev = pdfz.EvalHist(samples, 4, 2, [0.0, 0.0], [1.0, 1.0], [3, 3], dataset=7)
+    got = ev.GetSamples().reshape(-1, 3)
+    assert np.array_equal(got[:, :2], samples[:, :2]) and np.all(got[:, 2] == 7.0)
+
+
+def test_eval_before_binding_buffers_is_an_error():
+    ev = pdfz.EvalHist(np.zeros((4, 1), np.float32), 1, 1, [0.0], [1.0], [2])
+    with pytest.raises(capi.SxmcError):
+        ev.EvalAsync()
+
+
+# ---------------------------------------------------------------- group (batched) evaluation
+def build_group(rng, sizes, nobs, nbins, systs, params, nfields=None, points=None):
+    nfields = nfields or nobs + 1
+    evs, tabs = [], []
+    S = len(sizes)
+    E = 0 if points is None else points.shape[0]
+    lut = DeviceArray(np.full(max(1, S * E), 777.0, np.float32))
+    norms = DeviceArray(np.full(S, 55, np.uint32))
+    pbuf = DeviceArray(np.asarray(params, np.float64))
+    for j, n in enumerate(sizes):
+        t = table(rng, n, nfields)
+        tabs.append(t)
+        ev = pdfz.EvalHist(t, nfields, nobs, [0.0] * nobs, [1.0] * nobs, nbins, dataset=j % 2)
+        for s in systs:
+            ev.AddSystematic(make_systematic(s))
+        if points is not None:
+            ev.SetEvalPoints(points)
+            ev.SetPDFValueBuffer(lut, j * E, 1)
+        ev.SetNormalizationBuffer(norms, j)
+        ev.SetParameterBuffer(pbuf, 0, 1)
+        evs.append(ev)
+    return evs, tabs, lut, norms, pbuf
+
+
+def test_group_matches_oracle_per_signal_ragged_sizes():
+    rng = np.random.default_rng(12)
+    sizes = [1000, 200000, 10007, 3, 0, 50001, 1, 999, 123457]      # ragged, one empty, tiny ones
+    nobs, nbins = 2, [16, 11]
+    systs = [dict(type="shift", obs=1, pars=[0]), dict(type="resolution_scale", obs=0, true_obs=2, pars=[1])]
+    params = [0.03, -0.2]
+    pts = np.concatenate([table(rng, 333, 2), rng.integers(0, 2, size=(333, 1)).astype(np.float32)], axis=1)
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=3, points=pts)
+    group = nll.EvalGroup(evs)
+    for launch in [(0, 0), (256, 4), (1024, 1)]:
+        group.SetLaunchConfig(*launch)
+        group.EvalAsync(True)
+        group.EvalFinished()
+        got_lut = lut.get().reshape(len(sizes), -1)
+        got_norms = norms.get()
+        for j, t in enumerate(tabs):
+            o = oracle_eval(t, 3, [0.0] * 2, [1.0] * 2, nbins, systs, params, points=pts, dataset=j % 2)
+            assert np.array_equal(evs[j].GetBins(), o["bins"]), (launch, j)
+            assert got_norms[j] == o["norm"]
+            assert_same_bits(got_lut[j], o["out"])
+
+
+def test_group_with_mixed_shapes_and_histogram_modes():
+    rng = np.random.default_rng(13)
+    # member 0: 1-D LDS; member 1: 2-D global-atomic (too many bins); member 2: 3-D with truth column
+    t0, t1, t2 = table(rng, 40001, 1), table(rng, 50001, 2), table(rng, 30001, 4)
+    e0 = pdfz.EvalHist(t0, 1, 1, [0.0], [1.0], [1000])
+    e1 = pdfz.EvalHist(t1, 2, 2, [0.0, 0.0], [1.0, 1.0], [250, 250])
+    e2 = pdfz.EvalHist(t2, 4, 3, [0.0] * 3, [1.0] * 3, [8, 8, 8])
+    e2.AddSystematic(pdfz.ResolutionScaleSystematic(0, 3, 0))
+    norms = DeviceArray.zeros(3, np.uint32)
+    pbuf = DeviceArray(np.array([0.1]))
+    for j, e in enumerate((e0, e1, e2)):
+        e.SetNormalizationBuffer(norms, j)
+        e.SetParameterBuffer(pbuf)
+    g = nll.EvalGroup([e0, e1, e2])
+    g.EvalAsync(False)
+    g.EvalFinished()
+    o0 = oracle_eval(t0, 1, [0.0], [1.0], [1000], [], [0.1])
+    o1 = oracle_eval(t1, 2, [0.0, 0.0], [1.0, 1.0], [250, 250], [], [0.1])
+    o2 = oracle_eval(t2, 4, [0.0] * 3, [1.0] * 3, [8, 8, 8],
+                     [dict(type="resolution_scale", obs=0, true_obs=3, pars=[0])], [0.1])
+    for e, o in ((e0, o0), (e1, o1), (e2, o2)):
+        assert np.array_equal(e.GetBins(), o["bins"])
+    assert list(norms.get()) == [o0["norm"], o1["norm"], o2["norm"]]
