@@ -149,6 +149,11 @@ int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_p
 int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* out);
 int sxmc_group_destroy(sxmc_group_t g);
 int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks_per_cu);
+/* Measurement hook for roofline analysis (RESULTS ARE WRONG when mode != 0; default 0):
+ * bit 0 = histogram-fill kernel streams its columns but skips arithmetic and histogram,
+ * bit 1 = arithmetic and histogram run but every reload hits one cached address,
+ * bit 2 = skip only the histogram update. */
+int sxmc_group_set_debug_mode(sxmc_group_t g, int mode);
 int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s);
 /* As sxmc_group_eval_async(g, 1, s) followed by nll_event_chunks (nll_kernels.cpp:89-116) over
  * the members' lookup table, with the table lookup and the event sum fused in one kernel: the

@@ -79,6 +79,7 @@ SIGNATURES = {
     "sxmc_group_create": [_vp, _i, _pvp],
     "sxmc_group_destroy": [_vp],
     "sxmc_group_set_launch_config": [_vp, _i, _i],
+    "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_group_eval_async": [_vp, _i, _vp],
     "sxmc_group_eval_nll_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi],
     "sxmc_group_synchronize": [_vp],

@@ -108,37 +108,94 @@ __device__ __forceinline__ void apply_transform(double (&f)[NSLOT][SXMC_VEC], in
   }
 }
 
-// One systematic whose p is a wave-uniform constant (npars == 1: p = 0 + c0 * x^0).
-template <int NSLOT>
-__device__ __forceinline__ void apply_op_const(double (&f)[NSLOT][SXMC_VEC], int type,
-                                               int obs_slot, int extra_slot, double pc) {
-  if (type < 0) return;
-  with_slot<NSLOT>(obs_slot, [&](auto K) {
-    const double p[SXMC_VEC] = {pc, pc, pc, pc};
-    apply_transform<NSLOT>(f, type, f[K], extra_slot, p);
-  });
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
 }
 
-// General systematic: p = sum_i c_i * x^i at the current x (pdfz.cpp:310-314).
+// The systematics of one member as a "program" held in two lane-indexed registers:
+//   lane s of `opword` = type | obs_slot << 4 | extra_slot << 8 | npars << 12 | coef_start << 16
+//   lane c of `coef`   = the c-th polynomial coefficient, already read from the parameter buffer
+__device__ __forceinline__ unsigned pack_opword(const SxSystOp& op) {
+  return (unsigned)op.type | ((unsigned)op.obs_slot << 4) | ((unsigned)op.extra_slot << 8) |
+         ((unsigned)op.npars << 12) | ((unsigned)op.coef_start << 16);
+}
+
+// DYNAMIC program: one systematic (apply_systematic, pdfz.cpp:306-331) on SXMC_VEC samples per
+// lane, decoded at run time.  A wave-uniform loop over the systematics reads `opword` / `coef`
+// back with v_readlane, so any number of systematics of any kind runs through one copy of this
+// code.  It costs scalar-unit time (decode + branches), which the CU's 16 waves share: the
+// STATIC programs below exist because that, not HBM, bounded the kernel.
 template <int NSLOT>
-__device__ __forceinline__ void apply_op_poly(double (&f)[NSLOT][SXMC_VEC], const SxSystOp& op,
-                                              gptr<const double> params, int param_stride) {
-  const int type = uniform_i(op.type);
-  const int npars = uniform_i(op.npars);
-  const int extra_slot = uniform_i(op.extra_slot);
-  with_slot<NSLOT>(uniform_i(op.obs_slot), [&](auto K) {
-    double p[SXMC_VEC] = {0.0, 0.0, 0.0, 0.0};
-    double pw[SXMC_VEC] = {1.0, 1.0, 1.0, 1.0};
-    for (int i = 0; i < npars; i++) {
-      const double c = uniform_d(params[(long)op.pars[i] * param_stride]);
+__device__ __forceinline__ void apply_op(double (&f)[NSLOT][SXMC_VEC], unsigned w, double coef) {
+  const int type = (int)(w & 15u);
+  const int obs_slot = (int)((w >> 4) & 15u);
+  const int extra_slot = (int)((w >> 8) & 15u);
+  const int npars = (int)((w >> 12) & 15u);
+  const int cstart = (int)(w >> 16);
+  with_slot<NSLOT>(obs_slot, [&](auto K) {
+    double p[SXMC_VEC];
+    if (npars == 1) {
+      // p = 0 + c0 * pow(x, 0) = 0 + c0 * 1 for every x (pdfz.cpp:310-314)
+      const double pc = 0.0 + readlane_d(coef, cstart) * 1.0;
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) p[q] = pc;
+    } else {
+      // p = sum_i c_i * x^i at the current x; x^i by repeated multiplication
+      double pw[SXMC_VEC];
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
-        p[q] = p[q] + c * pw[q];
-        pw[q] = pw[q] * f[K][q];
+        p[q] = 0.0;
+        pw[q] = 1.0;
+      }
+      for (int i = 0; i < npars; i++) {
+        const double c = readlane_d(coef, cstart + i);
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          p[q] = p[q] + c * pw[q];
+          pw[q] = pw[q] * f[K][q];
+        }
       }
     }
     apply_transform<NSLOT>(f, type, f[K], extra_slot, p);
   });
+}
+
+// STATIC program: the list of one-coefficient systematics is a template argument, so the sample
+// loop is straight-line vector code with the p's in scalar registers -- no decode, no branches.
+// The host picks a static kernel when a launch's program matches one in the table at the end of
+// this file, and the dynamic kernel otherwise.
+constexpr unsigned sx_op(int type, int obs_slot, int extra_slot = 0) {
+  return (unsigned)type | ((unsigned)obs_slot << 4) | ((unsigned)extra_slot << 8);
+}
+template <unsigned... OPS>
+struct StaticProg {
+  static constexpr bool dynamic = false;
+  static constexpr int n = (int)sizeof...(OPS);
+};
+struct DynamicProg {
+  static constexpr bool dynamic = true;
+  static constexpr int n = 0;
+};
+
+template <int NSLOT, unsigned OPC>
+__device__ __forceinline__ void apply_static(double (&f)[NSLOT][SXMC_VEC], double pc) {
+  constexpr int type = (int)(OPC & 15u), K = (int)((OPC >> 4) & 15u), E = (int)((OPC >> 8) & 15u);
+  static_assert(K < NSLOT && E < NSLOT, "slot out of range");
+#pragma unroll
+  for (int q = 0; q < SXMC_VEC; q++) {
+    if constexpr (type == SXMC_SYST_SHIFT) f[K][q] = f[K][q] + pc;
+    if constexpr (type == SXMC_SYST_SCALE) f[K][q] = f[K][q] * (1 + pc);
+    if constexpr (type == SXMC_SYST_CTSCALE) f[K][q] = 1 + (f[K][q] - 1) * (1 + pc);
+    if constexpr (type == SXMC_SYST_RESOLUTION_SCALE) f[K][q] = f[K][q] + (pc * (f[K][q] - f[E][q]));
+  }
+}
+
+template <int NSLOT, unsigned... OPS, size_t... I>
+__device__ __forceinline__ void run_static(double (&f)[NSLOT][SXMC_VEC], const double* pc, StaticProg<OPS...>,
+                                           std::index_sequence<I...>) {
+  (apply_static<NSLOT, OPS>(f, pc[I]), ...);
 }
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load per lane
@@ -151,30 +208,40 @@ struct Columns {
 template <int NSLOT>
 __device__ __forceinline__ void load_columns(Columns<NSLOT>& c, const gptr<const vfloat4> (&col)[NSLOT],
                                              unsigned long long v) {
+  // Issue order is pinned (sched_barrier): the wait-counter bookkeeping at the loop header merges
+  // the prologue's and the steady state's load order, and only identical orders give counted
+  // waits (vmcnt(NSLOT)) instead of a full drain.
 #pragma unroll
   for (int k = 0; k < NSLOT; k++) {
     c.v[k] = col[k][v];
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // The histogram fill.  grid = a few workgroups per CU; workgroup b owns the slice
 // [total_vec*b/G, total_vec*(b+1)/G) of the concatenated (over members) 4-sample units and
 // walks the members that intersect it.
-template <int NOBS, int NSLOT, bool LDS_HIST>
+//
+// LDS layout (LDS_HIST): word 0 workgroup in-domain counter, words 4.. the histogram (hist_words
+// = largest member), then 64 "trash" words, one per lane: a sample that is outside the domain
+// adds to its lane's trash word instead of being branched around, so the whole per-sample path
+// is unpredicated vector code (no exec-mask juggling on the scalar unit).
+template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG>
 __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restrict__ descs,
                                                     int nsig, unsigned long long total_vec,
-                                                    unsigned hist_words) {
-  extern __shared__ unsigned lds[];  // LDS_HIST: [hist_words] histogram, then 1 word norm
+                                                    unsigned hist_words, unsigned dbg) {
+  extern __shared__ unsigned lds[];
   const unsigned tid = threadIdx.x;
   const unsigned nthreads = blockDim.x;
+  const unsigned lane = tid & (kWave - 1);
 
   const unsigned long long G = gridDim.x;
   unsigned long long r0 = total_vec * blockIdx.x / G;
   const unsigned long long r1 = total_vec * (blockIdx.x + 1ull) / G;
 
-  // LDS layout: word 0 = workgroup norm counter, histogram from word 4 (16-byte aligned)
   unsigned* s_norm = lds;
   unsigned* hist = lds + 4;
+  const unsigned trash = hist_words + lane;
 
   int j = 0;
   while (j + 1 < nsig && descs[j + 1].vec_start <= r0) j++;
@@ -202,7 +269,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
       __syncthreads();
     }
 
-    // ---- wave-uniform geometry and systematics into scalar registers
+    // ---- wave-uniform geometry into scalar registers
     double lo[NOBS], hi[NOBS], sc[NOBS];
     int st[NOBS];
 #pragma unroll
@@ -218,85 +285,118 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
       col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
     }
 
+    // ---- the member's systematics: coefficients (and, for the dynamic program, the op words)
+    // into lane-indexed registers
     const int nsyst = d.nsyst;
-    const bool fast = d.fast_syst != 0;
-    gptr<const double> params = to_global(d.params);
-    const int pstride = d.param_stride;
-    int op_type[SXMC_FAST_SYST], op_obs[SXMC_FAST_SYST], op_extra[SXMC_FAST_SYST];
-    double op_p[SXMC_FAST_SYST];
+    unsigned opword = 0u;
+    double coef = 0.0;
+    if (PROG::dynamic && (int)lane < nsyst) opword = pack_opword(d.syst[lane]);
+    if ((int)lane < d.ncoef) coef = to_global(d.params)[(long)d.coef_par[lane] * d.param_stride];
+    // static program: p_s = 0 + c_s * pow(x, 0) = 0 + c_s * 1 (pdfz.cpp:310-314), wave-uniform
+    double pc[PROG::n > 0 ? PROG::n : 1];
 #pragma unroll
-    for (int s = 0; s < SXMC_FAST_SYST; s++) {
-      const bool on = fast && s < nsyst;
-      op_type[s] = on ? (int)d.syst[s].type : SXMC_OP_NOP;
-      op_obs[s] = on ? (int)d.syst[s].obs_slot : 0;
-      op_extra[s] = on ? (int)d.syst[s].extra_slot : 0;
-      // p = 0 + c0 * pow(x, 0) = 0 + c0 * 1 (pdfz.cpp:310-314 with npars == 1)
-      const double c0 = on ? uniform_d(params[(long)d.syst[s].pars[0] * pstride]) : 0.0;
-      op_p[s] = 0.0 + c0 * 1.0;
-    }
+    for (int s = 0; s < PROG::n; s++) pc[s] = 0.0 + readlane_d(coef, s) * 1.0;
 
     unsigned cnt = 0;
 
-    unsigned long long v = v0 + tid;
-    Columns<NSLOT> cur, nxt;
-    if (v < v1) load_columns<NSLOT>(cur, col, v);
-    while (v < v1) {
-      // Next unit's loads are issued unconditionally (index clamped into the slice) so that the
-      // wait counters stay exact: a branch around them makes the compiler wait for them at once.
-      const unsigned long long vn = v + nthreads;
-      load_columns<NSLOT>(nxt, col, vn < v1 ? vn : v1 - 1);
-
+    // ---- the sample loop: a two-deep ring of raw column registers.  One stage = wait for a
+    // buffer, widen it to double, immediately re-issue the buffer's loads for two units ahead,
+    // then do the arithmetic: two units (2 x NSLOT KiB per wave) stay in flight under the
+    // compute.  Loads are unconditional (index clamped into the slice) so the wait counters stay
+    // exact; lanes past the end of the slice are treated like out-of-domain samples.
+    const unsigned long long vlast = v1 - 1;
+    auto stage = [&](Columns<NSLOT>& buf, const unsigned long long vc) {
       double f[NSLOT][SXMC_VEC];
 #pragma unroll
       for (int k = 0; k < NSLOT; k++) {
-        f[k][0] = (double)cur.v[k].x;
-        f[k][1] = (double)cur.v[k].y;
-        f[k][2] = (double)cur.v[k].z;
-        f[k][3] = (double)cur.v[k].w;
+        f[k][0] = (double)buf.v[k].x;
+        f[k][1] = (double)buf.v[k].y;
+        f[k][2] = (double)buf.v[k].z;
+        f[k][3] = (double)buf.v[k].w;
+      }
+      // Pin every widening BEFORE the buffer is re-loaded: if the compiler sinks one of them
+      // below, that column's registers stay live across the reload, the reload lands in fresh
+      // registers and the loop latch copies them back behind a vmcnt(0) that drains the ring.
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f[k][q]));
+      }
+      // dbg is a measurement hook (sxmc_group_set_debug_mode), 0 in production:
+      //   bit 1: every reload hits one cached address -> the kernel without its HBM stream
+      //   bit 0: skip the arithmetic and the histogram -> the HBM stream alone
+      //   bit 2: skip only the histogram update
+      const unsigned long long vl = vc + 2ull * nthreads;
+      load_columns<NSLOT>(buf, col, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
+      if (dbg & 1u) {
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) cnt += (f[k][q] == 12345.678) ? 1u : 0u;
+        }
+        return;
       }
 
-      if (fast) {
-#pragma unroll
-        for (int s = 0; s < SXMC_FAST_SYST; s++) {
-          apply_op_const<NSLOT>(f, op_type[s], op_obs[s], op_extra[s], op_p[s]);
+      if constexpr (PROG::dynamic) {
+        for (int s = 0; s < nsyst; s++) {
+          apply_op<NSLOT>(f, (unsigned)__builtin_amdgcn_readlane((int)opword, s), coef);
         }
       } else {
-        for (int s = 0; s < nsyst; s++) {
-          apply_op_poly<NSLOT>(f, d.syst[s], params, pstride);
-        }
+        run_static<NSLOT>(f, pc, PROG{}, std::make_index_sequence<(size_t)PROG::n>{});
       }
 
+      // lanes past the end of the slice hold clamped duplicates: count them as failures
+      const unsigned dead = (vc < v1) ? 0u : 1u;
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
-        bool ok = true;
+        // pdfz.cpp:388-398.  `bad` counts failed domain tests (each a vector compare feeding an
+        // add-with-carry, nothing on the scalar unit); the tests are written so that NaN fails.
+        unsigned bad = dead;
         int bin = 0;
 #pragma unroll
         for (int k = 0; k < NOBS; k++) {
           const double x = f[k][q];
-          // in-domain test of pdfz.cpp:391 written so that NaN is outside
-          ok = ok && (x >= lo[k]) && (x < hi[k]);
-          bin += (int)((x - lo[k]) * sc[k]) * st[k];
+          bad += !(x >= lo[k]) ? 1u : 0u;
+          bad += !(x < hi[k]) ? 1u : 0u;
+          const int idx = (int)((x - lo[k]) * sc[k]);
+          if (LDS_HIST) {
+            // histogram fits LDS => every index and stride is far below 2^23
+            bin = (k == NOBS - 1) ? bin + idx : __mul24(idx, st[k]) + bin;
+          } else {
+            bin += idx * st[k];
+          }
         }
-        if (ok) {
-          cnt += 1u;
-          if ((unsigned)bin < B) {
-            if (LDS_HIST) {
-              __hip_atomic_fetch_add(&hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-              __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        const unsigned in_domain = (bad == 0u) ? 1u : 0u;
+        cnt += in_domain;
+        if (LDS_HIST) {
+          // in domain but index out of range (the reference's one-past-the-end case) still counts
+          // in the norm; it and every failure go to the lane's trash word
+          const bool store = (bad == 0u) && ((unsigned)bin < B) && !(dbg & 4u);
+          const unsigned slot = store ? (unsigned)bin : trash;
+          __hip_atomic_fetch_add(&hist[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          if (bad == 0u && (unsigned)bin < B && !(dbg & 4u)) {
+            __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
+    };
 
-      cur = nxt;
-      v = vn;
+    // wave-uniform trip count: every lane runs the same number of stage pairs
+    unsigned long long v = v0 + tid;
+    const unsigned long long npairs = (v1 - v0 + 2ull * nthreads - 1) / (2ull * nthreads);
+    Columns<NSLOT> bufA, bufB;
+    load_columns<NSLOT>(bufA, col, v < v1 ? v : vlast);
+    load_columns<NSLOT>(bufB, col, v + nthreads < v1 ? v + nthreads : vlast);
+    for (unsigned long long it = 0; it < npairs; ++it, v += 2ull * nthreads) {
+      stage(bufA, v);
+      stage(bufB, v + nthreads);
     }
 
     // ---- in-domain count: lane registers -> wave -> workgroup -> one global atomic
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
-    if ((tid & (kWave - 1)) == 0 && cnt != 0u) {
+    if (lane == 0 && cnt != 0u) {
       __hip_atomic_fetch_add(s_norm, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
@@ -524,24 +624,67 @@ __global__ __launch_bounds__(256) void untranspose_obs_kernel(const float* __res
   }
 }
 
-template <int NOBS, int NSLOT>
-hipError_t launch_fill_t(const SxLaunchShape& sh, const SxSignalDesc* descs, int nsig,
+template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG>
+hipError_t launch_fill_k(const SxLaunchShape& sh, const SxSignalDesc* descs, int nsig,
                          unsigned long long total_vec, hipStream_t s) {
-  hipError_t e = hipSuccess;
-  if (sh.lds_hist) {
-    auto k = fill_kernel<NOBS, NSLOT, true>;
-    if (sh.lds_bytes > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sh.lds_bytes);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, nsig, total_vec,
-                       (unsigned)(sh.lds_bytes / 4 - 4));
-  } else {
-    hipLaunchKernelGGL((fill_kernel<NOBS, NSLOT, false>), dim3(sh.grid), dim3(sh.threads), 64, s, descs,
-                       nsig, total_vec, 0u);
+  auto k = fill_kernel<NOBS, NSLOT, LDS_HIST, PROG>;
+  if (LDS_HIST && sh.lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
+    if (e != hipSuccess) return e;
   }
+  // LDS: 4 header words + hist_words + 64 trash words
+  const unsigned hist_words = LDS_HIST ? (unsigned)(sh.lds_bytes / 4 - 4 - 64) : 0u;
+  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), LDS_HIST ? sh.lds_bytes : 64, s, descs, nsig,
+                     total_vec, hist_words, (unsigned)sh.debug_mode);
   return hipGetLastError();
+}
+
+typedef hipError_t (*FillLauncher)(const SxLaunchShape&, const SxSignalDesc*, int, unsigned long long,
+                                   hipStream_t);
+
+// Static programs (LDS-histogram launches only).  Slots: observables 0..nobs-1, then the
+// referenced extra fields in ascending order.
+struct StaticEntry {
+  int nobs, nslot, nops;
+  unsigned ops[4];
+  FillLauncher fn;
+};
+#define SX_SHIFT(o) sx_op(SXMC_SYST_SHIFT, o)
+#define SX_SCALE(o) sx_op(SXMC_SYST_SCALE, o)
+#define SX_CTSC(o) sx_op(SXMC_SYST_CTSCALE, o)
+#define SX_RES(o, e) sx_op(SXMC_SYST_RESOLUTION_SCALE, o, e)
+#define SX_P1(NO, NS, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>}
+#define SX_P2(NO, NS, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>}
+#define SX_P3(NO, NS, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>}
+const StaticEntry kStaticPrograms[] = {
+    // 1-D (bench_sxmc pdfz: one shift; config/example.json: scale + resolution_scale)
+    SX_P1(1, 1, SX_SHIFT(0)),
+    SX_P1(1, 1, SX_SCALE(0)),
+    SX_P2(1, 1, SX_SHIFT(0), SX_SCALE(0)),
+    SX_P1(1, 2, SX_RES(0, 1)),
+    SX_P2(1, 2, SX_SCALE(0), SX_RES(0, 1)),
+    SX_P3(1, 2, SX_SHIFT(0), SX_SCALE(0), SX_RES(0, 1)),
+    // 2-D
+    SX_P1(2, 2, SX_SHIFT(0)),
+    SX_P1(2, 2, SX_SCALE(0)),
+    SX_P1(2, 2, SX_SHIFT(1)),
+    SX_P2(2, 3, SX_SCALE(0), SX_RES(0, 2)),
+    SX_P3(2, 3, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 2)),
+    // 3-D (BASELINE config 3: shift(r) + scale(e) + resolution_scale(e | e_true))
+    SX_P1(3, 3, SX_SHIFT(0)),
+    SX_P1(3, 3, SX_SCALE(0)),
+    SX_P1(3, 4, SX_RES(0, 3)),
+    SX_P2(3, 4, SX_SCALE(0), SX_RES(0, 3)),
+    SX_P3(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
+};
+constexpr int kNumStatic = (int)(sizeof(kStaticPrograms) / sizeof(kStaticPrograms[0]));
+
+template <int NOBS, int NSLOT>
+hipError_t launch_fill_dyn(const SxLaunchShape& sh, const SxSignalDesc* descs, int nsig,
+                           unsigned long long total_vec, hipStream_t s) {
+  return sh.lds_hist ? launch_fill_k<NOBS, NSLOT, true, DynamicProg>(sh, descs, nsig, total_vec, s)
+                     : launch_fill_k<NOBS, NSLOT, false, DynamicProg>(sh, descs, nsig, total_vec, s);
 }
 
 }  // namespace
@@ -550,11 +693,25 @@ bool sx_fill_has_specialization(int nobs, int nslot) {
   return nobs >= 1 && nobs <= 5 && nslot >= nobs && nslot <= nobs + 2;
 }
 
+int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops) {
+  for (int i = 0; i < kNumStatic; i++) {
+    const StaticEntry& e = kStaticPrograms[i];
+    if (e.nobs != nobs || e.nslot != nslot || e.nops != nops) continue;
+    bool same = true;
+    for (int k = 0; k < nops; k++) same = same && e.ops[k] == ops[k];
+    if (same) return i;
+  }
+  return -1;
+}
+
 hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, int nsig,
                           unsigned long long total_vec, hipStream_t s) {
   if (total_vec == 0 || nsig == 0) return hipSuccess;
+  if (sh.lds_hist && sh.static_prog >= 0 && sh.static_prog < kNumStatic) {
+    return kStaticPrograms[sh.static_prog].fn(sh, descs, nsig, total_vec, s);
+  }
 #define SX_CASE(NO, NS) \
-  if (sh.nobs == NO && sh.nslot == NS) return launch_fill_t<NO, NS>(sh, descs, nsig, total_vec, s);
+  if (sh.nobs == NO && sh.nslot == NS) return launch_fill_dyn<NO, NS>(sh, descs, nsig, total_vec, s);
   SX_CASE(1, 1) SX_CASE(1, 2) SX_CASE(1, 3)
   SX_CASE(2, 2) SX_CASE(2, 3) SX_CASE(2, 4)
   SX_CASE(3, 3) SX_CASE(3, 4) SX_CASE(3, 5)
@@ -569,7 +726,7 @@ hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, in
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, nsig, total_vec,
-                       (unsigned)(sh.lds_bytes / 4 - 4));
+                       (unsigned)(sh.lds_bytes / 4 - 4 - 64));
   } else {
     hipLaunchKernelGGL(fill_kernel_generic<false>, dim3(sh.grid), dim3(sh.threads), 64, s, descs, nsig,
                        total_vec, 0u);

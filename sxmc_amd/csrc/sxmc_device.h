@@ -7,7 +7,6 @@
 
 #include "../../include/sxmc_hip.h"
 
-#define SXMC_FAST_SYST 4   // systematics whose operands are hoisted into scalar registers
 #define SXMC_VEC 4         // samples per lane per iteration (one 16-byte load per column)
 #define SXMC_OP_NOP (-1)
 
@@ -19,6 +18,8 @@ struct SxSystOp {
   short extra_slot;
   short npars;
   short pars[SXMC_MAX_SYST_PARS];
+  short coef_start;  // first lane of this systematic's coefficients in the coefficient table
+  short pad[3];
 };
 
 // Everything the kernels need to know about one evaluator (one signal's PDF).
@@ -39,7 +40,8 @@ struct SxSignalDesc {
   int nobs;
   int nslot;                     // columns loaded: nobs observables + referenced extra fields
   int nsyst;
-  int fast_syst;                 // nsyst <= SXMC_FAST_SYST and every npars == 1
+  int ncoef;                     // total polynomial coefficients of all systematics (<= 64 for the
+                                 // specialized kernels: one lane each)
   int param_stride;
   const double* params;          // param_buffer + param_offset
   int slot_col[SXMC_MAX_NFIELDS];
@@ -48,6 +50,7 @@ struct SxSignalDesc {
   double upper[SXMC_MAX_NFIELDS];
   double scale[SXMC_MAX_NFIELDS];  // nbins / (upper - lower), computed on the host in double
   SxSystOp syst[SXMC_MAX_SYST];
+  short coef_par[64];            // coefficient lane -> parameter index
   // --- evaluation at the data events
   const int* read_bins;
   unsigned long long npoints;
@@ -65,12 +68,15 @@ struct SxLaunchShape {
   int threads;      // 256 / 512 / 1024
   int grid;
   size_t lds_bytes;
+  int debug_mode;   // measurement hook, see fill_kernel
+  int static_prog;  // index into the static program table, or -1: decode the program at run time
 };
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, hipStream_t s);
 hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, int nsig,
                           unsigned long long total_vec, hipStream_t s);
 bool sx_fill_has_specialization(int nobs, int nslot);
+int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
 hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,
                               hipStream_t s);
 hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,

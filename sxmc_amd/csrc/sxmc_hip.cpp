@@ -54,7 +54,7 @@ int fail(int code, const std::string& msg) {
     if (!(cond)) return fail(SXMC_ERR_INVALID, msg); \
   } while (0)
 
-constexpr int kLdsMaxBins = 40960 - 64;  // 160 KiB of LDS per workgroup minus the counter words
+constexpr int kLdsMaxBins = 40960 - 128;  // 160 KiB of LDS per workgroup minus header and trash words
 
 struct HostSyst {
   int type, obs, extra_field;
@@ -116,6 +116,8 @@ struct sxmc_hist {
 namespace {
 struct LaunchClass {
   SxLaunchShape shape;
+  std::vector<unsigned> prog;  // one word per systematic when every one has a single coefficient
+  bool prog_simple = false;
   std::vector<int> member_idx;
   SxSignalDesc* d_descs = nullptr;
   unsigned long long total_vec = 0;
@@ -130,6 +132,7 @@ struct sxmc_group {
   std::vector<LaunchClass> classes;
   int cfg_threads = 0, cfg_bpc = 0;
   int cfg_seen_threads = -1, cfg_seen_bpc = -1;
+  int debug_mode = 0;
   int max_bins = 0;
   unsigned long long max_points = 0;
   bool same_points = false;
@@ -187,7 +190,7 @@ int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
     d.upper[k] = h->upper[k];
     d.scale[k] = h->scale[k];
   }
-  bool fast = d.nsyst <= SXMC_FAST_SYST;
+  int ncoef = 0;
   for (int s = 0; s < d.nsyst; s++) {
     const HostSyst& hs = h->systs[s];
     SxSystOp& op = d.syst[s];
@@ -195,10 +198,14 @@ int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
     op.obs_slot = (short)slot_of(slot_col, hs.obs);
     op.extra_slot = (short)(hs.type == SXMC_SYST_RESOLUTION_SCALE ? slot_of(slot_col, hs.extra_field) : 0);
     op.npars = (short)hs.pars.size();
-    for (size_t i = 0; i < hs.pars.size(); i++) op.pars[i] = hs.pars[i];
-    if (hs.pars.size() != 1) fast = false;
+    op.coef_start = (short)ncoef;
+    for (size_t i = 0; i < hs.pars.size(); i++) {
+      op.pars[i] = hs.pars[i];
+      if (ncoef < 64) d.coef_par[ncoef] = hs.pars[i];
+      ncoef++;
+    }
   }
-  d.fast_syst = fast ? 1 : 0;
+  d.ncoef = ncoef;
   d.read_bins = h->has_points ? h->d_read_bins : nullptr;
   d.npoints = h->has_points ? h->npoints : 0;
   d.pdf_out = h->pdf ? h->pdf + h->pdf_off : nullptr;
@@ -237,11 +244,22 @@ int group_rebuild(sxmc_group* g) {
     if (!h->has_points || h->npoints != g->members[0]->npoints) g->same_points = false;
 
     const int lds_hist = h->total_nbins <= kLdsMaxBins ? 1 : 0;
-    const bool spec = sx_fill_has_specialization(d.nobs, d.nslot);
+    const bool spec = sx_fill_has_specialization(d.nobs, d.nslot) && d.ncoef <= 64;
     const int key_nobs = spec ? d.nobs : 0, key_nslot = spec ? d.nslot : 0;
+    // the member's program as static-table words (type | obs_slot << 4 | extra_slot << 8)
+    std::vector<unsigned> prog;
+    bool prog_simple = spec && lds_hist && d.nsyst <= 4;
+    for (int q = 0; q < d.nsyst; q++) {
+      if (d.syst[q].npars != 1) prog_simple = false;
+      prog.push_back((unsigned)d.syst[q].type | ((unsigned)d.syst[q].obs_slot << 4) |
+                     ((unsigned)d.syst[q].extra_slot << 8));
+    }
     LaunchClass* cls = nullptr;
     for (LaunchClass& c : g->classes) {
-      if (c.shape.nobs == key_nobs && c.shape.nslot == key_nslot && c.shape.lds_hist == lds_hist) cls = &c;
+      if (c.shape.nobs == key_nobs && c.shape.nslot == key_nslot && c.shape.lds_hist == lds_hist &&
+          c.prog_simple == prog_simple && (!prog_simple || c.prog == prog)) {
+        cls = &c;
+      }
     }
     if (!cls) {
       g->classes.push_back(LaunchClass{});
@@ -250,6 +268,12 @@ int group_rebuild(sxmc_group* g) {
       cls->shape.nslot = key_nslot;
       cls->shape.lds_hist = lds_hist;
       cls->shape.threads = threads;
+      cls->shape.debug_mode = 0;
+      cls->prog = prog;
+      cls->prog_simple = prog_simple;
+      cls->shape.static_prog = (prog_simple && !prog.empty())
+                                   ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
+                                   : -1;
     }
     cls->member_idx.push_back(i);
   }
@@ -269,7 +293,7 @@ int group_rebuild(sxmc_group* g) {
       descs.push_back(d);
     }
     c.total_vec = prefix;
-    c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4) * 4 : 64;
+    c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4 + 64) * 4 : 64;
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, 1024 / threads);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
     bpc = std::min(bpc, lds_limit);
@@ -311,6 +335,7 @@ int group_fill(sxmc_group* g, hipStream_t s) {
   for (LaunchClass& c : g->classes) {
     const bool rec = g->prof && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
+    c.shape.debug_mode = g->debug_mode;
     SX_HIP(sx_launch_fill(c.shape, c.d_descs, (int)c.member_idx.size(), c.total_vec, s));
     if (rec) {
       SX_HIP(hipEventRecord(g->ev1[g->prof_n], s));
@@ -764,6 +789,12 @@ int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks
   SX_REQUIRE(bin_blocks_per_cu >= 0 && bin_blocks_per_cu <= 16, "bin_blocks_per_cu out of range");
   g->cfg_threads = bin_threads;
   g->cfg_bpc = bin_blocks_per_cu;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_debug_mode(sxmc_group_t g, int mode) {
+  SX_REQUIRE(g, "null group");
+  g->debug_mode = mode;
   return SXMC_OK;
 }
 
