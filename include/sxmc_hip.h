@@ -149,6 +149,10 @@ int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_p
 int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* out);
 int sxmc_group_destroy(sxmc_group_t g);
 int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks_per_cu);
+/* How the fill kernel's work is cut over workgroups: 0 = automatic, 1 = sliced (each workgroup one
+ * contiguous slice of the concatenated members), 2 = interleaved (each member's workgroups stride
+ * through it chunk by chunk, like a grid-stride copy). */
+int sxmc_group_set_partition(sxmc_group_t g, int mode);
 /* Measurement hook for roofline analysis (RESULTS ARE WRONG when mode != 0; default 0):
  * bit 0 = histogram-fill kernel streams its columns but skips arithmetic and histogram,
  * bit 1 = arithmetic and histogram run but every reload hits one cached address,

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsxmc_hip.so")
+# SXMC_HIP_LIB selects another build of the same library (A/B experiments on kernel variants)
+LIB_PATH = os.environ.get("SXMC_HIP_LIB") or os.path.join(_HERE, "csrc", "libsxmc_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE = 0, 1, 2, 3
 MAX_NFIELDS, MAX_SYST, MAX_SYST_PARS = 10, 16, 8
@@ -79,6 +80,7 @@ SIGNATURES = {
     "sxmc_group_create": [_vp, _i, _pvp],
     "sxmc_group_destroy": [_vp],
     "sxmc_group_set_launch_config": [_vp, _i, _i],
+    "sxmc_group_set_partition": [_vp, _i],
     "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_group_eval_async": [_vp, _i, _vp],
     "sxmc_group_eval_nll_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi],

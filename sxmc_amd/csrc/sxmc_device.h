@@ -60,6 +60,13 @@ struct SxSignalDesc {
   double bin_volume;
 };
 
+// One piece of fill work: units v0 + tid, + step, ... < v1 of member `sig` (a unit = SXMC_VEC samples).
+struct SxSegment {
+  int sig;
+  int pad;
+  unsigned long long v0, v1, step;
+};
+
 // Host-callable launchers implemented in the .hip files -------------------------------------
 struct SxLaunchShape {
   int nobs;
@@ -73,8 +80,8 @@ struct SxLaunchShape {
 };
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, hipStream_t s);
-hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, int nsig,
-                          unsigned long long total_vec, hipStream_t s);
+hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,
+                          const unsigned* d_blk_off, hipStream_t s);
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
 hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,

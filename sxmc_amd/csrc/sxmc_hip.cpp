@@ -120,8 +120,101 @@ struct LaunchClass {
   bool prog_simple = false;
   std::vector<int> member_idx;
   SxSignalDesc* d_descs = nullptr;
+  SxSegment* d_segs = nullptr;
+  unsigned* d_blk_off = nullptr;
   unsigned long long total_vec = 0;
+  int partition = 0;  // 1 sliced, 2 interleaved (what build_partition chose)
 };
+
+void free_class(LaunchClass& c) {
+  if (c.d_descs) (void)hipFree(c.d_descs);
+  if (c.d_segs) (void)hipFree(c.d_segs);
+  if (c.d_blk_off) (void)hipFree(c.d_blk_off);
+  c.d_descs = nullptr;
+  c.d_segs = nullptr;
+  c.d_blk_off = nullptr;
+}
+
+// Cut the class's work (units of SXMC_VEC samples) into per-workgroup segment lists.
+//  interleaved: member j gets K_j workgroups (proportional to its size, sum = grid); workgroup i of
+//    the member takes chunks i, i + K_j, ... of `threads` units: neighbouring workgroups read
+//    neighbouring chunks at the same time and every workgroup flushes one histogram once.
+//  sliced: workgroup b owns the contiguous slice [total*b/G, total*(b+1)/G) of the concatenated
+//    members: perfectly balanced, used when members outnumber workgroups or are tiny.
+void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threads, int want_mode,
+                     std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off, int& mode_out) {
+  segs.clear();
+  blk_off.assign(1, 0u);
+  unsigned long long total = 0;
+  int nonempty = 0;
+  for (const SxSignalDesc& d : descs) {
+    total += d.nvec;
+    if (d.nvec) nonempty++;
+  }
+  bool interleave = want_mode == 2 || (want_mode == 0 && nonempty > 0 && grid >= 2 * nonempty &&
+                                       total >= (unsigned long long)grid * threads * 8ull);
+  if (want_mode == 2 && (nonempty == 0 || grid < nonempty)) interleave = false;
+  std::vector<int> K(descs.size(), 0);
+  if (interleave) {
+    // largest-remainder apportionment of the workgroups, at least one per non-empty member and never
+    // more than the member has chunks
+    int used = 0;
+    std::vector<std::pair<double, int>> frac;
+    for (size_t j = 0; j < descs.size(); j++) {
+      if (!descs[j].nvec) continue;
+      const double share = (double)grid * (double)descs[j].nvec / (double)total;
+      const unsigned long long chunks = (descs[j].nvec + threads - 1) / threads;
+      K[j] = (int)std::min<unsigned long long>(chunks, std::max<unsigned long long>(1, (unsigned long long)share));
+      used += K[j];
+      frac.push_back({share - std::floor(share), (int)j});
+    }
+    std::sort(frac.begin(), frac.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    for (size_t i = 0; used < grid && !frac.empty() && i < 4 * frac.size(); i++) {
+      const int j = frac[i % frac.size()].second;
+      const unsigned long long chunks = (descs[j].nvec + threads - 1) / threads;
+      if ((unsigned long long)K[j] < chunks) {
+        K[j]++;
+        used++;
+      }
+    }
+    if (used > grid) interleave = false;  // more non-empty members than workgroups
+  }
+  if (interleave) {
+    for (size_t j = 0; j < descs.size(); j++) {
+      for (int i = 0; i < K[j]; i++) {
+        SxSegment sg{};
+        sg.sig = (int)j;
+        sg.v0 = (unsigned long long)i * threads;
+        sg.v1 = descs[j].nvec;
+        sg.step = (unsigned long long)K[j] * threads;
+        segs.push_back(sg);
+        blk_off.push_back((unsigned)segs.size());
+      }
+    }
+    while ((int)blk_off.size() < grid + 1) blk_off.push_back((unsigned)segs.size());  // idle workgroups
+    mode_out = 2;
+    return;
+  }
+  for (int b = 0; b < grid; b++) {
+    unsigned long long r0 = total * (unsigned long long)b / grid;
+    const unsigned long long r1 = total * (unsigned long long)(b + 1) / grid;
+    unsigned long long start = 0;
+    for (size_t j = 0; j < descs.size() && r0 < r1; j++) {
+      const unsigned long long s0 = start, s1 = start + descs[j].nvec;
+      start = s1;
+      if (s1 <= r0) continue;
+      SxSegment sg{};
+      sg.sig = (int)j;
+      sg.v0 = r0 - s0;
+      sg.v1 = std::min(r1, s1) - s0;
+      sg.step = (unsigned long long)threads;
+      segs.push_back(sg);
+      r0 = std::min(r1, s1);
+    }
+    blk_off.push_back((unsigned)segs.size());
+  }
+  mode_out = 1;
+}
 }  // namespace
 
 struct sxmc_group {
@@ -132,6 +225,7 @@ struct sxmc_group {
   std::vector<LaunchClass> classes;
   int cfg_threads = 0, cfg_bpc = 0;
   int cfg_seen_threads = -1, cfg_seen_bpc = -1;
+  int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
   int debug_mode = 0;
   int max_bins = 0;
   unsigned long long max_points = 0;
@@ -224,9 +318,7 @@ int group_rebuild(sxmc_group* g) {
 
   const int n = (int)g->members.size();
   g->h_descs.assign((size_t)n, SxSignalDesc{});
-  for (LaunchClass& c : g->classes) {
-    if (c.d_descs) (void)hipFree(c.d_descs);
-  }
+  for (LaunchClass& c : g->classes) free_class(c);
   g->classes.clear();
   g->max_bins = 0;
   g->max_points = 0;
@@ -300,21 +392,34 @@ int group_rebuild(sxmc_group* g) {
     unsigned long long grid = (unsigned long long)props.cus * bpc;
     const unsigned long long want = (c.total_vec + threads - 1) / threads;  // >= 1 unit per lane
     grid = std::max<unsigned long long>(1, std::min(grid, want));
-    c.shape.grid = (int)grid;
+    c.shape.grid = c.total_vec ? (int)grid : 0;
     SX_HIP(hipMalloc((void**)&c.d_descs, sizeof(SxSignalDesc) * descs.size()));
     SX_HIP(hipMemcpy(c.d_descs, descs.data(), sizeof(SxSignalDesc) * descs.size(), hipMemcpyHostToDevice));
+    if (c.shape.grid > 0) {
+      std::vector<SxSegment> segs;
+      std::vector<unsigned> blk_off;
+      build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition);
+      SX_HIP(hipMalloc((void**)&c.d_segs, sizeof(SxSegment) * std::max<size_t>(segs.size(), 1)));
+      SX_HIP(hipMalloc((void**)&c.d_blk_off, sizeof(unsigned) * blk_off.size()));
+      if (!segs.empty()) {
+        SX_HIP(hipMemcpy(c.d_segs, segs.data(), sizeof(SxSegment) * segs.size(), hipMemcpyHostToDevice));
+      }
+      SX_HIP(hipMemcpy(c.d_blk_off, blk_off.data(), sizeof(unsigned) * blk_off.size(), hipMemcpyHostToDevice));
+    }
   }
 
   g->seen.resize((size_t)n);
   for (int i = 0; i < n; i++) g->seen[i] = g->members[i]->version;
   g->cfg_seen_threads = g->cfg_threads;
   g->cfg_seen_bpc = g->cfg_bpc;
+  g->cfg_seen_partition = g->cfg_partition;
   g->built = true;
   return SXMC_OK;
 }
 
 int group_refresh(sxmc_group* g) {
-  bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc;
+  bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc ||
+               g->cfg_seen_partition != g->cfg_partition;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
   }
@@ -336,7 +441,7 @@ int group_fill(sxmc_group* g, hipStream_t s) {
     const bool rec = g->prof && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
     c.shape.debug_mode = g->debug_mode;
-    SX_HIP(sx_launch_fill(c.shape, c.d_descs, (int)c.member_idx.size(), c.total_vec, s));
+    SX_HIP(sx_launch_fill(c.shape, c.d_descs, c.d_segs, c.d_blk_off, s));
     if (rec) {
       SX_HIP(hipEventRecord(g->ev1[g->prof_n], s));
       g->prof_n++;
@@ -773,8 +878,7 @@ int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* ou
 int sxmc_group_destroy(sxmc_group_t g) {
   if (!g) return SXMC_OK;
   (void)hipDeviceSynchronize();
-  for (LaunchClass& c : g->classes)
-    if (c.d_descs) (void)hipFree(c.d_descs);
+  for (LaunchClass& c : g->classes) free_class(c);
   if (g->d_descs) (void)hipFree(g->d_descs);
   for (hipEvent_t e : g->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : g->ev1) (void)hipEventDestroy(e);
@@ -789,6 +893,13 @@ int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks
   SX_REQUIRE(bin_blocks_per_cu >= 0 && bin_blocks_per_cu <= 16, "bin_blocks_per_cu out of range");
   g->cfg_threads = bin_threads;
   g->cfg_bpc = bin_blocks_per_cu;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_partition(sxmc_group_t g, int mode) {
+  SX_REQUIRE(g, "null group");
+  SX_REQUIRE(mode >= 0 && mode <= 2, "partition mode must be 0 (auto), 1 (sliced) or 2 (interleaved)");
+  g->cfg_partition = mode;
   return SXMC_OK;
 }
 

@@ -74,6 +74,10 @@ class EvalGroup:
     def SetLaunchConfig(self, bin_threads=0, bin_blocks_per_cu=0):
         capi.call("sxmc_group_set_launch_config", self._g, int(bin_threads), int(bin_blocks_per_cu))
 
+    def SetPartition(self, mode):
+        """0 automatic, 1 sliced, 2 interleaved (see include/sxmc_hip.h)."""
+        capi.call("sxmc_group_set_partition", self._g, int(mode))
+
     def SetDebugMode(self, mode):
         """Measurement hook (results are wrong when mode != 0), see include/sxmc_hip.h."""
         capi.call("sxmc_group_set_debug_mode", self._g, int(mode))

@@ -292,15 +292,16 @@ def build_group(rng, sizes, nobs, nbins, systs, params, nfields=None, points=Non
 
 def test_group_matches_oracle_per_signal_ragged_sizes():
     rng = np.random.default_rng(12)
-    sizes = [1000, 200000, 10007, 3, 0, 50001, 1, 999, 123457]      # ragged, one empty, tiny ones
+    sizes = [1000, 2000000, 10007, 3, 0, 500001, 1, 999, 1234567]   # ragged, one empty, tiny ones
     nobs, nbins = 2, [16, 11]
     systs = [dict(type="shift", obs=1, pars=[0]), dict(type="resolution_scale", obs=0, true_obs=2, pars=[1])]
     params = [0.03, -0.2]
     pts = np.concatenate([table(rng, 333, 2), rng.integers(0, 2, size=(333, 1)).astype(np.float32)], axis=1)
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=3, points=pts)
     group = nll.EvalGroup(evs)
-    for launch in [(0, 0), (256, 4), (1024, 1)]:
+    for launch, partition in [((0, 0), 0), ((256, 4), 1), ((1024, 1), 2), ((512, 2), 2), ((256, 1), 1)]:
         group.SetLaunchConfig(*launch)
+        group.SetPartition(partition)
         group.EvalAsync(True)
         group.EvalFinished()
         got_lut = lut.get().reshape(len(sizes), -1)
@@ -335,3 +336,22 @@ def test_group_with_mixed_shapes_and_histogram_modes():
     for e, o in ((e0, o0), (e1, o1), (e2, o2)):
         assert np.array_equal(e.GetBins(), o["bins"])
     assert list(norms.get()) == [o0["norm"], o1["norm"], o2["norm"]]
+
+
+def test_interleaved_and_sliced_partitions_agree_on_equal_members():
+    rng = np.random.default_rng(14)
+    sizes = [400003] * 12
+    systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+             dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]        # the C3 program (static kernel)
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], systs, [0.02, -0.01, 0.07], nfields=5)
+    group = nll.EvalGroup(evs)
+    results = []
+    for partition in (1, 2, 0):
+        group.SetPartition(partition)
+        group.EvalAsync(False)
+        group.EvalFinished()
+        results.append(([e.GetBins() for e in evs], norms.get()))
+    for bins, nrm in results[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(bins, results[0][0])) and np.array_equal(nrm, results[0][1])
+    o = oracle_eval(tabs[5], 5, [0.0] * 3, [1.0] * 3, [20, 20, 20], systs, [0.02, -0.01, 0.07])
+    assert np.array_equal(results[0][0][5], o["bins"]) and results[0][1][5] == o["norm"]
