@@ -223,6 +223,13 @@ __global__ void nll_total_kernel(size_t npars, const double* pars, size_t nsigna
   }
 }
 
+// The fused end of an MCMC step (nll_kernels.cpp:230-271): reduce the event partial sums, total the
+// NLL at the proposed vector, Metropolis accept/reject + append to the jump buffer, draw the next
+// proposal.  One workgroup.  Every small array is staged into LDS by all lanes at once and the
+// vector copy / buffer append / proposal run one parameter per lane: the kernel is a handful of
+// memory latencies long instead of one per element.
+constexpr int kStage = 256;
+
 __global__ void finish_nll_jump_pick_combo_kernel(size_t npartial_sums, const double* sums, size_t nsignals,
                                                   size_t nsources, const double* means, const double* sigmas,
                                                   sxmc_rng_state* rng, double* nll_current,
@@ -233,18 +240,70 @@ __global__ void finish_nll_jump_pick_combo_kernel(size_t npartial_sums, const do
                                                   const short* source_id, const unsigned* norms,
                                                   bool debug_mode) {
   __shared__ double s_wave[17];
-  double total_sum = block_sum(npartial_sums, sums, s_wave);
+  __shared__ double s_vprop[kStage], s_means[kStage], s_sigmas[kStage], s_nexp[kStage];
+  __shared__ unsigned s_nmc[kStage], s_norms[kStage];
+  __shared__ short s_sid[kStage];
+  __shared__ int s_accept, s_count;
+  __shared__ double s_nllcur;
+
+  const bool staged = nparameters <= kStage && nsignals <= (size_t)kStage;
+  if (staged) {
+    for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
+      s_vprop[i] = v_proposed[i];
+      s_means[i] = means[i];
+      s_sigmas[i] = sigmas[i];
+    }
+    for (int i = threadIdx.x; i < (int)nsignals; i += blockDim.x) {
+      s_nexp[i] = nexpected[i];
+      s_nmc[i] = n_mc[i];
+      s_norms[i] = norms[i];
+      s_sid[i] = source_id[i];
+    }
+  }
+  double total_sum = block_sum(npartial_sums, sums, s_wave);  // barriers inside: staging is visible after
 
   if (threadIdx.x == 0) {
-    nll_total_device(nparameters, nsignals, nsources, v_proposed, means, sigmas, &total_sum, nexpected, n_mc,
-                     source_id, norms, nll_proposed);
-    jump_decider_device(rng, nll_current, nll_proposed, v_current, v_proposed, nparameters, accepted, counter,
-                        jump_buffer, debug_mode);
+    if (staged) {
+      nll_total_device(nparameters, nsignals, nsources, s_vprop, s_means, s_sigmas, &total_sum, s_nexp, s_nmc,
+                       s_sid, s_norms, nll_proposed);
+    } else {
+      nll_total_device(nparameters, nsignals, nsources, v_proposed, means, sigmas, &total_sum, nexpected, n_mc,
+                       source_id, norms, nll_proposed);
+    }
+    // jump_decider_device (nll_kernels.cpp:56-86), scalar part
+    const double u = rng_uniform(&rng[0]);
+    const double np = nll_proposed[0];
+    const double nc = nll_current[0];
+    const bool accept = debug_mode || (np < nc || u <= exp(nc - np));
+    if (accept) {
+      nll_current[0] = np;
+      accepted[0] += 1;
+    }
+    const int count = counter[0];
+    counter[0] = count + 1;
+    s_accept = accept ? 1 : 0;
+    s_count = count;
+    s_nllcur = accept ? np : nc;
   }
   __threadfence_block();
   __syncthreads();
 
-  pick_new_vector_device(nparameters, rng, jump_width, v_current, v_proposed);
+  const bool accept = s_accept != 0;
+  const size_t row = (size_t)s_count * (size_t)(nparameters + 1);
+  for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
+    // accepted: v_current <- v_proposed; every step: append v_current (as float) to the jump buffer
+    const double cur = accept ? (staged ? s_vprop[i] : v_proposed[i]) : v_current[i];
+    if (accept) v_current[i] = cur;
+    jump_buffer[row + i] = (float)cur;
+    // pick_new_vector_device (nll_kernels.cpp:30-53): next proposal around the (new) current vector
+    if (jump_width[i] > 0) {
+      const double z = rng_normal(&rng[i]);
+      v_proposed[i] = cur + jump_width[i] * z;
+    } else {
+      v_proposed[i] = cur;
+    }
+  }
+  if (threadIdx.x == 0) jump_buffer[row + nparameters] = (float)s_nllcur;
 }
 
 }  // namespace

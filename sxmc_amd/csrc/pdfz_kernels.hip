@@ -547,7 +547,18 @@ __global__ __launch_bounds__(256) void eval_pdf_kernel(const SxSignalDesc* __res
 
 // eval_pdf for all members fused with nll_event_chunks (nll_kernels.cpp:89-116): per event the
 // lookup-table values are produced, stored (the lut is the API contract) and consumed in
-// registers.  One partial sum per workgroup.
+// registers.  One partial sum per workgroup.  The kernel is a chain of dependent gathers
+// (read_bins -> bins), so the per-member pointers are staged in LDS and the members are walked
+// eight at a time with their loads issued together.
+struct EvalMember {
+  const int* read_bins;
+  const unsigned* bins;
+  float* out;
+  long stride;
+  double bin_norm;
+  double coef;  // pars[sid] * nexpected * eff, the event-independent factor of nll_kernels.cpp:107
+};
+
 __global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
                                                        unsigned long long npoints,
                                                        const double* __restrict__ pars,
@@ -556,26 +567,45 @@ __global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __res
                                                        const short* __restrict__ source_id,
                                                        const unsigned* __restrict__ norms,
                                                        double* __restrict__ sums) {
-  extern __shared__ double sh[];  // [nsig] bin_norm, [nsig] rate coefficient, [4] wave sums
-  double* s_binnorm = sh;
-  double* s_coef = sh + nsig;
-  double* s_wave = sh + 2 * nsig;
+  extern __shared__ double sh[];  // [16] wave sums, then nsig EvalMember records
+  double* s_wave = sh;
+  EvalMember* s_mem = reinterpret_cast<EvalMember*>(sh + 16);
   for (int j = threadIdx.x; j < nsig; j += blockDim.x) {
-    s_binnorm[j] = (double)(*to_global((const unsigned*)descs[j].norm)) * descs[j].bin_volume;
-    const float eff = (float)(1.0 * norms[j] / n_mc[j]);       // nll_kernels.cpp:105
-    s_coef[j] = pars[source_id[j]] * nexpected[j] * eff;       // left-to-right, :107
+    const SxSignalDesc& d = descs[j];
+    s_mem[j].read_bins = d.read_bins;
+    s_mem[j].bins = d.bins;
+    s_mem[j].out = d.pdf_out;
+    s_mem[j].stride = d.pdf_stride;
+    s_mem[j].bin_norm = (double)(*to_global((const unsigned*)d.norm)) * d.bin_volume;
+    const float eff = (float)(1.0 * norms[j] / n_mc[j]);             // nll_kernels.cpp:105
+    s_mem[j].coef = pars[source_id[j]] * nexpected[j] * eff;         // left-to-right, :107
   }
   __syncthreads();
 
+  constexpr int U = 8;
   double sum = 0.0;
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < npoints; i += step) {
     double s = 0.0;
-    for (int j = 0; j < nsig; j++) {
-      const SxSignalDesc& d = descs[j];
-      const float v = pdf_value(to_global(d.read_bins)[i], to_global((const unsigned*)d.bins), s_binnorm[j]);
-      to_global(d.pdf_out)[(long)d.pdf_stride * (long)i] = v;
-      s = s + s_coef[j] * (double)(!isnan(v) ? v : 0.0f);
+    for (int j0 = 0; j0 < nsig; j0 += U) {
+      int rb[U];
+      unsigned count[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) rb[u] = (j0 + u < nsig) ? to_global(s_mem[j0 + u].read_bins)[i] : -2;
+#pragma unroll
+      for (int u = 0; u < U; u++) count[u] = (rb[u] >= 0) ? to_global(s_mem[j0 + u].bins)[rb[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (j0 + u < nsig) {
+          // pdfz.cpp:423-434: -2 -> 0, other negatives -> NaN, else (float)(bins / (norm * volume))
+          float v;
+          if (rb[u] == -2) v = 0.0f;
+          else if (rb[u] < 0) v = __int_as_float(0x7fc00000);
+          else v = (float)((double)count[u] / s_mem[j0 + u].bin_norm);
+          to_global(s_mem[j0 + u].out)[s_mem[j0 + u].stride * (long)i] = v;
+          s = s + s_mem[j0 + u].coef * (double)(!isnan(v) ? v : 0.0f);
+        }
+      }
     }
     if (s > 0) sum += log(s);
   }
@@ -749,7 +779,7 @@ hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned lo
                               const double* pars, const double* nexpected, const unsigned* n_mc,
                               const short* source_id, const unsigned* norms, double* sums,
                               int grid, int block, hipStream_t s) {
-  const size_t shmem = (2 * (size_t)nsig + 16) * sizeof(double);
+  const size_t shmem = 16 * sizeof(double) + (size_t)nsig * sizeof(EvalMember);
   hipLaunchKernelGGL(eval_nll_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, pars,
                      nexpected, n_mc, source_id, norms, sums);
   return hipGetLastError();

@@ -941,9 +941,11 @@ int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s, const double* d_p
   rc = group_fill(g, st);
   if (rc) return rc;
   const unsigned long long ne = g->members[0]->npoints;
-  int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + 255) / 256));
+  SX_REQUIRE(g->members.size() <= 1024, "too many members for the fused evaluation");
+  const int block = 128;
+  int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
   SX_HIP(sx_launch_eval_nll(g->d_descs, (int)g->members.size(), ne, d_pars, d_nexpected, d_n_mc, d_source_id,
-                            d_norms, d_sums, grid, 256, st));
+                            d_norms, d_sums, grid, block, st));
   *npartial_out = grid;
   return SXMC_OK;
 }
