@@ -765,6 +765,7 @@ int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints
 
 int sxmc_hist_set_pdf_value_buffer(sxmc_hist_t h, float* d_output, int offset, int stride) {
   SX_REQUIRE(h, "null evaluator");
+  if (h->pdf == d_output && h->pdf_off == offset && h->pdf_stride == stride) return SXMC_OK;
   h->pdf = d_output;
   h->pdf_off = offset;
   h->pdf_stride = stride;
@@ -773,6 +774,7 @@ int sxmc_hist_set_pdf_value_buffer(sxmc_hist_t h, float* d_output, int offset, i
 }
 int sxmc_hist_set_normalization_buffer(sxmc_hist_t h, unsigned* d_norm, int offset) {
   SX_REQUIRE(h, "null evaluator");
+  if (h->norm == d_norm && h->norm_off == offset) return SXMC_OK;
   h->norm = d_norm;
   h->norm_off = offset;
   h->version++;
@@ -780,6 +782,7 @@ int sxmc_hist_set_normalization_buffer(sxmc_hist_t h, unsigned* d_norm, int offs
 }
 int sxmc_hist_set_parameter_buffer(sxmc_hist_t h, const double* d_params, int offset, int stride) {
   SX_REQUIRE(h, "null evaluator");
+  if (h->params == d_params && h->par_off == offset && h->par_stride == stride) return SXMC_OK;
   h->params = d_params;
   h->par_off = offset;
   h->par_stride = stride;

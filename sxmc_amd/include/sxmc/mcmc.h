@@ -1,0 +1,300 @@
+// mcmc.h -- ROOT-free MCMC driver in the shape of the reference's MCMC class (src/mcmc.{h,cpp}): the
+// caller of the hot path.  Same constructor arguments and call operator; the chain comes back as a
+// plain table (sxmc::Chain) instead of a TNtuple wrapped in a LikelihoodSpace.
+//
+// What it does per step (mcmc.cpp:261-348): re-evaluate every signal's PDF at the proposed vector
+// (when systematics float), event log-sum, then the fused reduce + nll_total + Metropolis + next
+// proposal.  Here the S evaluators are stepped as ONE batched launch sequence through
+// sxmc_group_eval_nll_async (fill of all signals in one kernel, lookup fused with the event sum) --
+// 4 launches per step instead of the reference's 3*S + 2.  `reference_form = true` issues the
+// reference's own sequence of entry points instead (per-evaluator EvalAsync/EvalFinished,
+// nll_event_chunks, finish_nll_jump_pick_combo); both forms give the same numbers up to the
+// summation order of the event partial sums.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "fit_types.h"
+#include "nll_kernels.h"
+
+namespace sxmc {
+
+/** The sampled likelihood space: one row per kept step = parameters..., likelihood (mcmc.cpp:100-114). */
+struct Chain {
+  std::vector<std::string> names;  //!< parameter names, then "likelihood"
+  std::vector<float> rows;         //!< row-major [nrows][names.size()]
+  size_t accepted = 0;             //!< accepted proposals over the whole walk
+  size_t nrows() const { return names.empty() ? 0 : rows.size() / names.size(); }
+  float at(size_t row, size_t col) const { return rows[row * names.size() + col]; }
+};
+
+class MCMC {
+ public:
+  bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
+  bool verbose = false;
+  unsigned long long seed = 0;  //!< gRandom->GetSeed() in the reference (mcmc.cpp:125)
+
+  MCMC(const std::vector<Source>& sources, const std::vector<Signal>& signals,
+       const std::vector<Systematic>& systematics, const std::vector<Observable>& observables,
+       unsigned long long _seed = 1)
+      : seed(_seed),
+        nsources(sources.size()),
+        nsignals(signals.size()),
+        nsystematics(systematics.size()),
+        nobservables(observables.size()) {
+    // mcmc.cpp:37-45: launch shapes of the NLL kernels
+    nnllblocks = 64;
+    nllblocksize = 256;
+    nnllthreads = nnllblocks * nllblocksize;
+    nreducethreads = 128;
+
+    size_t npars = 0;
+    for (const Systematic& s : systematics) npars += s.npars;
+    nparameters = nsources + npars;
+    parameter_means.reset(new pdfz::Array<double>(nparameters, true));
+    parameter_sigma.reset(new pdfz::Array<double>(nparameters, true));
+    parameter_fixed.resize(nparameters);
+    nfloat = 0;
+    for (size_t i = 0; i < nsources; i++) {
+      parameter_means->writeOnlyHostPtr()[i] = sources[i].mean;
+      parameter_sigma->writeOnlyHostPtr()[i] = sources[i].sigma;
+      parameter_fixed[i] = sources[i].fixed;
+      nfloat += sources[i].fixed ? 0 : 1;
+      parameter_names.push_back(sources[i].name);
+    }
+    systematics_fixed = true;
+    size_t k = nsources;
+    for (const Systematic& s : systematics) {
+      if (!s.fixed) systematics_fixed = false;
+      for (size_t j = 0; j < s.npars; j++) {
+        parameter_means->writeOnlyHostPtr()[k] = s.means[j];
+        parameter_sigma->writeOnlyHostPtr()[k] = s.sigmas[j];
+        parameter_fixed[k] = s.fixed;
+        nfloat += s.fixed ? 0 : 1;
+        parameter_names.push_back(s.name + "_" + std::to_string(j));
+        k++;
+      }
+    }
+    parameter_names.push_back("likelihood");
+
+    nexpected.reset(new pdfz::Array<double>(nsignals, true));
+    n_mc.reset(new pdfz::Array<unsigned>(nsignals, true));
+    source_id.reset(new pdfz::Array<short>(nsignals, true));
+    for (size_t i = 0; i < nsignals; i++) {
+      pdfs.push_back(signals[i].histogram);
+      nexpected->writeOnlyHostPtr()[i] = signals[i].nexpected;
+      n_mc->writeOnlyHostPtr()[i] = (unsigned)signals[i].n_mc;
+      source_id->writeOnlyHostPtr()[i] = (short)signals[i].source.index;
+    }
+
+    rngs.reset(new pdfz::Array<RNGState>(nparameters, true));
+    const int bs = 128;
+    const int nb = (int)(nparameters / bs + 1);
+    SXMC_KERNEL_LAUNCH(init_device_rngs, nb, bs, 0, 0, (int)nparameters, seed, rngs->writeOnlyPtr());
+
+    // the batched form needs every evaluator to be a histogram evaluator of this library
+    std::vector<sxmc_hist_t> handles;
+    for (pdfz::Eval* p : pdfs) {
+      pdfz::EvalHist* h = dynamic_cast<pdfz::EvalHist*>(p);
+      if (!h) {
+        handles.clear();
+        break;
+      }
+      handles.push_back(h->Handle());
+    }
+    if (!handles.empty()) check(sxmc_group_create(handles.data(), (int)handles.size(), &group));
+  }
+
+  ~MCMC() {
+    if (group) sxmc_group_destroy(group);
+  }
+  MCMC(const MCMC&) = delete;
+  MCMC& operator=(const MCMC&) = delete;
+
+  /** Initial proposal widths, mcmc.cpp:198-228 (including its `i < nsignals` test at :217). */
+  std::vector<float> initial_jump_widths() const {
+    std::vector<float> w(nparameters);
+    const float scale_factor = 2.4 * 2.4 / nfloat;  // Haario, 2001
+    for (size_t i = 0; i < nparameters; i++) {
+      if (parameter_fixed[i]) {
+        w[i] = -1;
+        continue;
+      }
+      const float mean = parameter_means->readOnlyHostPtr()[i];
+      const float sigma = parameter_sigma->readOnlyHostPtr()[i];
+      float width = 0.1;
+      if (sigma > 0) {
+        width = sigma;
+      } else if (i < nsignals) {
+        const float m = std::max(mean, (float)10);
+        width = std::sqrt(m) / m;
+      } else {
+        width = std::sqrt(std::max(mean, (float)1));
+      }
+      w[i] = 0.1 * width * scale_factor;
+    }
+    return w;
+  }
+
+  /** MCMC::operator() (mcmc.cpp:143-387).  data: rows of nobservables+1 floats (last = dataset id). */
+  Chain operator()(std::vector<float>& data, unsigned nsteps, float burnin_fraction,
+                   const bool debug_mode = false, unsigned sync_interval = 10000) {
+    const unsigned burnin_steps = nsteps * burnin_fraction;
+    Chain chain;
+    chain.names = parameter_names;
+    const size_t ncol = nparameters + 1;
+
+    pdfz::Array<double> current_vector(nparameters, true), proposed_vector(nparameters, true);
+    for (size_t i = 0; i < nparameters; i++)
+      current_vector.writeOnlyHostPtr()[i] = parameter_means->readOnlyHostPtr()[i];
+    proposed_vector.writeOnlyHostPtr();
+    pdfz::Array<unsigned> normalizations(nsignals, true);
+    normalizations.writeOnlyHostPtr();
+    pdfz::Array<double> event_partial_sums(std::max<size_t>(nnllthreads, 1024), true);
+    event_partial_sums.writeOnlyHostPtr();
+    pdfz::Array<double> event_total_sum(1, true);
+    event_total_sum.writeOnlyHostPtr();
+    pdfz::Array<int> jump_counter(1, true), accept_counter(1, true);
+    jump_counter.writeOnlyHostPtr()[0] = 0;
+    accept_counter.writeOnlyHostPtr()[0] = 0;
+    pdfz::Array<float> jump_buffer((size_t)sync_interval * ncol, true);
+    pdfz::Array<double> current_nll(1, true), proposed_nll(1, true);
+    current_nll.writeOnlyHostPtr();
+    proposed_nll.writeOnlyHostPtr();
+
+    pdfz::Array<float> jump_width(nparameters, true);
+    {
+      const std::vector<float> w = initial_jump_widths();
+      for (size_t i = 0; i < nparameters; i++) jump_width.writeOnlyHostPtr()[i] = w[i];
+    }
+    const float scale_factor = 2.4 * 2.4 / nfloat;
+
+    // mcmc.cpp:230-242: bind, first evaluation at the current vector, then re-point at the proposal
+    const size_t nevents = data.size() / (nobservables + 1);
+    pdfz::Array<float> lut(nevents * nsignals, true);
+    for (size_t i = 0; i < pdfs.size(); i++) {
+      pdfz::Eval* p = pdfs[i];
+      p->SetEvalPoints(data);
+      p->SetPDFValueBuffer(&lut, (int)(i * nevents), 1);
+      p->SetNormalizationBuffer(&normalizations, (int)i);
+      p->SetParameterBuffer(&current_vector, (int)nsources);
+      p->EvalAsync();
+      p->EvalFinished();
+      p->SetParameterBuffer(&proposed_vector, (int)nsources);
+    }
+
+    nll(lut.readOnlyPtr(), nevents, current_vector.readOnlyPtr(), current_nll.writeOnlyPtr(),
+        normalizations.readOnlyPtr(), event_partial_sums.ptr(), event_total_sum.ptr());
+    SXMC_KERNEL_LAUNCH(pick_new_vector, 1, 64, 0, 0, (int)nparameters, rngs->ptr(), jump_width.readOnlyPtr(),
+                       current_vector.readOnlyPtr(), proposed_vector.writeOnlyPtr());
+
+    const bool batched = group != nullptr && !reference_form;
+    if (batched) {
+      // bindings must be current before the group reads them (proposal vector as parameter buffer)
+      for (pdfz::Eval* p : pdfs) dynamic_cast<pdfz::EvalHist*>(p)->Bind();
+    }
+    const bool reevaluate = nsystematics > 0 && !systematics_fixed;
+
+    for (unsigned i = 0; i < nsteps; i++) {
+      // Re-tune the proposal from the burn-in samples (mcmc.cpp:274-311); the width becomes
+      // scale_factor x the standard deviation of the parameter over the steps kept so far
+      if (i == burnin_steps || i == 2 * burnin_steps) {
+        for (size_t j = 0; j < nparameters; j++) {
+          if (parameter_fixed[j]) continue;
+          const double sd = column_stddev(chain, j);
+          const double fit_width = sd > 0 ? sd : jump_width.readOnlyHostPtr()[j];
+          jump_width.hostPtr()[j] = scale_factor * fit_width;
+        }
+        if (!debug_mode) chain.rows.clear();
+      }
+
+      int npartial = (int)nnllthreads;
+      if (batched && reevaluate) {
+        check(sxmc_group_eval_nll_async(group, nullptr, proposed_vector.readOnlyPtr(), nexpected->readOnlyPtr(),
+                                        n_mc->readOnlyPtr(), source_id->readOnlyPtr(),
+                                        normalizations.ptr(), event_partial_sums.ptr(), &npartial));
+      } else {
+        if (reevaluate) {
+          for (pdfz::Eval* p : pdfs) p->EvalAsync();
+          for (pdfz::Eval* p : pdfs) p->EvalFinished();
+        }
+        SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, 0, lut.readOnlyPtr(),
+                           proposed_vector.readOnlyPtr(), nevents, nsignals, nexpected->readOnlyPtr(),
+                           n_mc->readOnlyPtr(), source_id->readOnlyPtr(), normalizations.readOnlyPtr(),
+                           event_partial_sums.ptr());
+      }
+      SXMC_KERNEL_LAUNCH(finish_nll_jump_pick_combo, 1, nreducethreads, nreducethreads * sizeof(double), 0,
+                         (size_t)npartial, event_partial_sums.ptr(), nsignals, nsources,
+                         parameter_means->readOnlyPtr(), parameter_sigma->readOnlyPtr(), rngs->ptr(),
+                         current_nll.ptr(), proposed_nll.ptr(), current_vector.ptr(), proposed_vector.ptr(),
+                         accept_counter.ptr(), jump_counter.ptr(), jump_buffer.writeOnlyPtr(), (int)nparameters,
+                         jump_width.readOnlyPtr(), nexpected->readOnlyPtr(), n_mc->readOnlyPtr(),
+                         source_id->readOnlyPtr(), normalizations.readOnlyPtr(), debug_mode);
+
+      // Flush the jump buffer periodically (mcmc.cpp:351-377)
+      if (i % sync_interval == 0 || i == nsteps - 1 || i == burnin_steps - 1 || i == 2 * burnin_steps - 1) {
+        const int njumps = jump_counter.readOnlyHostPtr()[0];
+        const int naccepted = accept_counter.readOnlyHostPtr()[0];
+        if (verbose) {
+          std::printf("MCMC: Step %u/%u (%d in buffer, %d accepted)\n", i + 1, nsteps, njumps, naccepted);
+        }
+        const float* jb = jump_buffer.readOnlyHostPtr();
+        chain.rows.insert(chain.rows.end(), jb, jb + (size_t)njumps * ncol);
+        chain.accepted += (size_t)naccepted;
+        jump_counter.writeOnlyHostPtr()[0] = 0;
+        accept_counter.writeOnlyHostPtr()[0] = 0;
+      }
+    }
+    check(sxmc_device_synchronize());
+    return chain;
+  }
+
+  size_t NumParameters() const { return nparameters; }
+
+ protected:
+  /** MCMC::nll (mcmc.cpp:390-415): three launches over an evaluated lookup table. */
+  void nll(const float* lut, size_t nevents, const double* v, double* out, const unsigned* norms,
+           double* event_partial_sums, double* event_total_sum) {
+    SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, 0, lut, v, nevents, nsignals,
+                       nexpected->readOnlyPtr(), n_mc->readOnlyPtr(), source_id->readOnlyPtr(), norms,
+                       event_partial_sums);
+    SXMC_KERNEL_LAUNCH(nll_event_reduce, 1, nreducethreads, nreducethreads * sizeof(double), 0,
+                       (size_t)nnllthreads, event_partial_sums, event_total_sum);
+    SXMC_KERNEL_LAUNCH(nll_total, 1, 1, 0, 0, nparameters, v, nsignals, nsources,
+                       parameter_means->readOnlyPtr(), parameter_sigma->readOnlyPtr(), event_total_sum,
+                       nexpected->readOnlyPtr(), n_mc->readOnlyPtr(), source_id->readOnlyPtr(), norms, out);
+  }
+
+  static double column_stddev(const Chain& c, size_t col) {
+    const size_t n = c.nrows();
+    if (n < 2) return 0.0;
+    double s = 0, s2 = 0;
+    for (size_t r = 0; r < n; r++) {
+      const double x = c.at(r, col);
+      s += x;
+      s2 += x * x;
+    }
+    const double var = s2 / n - (s / n) * (s / n);
+    return var > 0 ? std::sqrt(var) : 0.0;
+  }
+
+ private:
+  size_t nsources, nsignals, nsystematics, nobservables;
+  size_t nparameters = 0, nfloat = 0;
+  bool systematics_fixed = true;
+  unsigned nnllblocks, nllblocksize, nnllthreads, nreducethreads;
+  std::unique_ptr<pdfz::Array<double>> parameter_means, parameter_sigma, nexpected;
+  std::unique_ptr<pdfz::Array<unsigned>> n_mc;
+  std::unique_ptr<pdfz::Array<short>> source_id;
+  std::unique_ptr<pdfz::Array<RNGState>> rngs;
+  std::vector<std::string> parameter_names;
+  std::vector<bool> parameter_fixed;
+  std::vector<pdfz::Eval*> pdfs;
+  sxmc_group_t group = nullptr;
+};
+
+}  // namespace sxmc

@@ -1,0 +1,469 @@
+// test_cpp_api.cpp -- GPU tests of the C++ mirror of the reference's interface
+// (sxmc_amd/include/sxmc/{device_array,pdfz,nll_kernels,mcmc}.h), written with the reference's own
+// spelling (hemi::Array, HEMI_KERNEL_LAUNCH, pdfz::EvalHist) through sxmc_amd/include/spelling/.
+//
+// The pdfz cases are the reference's known-answer tests (test/test_pdfz.cpp, test_pdfz_2d.cpp,
+// test_pdfz_syst.cpp) against the CURRENT reference API: evaluation points carry the dataset column
+// and systematics take a parameter-index array.  Run by tests/test_gpu_cpp_api.py.
+#include <sxmc/nll_kernels.h>  // spelling/: HEMI_KERNEL_LAUNCH, hemi::Array
+#include <sxmc/pdfz.h>
+
+#include "../../sxmc_amd/include/sxmc/mcmc.h"
+#include "mini_test.h"
+
+using std::isnan;
+
+// ------------------------------------------------------------------ fixtures (test_pdfz_fixtures*.h)
+static std::vector<float> with_dataset(const std::vector<float>& pts, int nobs, float dataset = 0) {
+  std::vector<float> out;
+  for (size_t i = 0; i < pts.size() / nobs; i++) {
+    for (int k = 0; k < nobs; k++) out.push_back(pts[i * nobs + k]);
+    out.push_back(dataset);
+  }
+  return out;
+}
+
+struct EvalHistConstructor {
+  void SetUp() {
+    nobservables = 1;
+    nfields = 1;
+    samples = {0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 1.1f, -0.1f};
+    lower = {0.0};
+    upper = {1.0};
+    nbins = {2};
+  }
+  void TearDown() {}
+  int nobservables, nfields;
+  std::vector<float> samples;
+  std::vector<double> lower, upper;
+  std::vector<int> nbins;
+};
+
+struct EvalHistMethods : EvalHistConstructor {
+  void SetUp() {
+    EvalHistConstructor::SetUp();
+    MakeEvaluator();
+  }
+  void MakeEvaluator() {
+    evaluator = new pdfz::EvalHist(samples, nfields, nobservables, lower, upper, nbins);
+    eval_points = with_dataset({-0.1f, 0.0f, 0.25f, 0.5f, 0.75f, 1.0f}, 1);
+    pdf_values = new hemi::Array<float>(20, true);
+    norm = new hemi::Array<unsigned int>(3, true);
+    params = new hemi::Array<double>(5, true);
+    params->writeOnlyHostPtr();
+  }
+  void TearDown() {
+    delete evaluator;
+    delete pdf_values;
+    delete norm;
+    delete params;
+  }
+  pdfz::EvalHist* evaluator;
+  std::vector<float> eval_points;
+  hemi::Array<float>* pdf_values;
+  hemi::Array<unsigned int>* norm;
+  hemi::Array<double>* params;
+};
+
+// ------------------------------------------------------------------ test_pdfz.cpp
+TEST(PdfzError, Constructor) {
+  pdfz::Error err("test");
+  EXPECT_EQ(err.msg, std::string("test"));
+}
+
+TEST(SystematicObjects, Constructors) {
+  hemi::Array<short> pars(1, true);
+  pdfz::ShiftSystematic a(1, &pars);
+  EXPECT_EQ(pdfz::Systematic::SHIFT, a.type);
+  EXPECT_EQ(1, a.obs);
+  pdfz::ScaleSystematic b(0, &pars);
+  EXPECT_EQ(pdfz::Systematic::SCALE, b.type);
+  pdfz::ResolutionScaleSystematic c(0, 2, &pars);
+  EXPECT_EQ(pdfz::Systematic::RESOLUTION_SCALE, c.type);
+  EXPECT_EQ(2, c.true_obs);
+  // enum values are part of the descriptor format (pdfz.h:111-116)
+  EXPECT_EQ(0, (int)pdfz::Systematic::SHIFT);
+  EXPECT_EQ(1, (int)pdfz::Systematic::SCALE);
+  EXPECT_EQ(2, (int)pdfz::Systematic::RESOLUTION_SCALE);
+  EXPECT_EQ(3, (int)pdfz::Systematic::CTSCALE);
+}
+
+TEST_F(EvalHistConstructor, WrongSampleSize) {
+  ASSERT_THROW(pdfz::EvalHist(samples, 2 /* nfields */, nobservables, lower, upper, nbins), pdfz::Error);
+}
+TEST_F(EvalHistConstructor, NobsLargerThanNfields) {
+  ASSERT_THROW(pdfz::EvalHist(samples, nfields, 7 /* nobservables */, lower, upper, nbins), pdfz::Error);
+}
+TEST_F(EvalHistConstructor, WrongLowerSize) {
+  lower.resize(2);
+  ASSERT_THROW(pdfz::EvalHist(samples, nfields, nobservables, lower, upper, nbins), pdfz::Error);
+}
+TEST_F(EvalHistConstructor, WrongUpperSize) {
+  upper.resize(2);
+  ASSERT_THROW(pdfz::EvalHist(samples, nfields, nobservables, lower, upper, nbins), pdfz::Error);
+}
+TEST_F(EvalHistConstructor, WrongNbinsSize) {
+  nbins.resize(2);
+  ASSERT_THROW(pdfz::EvalHist(samples, nfields, nobservables, lower, upper, nbins), pdfz::Error);
+}
+TEST_F(EvalHistConstructor, ZeroBins) {
+  nbins[0] = 0;
+  ASSERT_THROW(pdfz::EvalHist(samples, nfields, nobservables, lower, upper, nbins), pdfz::Error);
+}
+
+static void expect_1d(float* r, int off, int st, double v1, double v2, double v3, double v4) {
+  ASSERT_TRUE(isnan(r[off + 0 * st]));
+  ASSERT_FLOAT_EQ(v1, r[off + 1 * st]);
+  ASSERT_FLOAT_EQ(v2, r[off + 2 * st]);
+  ASSERT_FLOAT_EQ(v3, r[off + 3 * st]);
+  ASSERT_FLOAT_EQ(v4, r[off + 4 * st]);
+  ASSERT_TRUE(isnan(r[off + 5 * st]));
+}
+
+TEST_F(EvalHistMethods, Evaluation) {
+  evaluator->SetEvalPoints(eval_points);
+  evaluator->SetPDFValueBuffer(pdf_values);
+  evaluator->SetNormalizationBuffer(norm);
+  evaluator->SetParameterBuffer(params);
+  evaluator->EvalAsync();
+  evaluator->EvalFinished();
+  EXPECT_EQ((unsigned int)5, *norm->readOnlyHostPtr());
+  expect_1d(pdf_values->hostPtr(), 0, 1, 1.6, 1.6, 0.4, 0.4);
+}
+
+TEST_F(EvalHistMethods, EvaluationOffsetStride) {
+  evaluator->SetEvalPoints(eval_points);
+  evaluator->SetPDFValueBuffer(pdf_values, 3, 2);
+  evaluator->SetNormalizationBuffer(norm, 1);
+  evaluator->SetParameterBuffer(params);
+  norm->writeOnlyHostPtr()[0] = 77;  // detect incorrect writes
+  norm->writeOnlyHostPtr()[1] = 88;
+  norm->writeOnlyHostPtr()[2] = 99;
+  norm->readOnlyDevicePtr();  // force flush to device
+  evaluator->EvalAsync();
+  evaluator->EvalFinished();
+  EXPECT_EQ((unsigned int)77, norm->readOnlyHostPtr()[0]);
+  EXPECT_EQ((unsigned int)5, norm->readOnlyHostPtr()[1]);
+  EXPECT_EQ((unsigned int)99, norm->readOnlyHostPtr()[2]);
+  expect_1d(pdf_values->hostPtr(), 3, 2, 1.6, 1.6, 0.4, 0.4);
+}
+
+TEST_F(EvalHistMethods, CreateHistogram1D) {
+  // ROOT-free CreateHistogram: integral over the domain is 1 (test_pdfz.cpp:128-140)
+  evaluator->SetNormalizationBuffer(norm);
+  evaluator->SetParameterBuffer(params);
+  std::vector<double> h = evaluator->GetNormalizedHistogram();
+  EXPECT_EQ((size_t)2, h.size());
+  ASSERT_FLOAT_EQ(1.0, (h[0] + h[1]) * 0.5);
+  ASSERT_FLOAT_EQ(1.6, h[0]);
+  ASSERT_FLOAT_EQ(0.4, h[1]);
+}
+
+// ------------------------------------------------------------------ test_pdfz_syst.cpp
+struct EvalSystematics : EvalHistMethods {
+  void SetUp() {
+    EvalHistMethods::SetUp();
+    evaluator->SetEvalPoints(eval_points);
+    evaluator->SetPDFValueBuffer(pdf_values);
+    evaluator->SetNormalizationBuffer(norm);
+    evaluator->SetParameterBuffer(params);
+    pars = new hemi::Array<short>(1, true);
+    pars->writeOnlyHostPtr()[0] = 0;
+  }
+  void TearDown() {
+    delete pars;
+    EvalHistMethods::TearDown();
+  }
+  void Run(double p, unsigned expect_norm, double v1, double v2, double v3, double v4) {
+    params->writeOnlyHostPtr()[0] = p;
+    evaluator->EvalAsync();
+    evaluator->EvalFinished();
+    EXPECT_EQ(expect_norm, *norm->readOnlyHostPtr());
+    expect_1d(pdf_values->hostPtr(), 0, 1, v1, v2, v3, v4);
+  }
+  hemi::Array<short>* pars;
+};
+
+TEST_F(EvalSystematics, Shift) {
+  evaluator->AddSystematic(pdfz::ShiftSystematic(0, pars));
+  Run(0.0, 5, 1.6, 1.6, 0.4, 0.4);
+  Run(-0.25, 4, 1.5, 1.5, 0.5, 0.5);
+  Run(0.25, 6, 1.0, 1.0, 1.0, 1.0);
+}
+
+TEST_F(EvalSystematics, Scale) {
+  evaluator->AddSystematic(pdfz::ScaleSystematic(0, pars));
+  Run(0.0, 5, 1.6, 1.6, 0.4, 0.4);
+  Run(-0.1, 6, 5.0 / 3, 5.0 / 3, 1.0 / 3, 1.0 / 3);
+  Run(1.0, 4, 1.0, 1.0, 1.0, 1.0);  // remember scale is 1 + 1.0
+}
+
+struct EvalResolution : EvalSystematics {
+  void SetUp() {
+    EvalHistConstructor::SetUp();
+    nfields = 2;  // observable + a true-energy field fixed at 0.7 (test_pdfz_syst.cpp:168-176)
+    samples = {0.1f, 0.7f, 0.2f, 0.7f, 0.3f, 0.7f, 0.4f, 0.7f, 0.5f, 0.7f, 1.1f, 0.7f, -0.1f, 0.7f};
+    MakeEvaluator();
+    evaluator->SetEvalPoints(eval_points);
+    evaluator->SetPDFValueBuffer(pdf_values);
+    evaluator->SetNormalizationBuffer(norm);
+    evaluator->SetParameterBuffer(params);
+    pars = new hemi::Array<short>(1, true);
+    pars->writeOnlyHostPtr()[0] = 0;
+    evaluator->AddSystematic(pdfz::ResolutionScaleSystematic(0, 1, pars));
+  }
+};
+
+TEST_F(EvalResolution, ZeroNegPos) {
+  Run(0.0, 5, 1.6, 1.6, 0.4, 0.4);
+  Run(-0.30, 7, 2.0 * 5 / 7, 2.0 * 5 / 7, 2.0 * 2 / 7, 2.0 * 2 / 7);
+  Run(0.30, 4, 2.0, 2.0, 0.0, 0.0);
+}
+
+// ------------------------------------------------------------------ test_pdfz_2d.cpp
+struct EvalHist2D {
+  void SetUp() {
+    samples = {0.4f, 10.5f, 0.5f, 11.0f, 0.75f, 11.0f, 0.6f, 11.5f, 0.6f, 11.8f, 0.9f, 11.5f, 0.4f, 12.0f};
+    lower = {0.0, 10.0};
+    upper = {1.0, 12.0};
+    nbins = {2, 3};
+    evaluator = new pdfz::EvalHist(samples, 2, 2, lower, upper, nbins);
+    eval_points = with_dataset({0.2f, 10.2f, 0.7f, 10.4f, 0.5f, 11.0f, 0.25f, 11.8f, 0.9f, 11.9f, 0.3f, 12.0f,
+                                0.3f, 13.0f, 0.3f, 5.0f}, 2);
+    pdf_values = new hemi::Array<float>(40, true);
+    norm = new hemi::Array<unsigned int>(3, true);
+    params = new hemi::Array<double>(5, true);
+    params->writeOnlyHostPtr();
+  }
+  void TearDown() {
+    delete evaluator;
+    delete pdf_values;
+    delete norm;
+    delete params;
+  }
+  std::vector<float> samples, eval_points;
+  std::vector<double> lower, upper;
+  std::vector<int> nbins;
+  pdfz::EvalHist* evaluator;
+  hemi::Array<float>* pdf_values;
+  hemi::Array<unsigned int>* norm;
+  hemi::Array<double>* params;
+};
+
+TEST_F(EvalHist2D, EvaluationOffsetStride) {
+  evaluator->SetEvalPoints(eval_points);
+  evaluator->SetPDFValueBuffer(pdf_values, 3, 2);
+  evaluator->SetNormalizationBuffer(norm, 1);
+  evaluator->SetParameterBuffer(params);
+  norm->writeOnlyHostPtr()[0] = 77;
+  norm->writeOnlyHostPtr()[1] = 88;
+  norm->writeOnlyHostPtr()[2] = 99;
+  norm->readOnlyDevicePtr();
+  evaluator->EvalAsync();
+  evaluator->EvalFinished();
+  EXPECT_EQ((unsigned int)77, norm->readOnlyHostPtr()[0]);
+  EXPECT_EQ((unsigned int)6, norm->readOnlyHostPtr()[1]);
+  EXPECT_EQ((unsigned int)99, norm->readOnlyHostPtr()[2]);
+  const double n = 6 * (0.5 * (2.0 / 3.0));  // samples in boundary * bin area
+  float* r = pdf_values->hostPtr();
+  ASSERT_FLOAT_EQ(1 / n, r[3]);
+  ASSERT_FLOAT_EQ(0 / n, r[5]);
+  ASSERT_FLOAT_EQ(2 / n, r[7]);
+  ASSERT_FLOAT_EQ(0 / n, r[9]);
+  ASSERT_FLOAT_EQ(3 / n, r[11]);
+  ASSERT_TRUE(isnan(r[13]));
+  ASSERT_TRUE(isnan(r[15]));
+  ASSERT_TRUE(isnan(r[17]));
+}
+
+TEST_F(EvalHist2D, CreateHistogram2D) {
+  evaluator->SetNormalizationBuffer(norm);
+  evaluator->SetParameterBuffer(params);
+  std::vector<double> h = evaluator->GetNormalizedHistogram();  // row-major [x][y]
+  const double n = 6 * (0.5 * (2.0 / 3.0));
+  double integral = 0;
+  for (double v : h) integral += v * 0.5 * (2.0 / 3.0);
+  ASSERT_FLOAT_EQ(1.0, integral);
+  ASSERT_FLOAT_EQ(1 / n, h[0 * 3 + 0]);
+  ASSERT_FLOAT_EQ(0 / n, h[1 * 3 + 0]);
+  ASSERT_FLOAT_EQ(2 / n, h[1 * 3 + 1]);
+  ASSERT_FLOAT_EQ(3 / n, h[1 * 3 + 2]);
+}
+
+TEST_F(EvalHist2D, GetSamples) {
+  std::vector<float> sv;
+  evaluator->GetSamples(sv);
+  EXPECT_EQ((size_t)21, sv.size());
+  ASSERT_FLOAT_EQ(0.4, sv[0]);
+  ASSERT_FLOAT_EQ(10.5, sv[1]);
+  ASSERT_FLOAT_EQ(0.0, sv[2]);
+  ASSERT_FLOAT_EQ(12.0, sv[19]);
+}
+
+// ------------------------------------------------------------------ device array semantics (Appendix B)
+TEST(DeviceArray, LazyMirrorSemantics) {
+  hemi::Array<int> a(4, true);
+  EXPECT_EQ((size_t)4, a.size());
+  int* h = a.writeOnlyHostPtr();
+  for (int i = 0; i < 4; i++) h[i] = i + 1;
+  const int* d = a.readOnlyDevicePtr();  // uploads
+  EXPECT_TRUE(d != nullptr);
+  EXPECT_EQ(3, a.readOnlyHostPtr()[2]);  // host still valid, no copy back needed
+  a.ptr();                               // read-write device: host goes stale
+  EXPECT_EQ(4, a.readOnlyHostPtr()[3]);  // copied back from device
+  int src[2] = {7, 8};
+  a.copyFromHost(src, 2);  // re-sizes
+  EXPECT_EQ((size_t)2, a.size());
+  a.readOnlyDevicePtr();
+  EXPECT_EQ(8, a.hostPtr()[1]);
+  hemi::Array<double> z(3, false);  // never written: reads as zeros on both sides
+  z.readOnlyDevicePtr();
+  EXPECT_EQ(0.0, z.readOnlyHostPtr()[1]);
+}
+
+// ------------------------------------------------------------------ NLL launch points + MCMC driver
+static unsigned lcg(unsigned& s) {
+  s = s * 1664525u + 1013904223u;
+  return s;
+}
+static float uni(unsigned& s) { return (lcg(s) >> 8) * (1.0f / 16777216.0f); }
+
+struct SmallFit {
+  // 3 signals, 2 observables + truth + dataset, shift + resolution systematics
+  void SetUp() {
+    unsigned s = 12345;
+    observables.resize(2);
+    observables[0].field_index = 0; observables[0].bins = 12; observables[0].lower = 0; observables[0].upper = 1;
+    observables[1].field_index = 1; observables[1].bins = 9; observables[1].lower = 0; observables[1].upper = 2;
+    systematics.resize(2);
+    systematics[0].name = "shift"; systematics[0].type = pdfz::Systematic::SHIFT;
+    systematics[0].observable_field_index = 1; systematics[0].means = {0.0}; systematics[0].sigmas = {0.05};
+    systematics[0].pidx = {0};
+    systematics[1].name = "res"; systematics[1].type = pdfz::Systematic::RESOLUTION_SCALE;
+    systematics[1].observable_field_index = 0; systematics[1].truth_field_index = 2;
+    systematics[1].means = {0.0}; systematics[1].sigmas = {0.1}; systematics[1].pidx = {1};
+    for (int j = 0; j < 3; j++) {
+      const size_t n = 20000 + 777 * j;
+      std::vector<float> tab(n * 4);
+      for (size_t i = 0; i < n; i++) {
+        const float t = 0.2f + 0.25f * j + 0.3f * uni(s);
+        tab[i * 4 + 0] = t + 0.2f * (uni(s) - 0.5f);
+        tab[i * 4 + 1] = 2.2f * uni(s) - 0.1f;
+        tab[i * 4 + 2] = t;
+        tab[i * 4 + 3] = 0;
+      }
+      sxmc::Signal sig;
+      sig.name = "sig" + std::to_string(j);
+      sig.source = sxmc::Source("src" + std::to_string(j), j, 1.0f, 0.0f, false);
+      sig.nexpected = 100 + 50 * j;
+      sxmc::build_pdfz(sig, tab, 4, observables, systematics);
+      signals.push_back(sig);
+      sources.push_back(sig.source);
+      for (int e = 0; e < 150; e++) {
+        const size_t i = lcg(s) % n;
+        data.push_back(tab[i * 4 + 0]);
+        data.push_back(tab[i * 4 + 1]);
+        data.push_back(0);
+      }
+    }
+  }
+  void TearDown() {
+    for (sxmc::Signal& s : signals) delete s.histogram;
+  }
+  std::vector<sxmc::Source> sources;
+  std::vector<sxmc::Signal> signals;
+  std::vector<sxmc::Systematic> systematics;
+  std::vector<sxmc::Observable> observables;
+  std::vector<float> data;
+};
+
+TEST_F(SmallFit, EfficiencyIsInDomainFraction) {
+  const double eff = sxmc::get_efficiency(signals[0], systematics);
+  EXPECT_TRUE(eff > 0.5 && eff < 1.0);
+  size_t inside = 0;
+  std::vector<float> sv;
+  dynamic_cast<pdfz::EvalHist*>(signals[0].histogram)->GetSamples(sv);
+  for (size_t i = 0; i < sv.size() / 3; i++) {
+    if (sv[3 * i] >= 0 && sv[3 * i] < 1 && sv[3 * i + 1] >= 0 && sv[3 * i + 1] < 2) inside++;
+  }
+  ASSERT_NEAR_REL(eff, (double)inside / signals[0].n_mc, 1e-12);
+}
+
+TEST_F(SmallFit, BatchedAndReferenceFormsWalkTheSameChain) {
+  // debug_mode accepts every step, so the walk depends only on the proposal stream: the batched
+  // form (one fill kernel for all signals, fused lookup + event sum) and the reference's own call
+  // sequence must visit the same points and agree on the NLL to summation-order precision.
+  sxmc::MCMC a(sources, signals, systematics, observables, 99);
+  sxmc::Chain ca = a(data, 40, 0.0f, true, 16);
+  sxmc::MCMC b(sources, signals, systematics, observables, 99);
+  b.reference_form = true;
+  sxmc::Chain cb = b(data, 40, 0.0f, true, 16);
+  EXPECT_EQ((size_t)40, ca.nrows());
+  EXPECT_EQ((size_t)40, cb.nrows());
+  EXPECT_EQ((size_t)40, ca.accepted);
+  EXPECT_EQ((size_t)6, ca.names.size());
+  EXPECT_EQ(std::string("likelihood"), ca.names.back());
+  for (size_t r = 0; r < 40; r++) {
+    for (size_t c = 0; c < 5; c++) EXPECT_EQ(ca.at(r, c), cb.at(r, c));
+    ASSERT_NEAR_REL(ca.at(r, 5), cb.at(r, 5), 1e-6);
+    EXPECT_TRUE(std::isfinite(ca.at(r, 5)));
+  }
+}
+
+TEST_F(SmallFit, MetropolisWalkWithBurnIn) {
+  sxmc::MCMC m(sources, signals, systematics, observables, 7);
+  sxmc::Chain c = m(data, 600, 0.2f, false, 100);
+  // steps before 2 * burnin_steps are dropped when the widths are re-tuned (mcmc.cpp:307-310)
+  EXPECT_EQ((size_t)(600 - 240), c.nrows());
+  EXPECT_TRUE(c.accepted > 10 && c.accepted < 600);
+  double mean_rate0 = 0;
+  for (size_t r = 0; r < c.nrows(); r++) mean_rate0 += c.at(r, 0);
+  mean_rate0 /= c.nrows();
+  EXPECT_TRUE(mean_rate0 > 0.0 && mean_rate0 < 5.0);
+}
+
+TEST(NllLaunch, ReferenceSpelling) {
+  // the launch macro with the reference's argument order (mcmc.cpp:396-414)
+  const size_t ne = 5, ns = 2, np = 2;
+  hemi::Array<float> lut(ne * ns, true);
+  for (size_t i = 0; i < ne * ns; i++) lut.writeOnlyHostPtr()[i] = 0.5f + 0.1f * i;
+  hemi::Array<double> pars(np, true), means(np, true), sigmas(np, true), nexp(ns, true);
+  hemi::Array<unsigned> n_mc(ns, true), norms(ns, true);
+  hemi::Array<short> sid(ns, true);
+  for (size_t j = 0; j < ns; j++) {
+    pars.writeOnlyHostPtr()[j] = 1.0 + j;
+    means.writeOnlyHostPtr()[j] = 1.0;
+    sigmas.writeOnlyHostPtr()[j] = 0.0;
+    nexp.writeOnlyHostPtr()[j] = 10.0 * (j + 1);
+    n_mc.writeOnlyHostPtr()[j] = 1000;
+    norms.writeOnlyHostPtr()[j] = 500;
+    sid.writeOnlyHostPtr()[j] = (short)j;
+  }
+  hemi::Array<double> sums(64 * 256, true), total(1, true), nll(1, true);
+  sums.writeOnlyHostPtr();
+  HEMI_KERNEL_LAUNCH(nll_event_chunks, 64, 256, 0, 0, lut.readOnlyPtr(), pars.readOnlyPtr(), ne, ns,
+                     nexp.readOnlyPtr(), n_mc.readOnlyPtr(), sid.readOnlyPtr(), norms.readOnlyPtr(), sums.ptr());
+  HEMI_KERNEL_LAUNCH(nll_event_reduce, 1, 128, 128 * sizeof(double), 0, (size_t)(64 * 256), sums.ptr(),
+                     total.ptr());
+  HEMI_KERNEL_LAUNCH(nll_total, 1, 1, 0, 0, np, pars.readOnlyPtr(), ns, np, means.readOnlyPtr(),
+                     sigmas.readOnlyPtr(), total.ptr(), nexp.readOnlyPtr(), n_mc.readOnlyPtr(),
+                     sid.readOnlyPtr(), norms.readOnlyPtr(), nll.ptr());
+  double ev = 0;
+  for (size_t i = 0; i < ne; i++) {
+    double s = 0;
+    for (size_t j = 0; j < ns; j++) s += (1.0 + j) * 10.0 * (j + 1) * 0.5f * (0.5f + 0.1f * (j * ne + i));
+    ev += std::log(s);
+  }
+  const double want = -ev + 1.0 * 10.0 * 500 / 1000 + 2.0 * 20.0 * 500 / 1000;
+  ASSERT_NEAR_REL(total.readOnlyHostPtr()[0], ev, 1e-6);
+  ASSERT_NEAR_REL(nll.readOnlyHostPtr()[0], want, 1e-6);
+}
+
+int main(int argc, char** argv) {
+  int ndev = 0;
+  if (sxmc_device_count(&ndev) != SXMC_OK || ndev < 1) {
+    std::printf("no GPU: %s\n", sxmc_last_error());
+    return 2;
+  }
+  return mini::run_all(argc > 1 ? argv[1] : nullptr);
+}
