@@ -206,6 +206,17 @@ def main():
     fill_ms = fill_ms_total / max(nfill, 1)
     achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
 
+    # HBM bytes of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc
+    # passes (tools/profile_on_gpu.sh), corrected as MI355X_MICROARCH.md prescribes, kept per workload
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f).get(w.name)
+        if t and args.scale == 1.0 and args.nsyst < 0:
+            traffic = t["bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+
     result = {
         "metric": "NLL evals/sec (10^8 samples, 3 obs, 12 signals)",
         "value": value,
@@ -233,7 +244,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "fill_kernel (histogram fill, all signals batched)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": fill_ms, "launches_timed": nfill,
             "whole_step_algorithmic_bytes": fill_bytes + ab["event"],
             "whole_step_frac": (fill_bytes + ab["event"]) * value / world / 1e9 / HBM_PEAK_GBS,
