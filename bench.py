@@ -127,7 +127,10 @@ def main():
     ap.add_argument("--workload", default="c3", help="c3 (default, the metric's config), c1, c2, c5, bench_pdfz")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the sample counts (testing only)")
     ap.add_argument("--events", type=int, default=100000)
-    ap.add_argument("--form", default="fused", choices=["fused", "reference"])
+    ap.add_argument("--form", default="fused", choices=["step", "fused", "reference"],
+                    help="fused (default): zero, fill, lookup+event sum, step end = 4 launches; step: the last two "
+                         "merged (measured slower: every workgroup pays a release + ticket); reference: the "
+                         "reference's own sequence with the lut re-read")
     ap.add_argument("--launch", default="0,0", help="bin_threads,bin_blocks_per_cu (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=2)
@@ -168,7 +171,7 @@ def main():
     want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1
     host_tables = [t.cpu().numpy() for t in tensors] if want_cpu else None
 
-    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=(args.form == "fused"), samples_on_device=tensors)
+    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused={"step": "step", "fused": True, "reference": False}[args.form], samples_on_device=tensors)
     del tensors
     torch.cuda.empty_cache()
     threads, bpc = (int(x) for x in args.launch.split(","))

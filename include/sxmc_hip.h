@@ -168,6 +168,19 @@ int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s,
                               const double* d_pars, const double* d_nexpected,
                               const unsigned* d_n_mc, const short* d_source_id,
                               const unsigned* d_norms, double* d_sums, int* npartial_out);
+/* EXPERIMENTAL (measured ~3% slower per step than sxmc_group_eval_nll_async + finish_nll_jump_pick_combo at
+ * E = 1e5: every workgroup pays an agent-scope release and a ticket on one counter).
+ * One whole MCMC step (mcmc.cpp:264-271 + 314-348) as three launches: zero, fill of all members, and
+ * one kernel doing lookup + nll_event_chunks + finish_nll_jump_pick_combo (the workgroup that finishes
+ * its event partial sum last also runs the step end).  The NLL is evaluated at d_v_proposed, which is
+ * also the members' parameter buffer in an MCMC walk (mcmc.cpp:241).  Arguments as
+ * finish_nll_jump_pick_combo (nll_kernels.h:190-207) without the partial-sum buffer. */
+int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means, const double* d_sigmas,
+                               sxmc_rng_state* d_rng, double* d_nll_current, double* d_nll_proposed,
+                               double* d_v_current, double* d_v_proposed, int* d_accepted, int* d_counter,
+                               float* d_jump_buffer, int nparameters, size_t nsources,
+                               const float* d_jump_width, const double* d_nexpected, const unsigned* d_n_mc,
+                               const short* d_source_id, const unsigned* d_norms, int debug_mode);
 int sxmc_group_synchronize(sxmc_group_t g);
 /* Live timing of the dominant kernel (the histogram fill) with HIP events on the stream it is
  * launched on.  enable!=0 starts recording (at most `capacity` launches are kept). */

@@ -16,9 +16,10 @@
 // -ffp-contract=off plus the pragma below), in the reference's operation order, so bin
 // indices are bit-identical to the reference CPU loop.  x^i is formed by repeated
 // multiplication (exact for i <= 1, correctly rounded for i == 2).
-#include "sxmc_device.h"
+#include "nll_device.h"
 
 #include <type_traits>
+#include <utility>
 
 #pragma clang fp contract(off)
 
@@ -46,7 +47,7 @@ __device__ __forceinline__ double uniform_d(double x) {
 
 // ------------------------------------------------------------------------------------ zero
 // bins <- 0, norm <- 0 for every member (blockIdx.y = member).
-__global__ __launch_bounds__(256) void zero_kernel(const SxSignalDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256) void zero_kernel(const SxSignalDesc* __restrict__ descs, unsigned* ticket) {
   const SxSignalDesc& d = descs[blockIdx.y];
   unsigned* bins = d.bins;
   const unsigned n = (unsigned)d.total_nbins;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void zero_kernel(const SxSignalDesc* __restric
   if (blockIdx.x == 0) {
     if (threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
     if (threadIdx.x == 0) *d.norm = 0u;
+    if (threadIdx.x == 0 && blockIdx.y == 0 && ticket) *ticket = 0u;  // arrival counter of the fused step end
   }
 }
 
@@ -559,16 +561,15 @@ struct EvalMember {
   double coef;  // pars[sid] * nexpected * eff, the event-independent factor of nll_kernels.cpp:107
 };
 
-__global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
-                                                       unsigned long long npoints,
-                                                       const double* __restrict__ pars,
-                                                       const double* __restrict__ nexpected,
-                                                       const unsigned* __restrict__ n_mc,
-                                                       const short* __restrict__ source_id,
-                                                       const unsigned* __restrict__ norms,
-                                                       double* __restrict__ sums) {
-  extern __shared__ double sh[];  // [16] wave sums, then nsig EvalMember records
-  double* s_wave = sh;
+// Body shared by eval_nll_kernel and eval_nll_finish_kernel: returns the workgroup's partial event sum
+// (valid in thread 0).
+__device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                 unsigned long long npoints, const double* __restrict__ pars,
+                                                 const double* __restrict__ nexpected,
+                                                 const unsigned* __restrict__ n_mc,
+                                                 const short* __restrict__ source_id,
+                                                 const unsigned* __restrict__ norms, double* sh) {
+  double* s_wave = sh;  // [16] wave sums, then nsig EvalMember records
   EvalMember* s_mem = reinterpret_cast<EvalMember*>(sh + 16);
   for (int j = threadIdx.x; j < nsig; j += blockDim.x) {
     const SxSignalDesc& d = descs[j];
@@ -615,11 +616,57 @@ __global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __res
   const int wave = threadIdx.x / kWave;
   if ((threadIdx.x & (kWave - 1)) == 0) s_wave[wave] = sum;
   __syncthreads();
+  double t = 0.0;
   if (threadIdx.x == 0) {
-    double t = 0.0;
     for (int w = 0; w < (int)(blockDim.x / kWave); w++) t += s_wave[w];
-    if (!isnan(t)) sums[blockIdx.x] = t;
   }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                       unsigned long long npoints,
+                                                       const double* __restrict__ pars,
+                                                       const double* __restrict__ nexpected,
+                                                       const unsigned* __restrict__ n_mc,
+                                                       const short* __restrict__ source_id,
+                                                       const unsigned* __restrict__ norms,
+                                                       double* __restrict__ sums) {
+  extern __shared__ double sh[];
+  const double t = eval_nll_block(descs, nsig, npoints, pars, nexpected, n_mc, source_id, norms, sh);
+  if (threadIdx.x == 0 && !isnan(t)) sums[blockIdx.x] = t;
+}
+
+// The whole end of an MCMC step in one launch: lookup + event partial sums as above, and the
+// workgroup that arrives LAST (a ticket counter, no waiting, so no co-residency assumption) also runs
+// finish_nll_jump_pick_combo.  Hand-off of the partial sums follows the agent-scope release/acquire
+// recipe for gfx950: partial stored, drained and released by lane 0 before its ticket; the last arriver
+// acquires (invalidating its CU's L1) before any of its lanes read the partials.
+__global__ __launch_bounds__(256) void eval_nll_finish_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                              unsigned long long npoints, double* sums,
+                                                              unsigned* ticket, SxStepArgs a) {
+  extern __shared__ double sh[];
+  const double t = eval_nll_block(descs, nsig, npoints, a.v_proposed, a.nexpected, a.n_mc, a.source_id, a.norms, sh);
+  int* s_last = reinterpret_cast<int*>(sh + 15);  // last wave-sum slot: at most 4 waves are in use
+  if (threadIdx.x == 0) {
+    sums[blockIdx.x] = isnan(t) ? 0.0 : t;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = arrived == gridDim.x - 1u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_last = last;
+  }
+  __syncthreads();
+  if (!*s_last) return;
+  __syncthreads();
+  sxdev::finish_step_device(gridDim.x, sums, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                            a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                            a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
+                            a.debug_mode != 0);
 }
 
 // ------------------------------------------------------------------------------------ layout
@@ -757,12 +804,12 @@ hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, co
   return hipGetLastError();
 }
 
-hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, hipStream_t s) {
+hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s) {
   if (nsig == 0) return hipSuccess;
   int bx = (max_bins / 4 + 255) / 256;
   if (bx < 1) bx = 1;
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(zero_kernel, dim3(bx, nsig), dim3(256), 0, s, d_descs);
+  hipLaunchKernelGGL(zero_kernel, dim3(bx, nsig), dim3(256), 0, s, d_descs, ticket);
   return hipGetLastError();
 }
 
@@ -782,6 +829,14 @@ hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned lo
   const size_t shmem = 16 * sizeof(double) + (size_t)nsig * sizeof(EvalMember);
   hipLaunchKernelGGL(eval_nll_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, pars,
                      nexpected, n_mc, source_id, norms, sums);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints, double* sums,
+                                      unsigned* ticket, const SxStepArgs& a, int grid, int block, hipStream_t s) {
+  const size_t shmem = 16 * sizeof(double) + (size_t)nsig * sizeof(EvalMember);
+  hipLaunchKernelGGL(eval_nll_finish_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, sums,
+                     ticket, a);
   return hipGetLastError();
 }
 

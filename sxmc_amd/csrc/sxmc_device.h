@@ -67,6 +67,28 @@ struct SxSegment {
   unsigned long long v0, v1, step;
 };
 
+// Arguments of finish_nll_jump_pick_combo (nll_kernels.h:190-207) for the fused step end.
+struct SxStepArgs {
+  size_t nsignals, nsources;
+  const double* means;
+  const double* sigmas;
+  sxmc_rng_state* rng;
+  double* nll_current;
+  double* nll_proposed;
+  double* v_current;
+  double* v_proposed;
+  int* accepted;
+  int* counter;
+  float* jump_buffer;
+  int nparameters;
+  int debug_mode;
+  const float* jump_width;
+  const double* nexpected;
+  const unsigned* n_mc;
+  const short* source_id;
+  const unsigned* norms;
+};
+
 // Host-callable launchers implemented in the .hip files -------------------------------------
 struct SxLaunchShape {
   int nobs;
@@ -79,7 +101,9 @@ struct SxLaunchShape {
   int static_prog;  // index into the static program table, or -1: decode the program at run time
 };
 
-hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, hipStream_t s);
+hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
+hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints, double* sums,
+                                      unsigned* ticket, const SxStepArgs& a, int grid, int block, hipStream_t s);
 hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,
                           const unsigned* d_blk_off, hipStream_t s);
 bool sx_fill_has_specialization(int nobs, int nslot);

@@ -232,6 +232,8 @@ struct sxmc_group {
   bool same_points = false;
   hipStream_t last_stream = nullptr;
   bool built = false;
+  unsigned* d_ticket = nullptr;  // arrival counter of the fused step end, zeroed by the zero kernel
+  double* d_step_sums = nullptr; // 1024 partial sums of the fused step
   // profiling of the fill kernel
   bool prof = false;
   std::vector<hipEvent_t> ev0, ev1;
@@ -436,7 +438,7 @@ int group_check_bound(sxmc_group* g, bool need_pdf) {
 }
 
 int group_fill(sxmc_group* g, hipStream_t s) {
-  SX_HIP(sx_launch_zero(g->d_descs, (int)g->members.size(), g->max_bins, s));
+  SX_HIP(sx_launch_zero(g->d_descs, (int)g->members.size(), g->max_bins, g->d_ticket, s));
   for (LaunchClass& c : g->classes) {
     const bool rec = g->prof && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
@@ -874,6 +876,14 @@ int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* ou
   for (int i = 0; i < nmembers; i++) SX_REQUIRE(members[i], "null member");
   sxmc_group* g = new sxmc_group;
   g->members.assign(members, members + nmembers);
+  hipError_t e = hipMalloc((void**)&g->d_ticket, 256);
+  if (e == hipSuccess) e = hipMemset(g->d_ticket, 0, 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&g->d_step_sums, 1024 * sizeof(double));
+  if (e != hipSuccess) {
+    if (g->d_ticket) (void)hipFree(g->d_ticket);
+    delete g;
+    return fail(SXMC_ERR_HIP, std::string("group allocation: ") + hipGetErrorString(e));
+  }
   *out = g;
   return SXMC_OK;
 }
@@ -883,6 +893,8 @@ int sxmc_group_destroy(sxmc_group_t g) {
   (void)hipDeviceSynchronize();
   for (LaunchClass& c : g->classes) free_class(c);
   if (g->d_descs) (void)hipFree(g->d_descs);
+  if (g->d_ticket) (void)hipFree(g->d_ticket);
+  if (g->d_step_sums) (void)hipFree(g->d_step_sums);
   for (hipEvent_t e : g->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : g->ev1) (void)hipEventDestroy(e);
   delete g;
@@ -950,6 +962,55 @@ int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s, const double* d_p
   SX_HIP(sx_launch_eval_nll(g->d_descs, (int)g->members.size(), ne, d_pars, d_nexpected, d_n_mc, d_source_id,
                             d_norms, d_sums, grid, block, st));
   *npartial_out = grid;
+  return SXMC_OK;
+}
+
+int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means, const double* d_sigmas,
+                               sxmc_rng_state* d_rng, double* d_nll_current, double* d_nll_proposed,
+                               double* d_v_current, double* d_v_proposed, int* d_accepted, int* d_counter,
+                               float* d_jump_buffer, int nparameters, size_t nsources, const float* d_jump_width,
+                               const double* d_nexpected, const unsigned* d_n_mc, const short* d_source_id,
+                               const unsigned* d_norms, int debug_mode) {
+  SX_REQUIRE(g && d_means && d_sigmas && d_rng && d_nll_current && d_nll_proposed && d_v_current && d_v_proposed &&
+                 d_accepted && d_counter && d_jump_buffer && d_jump_width && d_nexpected && d_n_mc && d_source_id &&
+                 d_norms,
+             "null argument");
+  SX_REQUIRE(nparameters > 0, "nparameters must be positive");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  rc = group_check_bound(g, true);
+  if (rc) return rc;
+  if (!g->same_points) return fail(SXMC_ERR_STATE, "members do not share one set of evaluation points");
+  SX_REQUIRE(g->members.size() <= 1024, "too many members for the fused step");
+  hipStream_t st = (hipStream_t)s;
+  g->last_stream = st;
+  rc = group_fill(g, st);  // zero (also clears the ticket) + fill
+  if (rc) return rc;
+  const unsigned long long ne = g->members[0]->npoints;
+  const int block = 128;
+  const int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
+  SxStepArgs a;
+  a.nsignals = g->members.size();
+  a.nsources = nsources;
+  a.means = d_means;
+  a.sigmas = d_sigmas;
+  a.rng = d_rng;
+  a.nll_current = d_nll_current;
+  a.nll_proposed = d_nll_proposed;
+  a.v_current = d_v_current;
+  a.v_proposed = d_v_proposed;
+  a.accepted = d_accepted;
+  a.counter = d_counter;
+  a.jump_buffer = d_jump_buffer;
+  a.nparameters = nparameters;
+  a.debug_mode = debug_mode;
+  a.jump_width = d_jump_width;
+  a.nexpected = d_nexpected;
+  a.n_mc = d_n_mc;
+  a.source_id = d_source_id;
+  a.norms = d_norms;
+  SX_HIP(sx_launch_eval_nll_finish(g->d_descs, (int)g->members.size(), ne, g->d_step_sums, g->d_ticket, a, grid,
+                                   block, st));
   return SXMC_OK;
 }
 

@@ -5,8 +5,8 @@
 // What it does per step (mcmc.cpp:261-348): re-evaluate every signal's PDF at the proposed vector
 // (when systematics float), event log-sum, then the fused reduce + nll_total + Metropolis + next
 // proposal.  Here the S evaluators are stepped as ONE batched launch sequence through
-// sxmc_group_eval_nll_async (fill of all signals in one kernel, lookup fused with the event sum) --
-// 4 launches per step instead of the reference's 3*S + 2.  `reference_form = true` issues the
+// sxmc_group_eval_nll_async (zero; fill of all signals in one kernel; lookup fused with the event sum)
+// followed by the fused step end -- 4 launches per step instead of the reference's 3*S + 2.  `reference_form = true` issues the
 // reference's own sequence of entry points instead (per-evaluator EvalAsync/EvalFinished,
 // nll_event_chunks, finish_nll_jump_pick_combo); both forms give the same numbers up to the
 // summation order of the event partial sums.
@@ -214,6 +214,7 @@ class MCMC {
 
       int npartial = (int)nnllthreads;
       if (batched && reevaluate) {
+        // zero, fill of all signals in one kernel, lookup fused with the event partial sums
         check(sxmc_group_eval_nll_async(group, nullptr, proposed_vector.readOnlyPtr(), nexpected->readOnlyPtr(),
                                         n_mc->readOnlyPtr(), source_id->readOnlyPtr(),
                                         normalizations.ptr(), event_partial_sums.ptr(), &npartial));

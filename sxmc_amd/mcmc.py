@@ -6,7 +6,8 @@ forms are offered:
   * reference form   -- group.EvalAsync (zero, fill, lookup) ; nll_event_chunks ;
                         finish_nll_jump_pick_combo      (4 kernels, lut written and re-read)
   * fused form       -- group.EvalNllAsync (zero, fill, lookup+event sum) ;
-                        finish_nll_jump_pick_combo      (3 kernels)
+                        finish_nll_jump_pick_combo      (4 kernels, lut written, not re-read)
+  * step form        -- group.McmcStepAsync: zero, fill, lookup + event sum + step end (3 kernels)
 Both produce the same numbers up to the order of the partial sums.
 """
 import numpy as np
@@ -135,6 +136,13 @@ class MCMC:
     def step(self, debug_mode=False):
         """One pass of the hot path = one NLL evaluation at the proposed vector + the fused
         accept/reject/propose (mcmc.cpp:264-271, 314-348).  Asynchronous."""
+        if self.fused == "step":
+            self.group.McmcStepAsync(self.stream, self.parameter_means, self.parameter_sigma, self.rngs,
+                                     self.current_nll, self.proposed_nll, self.current_vector,
+                                     self.proposed_vector, self.accept_counter, self.jump_counter,
+                                     self.jump_buffer, self.nparameters, self.nsources, self.jump_width,
+                                     self.nexpected, self.n_mc, self.source_id, self.normalizations, debug_mode)
+            return
         if self.fused:
             npartial = self.group.EvalNllAsync(self.stream, self.proposed_vector, self.nexpected, self.n_mc,
                                                self.source_id, self.normalizations, self.event_partial_sums)

@@ -92,6 +92,15 @@ class EvalGroup:
                   ptr(source_id), ptr(norms), ptr(sums), C.byref(n))
         return n.value
 
+    def McmcStepAsync(self, stream, means, sigmas, rng, nll_current, nll_proposed, v_current, v_proposed,
+                      accepted, counter, jump_buffer, nparameters, nsources, jump_width, nexpected, n_mc,
+                      source_id, norms, debug_mode=False):
+        """One whole MCMC step in three launches (zero, fill, lookup + event sum + step end)."""
+        capi.call("sxmc_group_mcmc_step_async", self._g, ptr(stream), ptr(means), ptr(sigmas), ptr(rng),
+                  ptr(nll_current), ptr(nll_proposed), ptr(v_current), ptr(v_proposed), ptr(accepted),
+                  ptr(counter), ptr(jump_buffer), int(nparameters), int(nsources), ptr(jump_width),
+                  ptr(nexpected), ptr(n_mc), ptr(source_id), ptr(norms), int(bool(debug_mode)))
+
     def EvalFinished(self):
         capi.call("sxmc_group_synchronize", self._g)
 

@@ -217,7 +217,7 @@ def oracle_nll_of_workload(w, vector):
 
 @pytest.mark.parametrize("make,scale,nevents", [(workloads.config1, 1.0, None), (workloads.config2, 0.02, 5000),
                                                 (workloads.config3, 0.004, 5000), (workloads.bench_pdfz, 0.03, 4000)])
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "step"])
 def test_mcmc_step_matches_oracle_on_baseline_shapes(make, scale, nevents, fused):
     w = make(scale) if nevents is None else make(scale, nevents=nevents)
     m = MCMC(w, seed=99, fused=fused)
@@ -249,9 +249,25 @@ def test_mcmc_step_matches_oracle_on_baseline_shapes(make, scale, nevents, fused
 
 def test_free_chain_runs_and_accepts_some():
     w = workloads.config3(0.002, nevents=2000)
-    m = MCMC(w, seed=5, fused=True)
+    m = MCMC(w, seed=5, fused="step")
     m.setup(sync_interval=64)
     chain, acc = m.run(128)
     assert chain.shape == (128, w.nparameters + 1)
     assert 0 < acc < 128
     assert np.all(np.isfinite(chain))
+
+
+def test_step_forms_walk_the_same_chain():
+    """Same seed => same proposals and uniforms: the three step forms must accept the same steps and
+    store the same chain (NLL equal to summation-order precision, compared as stored floats)."""
+    w = workloads.config3(0.003, nevents=3000)
+    chains = []
+    for form in (False, True, "step"):
+        m = MCMC(w, seed=11, fused=form)
+        m.setup(sync_interval=64)
+        chain, acc = m.run(64)
+        chains.append((chain, acc))
+    for chain, acc in chains[1:]:
+        assert acc == chains[0][1]
+        assert np.array_equal(chain[:, :-1], chains[0][0][:, :-1])
+        assert np.allclose(chain[:, -1], chains[0][0][:, -1], rtol=1e-6, atol=0)
