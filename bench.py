@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--cpu-evals", type=int, default=2)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
+    ap.add_argument("--no-prebin", action="store_true", help="bin every observable in the kernel (no pre-binned column)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
     ap.add_argument("--debug-mode", type=int, default=0,
                     help="roofline measurement hook (wrong results): 1 stream only, 2 compute only, 4 no histogram")
@@ -177,6 +178,7 @@ def main():
     threads, bpc = (int(x) for x in args.launch.split(","))
     m.group.SetLaunchConfig(threads, bpc)
     m.group.SetPartition(args.partition)
+    m.group.SetPrebinning(not args.no_prebin)
     if args.debug_mode:
         want_cpu = False
     m.setup(sync_interval=max(args.steps, args.warmup, 1))
@@ -237,7 +239,7 @@ def main():
             "workload": "%s: %s" % (w.name, w.description),
             "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
             "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
-            "step_form": args.form, "debug_mode": args.debug_mode, "partition": args.partition, "launch": args.launch, "scale": args.scale,
+            "step_form": args.form, "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,
             "experiments_per_sec_at_1e5_steps": value / 1e5,

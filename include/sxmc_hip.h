@@ -153,6 +153,11 @@ int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks
  * contiguous slice of the concatenated members), 2 = interleaved (each member's workgroups stride
  * through it chunk by chunk, like a grid-stride copy). */
 int sxmc_group_set_partition(sxmc_group_t g, int mode);
+/* Pre-binning (default on): an observable that no systematic writes has the same bin index at every
+ * evaluation, so for launches that run a static program the evaluators build, once, a 1- or 2-byte column
+ * with the partial flat index of those observables and the fill streams it instead of their float
+ * columns.  Results are identical; sxmc_group_algorithmic_bytes counts the bytes actually needed. */
+int sxmc_group_set_prebinning(sxmc_group_t g, int enable);
 /* Measurement hook for roofline analysis (RESULTS ARE WRONG when mode != 0; default 0):
  * bit 0 = histogram-fill kernel streams its columns but skips arithmetic and histogram,
  * bit 1 = arithmetic and histogram run but every reload hits one cached address,

@@ -175,10 +175,13 @@ template <unsigned... OPS>
 struct StaticProg {
   static constexpr bool dynamic = false;
   static constexpr int n = (int)sizeof...(OPS);
+  // bit k set: some systematic writes slot k (its value changes from evaluation to evaluation)
+  static constexpr unsigned touched = (0u | ... | (1u << ((OPS >> 4) & 15u)));
 };
 struct DynamicProg {
   static constexpr bool dynamic = true;
   static constexpr int n = 0;
+  static constexpr unsigned touched = ~0u;
 };
 
 template <int NSLOT, unsigned OPC>
@@ -202,21 +205,57 @@ __device__ __forceinline__ void run_static(double (&f)[NSLOT][SXMC_VEC], const d
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load per lane
 
-template <int NSLOT>
+// PRE-BINNING.  An observable that no systematic writes has the same value, hence the same bin index
+// and the same in/out-of-domain status, at every evaluation.  For static programs the host builds, once,
+// a narrow column holding sum_k idx_k * stride_k over those observables (all ones = outside the domain)
+// with exactly the arithmetic below, and the fill streams that column (PREW = 1, 2 or 4 bytes per
+// sample) instead of the float columns it replaces.  PREW = 0: every observable is read and binned here.
+template <int PREW> struct PreVec { typedef unsigned type; };
+template <> struct PreVec<2> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+template <> struct PreVec<4> { typedef unsigned type __attribute__((ext_vector_type(4))); };
+
+template <int NSLOT, int PREW>
 struct Columns {
   vfloat4 v[NSLOT];
+  typename PreVec<PREW>::type pre;
 };
 
-template <int NSLOT>
-__device__ __forceinline__ void load_columns(Columns<NSLOT>& c, const gptr<const vfloat4> (&col)[NSLOT],
-                                             unsigned long long v) {
+// slot k is streamed unless it is an observable that the pre-binned column covers
+template <int NOBS, int PREW, typename PROG>
+constexpr bool slot_loaded(int k) {
+  return PREW == 0 || k >= NOBS || ((PROG::touched >> k) & 1u);
+}
+
+template <int PREW>
+__device__ __forceinline__ unsigned pre_value(const typename PreVec<PREW>::type& p, int q) {
+  if constexpr (PREW == 1) return (p >> (8 * q)) & 0xFFu;
+  if constexpr (PREW == 2) return (p[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+  if constexpr (PREW == 4) return p[q];
+  return 0u;
+}
+template <int PREW>
+constexpr unsigned pre_sentinel() {
+  return PREW == 1 ? 0xFFu : PREW == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+}
+
+template <int NOBS, int NSLOT, int PREW, typename PROG>
+__device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr<const vfloat4> (&col)[NSLOT],
+                                             gptr<const typename PreVec<PREW>::type> pre, unsigned long long v) {
   // Issue order is pinned (sched_barrier): the wait-counter bookkeeping at the loop header merges
   // the prologue's and the steady state's load order, and only identical orders give counted
-  // waits (vmcnt(NSLOT)) instead of a full drain.
+  // waits (vmcnt(#loads)) instead of a full drain.
 #pragma unroll
   for (int k = 0; k < NSLOT; k++) {
-    // streamed once per evaluation and far larger than the caches: nontemporal (+3% measured)
-    c.v[k] = __builtin_nontemporal_load(&col[k][v]);
+    if constexpr (true) {
+      if (slot_loaded<NOBS, PREW, PROG>(k)) {
+        // streamed once per evaluation and far larger than the caches: nontemporal (+3% measured)
+        c.v[k] = __builtin_nontemporal_load(&col[k][v]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if constexpr (PREW != 0) {
+    c.pre = __builtin_nontemporal_load(&pre[v]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -231,7 +270,7 @@ __device__ __forceinline__ void load_columns(Columns<NSLOT>& c, const gptr<const
 // = largest member), then 64 "trash" words, one per lane: a sample that is outside the domain
 // adds to its lane's trash word instead of being branched around, so the whole per-sample path
 // is unpredicated vector code (no exec-mask juggling on the scalar unit).
-template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG>
+template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>
 __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restrict__ descs,
                                                     const SxSegment* __restrict__ segs,
                                                     const unsigned* __restrict__ blk_off,
@@ -282,6 +321,8 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     for (int k = 0; k < NSLOT; k++) {
       col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
     }
+    gptr<const typename PreVec<PREW>::type> precol =
+        to_global(reinterpret_cast<const typename PreVec<PREW>::type*>(d.pre));
 
     // ---- the member's systematics: coefficients (and, for the dynamic program, the op words)
     // into lane-indexed registers
@@ -303,35 +344,44 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     // compute.  Loads are unconditional (index clamped into the slice) so the wait counters stay
     // exact; lanes past the end of the slice are treated like out-of-domain samples.
     const unsigned long long vlast = v1 - 1;
-    auto stage = [&](Columns<NSLOT>& buf, const unsigned long long vc) {
+    auto stage = [&](Columns<NSLOT, PREW>& buf, const unsigned long long vc) {
       double f[NSLOT][SXMC_VEC];
 #pragma unroll
       for (int k = 0; k < NSLOT; k++) {
-        f[k][0] = (double)buf.v[k].x;
-        f[k][1] = (double)buf.v[k].y;
-        f[k][2] = (double)buf.v[k].z;
-        f[k][3] = (double)buf.v[k].w;
+        if (slot_loaded<NOBS, PREW, PROG>(k)) {
+          f[k][0] = (double)buf.v[k].x;
+          f[k][1] = (double)buf.v[k].y;
+          f[k][2] = (double)buf.v[k].z;
+          f[k][3] = (double)buf.v[k].w;
+        } else {
+          f[k][0] = f[k][1] = f[k][2] = f[k][3] = 0.0;
+        }
       }
+      typename PreVec<PREW>::type prebits = buf.pre;
       // Pin every widening BEFORE the buffer is re-loaded: if the compiler sinks one of them
       // below, that column's registers stay live across the reload, the reload lands in fresh
       // registers and the loop latch copies them back behind a vmcnt(0) that drains the ring.
 #pragma unroll
       for (int k = 0; k < NSLOT; k++) {
+        if (slot_loaded<NOBS, PREW, PROG>(k)) {
 #pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f[k][q]));
+          for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f[k][q]));
+        }
       }
+      if constexpr (PREW != 0) asm volatile("" : "+v"(prebits));
       // dbg is a measurement hook (sxmc_group_set_debug_mode), 0 in production:
       //   bit 1: every reload hits one cached address -> the kernel without its HBM stream
       //   bit 0: skip the arithmetic and the histogram -> the HBM stream alone
       //   bit 2: skip only the histogram update
       const unsigned long long vl = vc + 2ull * step;
-      load_columns<NSLOT>(buf, col, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
+      load_columns<NOBS, NSLOT, PREW, PROG>(buf, col, precol, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
       if (dbg & 1u) {
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) cnt += (f[k][q] == 12345.678) ? 1u : 0u;
         }
+        if constexpr (PREW != 0) cnt += (pre_value<PREW>(prebits, 0) == 12345u) ? 1u : 0u;
         return;
       }
 
@@ -351,8 +401,14 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
         // add-with-carry, nothing on the scalar unit); the tests are written so that NaN fails.
         unsigned bad = dead;
         int bin = 0;
+        if constexpr (PREW != 0) {
+          const unsigned pv = pre_value<PREW>(prebits, q);
+          bad += (pv == pre_sentinel<PREW>()) ? 1u : 0u;
+          bin = (int)pv;
+        }
 #pragma unroll
         for (int k = 0; k < NOBS; k++) {
+          if (!slot_loaded<NOBS, PREW, PROG>(k)) continue;  // covered by the pre-binned column
           const double x = f[k][q];
           bad += !(x >= lo[k]) ? 1u : 0u;
           bad += !(x < hi[k]) ? 1u : 0u;
@@ -383,9 +439,9 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     // wave-uniform trip count: every lane runs the same number of stage pairs
     unsigned long long v = v0 + tid;
     const unsigned long long npairs = (v1 - v0 + 2ull * step - 1) / (2ull * step);
-    Columns<NSLOT> bufA, bufB;
-    load_columns<NSLOT>(bufA, col, v < v1 ? v : vlast);
-    load_columns<NSLOT>(bufB, col, v + step < v1 ? v + step : vlast);
+    Columns<NSLOT, PREW> bufA, bufB;
+    load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, v < v1 ? v : vlast);
+    load_columns<NOBS, NSLOT, PREW, PROG>(bufB, col, precol, v + step < v1 ? v + step : vlast);
     for (unsigned long long it = 0; it < npairs; ++it, v += 2ull * step) {
       stage(bufA, v);
       stage(bufB, v + step);
@@ -669,6 +725,35 @@ __global__ __launch_bounds__(256) void eval_nll_finish_kernel(const SxSignalDesc
                             a.debug_mode != 0);
 }
 
+// ------------------------------------------------------------------------------------ pre-binning
+// Builds the pre-binned column of one evaluator: for every sample, sum_k idx_k * stride_k over the
+// observables in `mask` with the fill kernel's arithmetic (pdfz.cpp:388-398), or all ones when one of
+// them is outside its domain (NaN included) or the row is padding.  width = bytes per sample.
+__global__ __launch_bounds__(256) void prebin_kernel(const SxSignalDesc* __restrict__ dp, unsigned mask, int width,
+                                                     void* out) {
+  const SxSignalDesc& d = *dp;
+  const unsigned long long npad = d.nvec * SXMC_VEC;
+  const unsigned sentinel = width == 1 ? 0xFFu : width == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += step) {
+    unsigned val = sentinel;
+    if (i < d.nsamples) {
+      bool ok = true;
+      int part = 0;
+      for (int k = 0; k < d.nobs; k++) {
+        if (!((mask >> k) & 1u)) continue;
+        const double x = (double)to_global(d.cols)[(unsigned long long)k * d.col_pitch + i];
+        ok = ok && (x >= d.lower[k]) && (x < d.upper[k]);
+        part += (int)((x - d.lower[k]) * d.scale[k]) * d.bin_stride[k];
+      }
+      if (ok) val = (unsigned)part;
+    }
+    if (width == 1) static_cast<unsigned char*>(out)[i] = (unsigned char)val;
+    else if (width == 2) static_cast<unsigned short*>(out)[i] = (unsigned short)val;
+    else static_cast<unsigned*>(out)[i] = val;
+  }
+}
+
 // ------------------------------------------------------------------------------------ layout
 // Row-major [n][F] -> column-major with pitch; pads [n, nvec*4) with NaN in every column.
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ aos, float* __restrict__ cols,
@@ -694,10 +779,10 @@ __global__ __launch_bounds__(256) void untranspose_obs_kernel(const float* __res
   }
 }
 
-template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG>
+template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW = 0>
 hipError_t launch_fill_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                          const unsigned* blk_off, hipStream_t s) {
-  auto k = fill_kernel<NOBS, NSLOT, LDS_HIST, PROG>;
+  auto k = fill_kernel<NOBS, NSLOT, LDS_HIST, PROG, PREW>;
   if (LDS_HIST && sh.lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
@@ -718,35 +803,40 @@ typedef hipError_t (*FillLauncher)(const SxLaunchShape&, const SxSignalDesc*, co
 struct StaticEntry {
   int nobs, nslot, nops;
   unsigned ops[4];
-  FillLauncher fn;
+  FillLauncher fn;         // all observables binned in the kernel
+  FillLauncher fn_pre[2];  // observables no systematic writes come pre-binned, 1 / 2 bytes per sample (with an
+                           // LDS-sized histogram the partial index of the table's programs is below 65535)
 };
 #define SX_SHIFT(o) sx_op(SXMC_SYST_SHIFT, o)
 #define SX_SCALE(o) sx_op(SXMC_SYST_SCALE, o)
 #define SX_CTSC(o) sx_op(SXMC_SYST_CTSCALE, o)
 #define SX_RES(o, e) sx_op(SXMC_SYST_RESOLUTION_SCALE, o, e)
-#define SX_P1(NO, NS, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>}
-#define SX_P2(NO, NS, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>}
-#define SX_P3(NO, NS, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>}
+#define SX_NOPRE {nullptr, nullptr}
+#define SX_PRE(NO, NS, ...) \
+  {launch_fill_k<NO, NS, true, StaticProg<__VA_ARGS__>, 1>, launch_fill_k<NO, NS, true, StaticProg<__VA_ARGS__>, 2>}
+#define SX_P1(NO, NS, PRE, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE}
+#define SX_P2(NO, NS, PRE, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE}
+#define SX_P3(NO, NS, PRE, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE}
 const StaticEntry kStaticPrograms[] = {
     // 1-D (bench_sxmc pdfz: one shift; config/example.json: scale + resolution_scale)
-    SX_P1(1, 1, SX_SHIFT(0)),
-    SX_P1(1, 1, SX_SCALE(0)),
-    SX_P2(1, 1, SX_SHIFT(0), SX_SCALE(0)),
-    SX_P1(1, 2, SX_RES(0, 1)),
-    SX_P2(1, 2, SX_SCALE(0), SX_RES(0, 1)),
-    SX_P3(1, 2, SX_SHIFT(0), SX_SCALE(0), SX_RES(0, 1)),
+    SX_P1(1, 1, SX_NOPRE, SX_SHIFT(0)),
+    SX_P1(1, 1, SX_NOPRE, SX_SCALE(0)),
+    SX_P2(1, 1, SX_NOPRE, SX_SHIFT(0), SX_SCALE(0)),
+    SX_P1(1, 2, SX_NOPRE, SX_RES(0, 1)),
+    SX_P2(1, 2, SX_NOPRE, SX_SCALE(0), SX_RES(0, 1)),
+    SX_P3(1, 2, SX_NOPRE, SX_SHIFT(0), SX_SCALE(0), SX_RES(0, 1)),
     // 2-D
-    SX_P1(2, 2, SX_SHIFT(0)),
-    SX_P1(2, 2, SX_SCALE(0)),
-    SX_P1(2, 2, SX_SHIFT(1)),
-    SX_P2(2, 3, SX_SCALE(0), SX_RES(0, 2)),
-    SX_P3(2, 3, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 2)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(0)), SX_SHIFT(0)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SCALE(0)), SX_SCALE(0)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(1)), SX_SHIFT(1)),
+    SX_P2(2, 3, SX_PRE(2, 3, SX_SCALE(0), SX_RES(0, 2)), SX_SCALE(0), SX_RES(0, 2)),
+    SX_P3(2, 3, SX_NOPRE, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 2)),
     // 3-D (BASELINE config 3: shift(r) + scale(e) + resolution_scale(e | e_true))
-    SX_P1(3, 3, SX_SHIFT(0)),
-    SX_P1(3, 3, SX_SCALE(0)),
-    SX_P1(3, 4, SX_RES(0, 3)),
-    SX_P2(3, 4, SX_SCALE(0), SX_RES(0, 3)),
-    SX_P3(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
+    SX_P1(3, 3, SX_PRE(3, 3, SX_SHIFT(0)), SX_SHIFT(0)),
+    SX_P1(3, 3, SX_PRE(3, 3, SX_SCALE(0)), SX_SCALE(0)),
+    SX_P1(3, 4, SX_PRE(3, 4, SX_RES(0, 3)), SX_RES(0, 3)),
+    SX_P2(3, 4, SX_PRE(3, 4, SX_SCALE(0), SX_RES(0, 3)), SX_SCALE(0), SX_RES(0, 3)),
+    SX_P3(3, 4, SX_PRE(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)), SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
 };
 constexpr int kNumStatic = (int)(sizeof(kStaticPrograms) / sizeof(kStaticPrograms[0]));
 
@@ -761,6 +851,19 @@ hipError_t launch_fill_dyn(const SxLaunchShape& sh, const SxSignalDesc* descs, c
 
 bool sx_fill_has_specialization(int nobs, int nslot) {
   return nobs >= 1 && nobs <= 5 && nslot >= nobs && nslot <= nobs + 2;
+}
+
+bool sx_fill_static_has_prebin(int prog) {
+  return prog >= 0 && prog < kNumStatic && kStaticPrograms[prog].fn_pre[0] != nullptr;
+}
+
+hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,
+                            hipStream_t s) {
+  if (npad == 0) return hipSuccess;
+  unsigned long long bx = (npad + 255) / 256;
+  if (bx > 8192) bx = 8192;
+  hipLaunchKernelGGL(prebin_kernel, dim3((unsigned)bx), dim3(256), 0, s, d_desc, mask, width, out);
+  return hipGetLastError();
 }
 
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops) {
@@ -778,7 +881,14 @@ hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, co
                           const unsigned* blk_off, hipStream_t s) {
   if (sh.grid <= 0) return hipSuccess;
   if (sh.lds_hist && sh.static_prog >= 0 && sh.static_prog < kNumStatic) {
-    return kStaticPrograms[sh.static_prog].fn(sh, descs, segs, blk_off, s);
+    const StaticEntry& e = kStaticPrograms[sh.static_prog];
+    if (sh.pre_width) {
+      if (sh.pre_width != 1 && sh.pre_width != 2) return hipErrorInvalidValue;
+      const int w = sh.pre_width - 1;
+      if (!e.fn_pre[w]) return hipErrorInvalidValue;
+      return e.fn_pre[w](sh, descs, segs, blk_off, s);
+    }
+    return e.fn(sh, descs, segs, blk_off, s);
   }
 #define SX_CASE(NO, NS) \
   if (sh.nobs == NO && sh.nslot == NS) return launch_fill_dyn<NO, NS>(sh, descs, segs, blk_off, s);

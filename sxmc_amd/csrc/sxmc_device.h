@@ -51,6 +51,7 @@ struct SxSignalDesc {
   double scale[SXMC_MAX_NFIELDS];  // nbins / (upper - lower), computed on the host in double
   SxSystOp syst[SXMC_MAX_SYST];
   short coef_par[64];            // coefficient lane -> parameter index
+  const void* pre;               // pre-binned column of the observables no systematic writes (or null)
   // --- evaluation at the data events
   const int* read_bins;
   unsigned long long npoints;
@@ -99,6 +100,7 @@ struct SxLaunchShape {
   size_t lds_bytes;
   int debug_mode;   // measurement hook, see fill_kernel
   int static_prog;  // index into the static program table, or -1: decode the program at run time
+  int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none
 };
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
@@ -108,6 +110,9 @@ hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_desc
                           const unsigned* d_blk_off, hipStream_t s);
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
+bool sx_fill_static_has_prebin(int prog);
+hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,
+                            hipStream_t s);
 hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,
                               hipStream_t s);
 hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,

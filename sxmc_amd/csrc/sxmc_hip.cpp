@@ -111,6 +111,10 @@ struct sxmc_hist {
   unsigned long long version = 1;
   sxmc_group* self = nullptr;
   int cfg_threads = 0, cfg_bpc = 0;
+  // pre-binned column of the observables in pre_mask (built on demand, samples never change)
+  void* d_pre = nullptr;
+  unsigned pre_mask = 0;
+  int pre_width = 0;
 };
 
 namespace {
@@ -118,6 +122,7 @@ struct LaunchClass {
   SxLaunchShape shape;
   std::vector<unsigned> prog;  // one word per systematic when every one has a single coefficient
   bool prog_simple = false;
+  unsigned pre_mask = 0;       // observables no systematic writes, streamed as one pre-binned column
   std::vector<int> member_idx;
   SxSignalDesc* d_descs = nullptr;
   SxSegment* d_segs = nullptr;
@@ -226,6 +231,7 @@ struct sxmc_group {
   int cfg_threads = 0, cfg_bpc = 0;
   int cfg_seen_threads = -1, cfg_seen_bpc = -1;
   int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
+  int cfg_prebin = 1, cfg_seen_prebin = -1;        // pre-bin the observables no systematic writes
   int debug_mode = 0;
   int max_bins = 0;
   unsigned long long max_points = 0;
@@ -348,10 +354,33 @@ int group_rebuild(sxmc_group* g) {
       prog.push_back((unsigned)d.syst[q].type | ((unsigned)d.syst[q].obs_slot << 4) |
                      ((unsigned)d.syst[q].extra_slot << 8));
     }
+    // pre-binning: observables that no systematic writes (static programs only)
+    const int static_prog = (prog_simple && !prog.empty())
+                                ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
+                                : -1;
+    unsigned pre_mask = 0;
+    int pre_width = 0;
+    if (g->cfg_prebin && sx_fill_static_has_prebin(static_prog)) {
+      unsigned touched = 0;
+      for (int q = 0; q < d.nsyst; q++) touched |= 1u << d.syst[q].obs_slot;
+      long long bound = 0;  // largest value the partial index can take (index == nbins included)
+      for (int k = 0; k < d.nobs; k++) {
+        if (!((touched >> k) & 1u)) {
+          pre_mask |= 1u << k;
+          bound += (long long)h->nbins[(size_t)k] * h->stride[(size_t)k];
+        }
+      }
+      pre_width = bound < 0xFF ? 1 : 2;
+      if (!pre_mask || bound >= 0xFFFF) {
+        pre_mask = 0;
+        pre_width = 0;
+      }
+    }
     LaunchClass* cls = nullptr;
     for (LaunchClass& c : g->classes) {
       if (c.shape.nobs == key_nobs && c.shape.nslot == key_nslot && c.shape.lds_hist == lds_hist &&
-          c.prog_simple == prog_simple && (!prog_simple || c.prog == prog)) {
+          c.prog_simple == prog_simple && (!prog_simple || c.prog == prog) && c.pre_mask == pre_mask &&
+          c.shape.pre_width == pre_width) {
         cls = &c;
       }
     }
@@ -365,9 +394,9 @@ int group_rebuild(sxmc_group* g) {
       cls->shape.debug_mode = 0;
       cls->prog = prog;
       cls->prog_simple = prog_simple;
-      cls->shape.static_prog = (prog_simple && !prog.empty())
-                                   ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
-                                   : -1;
+      cls->shape.static_prog = static_prog;
+      cls->shape.pre_width = pre_width;
+      cls->pre_mask = pre_mask;
     }
     cls->member_idx.push_back(i);
   }
@@ -381,6 +410,20 @@ int group_rebuild(sxmc_group* g) {
     int cls_max_bins = 0;
     for (int idx : c.member_idx) {
       SxSignalDesc d = g->h_descs[idx];
+      if (c.shape.pre_width) {
+        sxmc_hist* h = g->members[idx];
+        if (!h->d_pre || h->pre_mask != c.pre_mask || h->pre_width != c.shape.pre_width) {
+          if (h->d_pre) SX_HIP(hipFree(h->d_pre));
+          h->d_pre = nullptr;
+          const size_t npad = h->nvec * SXMC_VEC;
+          SX_HIP(hipMalloc(&h->d_pre, std::max<size_t>(npad * (size_t)c.shape.pre_width, 16)));
+          SX_HIP(sx_launch_prebin(g->d_descs + idx, npad, c.pre_mask, c.shape.pre_width, h->d_pre, nullptr));
+          SX_HIP(hipDeviceSynchronize());
+          h->pre_mask = c.pre_mask;
+          h->pre_width = c.shape.pre_width;
+        }
+        d.pre = h->d_pre;
+      }
       d.vec_start = prefix;
       prefix += d.nvec;
       cls_max_bins = std::max(cls_max_bins, d.total_nbins);
@@ -415,13 +458,14 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_threads = g->cfg_threads;
   g->cfg_seen_bpc = g->cfg_bpc;
   g->cfg_seen_partition = g->cfg_partition;
+  g->cfg_seen_prebin = g->cfg_prebin;
   g->built = true;
   return SXMC_OK;
 }
 
 int group_refresh(sxmc_group* g) {
   bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc ||
-               g->cfg_seen_partition != g->cfg_partition;
+               g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_prebin != g->cfg_prebin;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
   }
@@ -691,6 +735,7 @@ int sxmc_hist_destroy(sxmc_hist_t h) {
   if (h->d_cols) (void)hipFree(h->d_cols);
   if (h->d_bins) (void)hipFree(h->d_bins);
   if (h->d_read_bins) (void)hipFree(h->d_read_bins);
+  if (h->d_pre) (void)hipFree(h->d_pre);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SXMC_OK;
@@ -918,6 +963,12 @@ int sxmc_group_set_partition(sxmc_group_t g, int mode) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_prebinning(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_prebin = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
 int sxmc_group_set_debug_mode(sxmc_group_t g, int mode) {
   SX_REQUIRE(g, "null group");
   g->debug_mode = mode;
@@ -1059,7 +1110,17 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
   for (size_t i = 0; i < g->members.size(); i++) {
     const sxmc_hist* h = g->members[i];
     const SxSignalDesc& d = g->h_descs[i];
-    fr += 4.0 * (double)h->nsamples * d.nslot;
+    // columns the fill streams: float slots minus the observables covered by the pre-binned column
+    int pre_w = 0, pre_dims = 0;
+    for (const LaunchClass& c : g->classes) {
+      for (int idx : c.member_idx) {
+        if (idx == (int)i && c.shape.pre_width) {
+          pre_w = c.shape.pre_width;
+          for (int k = 0; k < d.nobs; k++) pre_dims += (c.pre_mask >> k) & 1u;
+        }
+      }
+    }
+    fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
     hb += 4.0 * (double)h->total_nbins * (h->total_nbins <= kLdsMaxBins ? 1.0 : 2.0);
     ev += 16.0 * (double)d.npoints;
   }

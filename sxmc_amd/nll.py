@@ -78,6 +78,10 @@ class EvalGroup:
         """0 automatic, 1 sliced, 2 interleaved (see include/sxmc_hip.h)."""
         capi.call("sxmc_group_set_partition", self._g, int(mode))
 
+    def SetPrebinning(self, enable):
+        """Stream observables that no systematic writes as one pre-binned narrow column (default on)."""
+        capi.call("sxmc_group_set_prebinning", self._g, int(bool(enable)))
+
     def SetDebugMode(self, mode):
         """Measurement hook (results are wrong when mode != 0), see include/sxmc_hip.h."""
         capi.call("sxmc_group_set_debug_mode", self._g, int(mode))

@@ -355,3 +355,49 @@ def test_interleaved_and_sliced_partitions_agree_on_equal_members():
         assert all(np.array_equal(a, b) for a, b in zip(bins, results[0][0])) and np.array_equal(nrm, results[0][1])
     o = oracle_eval(tabs[5], 5, [0.0] * 3, [1.0] * 3, [20, 20, 20], systs, [0.02, -0.01, 0.07])
     assert np.array_equal(results[0][0][5], o["bins"]) and results[0][1][5] == o["norm"]
+
+
+@pytest.mark.parametrize("nobs,nbins,systs,params", [
+    (3, [20, 20, 20], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+                       dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])], [0.02, -0.01, 0.07]),   # 1 byte
+    (3, [10, 30, 40], [dict(type="scale", obs=0, pars=[0])], [0.03]),                                       # 2 bytes
+    (3, [4, 3, 5], [dict(type="resolution_scale", obs=0, true_obs=3, pars=[0])], [0.2]),
+    (2, [200, 200], [dict(type="shift", obs=1, pars=[0])], [-0.02]),                                        # 40000 bins
+    (2, [9, 7], [dict(type="scale", obs=0, pars=[0]), dict(type="resolution_scale", obs=0, true_obs=2, pars=[1])],
+     [0.01, 0.1]),
+])
+def test_prebinned_observables_give_identical_histograms(nobs, nbins, systs, params):
+    """Observables no systematic writes are streamed as one pre-binned column (static programs): the
+    histograms must be those of the oracle and of the same launch with pre-binning off."""
+    rng = np.random.default_rng(15)
+    nfields = nobs + 2
+    sizes = [70001, 3, 123457]
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=nfields)
+    # edge cases in the pre-binned columns: NaN, exact edges, out of domain
+    group = nll.EvalGroup(evs)
+    results = []
+    for prebin in (True, False):
+        group.SetPrebinning(prebin)
+        group.EvalAsync(False)
+        group.EvalFinished()
+        results.append(([e.GetBins() for e in evs], norms.get()))
+        fr = group.AlgorithmicBytes()["fill_read"]
+        results[-1] += (fr,)
+    assert results[0][2] < results[1][2]                   # fewer bytes to stream
+    for j, t in enumerate(tabs):
+        o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, systs, params)
+        for bins, nrm, _ in results:
+            assert np.array_equal(bins[j], o["bins"]) and nrm[j] == o["norm"]
+
+
+def test_prebinned_column_edge_values():
+    # the untouched observable carries NaN / inf / exact edges / -0.0: same accept/reject as the oracle
+    edge = np.array([np.nan, np.inf, -np.inf, 0.0, 1.0, np.nextafter(np.float32(1), np.float32(0)), -0.0, 0.5,
+                     0.25, 0.999], np.float32)
+    tab = np.zeros((edge.size * 3, 3), np.float32)
+    tab[:, 0] = np.tile(np.array([0.1, 0.5, 0.9], np.float32), edge.size)
+    tab[:, 1] = np.repeat(edge, 3)
+    systs = [dict(type="shift", obs=0, pars=[0])]
+    kw = dict(samples=tab, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=[4, 5], systs=systs, params=[0.05])
+    g, o = compare(kw)
+    assert o["norm"] == 3 * 6 and g["bins"].sum() == o["norm"]     # 0, nextbelow(1), -0, 0.5, 0.25, 0.999
