@@ -119,6 +119,10 @@ def chain_intervals(chain, nparameters):
     return out
 
 
+def value_per_gpu_hint(args, elapsed):
+    return args.steps / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +139,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=2)
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--experiments", type=int, default=-1,
+                    help="fake experiments for the ensemble leg (fake data + MCMC + intervals), sharded k mod N; "
+                         "-1 = one per rank, 0 = skip")
+    ap.add_argument("--exp-steps", type=int, default=2000, help="MCMC steps per fake experiment in the ensemble leg")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
     ap.add_argument("--no-prebin", action="store_true", help="bin every observable in the kernel (no pre-binned column)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
@@ -204,6 +212,37 @@ def main():
     chain, accepted = m.flush()
     intervals = dist.gather_intervals(chain_intervals(chain, w.nparameters)[None], world, w.nparameters)
 
+    # ---- ensemble leg (sxmc.cpp:59-145): whole fake experiments, experiment k on rank k mod N, the MC
+    # tables stay resident; one RCCL all_gather of the per-experiment intervals at the end.  Outside the
+    # timed region of the headline metric; reported beside it.
+    experiments = None
+    nexp = world if args.experiments < 0 else args.experiments
+    if nexp > 0 and not args.debug_mode:
+        from sxmc_amd import ensemble
+        for s_ in w.signals:
+            s_.nexpected_saved = s_.nexpected
+        mine = dist.experiments_of_rank(nexp, rank, world)
+        local = np.zeros((len(mine), w.nparameters, 4), np.float32)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i, k in enumerate(mine):
+            local[i], _, _ = ensemble.run_experiment(w, dist.experiment_seed(args.seed, k), args.exp_steps,
+                                                     burnin_fraction=0.1, mcmc=m, sync_interval=args.exp_steps)
+        torch.cuda.synchronize()
+        dist.barrier()
+        exp_elapsed = dist.max_over_ranks(time.perf_counter() - t1)
+        allint = dist.gather_intervals(local, nexp, w.nparameters)
+        experiments = {
+            "count": nexp, "steps_each": args.exp_steps, "seconds": exp_elapsed,
+            "experiments_per_sec": nexp / exp_elapsed,
+            "steps_per_sec_inside": nexp * args.exp_steps / exp_elapsed,
+            "median_upper_limit_source0": dist.median(allint[:, 0, 2]),
+            "gathered_shape": [int(x) for x in allint.shape],
+            "note": "fake data set + MCMC walk with burn-in re-tuning + contour intervals per experiment; "
+                    "projected to 1e5-step chains: %.4f experiments/s" % (value_per_gpu_hint(args, elapsed) * world / 1e5),
+        }
+
     total_steps = args.steps * world
     value = total_steps / elapsed
     ab = m.group.AlgorithmicBytes()
@@ -216,7 +255,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f).get(w.name)
+            t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else ""))
         if t and args.scale == 1.0 and args.nsyst < 0:
             traffic = t["bytes_per_launch"]
     except (OSError, ValueError):
@@ -256,6 +295,7 @@ def main():
         },
         "cpu_baseline": None,
         "intervals_gathered": [int(x) for x in intervals.shape],
+        "experiments": experiments,
     }
 
     if want_cpu:

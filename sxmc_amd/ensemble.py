@@ -1,0 +1,174 @@
+"""The ensemble layer around the hot path: fake data sets, interval extraction, and the experiment
+loop that shards over GPUs.  ROOT-free restatements of
+
+  make_fake_dataset                 src/generator.cpp:10-48
+  EvalHist::RandomSample            src/pdfz.cpp:817-922   (ROOT TH1::GetRandom / GetRandom2 / GetRandom3)
+  Signal::get_efficiency            src/signal.cpp:172-199
+  LikelihoodSpace::get_contour      src/likelihood.cpp:90-102
+  Contour::get_interval             src/error_estimators/contour.cpp:18-69
+  Projection::get_interval          src/error_estimators/projection.cpp:14-77 (see note)
+  ensemble()                        src/sxmc.cpp:44-145
+
+Parity with the reference is statistical only ("parity unpinned"): every one of these draws on ROOT
+(TRandom, TH1::GetRandom, TMath::ChisquareQuantile, TH1::Fit) and the reference holds no test for them.
+Poisson and uniform deviates come from numpy's PCG64 here.  Note on Projection: the reference fits a
+Gaussian to an auto-binned TH1F with ROOT's minimiser to find the mode; here the mode is the vertex of a
+parabola fitted to the log-counts of the bins above half maximum of a 100-bin histogram (a Gaussian fit
+to the peak); the interval walk over the bins is the reference's.
+"""
+import math
+
+import numpy as np
+
+from . import capi
+from .capi import DeviceArray
+from .mcmc import MCMC
+
+INTERVAL_FIELDS = ("point_estimate", "lower", "upper", "coverage")
+
+
+# ------------------------------------------------------------------------------------ fake data
+def get_efficiency(ev, nsyst_pars, syst_means):
+    """Signal::get_efficiency: fraction of the MC samples inside the PDF domain with every systematic
+    at its mean.  Leaves the evaluator bound to scratch buffers; returns (efficiency, bins)."""
+    params = DeviceArray(np.asarray(syst_means, dtype=np.float64) if nsyst_pars else np.zeros(1))
+    norm = DeviceArray.zeros(1, np.uint32)
+    ev.SetNormalizationBuffer(norm)
+    ev.SetParameterBuffer(params)
+    ev.EvalAsync(False)
+    ev.EvalFinished()
+    n = int(norm.get()[0])
+    return n / float(ev.nsamples), ev.GetBins(), n
+
+
+def random_sample(rng, bins, lower, upper, nbins, nobserved):
+    """TH1::GetRandom (1-3 D): pick a bin with probability proportional to its content, then a point
+    uniform inside the bin.  bins: flat row-major counts."""
+    nbins = np.asarray(nbins)
+    D = nbins.size
+    if D > 3:
+        raise ValueError("Cannot sample histograms of more than 3 dimensions")   # pdfz.cpp:499-501
+    total = float(bins.sum())
+    if nobserved == 0 or total <= 0:
+        return np.zeros((0, D), np.float32)
+    cdf = np.cumsum(bins, dtype=np.float64) / total
+    flat = np.searchsorted(cdf, rng.random(nobserved), side="right")
+    flat = np.minimum(flat, bins.size - 1)
+    idx = np.stack(np.unravel_index(flat, nbins), axis=1)
+    width = (np.asarray(upper, np.float64) - np.asarray(lower, np.float64)) / nbins
+    pts = np.asarray(lower, np.float64) + (idx + rng.random((nobserved, D))) * width
+    return pts.astype(np.float32)
+
+
+def make_fake_dataset(rng, workload, evaluators, poisson=True):
+    """generator.cpp:10-48: per signal nexpected x efficiency events (Poisson fluctuated), drawn from
+    the signal's histogram at the mean systematics; rows of nobs + 1 floats (last = dataset id)."""
+    w = workload
+    syst_means = w.parameter_means()[w.nsources:]
+    rows, observed = [], []
+    for sig, ev in zip(w.signals, evaluators):
+        eff, bins, _ = get_efficiency(ev, w.nsyst_pars, syst_means)
+        nevents = sig.nexpected * eff
+        n = int(rng.poisson(nevents)) if poisson else int(math.floor(nevents + 0.5))
+        pts = random_sample(rng, bins, w.lower, w.upper, w.nbins, n)
+        rows.append(np.concatenate([pts, np.full((n, 1), sig.dataset, np.float32)], axis=1))
+        observed.append(n)
+    return np.concatenate(rows, axis=0).astype(np.float32), observed
+
+
+# ------------------------------------------------------------------------------------ intervals
+def chisquare_quantile_1dof(cl):
+    """TMath::ChisquareQuantile(cl, 1) = (Phi^-1((1 + cl) / 2))^2, by bisection on erf."""
+    target = cl
+    lo, hi = 0.0, 40.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if math.erf(math.sqrt(mid / 2.0)) < target:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
+def contour_intervals(chain, cl=0.9):
+    """Contour::get_interval for every parameter.  chain: [n, P + 1] (last column = NLL).
+    Returns float32 [P, 4]: point_estimate, lower, upper, coverage (-999 as in the reference)."""
+    nll = chain[:, -1]
+    lmin = nll.min()
+    delta = 0.5 * chisquare_quantile_1dof(cl)
+    contour = chain[nll - lmin < delta]                      # likelihood.cpp:90-102
+    assert contour.shape[0] > 0
+    cn = contour[:, -1]
+    clmin = cn.min()
+    dnll = 0.13
+    while True:                                              # contour.cpp:41-53
+        near = contour[cn - clmin < dnll]
+        dnll *= 5
+        if near.shape[0] >= 1:
+            break
+    P = chain.shape[1] - 1
+    out = np.zeros((P, 4), np.float32)
+    out[:, 0] = (near[:, :P].min(axis=0) + near[:, :P].max(axis=0)) / 2
+    out[:, 1] = contour[:, :P].min(axis=0)
+    out[:, 2] = contour[:, :P].max(axis=0)
+    out[:, 3] = -999
+    return out
+
+
+def projection_interval(values, cl=0.9, nbins=100):
+    """Projection::get_interval on one parameter's samples (see the module note on the mode estimate).
+    Returns (point_estimate, lower, upper, coverage, one_sided)."""
+    values = np.asarray(values, np.float64)
+    lo, hi = values.min(), values.max()
+    if hi <= lo:
+        return float(lo), float(lo), float(hi), 1.0, False
+    counts, edges = np.histogram(values, bins=nbins, range=(lo, hi))
+    total = counts.sum()
+    centers = 0.5 * (edges[:-1] + edges[1:])
+    peak = counts >= 0.5 * counts.max()
+    mu = float(centers[np.argmax(counts)])
+    if peak.sum() >= 3:
+        c2, c1, _ = np.polyfit(centers[peak], np.log(counts[peak]), 2, w=np.sqrt(counts[peak]))
+        if c2 < 0:
+            mu = float(-c1 / (2 * c2))
+    imax = int(np.searchsorted(edges, mu, side="right"))                        # 1-based bin of the mode
+    if imax < 1:                                                               # projection.cpp:28-31
+        imax, mu = 1, float(edges[0])
+    imax = min(imax, nbins)
+    csum = np.concatenate([[0], np.cumsum(counts)])                            # csum[i] = bins 1..i
+    ilo, ihi = 1, 0
+    if csum[imax] / total < cl / 2:                                            # projection.cpp:36-45
+        one_sided = True
+        for i in range(0, nbins + 1):
+            if csum[i] / total >= cl:
+                ihi = i
+                break
+    else:
+        one_sided = False
+        for i in range(imax, 0, -1):
+            if (csum[imax] - csum[i - 1]) / total >= cl / 2:
+                ilo = i
+                break
+        for i in range(imax + 1, nbins + 1):
+            if (csum[i] - csum[imax]) / total >= cl / 2:
+                ihi = i
+                break
+    ihi = max(ihi, ilo) if ihi else nbins
+    coverage = (csum[ihi] - csum[ilo - 1]) / total
+    return float(mu), float(edges[ilo - 1]), float(edges[ihi]), float(coverage), one_sided
+
+
+# ------------------------------------------------------------------------------------ the ensemble
+def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_interval=10000, mcmc=None,
+                   form="fused"):
+    """One iteration of the loop in sxmc.cpp:59-145: fake data -> MCMC -> intervals.
+    Reuses `mcmc` (evaluators with the MC tables resident in HBM) across experiments when given.
+    Returns (intervals float32 [P, 4], chain, accepted)."""
+    rng = np.random.default_rng(seed)
+    if mcmc is None:
+        mcmc = MCMC(workload, seed=seed & 0xFFFFFFFF, fused={"fused": True, "step": "step", "reference": False}[form])
+    else:
+        mcmc.reseed(seed & 0xFFFFFFFF)
+    data, _ = make_fake_dataset(rng, workload, mcmc.pdfs, poisson=True)
+    chain, accepted = mcmc.walk(data, nsteps, burnin_fraction, sync_interval=sync_interval)
+    return contour_intervals(chain, cl), chain, accepted

@@ -160,6 +160,43 @@ class MCMC:
                                        self.nexpected, self.n_mc, self.source_id, self.normalizations,
                                        debug_mode)
 
+    def reseed(self, seed):
+        """Fresh generator states (a new experiment on the same evaluators)."""
+        self.rngs = nll.make_rngs(self.nparameters, seed, self.stream)
+
+    def walk(self, data, nsteps, burnin_fraction, debug_mode=False, sync_interval=10000):
+        """MCMC::operator() (mcmc.cpp:143-387): start at the means, walk nsteps, re-tune the proposal
+        widths from the chain's spread at burnin_steps and 2 * burnin_steps (dropping the steps so far
+        unless debug_mode).  Returns (chain [nkept, P + 1] float32, accepted)."""
+        w = self.w
+        burnin_steps = int(nsteps * burnin_fraction)
+        self.current_vector.set(w.parameter_means().astype(np.float64))
+        self.jump_counter.set(np.zeros(1, np.int32))
+        self.accept_counter.set(np.zeros(1, np.int32))
+        self.setup(data, sync_interval=sync_interval)
+        nfloat = self.nparameters
+        scale_factor = np.float32(2.4 * 2.4 / nfloat)
+        ncol = self.nparameters + 1
+        rows, accepted = [np.zeros((0, ncol), np.float32)], 0
+        for i in range(nsteps):
+            if i == burnin_steps or i == 2 * burnin_steps:         # mcmc.cpp:274-311
+                sofar = np.concatenate(rows, axis=0)
+                jw = self.jump_width.get()
+                for j in range(self.nparameters):
+                    if jw[j] <= 0:
+                        continue
+                    sd = float(sofar[:, j].std()) if sofar.shape[0] > 1 else 0.0
+                    jw[j] = scale_factor * (sd if sd > 0 else jw[j])
+                self.jump_width.set(jw)
+                if not debug_mode:
+                    rows = [np.zeros((0, ncol), np.float32)]
+            self.step(debug_mode)
+            if i % sync_interval == 0 or i == nsteps - 1 or i == burnin_steps - 1 or i == 2 * burnin_steps - 1:
+                r, nacc = self.flush()                             # mcmc.cpp:351-377
+                rows.append(r)
+                accepted += nacc
+        return np.concatenate(rows, axis=0), accepted
+
     def flush(self):
         """mcmc.cpp:351-377: read back and reset the jump buffer.  Returns (rows, naccepted)."""
         capi.synchronize()

@@ -1,0 +1,57 @@
+"""GPU: the ensemble layer on the device path -- efficiency, fake data sets drawn from the evaluated
+histograms, and one whole fake experiment (fake data -> MCMC walk with burn-in -> contour intervals)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sxmc_amd import ensemble, workloads
+from sxmc_amd.mcmc import MCMC
+
+pytestmark = pytest.mark.gpu
+
+
+def test_efficiency_and_fake_dataset_follow_the_histograms():
+    w = workloads.config2(0.01, nevents=100)
+    for s in w.signals:
+        s.nexpected = 20000.0
+    m = MCMC(w, seed=1)
+    rng = np.random.default_rng(2)
+    data, observed = ensemble.make_fake_dataset(rng, w, m.pdfs, poisson=False)
+    geom = oracle.HistGeometry(w.lower, w.upper, w.nbins)
+    start = 0
+    for j, s in enumerate(w.signals):
+        bins, norm = oracle.bin_samples(geom, s.samples, s.nfields, [], np.zeros(1))
+        eff = norm / s.n_mc
+        assert observed[j] == int(np.floor(s.nexpected * eff + 0.5))      # nint(nexpected * efficiency)
+        ev = data[start:start + observed[j]]
+        start += observed[j]
+        assert np.all(ev[:, 2] == s.dataset)
+        assert np.all((ev[:, 0] >= 0) & (ev[:, 0] < 10) & (ev[:, 1] >= 0) & (ev[:, 1] < 6))
+        # drawn events, re-binned, follow the PDF: Pearson chi2 over well-populated bins
+        rb = oracle.set_eval_points(geom, ev, s.dataset)
+        got = np.bincount(rb, minlength=geom.total_nbins).astype(np.float64)
+        exp = bins.astype(np.float64) / norm * observed[j]
+        sel = exp > 20
+        chi2 = np.sum((got[sel] - exp[sel]) ** 2 / exp[sel])
+        assert chi2 < sel.sum() + 6 * np.sqrt(2 * sel.sum())
+        assert got[bins == 0].sum() == 0                                   # empty bins are never drawn
+    assert start == data.shape[0]
+
+
+def test_one_fake_experiment_end_to_end():
+    w = workloads.config3(0.003, nevents=100)
+    for s in w.signals:
+        s.nexpected = 400.0
+    m = MCMC(w, seed=3, fused=True)
+    iv, chain, acc = ensemble.run_experiment(w, seed=1234, nsteps=1500, burnin_fraction=0.2, mcmc=m,
+                                             sync_interval=500)
+    P = w.nparameters
+    assert iv.shape == (P, 4) and chain.shape == (1500 - 600, P + 1)
+    assert 0 < acc < 1500
+    assert np.all(np.isfinite(iv[:, :3])) and np.all(iv[:, 1] <= iv[:, 0]) and np.all(iv[:, 0] <= iv[:, 2])
+    # the systematics stay near their constraints, the rates stay positive
+    assert np.all(np.abs(iv[w.nsources:, 0]) < 0.3)
+    assert np.all(iv[: w.nsources, 1] >= 0)
+    # a second experiment on the same evaluators (tables stay resident) gives a different data set
+    iv2, chain2, _ = ensemble.run_experiment(w, seed=99, nsteps=300, burnin_fraction=0.1, mcmc=m)
+    assert chain2.shape[0] == 300 - 60 and not np.array_equal(iv, iv2)
