@@ -62,6 +62,37 @@ def make_c3_on_gpu(torch, dev, scale, seed, nevents):
     return w, tensors
 
 
+def make_c5_on_gpu(torch, dev, scale, seed, nevents, nbins=(200, 200, 200, 4, 4)):
+    """C5 tables on the GPU (same distributions as workloads.config5): S=20, D=5, F=7."""
+    from sxmc_amd import workloads
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    counts = workloads.split_counts(int(1e9 * scale), 20)
+    tensors, signals, ev_rows = [], [], []
+    per = max(1, nevents // 20)
+    for j, n in enumerate(counts):
+        def u(lo, hi):
+            return torch.empty(n, device=dev).uniform_(lo, hi, generator=g)
+        e_true = torch.empty(n, device=dev).normal_(2.0 + 0.3 * j, 1.2, generator=g)
+        e = e_true + torch.empty(n, device=dev).normal_(0.0, 0.3, generator=g)
+        cols = [e, 6.0 * u(0.0, 1.0) ** (1.0 / 3.0), u(-1.0, 1.0), u(0.0, 1.0), u(0.0, 1.0), e_true,
+                torch.zeros(n, device=dev)]
+        tab = torch.stack(cols, dim=1).contiguous()
+        del cols, e, e_true
+        tensors.append(tab)
+        ev_rows.append(tab[:per, :5].cpu().numpy())
+        signals.append(workloads.Signal(_Shape(n, 7), 7, nexpected=50.0 + j, source_id=j))
+    ev = np.concatenate(ev_rows, axis=0)[:nevents]
+    events = np.zeros((ev.shape[0], 6), dtype=np.float32)
+    events[:, :5] = ev
+    systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+             dict(type="resolution_scale", obs=0, true_obs=5, pars=[2])]
+    w = workloads.Workload("C5", 5, [0.0, 0.0, -1.0, 0.0, 0.0], [10.0, 6.0, 1.0, 1.0, 1.0], list(nbins), signals,
+                           systs, workloads.C3_SIGMAS, events,
+                           "S=20, N=%d, D=5, bins %s" % (sum(counts), "x".join(str(b) for b in nbins)))
+    return w, tensors
+
+
 class _Shape:
     """Stands in for a host table when the samples live only on the GPU."""
 
@@ -74,6 +105,9 @@ def make_workload(args, torch, dev, seed):
     name = args.workload.lower()
     if name == "c3":
         return make_c3_on_gpu(torch, dev, args.scale, seed, args.events)
+    if name == "c5":
+        nb = tuple(int(x) for x in args.c5_bins.split(","))
+        return make_c5_on_gpu(torch, dev, args.scale, seed, args.events, nb)
     makers = {"c1": workloads.config1, "c2": workloads.config2, "c5": workloads.config5,
               "bench_pdfz": workloads.bench_pdfz}
     w = makers[name](args.scale, seed=seed) if name == "c1" else makers[name](args.scale, seed=seed,
@@ -131,6 +165,7 @@ def main():
     ap.add_argument("--workload", default="c3", help="c3 (default, the metric's config), c1, c2, c5, bench_pdfz")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the sample counts (testing only)")
     ap.add_argument("--events", type=int, default=100000)
+    ap.add_argument("--c5-bins", default="200,200,200,4,4", help="bins per observable for --workload c5")
     ap.add_argument("--form", default="fused", choices=["step", "fused", "reference"],
                     help="fused (default): zero, fill, lookup+event sum, step end = 4 launches; step: the last two "
                          "merged (measured slower: every workgroup pays a release + ticket); reference: the "

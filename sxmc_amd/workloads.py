@@ -149,7 +149,7 @@ def config5(scale=1.0, seed=5, nevents=100000, nbins=(200, 200, 200, 4, 4)):
     infeasible, (200,200,200,4,4) = 1.28e8 bins is the HBM-resident-histogram regime."""
     rng = np.random.default_rng(seed)
     signals = []
-    for j, n in enumerate(split_counts(int(1e9 * scale), 20)):
+    for j, n in enumerate(split_counts(int(round(1e9 * scale)), 20)):
         e_true = rng.normal(2.0 + 0.3 * j, 1.2, size=n)
         e = e_true + rng.normal(0.0, 0.3, size=n)
         cols = [e, 6.0 * rng.uniform(size=n) ** (1.0 / 3.0), rng.uniform(-1, 1, size=n),

@@ -8,7 +8,7 @@
 #include <sxmc/nll_kernels.h>  // spelling/: HEMI_KERNEL_LAUNCH, hemi::Array
 #include <sxmc/pdfz.h>
 
-#include "../../sxmc_amd/include/sxmc/mcmc.h"
+#include "../../sxmc_amd/include/sxmc/ensemble.h"
 #include "mini_test.h"
 
 using std::isnan;
@@ -457,6 +457,62 @@ TEST(NllLaunch, ReferenceSpelling) {
   const double want = -ev + 1.0 * 10.0 * 500 / 1000 + 2.0 * 20.0 * 500 / 1000;
   ASSERT_NEAR_REL(total.readOnlyHostPtr()[0], ev, 1e-6);
   ASSERT_NEAR_REL(nll.readOnlyHostPtr()[0], want, 1e-6);
+}
+
+// ------------------------------------------------------------------ ensemble layer (sxmc.cpp:44-145)
+TEST(Ensemble, ChisquareQuantileAndMedian) {
+  ASSERT_NEAR_REL(sxmc::chisquare_quantile_1dof(0.9), 2.705543454, 1e-8);
+  ASSERT_NEAR_REL(sxmc::chisquare_quantile_1dof(0.95), 3.841458821, 1e-8);
+  EXPECT_EQ(2.0f, sxmc::median(std::vector<float>{3, 1, 2}));
+  EXPECT_EQ(2.5f, sxmc::median(std::vector<float>{4, 1, 3, 2}));
+}
+
+TEST(Ensemble, ContourIntervalOnAParabola) {
+  sxmc::Chain c;
+  c.names = {"x", "likelihood"};
+  for (int i = 0; i <= 6000; i++) {
+    const float x = 0.001f * i;
+    c.rows.push_back(x);
+    c.rows.push_back(0.5f * ((x - 3.0f) / 0.5f) * ((x - 3.0f) / 0.5f) + 10.0f);
+  }
+  std::vector<sxmc::Interval> iv = sxmc::contour_intervals(c, 0.9f);
+  const double half = 0.5 * std::sqrt(2.705543454);
+  EXPECT_TRUE(std::fabs(iv[0].point_estimate - 3.0) < 2e-3);
+  EXPECT_TRUE(std::fabs(iv[0].lower - (3.0 - half)) < 2e-3);
+  EXPECT_TRUE(std::fabs(iv[0].upper - (3.0 + half)) < 2e-3);
+  EXPECT_EQ(-999.0f, iv[0].coverage);
+}
+
+TEST_F(SmallFit, FakeDatasetAndWholeExperiments) {
+  std::mt19937_64 rng(5);
+  std::vector<unsigned> observed;
+  std::vector<float> ev = sxmc::make_fake_dataset(rng, signals, systematics, observables, false, &observed);
+  size_t total = 0;
+  for (size_t j = 0; j < signals.size(); j++) {
+    const double eff = sxmc::get_efficiency(signals[j], systematics);
+    EXPECT_EQ((unsigned)std::floor(signals[j].nexpected * eff + 0.5), observed[j]);
+    total += observed[j];
+  }
+  EXPECT_EQ(total * 3, ev.size());
+  for (size_t i = 0; i < total; i++) {
+    EXPECT_TRUE(ev[3 * i] >= 0 && ev[3 * i] < 1 && ev[3 * i + 1] >= 0 && ev[3 * i + 1] < 2);
+    EXPECT_EQ(0.0f, ev[3 * i + 2]);
+  }
+  // two whole fake experiments (this rank's share of an ensemble): fake data -> MCMC -> contour intervals
+  std::vector<sxmc::ExperimentResult> res =
+      sxmc::ensemble({0u, 3u}, 11, sources, signals, systematics, observables, 800, 0.2f, 0.9f, 200);
+  EXPECT_EQ((size_t)2, res.size());
+  EXPECT_EQ(3u, res[1].index);
+  for (const sxmc::ExperimentResult& r : res) {
+    EXPECT_EQ((size_t)5, r.intervals.size());
+    EXPECT_TRUE(r.accepted > 5 && r.nevents > 100);
+    for (const sxmc::Interval& iv : r.intervals) {
+      EXPECT_TRUE(iv.lower <= iv.point_estimate && iv.point_estimate <= iv.upper);
+      EXPECT_TRUE(std::isfinite(iv.lower) && std::isfinite(iv.upper));
+    }
+    EXPECT_TRUE(r.intervals[0].lower >= 0);  // negative rates are rejected by the NLL
+  }
+  EXPECT_TRUE(res[0].intervals[0].upper != res[1].intervals[0].upper);  // different data sets
 }
 
 int main(int argc, char** argv) {
