@@ -197,11 +197,12 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    capi.call("sxmc_set_device", local_rank)
-    dev = torch.device("cuda", local_rank)
+    device_index = local_rank % torch.cuda.device_count()   # one GPU per rank on the real node
+    torch.cuda.set_device(device_index)
+    capi.call("sxmc_set_device", device_index)
+    dev = torch.device("cuda", device_index)
     dist.init()
-    info = capi.device_info(local_rank)
+    info = capi.device_info(device_index)
 
     # ---- inputs: same MC tables on every rank (replica), own data events + chain seed per rank
     w, tensors = make_workload(args, torch, dev, args.seed)

@@ -28,12 +28,13 @@ def init(backend=None):
         if not dist.is_initialized():
             if backend is None:
                 import torch
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # SXMC_DIST_BACKEND=gloo rehearses a multi-rank run on a box with fewer GPUs than ranks
+                backend = os.environ.get("SXMC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             kw = {}
             if backend == "nccl":
                 import torch
-                kw["device_id"] = torch.device("cuda", local_rank)
+                kw["device_id"] = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
