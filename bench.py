@@ -176,8 +176,10 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--experiments", type=int, default=-1,
                     help="fake experiments for the ensemble leg (fake data + MCMC + intervals), sharded k mod N; "
-                         "-1 = one per rank, 0 = skip")
+                         "-1 = three per rank, 0 = skip")
     ap.add_argument("--exp-steps", type=int, default=2000, help="MCMC steps per fake experiment in the ensemble leg")
+    ap.add_argument("--exp-concurrent", type=int, default=3,
+                    help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
     ap.add_argument("--no-prebin", action="store_true", help="bin every observable in the kernel (no pre-binned column)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
@@ -252,25 +254,35 @@ def main():
     # tables stay resident; one RCCL all_gather of the per-experiment intervals at the end.  Outside the
     # timed region of the headline metric; reported beside it.
     experiments = None
-    nexp = world if args.experiments < 0 else args.experiments
+    nexp = 3 * world if args.experiments < 0 else args.experiments
     if nexp > 0 and not args.debug_mode:
         from sxmc_amd import ensemble
         for s_ in w.signals:
             s_.nexpected_saved = s_.nexpected
         mine = dist.experiments_of_rank(nexp, rank, world)
         local = np.zeros((len(mine), w.nparameters, 4), np.float32)
+        # chains for concurrent experiments: own non-blocking stream, own per-chain state, ONE copy of the tables
+        nconc = max(1, min(args.exp_concurrent, len(mine)))
+        form = {"step": "step", "fused": True, "reference": False}[args.form]
+        pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m) for _ in range(nconc)]
+        for c in pool:
+            c.group.SetLaunchConfig(threads, bpc)
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i, k in enumerate(mine):
-            local[i], _, _ = ensemble.run_experiment(w, dist.experiment_seed(args.seed, k), args.exp_steps,
-                                                     burnin_fraction=0.1, mcmc=m, sync_interval=args.exp_steps)
+        for lo in range(0, len(mine), nconc):
+            batch = mine[lo:lo + nconc]
+            res = ensemble.run_experiments_concurrently(
+                w, [dist.experiment_seed(args.seed, k) for k in batch], args.exp_steps, pool[:len(batch)],
+                burnin_fraction=0.1, sync_interval=args.exp_steps)
+            for i, r in enumerate(res):
+                local[lo + i] = r[0]
         torch.cuda.synchronize()
         dist.barrier()
         exp_elapsed = dist.max_over_ranks(time.perf_counter() - t1)
         allint = dist.gather_intervals(local, nexp, w.nparameters)
         experiments = {
-            "count": nexp, "steps_each": args.exp_steps, "seconds": exp_elapsed,
+            "count": nexp, "steps_each": args.exp_steps, "seconds": exp_elapsed, "concurrent_per_gpu": nconc,
             "experiments_per_sec": nexp / exp_elapsed,
             "steps_per_sec_inside": nexp * args.exp_steps / exp_elapsed,
             "median_upper_limit_source0": dist.median(allint[:, 0, 2]),

@@ -80,6 +80,8 @@ int sxmc_memset(void* d_dst, int value, size_t bytes);
 
 /* cudaStreamCreate / cudaStreamSynchronize (pdfz.cpp:91, 493) */
 int sxmc_stream_create(sxmc_stream_t* s);
+/* A stream that does not synchronise with the legacy default stream: one per concurrent chain. */
+int sxmc_stream_create_nonblocking(sxmc_stream_t* s);
 int sxmc_stream_destroy(sxmc_stream_t s);
 int sxmc_stream_synchronize(sxmc_stream_t s);
 
@@ -103,6 +105,11 @@ int sxmc_hist_create(const float* samples, size_t nsamples_floats, int samples_o
                      const double* upper, size_t n_upper,
                      const int* nbins, size_t n_nbins,
                      unsigned dataset, sxmc_hist_t* out);
+/* A second evaluator over the SAME sample table as `base` (shared, reference counted; nothing is
+ * copied): own histogram, evaluation points, bindings and stream, systematics copied from `base`.
+ * For several chains / fake experiments running concurrently on one GPU (BASELINE config 4: one
+ * experiment per stream) without holding the MC tables more than once. */
+int sxmc_hist_create_shared(sxmc_hist_t base, sxmc_hist_t* out);
 /* EvalHist::~EvalHist (pdfz.cpp:239-242); also destroys the evaluator's stream, which the
  * reference leaks (pdfz.cpp:100-103). */
 int sxmc_hist_destroy(sxmc_hist_t h);

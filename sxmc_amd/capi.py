@@ -52,6 +52,7 @@ SIGNATURES = {
     "sxmc_memcpy_d2h_async": [_vp, _vp, _sz, _vp],
     "sxmc_memset": [_vp, _i, _sz],
     "sxmc_stream_create": [_pvp],
+    "sxmc_stream_create_nonblocking": [_pvp],
     "sxmc_stream_destroy": [_vp],
     "sxmc_stream_synchronize": [_vp],
     "sxmc_event_create": [_pvp],
@@ -60,6 +61,7 @@ SIGNATURES = {
     "sxmc_event_synchronize": [_vp],
     "sxmc_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
     "sxmc_hist_create": [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _u, _pvp],
+    "sxmc_hist_create_shared": [_vp, _pvp],
     "sxmc_hist_destroy": [_vp],
     "sxmc_hist_add_systematic": [_vp, _i, _i, _i, _i, _vp],
     "sxmc_hist_set_eval_points": [_vp, _vp, _sz],
@@ -173,6 +175,14 @@ def device_info(device=0):
 
 def synchronize():
     call("sxmc_device_synchronize")
+
+
+def new_stream(nonblocking=True):
+    """A HIP stream handle (int address).  Non-blocking streams do not synchronise with the legacy
+    default stream, so kernels of different chains can overlap."""
+    s = C.c_void_p(0)
+    call("sxmc_stream_create_nonblocking" if nonblocking else "sxmc_stream_create", C.byref(s))
+    return s.value
 
 
 class DeviceArray:

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -87,7 +88,22 @@ int get_props(DeviceProps& p) {
 
 }  // namespace
 
+// The immutable part of an evaluator: the column-major sample table and (built on demand) the
+// pre-binned column.  Shared by evaluators created with sxmc_hist_create_shared, so that several
+// chains / experiments on one GPU read ONE copy of the MC tables.
+struct SampleStore {
+  float* d_cols = nullptr;
+  void* d_pre = nullptr;
+  unsigned pre_mask = 0;
+  int pre_width = 0;
+  ~SampleStore() {
+    if (d_cols) (void)hipFree(d_cols);
+    if (d_pre) (void)hipFree(d_pre);
+  }
+};
+
 struct sxmc_hist {
+  std::shared_ptr<SampleStore> store;
   int nfields = 0, nobs = 0;
   size_t nsamples = 0, nvec = 0, pitch = 0;
   unsigned dataset = 0;
@@ -95,7 +111,6 @@ struct sxmc_hist {
   std::vector<int> nbins, stride;
   int total_nbins = 0;
   double bin_volume = 0;
-  float* d_cols = nullptr;
   unsigned* d_bins = nullptr;
   int* d_read_bins = nullptr;
   bool has_points = false;
@@ -111,10 +126,6 @@ struct sxmc_hist {
   unsigned long long version = 1;
   sxmc_group* self = nullptr;
   int cfg_threads = 0, cfg_bpc = 0;
-  // pre-binned column of the observables in pre_mask (built on demand, samples never change)
-  void* d_pre = nullptr;
-  unsigned pre_mask = 0;
-  int pre_width = 0;
 };
 
 namespace {
@@ -273,7 +284,7 @@ int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
   std::memset(&d, 0, sizeof(d));
   std::vector<int> slot_col;
   member_slots(h, slot_col);
-  d.cols = h->d_cols;
+  d.cols = h->store->d_cols;
   d.col_pitch = h->pitch;
   d.nsamples = h->nsamples;
   d.nvec = h->nvec;
@@ -412,17 +423,18 @@ int group_rebuild(sxmc_group* g) {
       SxSignalDesc d = g->h_descs[idx];
       if (c.shape.pre_width) {
         sxmc_hist* h = g->members[idx];
-        if (!h->d_pre || h->pre_mask != c.pre_mask || h->pre_width != c.shape.pre_width) {
-          if (h->d_pre) SX_HIP(hipFree(h->d_pre));
-          h->d_pre = nullptr;
+        SampleStore& st = *h->store;
+        if (!st.d_pre || st.pre_mask != c.pre_mask || st.pre_width != c.shape.pre_width) {
+          if (st.d_pre) SX_HIP(hipFree(st.d_pre));
+          st.d_pre = nullptr;
           const size_t npad = h->nvec * SXMC_VEC;
-          SX_HIP(hipMalloc(&h->d_pre, std::max<size_t>(npad * (size_t)c.shape.pre_width, 16)));
-          SX_HIP(sx_launch_prebin(g->d_descs + idx, npad, c.pre_mask, c.shape.pre_width, h->d_pre, nullptr));
+          SX_HIP(hipMalloc(&st.d_pre, std::max<size_t>(npad * (size_t)c.shape.pre_width, 16)));
+          SX_HIP(sx_launch_prebin(g->d_descs + idx, npad, c.pre_mask, c.shape.pre_width, st.d_pre, nullptr));
           SX_HIP(hipDeviceSynchronize());
-          h->pre_mask = c.pre_mask;
-          h->pre_width = c.shape.pre_width;
+          st.pre_mask = c.pre_mask;
+          st.pre_width = c.shape.pre_width;
         }
-        d.pre = h->d_pre;
+        d.pre = h->store->d_pre;
       }
       d.vec_start = prefix;
       prefix += d.nvec;
@@ -587,6 +599,13 @@ int sxmc_stream_create(sxmc_stream_t* s) {
   *s = st;
   return SXMC_OK;
 }
+int sxmc_stream_create_nonblocking(sxmc_stream_t* s) {
+  SX_REQUIRE(s, "null argument");
+  hipStream_t st;
+  SX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *s = st;
+  return SXMC_OK;
+}
 int sxmc_stream_destroy(sxmc_stream_t s) {
   if (s) SX_HIP(hipStreamDestroy((hipStream_t)s));
   return SXMC_OK;
@@ -689,7 +708,6 @@ int sxmc_hist_create(const float* samples, size_t nsamples_floats, int samples_o
   h->pitch = std::max<size_t>(64, (h->nvec * SXMC_VEC + 63) / 64 * 64);
 
   auto cleanup = [&](int code) {
-    if (h->d_cols) (void)hipFree(h->d_cols);
     if (h->d_bins) (void)hipFree(h->d_bins);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -703,7 +721,8 @@ int sxmc_hist_create(const float* samples, size_t nsamples_floats, int samples_o
   } while (0)
 
   SX_HIP_H(hipStreamCreate(&h->stream));
-  SX_HIP_H(hipMalloc((void**)&h->d_cols, sizeof(float) * h->pitch * (size_t)nfields));
+  h->store = std::make_shared<SampleStore>();
+  SX_HIP_H(hipMalloc((void**)&h->store->d_cols, sizeof(float) * h->pitch * (size_t)nfields));
   SX_HIP_H(hipMalloc((void**)&h->d_bins, sizeof(unsigned) * (size_t)h->total_nbins));
   SX_HIP_H(hipMemset(h->d_bins, 0, sizeof(unsigned) * (size_t)h->total_nbins));
   if (h->nsamples) {
@@ -718,7 +737,7 @@ int sxmc_hist_create(const float* samples, size_t nsamples_floats, int samples_o
       }
       d_aos = staging;
     }
-    hipError_t e = sx_launch_transpose(d_aos, h->d_cols, h->nsamples, nfields, h->pitch, h->stream);
+    hipError_t e = sx_launch_transpose(d_aos, h->store->d_cols, h->nsamples, nfields, h->pitch, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (staging) (void)hipFree(staging);
     if (e != hipSuccess) return cleanup(fail(SXMC_ERR_HIP, std::string("transpose: ") + hipGetErrorString(e)));
@@ -728,14 +747,46 @@ int sxmc_hist_create(const float* samples, size_t nsamples_floats, int samples_o
   return SXMC_OK;
 }
 
+int sxmc_hist_create_shared(sxmc_hist_t base, sxmc_hist_t* out) {
+  SX_REQUIRE(base && out, "null argument");
+  *out = nullptr;
+  sxmc_hist* h = new sxmc_hist;
+  h->store = base->store;  // one copy of the MC table for every evaluator that shares it
+  h->nfields = base->nfields;
+  h->nobs = base->nobs;
+  h->nsamples = base->nsamples;
+  h->nvec = base->nvec;
+  h->pitch = base->pitch;
+  h->dataset = base->dataset;
+  h->lower = base->lower;
+  h->upper = base->upper;
+  h->scale = base->scale;
+  h->nbins = base->nbins;
+  h->stride = base->stride;
+  h->total_nbins = base->total_nbins;
+  h->bin_volume = base->bin_volume;
+  h->systs = base->systs;
+  h->cfg_threads = base->cfg_threads;
+  h->cfg_bpc = base->cfg_bpc;
+  hipError_t e = hipStreamCreate(&h->stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_bins, sizeof(unsigned) * (size_t)h->total_nbins);
+  if (e == hipSuccess) e = hipMemset(h->d_bins, 0, sizeof(unsigned) * (size_t)h->total_nbins);
+  if (e != hipSuccess) {
+    if (h->d_bins) (void)hipFree(h->d_bins);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return fail(SXMC_ERR_HIP, std::string("create_shared: ") + hipGetErrorString(e));
+  }
+  *out = h;
+  return SXMC_OK;
+}
+
 int sxmc_hist_destroy(sxmc_hist_t h) {
   if (!h) return SXMC_OK;
   (void)hipStreamSynchronize(h->stream);
   if (h->self) sxmc_group_destroy(h->self);
-  if (h->d_cols) (void)hipFree(h->d_cols);
   if (h->d_bins) (void)hipFree(h->d_bins);
   if (h->d_read_bins) (void)hipFree(h->d_read_bins);
-  if (h->d_pre) (void)hipFree(h->d_pre);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SXMC_OK;
@@ -892,7 +943,7 @@ int sxmc_hist_get_samples(sxmc_hist_t h, float* out, size_t n) {
   if (!n) return SXMC_OK;
   float* tmp = nullptr;
   SX_HIP(hipMalloc((void**)&tmp, sizeof(float) * n));
-  hipError_t e = sx_launch_untranspose_obs(h->d_cols, tmp, h->nsamples, h->nobs, h->pitch, (float)h->dataset,
+  hipError_t e = sx_launch_untranspose_obs(h->store->d_cols, tmp, h->nsamples, h->nobs, h->pitch, (float)h->dataset,
                                            h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e == hipSuccess) e = hipMemcpy(out, tmp, sizeof(float) * n, hipMemcpyDeviceToHost);

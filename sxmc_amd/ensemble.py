@@ -172,3 +172,24 @@ def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_int
     data, _ = make_fake_dataset(rng, workload, mcmc.pdfs, poisson=True)
     chain, accepted = mcmc.walk(data, nsteps, burnin_fraction, sync_interval=sync_interval)
     return contour_intervals(chain, cl), chain, accepted
+
+
+def run_experiments_concurrently(workload, seeds, nsteps, chains, burnin_fraction=0.1, cl=0.9, sync_interval=10000):
+    """len(chains) fake experiments at once on one GPU (BASELINE config 4: one experiment per stream):
+    the chains share one resident copy of the MC tables (MCMC(..., share_with=...), own non-blocking
+    streams) and are advanced in turn, so one experiment's small kernels overlap another's fill.
+    Returns a list of (intervals, chain, accepted) in the order of `seeds`."""
+    assert len(seeds) == len(chains)
+    for m, seed in zip(chains, seeds):
+        rng = np.random.default_rng(seed)
+        m.reseed(seed & 0xFFFFFFFF)
+        data, _ = make_fake_dataset(rng, workload, m.pdfs, poisson=True)
+        m.walk_begin(data, nsteps, burnin_fraction, sync_interval=sync_interval)
+    for i in range(nsteps):
+        for m in chains:
+            m.walk_advance(i)
+    out = []
+    for m in chains:
+        chain, accepted = m.walk_end()
+        out.append((contour_intervals(chain, cl), chain, accepted))
+    return out

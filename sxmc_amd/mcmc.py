@@ -32,7 +32,10 @@ def make_systematic(desc):
 
 
 class MCMC:
-    def __init__(self, workload, seed=1234, stream=None, fused=True, samples_on_device=None):
+    def __init__(self, workload, seed=1234, stream=None, fused=True, samples_on_device=None, share_with=None):
+        """share_with: another MCMC over the same workload -- this one's evaluators then share its sample
+        tables (one copy in HBM) and only the per-chain state is new; give each such chain its own
+        non-blocking `stream` to let their kernels overlap."""
         w = workload
         self.w = w
         self.stream = stream
@@ -44,6 +47,9 @@ class MCMC:
         # evaluators (signal.cpp:112-133 build_pdfz + AddSystematic)
         self.pdfs = []
         for j, s in enumerate(w.signals):
+            if share_with is not None:
+                self.pdfs.append(pdfz.EvalHist.Shared(share_with.pdfs[j]))
+                continue
             src = samples_on_device[j] if samples_on_device is not None else s.samples
             ev = pdfz.EvalHist(src, s.nfields, w.nobs, w.lower, w.upper, w.nbins, dataset=s.dataset)
             for d in w.systematics:
@@ -168,38 +174,53 @@ class MCMC:
         """MCMC::operator() (mcmc.cpp:143-387): start at the means, walk nsteps, re-tune the proposal
         widths from the chain's spread at burnin_steps and 2 * burnin_steps (dropping the steps so far
         unless debug_mode).  Returns (chain [nkept, P + 1] float32, accepted)."""
+        self.walk_begin(data, nsteps, burnin_fraction, debug_mode, sync_interval)
+        for i in range(nsteps):
+            self.walk_advance(i)
+        return self.walk_end()
+
+    # The same walk cut into per-step pieces, so that several chains can be advanced in turn and have
+    # their kernels in flight together (one stream per chain).
+    def walk_begin(self, data, nsteps, burnin_fraction, debug_mode=False, sync_interval=10000):
         w = self.w
-        burnin_steps = int(nsteps * burnin_fraction)
+        self._nsteps, self._debug = nsteps, debug_mode
+        self._burnin = int(nsteps * burnin_fraction)
         self.current_vector.set(w.parameter_means().astype(np.float64))
         self.jump_counter.set(np.zeros(1, np.int32))
         self.accept_counter.set(np.zeros(1, np.int32))
         self.setup(data, sync_interval=sync_interval)
-        nfloat = self.nparameters
-        scale_factor = np.float32(2.4 * 2.4 / nfloat)
-        ncol = self.nparameters + 1
-        rows, accepted = [np.zeros((0, ncol), np.float32)], 0
-        for i in range(nsteps):
-            if i == burnin_steps or i == 2 * burnin_steps:         # mcmc.cpp:274-311
-                sofar = np.concatenate(rows, axis=0)
-                jw = self.jump_width.get()
-                for j in range(self.nparameters):
-                    if jw[j] <= 0:
-                        continue
-                    sd = float(sofar[:, j].std()) if sofar.shape[0] > 1 else 0.0
-                    jw[j] = scale_factor * (sd if sd > 0 else jw[j])
-                self.jump_width.set(jw)
-                if not debug_mode:
-                    rows = [np.zeros((0, ncol), np.float32)]
-            self.step(debug_mode)
-            if i % sync_interval == 0 or i == nsteps - 1 or i == burnin_steps - 1 or i == 2 * burnin_steps - 1:
-                r, nacc = self.flush()                             # mcmc.cpp:351-377
-                rows.append(r)
-                accepted += nacc
-        return np.concatenate(rows, axis=0), accepted
+        self._scale_factor = np.float32(2.4 * 2.4 / self.nparameters)
+        self._rows, self._accepted = [np.zeros((0, self.nparameters + 1), np.float32)], 0
 
-    def flush(self):
-        """mcmc.cpp:351-377: read back and reset the jump buffer.  Returns (rows, naccepted)."""
-        capi.synchronize()
+    def walk_advance(self, i):
+        b = self._burnin
+        if i == b or i == 2 * b:                                   # mcmc.cpp:274-311
+            sofar = np.concatenate(self._rows, axis=0)
+            jw = self.jump_width.get()
+            for j in range(self.nparameters):
+                if jw[j] <= 0:
+                    continue
+                sd = float(sofar[:, j].std()) if sofar.shape[0] > 1 else 0.0
+                jw[j] = self._scale_factor * (sd if sd > 0 else jw[j])
+            self.jump_width.set(jw)
+            if not self._debug:
+                self._rows = [np.zeros((0, self.nparameters + 1), np.float32)]
+        self.step(self._debug)
+        if i % self.sync_interval == 0 or i == self._nsteps - 1 or i == b - 1 or i == 2 * b - 1:
+            r, nacc = self.flush(device_wide=False)                # mcmc.cpp:351-377
+            self._rows.append(r)
+            self._accepted += nacc
+
+    def walk_end(self):
+        return np.concatenate(self._rows, axis=0), self._accepted
+
+    def flush(self, device_wide=True):
+        """mcmc.cpp:351-377: read back and reset the jump buffer.  Returns (rows, naccepted).
+        device_wide=False waits for this chain's stream only (other chains keep running)."""
+        if device_wide or self.stream is None:
+            capi.synchronize()
+        else:
+            capi.call("sxmc_stream_synchronize", capi.ptr(self.stream))
         njumps = int(self.jump_counter.get()[0])
         nacc = int(self.accept_counter.get()[0])
         rows = self.jump_buffer.get()[: njumps * (self.nparameters + 1)].reshape(njumps, self.nparameters + 1)

@@ -94,6 +94,19 @@ class EvalHist:
         self.nfields, self.nobservables, self.dataset = int(nfields), int(nobservables), int(dataset)
         self._keep = {}
 
+    @classmethod
+    def Shared(cls, base):
+        """A second evaluator over the SAME sample table as `base` (nothing copied; systematics copied):
+        for concurrent chains / experiments on one GPU (sxmc_hist_create_shared)."""
+        self = cls.__new__(cls)
+        self._h = None
+        h = C.c_void_p(0)
+        _raise(capi.load().sxmc_hist_create_shared(base._h, C.byref(h)))
+        self._h = h
+        self.nfields, self.nobservables, self.dataset = base.nfields, base.nobservables, base.dataset
+        self._keep = {"base": base}
+        return self
+
     # -- Eval interface -------------------------------------------------------------------
     def SetEvalPoints(self, points):
         points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1)

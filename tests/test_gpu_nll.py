@@ -291,3 +291,26 @@ def test_c5_shape_five_observables_hbm_resident_histograms():
     assert np.array_equal(m.lut.get().view(np.uint32), lut.ravel().view(np.uint32))
     assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
     assert nacc == 1
+
+
+def test_concurrent_chains_share_one_sample_table():
+    """BASELINE config 4's per-GPU shape: several experiments at once, one per stream, over ONE resident
+    copy of the MC tables.  Each chain must produce exactly what it produces alone."""
+    w = workloads.config3(0.004, nevents=3000)
+    solo = []
+    for seed in (5, 6, 7):
+        m = MCMC(w, seed=seed, fused=True)
+        m.setup(sync_interval=64)
+        solo.append(m.run(48))
+        del m
+    base = MCMC(w, seed=5, fused=True, stream=capi.new_stream())
+    chains = [base] + [MCMC(w, seed=sd, fused=True, stream=capi.new_stream(), share_with=base) for sd in (6, 7)]
+    for m in chains:
+        m.setup(sync_interval=64)
+    capi.synchronize()
+    for _ in range(48):                       # interleaved: the three walks are in flight together
+        for m in chains:
+            m.step()
+    for m, (chain, acc) in zip(chains, solo):
+        got, nacc = m.flush()
+        assert nacc == acc and np.array_equal(got, chain)
