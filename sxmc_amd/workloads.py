@@ -16,10 +16,11 @@ class Signal:
         self.nexpected = float(nexpected)
         self.source_id = int(source_id)
         self.dataset = dataset
+        self.n_mc_total = None              # simulated events BEFORE cuts, when they differ (signal.cpp:28)
 
     @property
     def n_mc(self):
-        return self.samples.shape[0]
+        return self.samples.shape[0] if self.n_mc_total is None else self.n_mc_total
 
 
 class Workload:

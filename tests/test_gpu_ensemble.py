@@ -55,3 +55,22 @@ def test_one_fake_experiment_end_to_end():
     # a second experiment on the same evaluators (tables stay resident) gives a different data set
     iv2, chain2, _ = ensemble.run_experiment(w, seed=99, nsteps=300, burnin_fraction=0.1, mcmc=m)
     assert chain2.shape[0] == 300 - 60 and not np.array_equal(iv, iv2)
+
+
+def test_run_config_end_to_end(tmp_path):
+    """A fit described in the reference's JSON schema, from tables on disk to chains on disk."""
+    from sxmc_amd import io
+    from tests.test_io_cpu import EXAMPLE
+    rng = np.random.default_rng(0)
+    for name, n in (("a.npz", 40000), ("b.npz", 60000)):
+        mc = rng.uniform(4, 16, n).astype(np.float32)
+        io.write_table(tmp_path / name, np.stack([mc + rng.normal(0, 0.5, n).astype(np.float32),
+                                                  rng.uniform(0, 12, n).astype(np.float32), mc], axis=1),
+                       ["energy", "radius", "mc_energy"])
+    (tmp_path / "fit.json").write_text(EXAMPLE)
+    iv, limits, names = io.run_config(str(tmp_path / "fit.json"), out_dir=str(tmp_path), nexperiments=2, nsteps=400)
+    assert iv.shape == (2, 5, 4) and len(limits) == 2 and names[-1] == "likelihood"
+    assert np.all(iv[:, :, 1] <= iv[:, :, 2]) and np.all(np.isfinite(iv[:, :, :3]))
+    with np.load(tmp_path / "fit_test_1.npz") as z:
+        assert set(z.files) == set(names) and z["likelihood"].shape[0] == 400 - 80
+        assert np.all(np.isfinite(z["likelihood"]))
