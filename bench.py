@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--exp-concurrent", type=int, default=3,
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
+    ap.add_argument("--no-sparse", action="store_true", help="fill HBM-resident histograms densely (global atomics)")
     ap.add_argument("--no-prebin", action="store_true", help="bin every observable in the kernel (no pre-binned column)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
     ap.add_argument("--debug-mode", type=int, default=0,
@@ -225,6 +226,7 @@ def main():
     m.group.SetLaunchConfig(threads, bpc)
     m.group.SetPartition(args.partition)
     m.group.SetPrebinning(not args.no_prebin)
+    m.group.SetSparse(not args.no_sparse)
     if args.debug_mode:
         want_cpu = False
     m.setup(sync_interval=max(args.steps, args.warmup, 1))
@@ -349,11 +351,13 @@ def main():
     if want_cpu:
         # same inputs, same parameter vector: time the oracle and assert parity in the same run
         vector = m.proposed_vector.get()
-        m.group.EvalAsync(True, None)
+        m.group.EvalAsync(False, None)          # histograms (dense, as CreateHistogram would)
+        capi.synchronize()
+        gpu_bins = [p.GetBins() for p in m.pdfs]
+        m.group.EvalAsync(True, None)           # lookup + NLL
         m.nll(m.proposed_vector, m.proposed_nll)
         capi.synchronize()
         gpu_nll = float(m.proposed_nll.get()[0])
-        gpu_bins = [p.GetBins() for p in m.pdfs]
         gpu_norms = m.normalizations.get()
         sec1, bins, norms, cpu_nll = cpu_baseline(w, host_tables, vector, args.cpu_evals, 1)
         ncores = os.cpu_count() or 1

@@ -160,6 +160,13 @@ int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks
  * contiguous slice of the concatenated members), 2 = interleaved (each member's workgroups stride
  * through it chunk by chunk, like a grid-stride copy). */
 int sxmc_group_set_partition(sxmc_group_t g, int mode);
+/* Sparse counting (default on): a histogram too large for LDS (more than 40 832 bins) costs one scattered
+ * HBM atomic per sample plus zeroing the whole array, yet an evaluation for lookup (do_eval_pdf != 0, the
+ * fused evaluations, the MCMC step) reads it only at the data events' bins.  Such evaluations count into one
+ * counter per distinct event bin instead; lut, normalisations and NLL are identical.  The dense histogram
+ * is then NOT filled: sxmc_hist_get_bins returns SXMC_ERR_STATE until an evaluation with do_eval_pdf = 0
+ * (what CreateHistogram does, pdfz.cpp:503-506) has run. */
+int sxmc_group_set_sparse(sxmc_group_t g, int enable);
 /* Pre-binning (default on): an observable that no systematic writes has the same bin index at every
  * evaluation, so for launches that run a static program the evaluators build, once, a 1- or 2-byte column
  * with the partial flat index of those observables and the fill streams it instead of their float

@@ -83,6 +83,7 @@ SIGNATURES = {
     "sxmc_group_destroy": [_vp],
     "sxmc_group_set_launch_config": [_vp, _i, _i],
     "sxmc_group_set_partition": [_vp, _i],
+    "sxmc_group_set_sparse": [_vp, _i],
     "sxmc_group_set_prebinning": [_vp, _i],
     "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_group_eval_async": [_vp, _i, _vp],

@@ -205,6 +205,29 @@ __device__ __forceinline__ void run_static(double (&f)[NSLOT][SXMC_VEC], const d
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load per lane
 
+// SPARSE COUNTING.  A histogram too large for LDS costs one scattered HBM atomic per sample plus zeroing
+// the whole array, but the likelihood only ever looks it up at the data events' bins.  When an evaluation
+// is for lookup, such a member counts into one counter per distinct event bin instead: flat bin index ->
+// one-hash bit filter (rejects ~98 % of the samples with one cached word) -> open-addressing table ->
+// counter slot.  Same counts at the bins that are read, same norm.
+typedef unsigned vuint2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void sparse_count(const SxSignalDesc& d, gptr<unsigned> counters, unsigned bin) {
+  const unsigned hb = (bin * 0x9E3779B1u) >> d.sparse_filter_shift;
+  if (!((to_global(d.sparse_filter)[hb >> 5] >> (hb & 31u)) & 1u)) return;
+  const unsigned mask = (1u << (32 - d.sparse_table_shift)) - 1u;
+  unsigned hp = (bin * 0x85EBCA6Bu) >> d.sparse_table_shift;
+  for (unsigned probe = 0; probe <= mask; probe++) {
+    const vuint2 e = to_global(reinterpret_cast<const vuint2*>(d.sparse_table))[hp];
+    if (e[0] == bin) {
+      __hip_atomic_fetch_add(&counters[e[1]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (e[0] == 0xFFFFFFFFu) return;
+    hp = (hp + 1u) & mask;
+  }
+}
+
 // PRE-BINNING.  An observable that no systematic writes has the same value, hence the same bin index
 // and the same in/out-of-domain status, at every evaluation.  For static programs the host builds, once,
 // a narrow column holding sum_k idx_k * stride_k over those observables (all ones = outside the domain)
@@ -294,7 +317,8 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     const unsigned long long v1 = sg.v1;
     const unsigned long long step = sg.step;
 
-    const unsigned B = (unsigned)d.total_nbins;
+    const bool sparse = !LDS_HIST && d.sparse_table != nullptr;
+    const unsigned B = sparse ? (unsigned)d.sparse_real_nbins : (unsigned)d.total_nbins;
     gptr<unsigned> gbins = to_global(d.bins);
 
     if (!lds_clean) {
@@ -430,7 +454,11 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
           __hip_atomic_fetch_add(&hist[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
           if (bad == 0u && (unsigned)bin < B && !(dbg & 4u)) {
-            __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sparse) {
+              sparse_count(d, gbins, (unsigned)bin);
+            } else {
+              __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
       }
@@ -498,7 +526,8 @@ __global__ __launch_bounds__(1024) void fill_kernel_generic(const SxSignalDesc* 
     const unsigned long long v0 = sg.v0;
     const unsigned long long v1 = sg.v1;
     const unsigned long long step = sg.step;
-    const unsigned B = (unsigned)d.total_nbins;
+    const bool sparse = !LDS_HIST && d.sparse_table != nullptr;
+    const unsigned B = sparse ? (unsigned)d.sparse_real_nbins : (unsigned)d.total_nbins;
     gptr<unsigned> gbins = to_global(d.bins);
     if (!lds_clean) {
       // whole LDS histogram (sized for the largest member), once per workgroup
@@ -549,6 +578,8 @@ __global__ __launch_bounds__(1024) void fill_kernel_generic(const SxSignalDesc* 
         if ((unsigned)bin < B) {
           if (LDS_HIST) {
             __hip_atomic_fetch_add(&hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else if (sparse) {
+            sparse_count(d, gbins, (unsigned)bin);
           } else {
             __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }

@@ -52,6 +52,15 @@ struct SxSignalDesc {
   SxSystOp syst[SXMC_MAX_SYST];
   short coef_par[64];            // coefficient lane -> parameter index
   const void* pre;               // pre-binned column of the observables no systematic writes (or null)
+  // --- sparse counting (histograms too large for LDS, evaluation for lookup only): `bins` then points
+  //     at one counter per DISTINCT EVENT BIN, `read_bins` at the events' counter slots, and the fill maps
+  //     a sample's flat bin index to its slot through a one-hash bit filter and an open-addressing table
+  const unsigned* sparse_filter; // filter_bits / 32 words
+  const unsigned* sparse_table;  // pairs {flat bin index, slot}; empty key = 0xFFFFFFFF
+  int sparse_filter_shift;       // hash >> shift selects a filter bit
+  int sparse_table_shift;        // hash >> shift selects a table entry
+  int sparse_real_nbins;         // the histogram's true bin count (total_nbins is the counter count here)
+  int pad1;
   // --- evaluation at the data events
   const int* read_bins;
   unsigned long long npoints;

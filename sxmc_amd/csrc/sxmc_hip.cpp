@@ -126,6 +126,13 @@ struct sxmc_hist {
   unsigned long long version = 1;
   sxmc_group* self = nullptr;
   int cfg_threads = 0, cfg_bpc = 0;
+  // sparse counting (histogram too large for LDS): one counter per distinct event bin
+  unsigned* d_cnt = nullptr;       // [ntargets]
+  int* d_read_slot = nullptr;      // [npoints]: counter slot of each event, or -1 / -2
+  unsigned* d_filter = nullptr;
+  unsigned* d_table = nullptr;
+  int ntargets = 0, filter_shift = 0, table_shift = 0;
+  bool bins_valid = true;          // false after a sparse evaluation: the dense histogram was not filled
 };
 
 namespace {
@@ -136,6 +143,7 @@ struct LaunchClass {
   unsigned pre_mask = 0;       // observables no systematic writes, streamed as one pre-binned column
   std::vector<int> member_idx;
   SxSignalDesc* d_descs = nullptr;
+  SxSignalDesc* d_descs_sparse = nullptr;  // same members, sparse flavour (global-histogram classes)
   SxSegment* d_segs = nullptr;
   unsigned* d_blk_off = nullptr;
   unsigned long long total_vec = 0;
@@ -144,6 +152,8 @@ struct LaunchClass {
 
 void free_class(LaunchClass& c) {
   if (c.d_descs) (void)hipFree(c.d_descs);
+  if (c.d_descs_sparse) (void)hipFree(c.d_descs_sparse);
+  c.d_descs_sparse = nullptr;
   if (c.d_segs) (void)hipFree(c.d_segs);
   if (c.d_blk_off) (void)hipFree(c.d_blk_off);
   c.d_descs = nullptr;
@@ -238,6 +248,10 @@ struct sxmc_group {
   std::vector<unsigned long long> seen;
   std::vector<SxSignalDesc> h_descs;
   SxSignalDesc* d_descs = nullptr;  // member order: zero / eval kernels
+  SxSignalDesc* d_descs_sparse = nullptr;  // member order, sparse flavour where a member supports it
+  bool sparse_ready = false;        // some member has sparse structures and all of those have points
+  int max_bins_sparse = 0;
+  int cfg_sparse = 1;               // count only the event bins when evaluating for lookup
   std::vector<LaunchClass> classes;
   int cfg_threads = 0, cfg_bpc = 0;
   int cfg_seen_threads = -1, cfg_seen_bpc = -1;
@@ -278,6 +292,78 @@ int slot_of(const std::vector<int>& slot_col, int field) {
   for (size_t k = 0; k < slot_col.size(); k++)
     if (slot_col[k] == field) return (int)k;
   return 0;
+}
+
+void free_sparse(sxmc_hist* h) {
+  if (h->d_cnt) (void)hipFree(h->d_cnt);
+  if (h->d_read_slot) (void)hipFree(h->d_read_slot);
+  if (h->d_filter) (void)hipFree(h->d_filter);
+  if (h->d_table) (void)hipFree(h->d_table);
+  h->d_cnt = nullptr;
+  h->d_read_slot = nullptr;
+  h->d_filter = nullptr;
+  h->d_table = nullptr;
+  h->ntargets = 0;
+}
+
+int ceil_log2(size_t x) {
+  int b = 0;
+  while (((size_t)1 << b) < x) b++;
+  return b;
+}
+
+// Sparse-counting structures of one evaluator from its event bins (host side, once per SetEvalPoints).
+int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
+  free_sparse(h);
+  std::vector<unsigned> targets;
+  for (int b : rb)
+    if (b >= 0) targets.push_back((unsigned)b);
+  std::sort(targets.begin(), targets.end());
+  targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+  const size_t T = targets.size();
+  std::vector<int> slot(rb.size());
+  for (size_t i = 0; i < rb.size(); i++) {
+    slot[i] = rb[i] < 0 ? rb[i]
+                        : (int)(std::lower_bound(targets.begin(), targets.end(), (unsigned)rb[i]) - targets.begin());
+  }
+  const int fbits = std::min(26, std::max(16, ceil_log2(64 * std::max<size_t>(T, 1))));  // <= 1.6 % false positives
+  const int tbits = std::max(6, ceil_log2(2 * std::max<size_t>(T, 1)));                   // load <= 50 %
+  std::vector<unsigned> filter((size_t)1 << (fbits - 5), 0u);
+  std::vector<unsigned> table((size_t)2 << tbits, 0xFFFFFFFFu);
+  const unsigned mask = (1u << tbits) - 1u;
+  for (size_t t = 0; t < T; t++) {
+    const unsigned bin = targets[t];
+    const unsigned hb = (bin * 0x9E3779B1u) >> (32 - fbits);
+    filter[hb >> 5] |= 1u << (hb & 31u);
+    unsigned hp = (bin * 0x85EBCA6Bu) >> (32 - tbits);
+    while (table[2 * (size_t)hp] != 0xFFFFFFFFu) hp = (hp + 1u) & mask;
+    table[2 * (size_t)hp] = bin;
+    table[2 * (size_t)hp + 1] = (unsigned)t;
+  }
+  SX_HIP(hipMalloc((void**)&h->d_cnt, sizeof(unsigned) * std::max<size_t>(T, 4)));
+  SX_HIP(hipMemset(h->d_cnt, 0, sizeof(unsigned) * std::max<size_t>(T, 4)));
+  SX_HIP(hipMalloc((void**)&h->d_read_slot, sizeof(int) * std::max<size_t>(slot.size(), 1)));
+  if (!slot.empty()) SX_HIP(hipMemcpy(h->d_read_slot, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice));
+  SX_HIP(hipMalloc((void**)&h->d_filter, sizeof(unsigned) * filter.size()));
+  SX_HIP(hipMemcpy(h->d_filter, filter.data(), sizeof(unsigned) * filter.size(), hipMemcpyHostToDevice));
+  SX_HIP(hipMalloc((void**)&h->d_table, sizeof(unsigned) * table.size()));
+  SX_HIP(hipMemcpy(h->d_table, table.data(), sizeof(unsigned) * table.size(), hipMemcpyHostToDevice));
+  h->ntargets = (int)T;
+  h->filter_shift = 32 - fbits;
+  h->table_shift = 32 - tbits;
+  return SXMC_OK;
+}
+
+// The sparse flavour of a member's descriptor: counters instead of the histogram, slots instead of bins.
+void make_sparse_desc(const sxmc_hist* h, SxSignalDesc& d) {
+  d.sparse_real_nbins = h->total_nbins;
+  d.bins = h->d_cnt;
+  d.total_nbins = std::max(h->ntargets, 1);
+  d.read_bins = h->d_read_slot;
+  d.sparse_filter = h->d_filter;
+  d.sparse_table = h->d_table;
+  d.sparse_filter_shift = h->filter_shift;
+  d.sparse_table_shift = h->table_shift;
 }
 
 int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
@@ -414,6 +500,26 @@ int group_rebuild(sxmc_group* g) {
 
   if (!g->d_descs) SX_HIP(hipMalloc((void**)&g->d_descs, sizeof(SxSignalDesc) * std::max(n, 1)));
   if (n) SX_HIP(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
+  // sparse flavour: members whose histogram exceeds LDS count into per-event-bin counters
+  std::vector<SxSignalDesc> sparse_descs = g->h_descs;
+  g->sparse_ready = false;
+  g->max_bins_sparse = 0;
+  bool sparse_ok = true;
+  for (int i = 0; i < n; i++) {
+    sxmc_hist* h = g->members[i];
+    if (h->total_nbins > kLdsMaxBins) {
+      if (h->has_points && h->d_table) {
+        make_sparse_desc(h, sparse_descs[(size_t)i]);
+        g->sparse_ready = true;
+      } else {
+        sparse_ok = false;
+      }
+    }
+    g->max_bins_sparse = std::max(g->max_bins_sparse, sparse_descs[(size_t)i].total_nbins);
+  }
+  g->sparse_ready = g->sparse_ready && sparse_ok;
+  if (!g->d_descs_sparse) SX_HIP(hipMalloc((void**)&g->d_descs_sparse, sizeof(SxSignalDesc) * std::max(n, 1)));
+  if (n) SX_HIP(hipMemcpy(g->d_descs_sparse, sparse_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
 
   for (LaunchClass& c : g->classes) {
     std::vector<SxSignalDesc> descs;
@@ -452,6 +558,12 @@ int group_rebuild(sxmc_group* g) {
     c.shape.grid = c.total_vec ? (int)grid : 0;
     SX_HIP(hipMalloc((void**)&c.d_descs, sizeof(SxSignalDesc) * descs.size()));
     SX_HIP(hipMemcpy(c.d_descs, descs.data(), sizeof(SxSignalDesc) * descs.size(), hipMemcpyHostToDevice));
+    if (g->sparse_ready && !c.shape.lds_hist) {
+      std::vector<SxSignalDesc> sd = descs;
+      for (size_t q = 0; q < sd.size(); q++) make_sparse_desc(g->members[c.member_idx[q]], sd[q]);
+      SX_HIP(hipMalloc((void**)&c.d_descs_sparse, sizeof(SxSignalDesc) * sd.size()));
+      SX_HIP(hipMemcpy(c.d_descs_sparse, sd.data(), sizeof(SxSignalDesc) * sd.size(), hipMemcpyHostToDevice));
+    }
     if (c.shape.grid > 0) {
       std::vector<SxSegment> segs;
       std::vector<unsigned> blk_off;
@@ -493,13 +605,19 @@ int group_check_bound(sxmc_group* g, bool need_pdf) {
   return SXMC_OK;
 }
 
-int group_fill(sxmc_group* g, hipStream_t s) {
-  SX_HIP(sx_launch_zero(g->d_descs, (int)g->members.size(), g->max_bins, g->d_ticket, s));
+int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
+  sparse = sparse && g->sparse_ready && g->cfg_sparse;
+  SX_HIP(sx_launch_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
+                        sparse ? g->max_bins_sparse : g->max_bins, g->d_ticket, s));
+  for (size_t i = 0; i < g->members.size(); i++) {
+    if (g->members[i]->total_nbins > kLdsMaxBins) g->members[i]->bins_valid = !sparse;
+  }
   for (LaunchClass& c : g->classes) {
     const bool rec = g->prof && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
     c.shape.debug_mode = g->debug_mode;
-    SX_HIP(sx_launch_fill(c.shape, c.d_descs, c.d_segs, c.d_blk_off, s));
+    SX_HIP(sx_launch_fill(c.shape, (sparse && c.d_descs_sparse) ? c.d_descs_sparse : c.d_descs, c.d_segs,
+                          c.d_blk_off, s));
     if (rec) {
       SX_HIP(hipEventRecord(g->ev1[g->prof_n], s));
       g->prof_n++;
@@ -787,6 +905,7 @@ int sxmc_hist_destroy(sxmc_hist_t h) {
   if (h->self) sxmc_group_destroy(h->self);
   if (h->d_bins) (void)hipFree(h->d_bins);
   if (h->d_read_bins) (void)hipFree(h->d_read_bins);
+  free_sparse(h);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SXMC_OK;
@@ -858,6 +977,10 @@ int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints
   h->npoints = n;
   h->has_points = true;
   h->version++;
+  if (h->total_nbins > kLdsMaxBins) {
+    int rc = build_sparse(h, rb);
+    if (rc) return rc;
+  }
   return SXMC_OK;
 }
 
@@ -928,6 +1051,11 @@ int sxmc_hist_npoints(sxmc_hist_t h, size_t* v) {
 int sxmc_hist_get_bins(sxmc_hist_t h, unsigned* out, size_t n) {
   SX_REQUIRE(h && out, "null argument");
   SX_REQUIRE(n == (size_t)h->total_nbins, "bins buffer size mismatch");
+  if (!h->bins_valid) {
+    return fail(SXMC_ERR_STATE,
+                "the last evaluation counted only the event bins (sparse mode): evaluate with do_eval_pdf = 0 "
+                "to fill the histogram");
+  }
   SX_HIP(hipMemcpy(out, h->d_bins, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
   return SXMC_OK;
 }
@@ -989,6 +1117,7 @@ int sxmc_group_destroy(sxmc_group_t g) {
   (void)hipDeviceSynchronize();
   for (LaunchClass& c : g->classes) free_class(c);
   if (g->d_descs) (void)hipFree(g->d_descs);
+  if (g->d_descs_sparse) (void)hipFree(g->d_descs_sparse);
   if (g->d_ticket) (void)hipFree(g->d_ticket);
   if (g->d_step_sums) (void)hipFree(g->d_step_sums);
   for (hipEvent_t e : g->ev0) (void)hipEventDestroy(e);
@@ -1014,6 +1143,12 @@ int sxmc_group_set_partition(sxmc_group_t g, int mode) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_sparse(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_sparse = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
 int sxmc_group_set_prebinning(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_prebin = enable ? 1 : 0;
@@ -1034,11 +1169,13 @@ int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)s;
   g->last_stream = st;
-  rc = group_fill(g, st);
+  // lookup-only evaluation of histograms beyond LDS capacity counts just the event bins
+  const bool sparse = do_eval_pdf && g->sparse_ready && g->cfg_sparse;
+  rc = group_fill(g, st, sparse);
   if (rc) return rc;
   // pdfz.cpp:474-476: no lookup without evaluation points or when do_eval_pdf is false
   if (do_eval_pdf && g->max_points > 0) {
-    SX_HIP(sx_launch_eval_pdf(g->d_descs, (int)g->members.size(), g->max_points, st));
+    SX_HIP(sx_launch_eval_pdf(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(), g->max_points, st));
   }
   return SXMC_OK;
 }
@@ -1055,14 +1192,15 @@ int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s, const double* d_p
   if (!g->same_points) return fail(SXMC_ERR_STATE, "members do not share one set of evaluation points");
   hipStream_t st = (hipStream_t)s;
   g->last_stream = st;
-  rc = group_fill(g, st);
+  const bool sparse = g->sparse_ready && g->cfg_sparse;
+  rc = group_fill(g, st, sparse);
   if (rc) return rc;
   const unsigned long long ne = g->members[0]->npoints;
   SX_REQUIRE(g->members.size() <= 1024, "too many members for the fused evaluation");
   const int block = 128;
   int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
-  SX_HIP(sx_launch_eval_nll(g->d_descs, (int)g->members.size(), ne, d_pars, d_nexpected, d_n_mc, d_source_id,
-                            d_norms, d_sums, grid, block, st));
+  SX_HIP(sx_launch_eval_nll(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(), ne, d_pars,
+                            d_nexpected, d_n_mc, d_source_id, d_norms, d_sums, grid, block, st));
   *npartial_out = grid;
   return SXMC_OK;
 }
@@ -1086,7 +1224,8 @@ int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_
   SX_REQUIRE(g->members.size() <= 1024, "too many members for the fused step");
   hipStream_t st = (hipStream_t)s;
   g->last_stream = st;
-  rc = group_fill(g, st);  // zero (also clears the ticket) + fill
+  const bool sparse = g->sparse_ready && g->cfg_sparse;
+  rc = group_fill(g, st, sparse);  // zero (also clears the ticket) + fill
   if (rc) return rc;
   const unsigned long long ne = g->members[0]->npoints;
   const int block = 128;
@@ -1111,8 +1250,8 @@ int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_
   a.n_mc = d_n_mc;
   a.source_id = d_source_id;
   a.norms = d_norms;
-  SX_HIP(sx_launch_eval_nll_finish(g->d_descs, (int)g->members.size(), ne, g->d_step_sums, g->d_ticket, a, grid,
-                                   block, st));
+  SX_HIP(sx_launch_eval_nll_finish(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(), ne,
+                                   g->d_step_sums, g->d_ticket, a, grid, block, st));
   return SXMC_OK;
 }
 
@@ -1172,7 +1311,13 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
       }
     }
     fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
-    hb += 4.0 * (double)h->total_nbins * (h->total_nbins <= kLdsMaxBins ? 1.0 : 2.0);
+    if (h->total_nbins <= kLdsMaxBins) {
+      hb += 4.0 * (double)h->total_nbins;                       // LDS-private, flushed once
+    } else if (g->sparse_ready && g->cfg_sparse) {
+      hb += 2.0 * 4.0 * (double)std::max(h->ntargets, 1);      // event-bin counters: zero + update
+    } else {
+      hb += 2.0 * 4.0 * (double)h->total_nbins;                 // HBM-resident histogram: zero + update
+    }
     ev += 16.0 * (double)d.npoints;
   }
   *fill_read = fr;

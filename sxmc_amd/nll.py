@@ -78,6 +78,10 @@ class EvalGroup:
         """0 automatic, 1 sliced, 2 interleaved (see include/sxmc_hip.h)."""
         capi.call("sxmc_group_set_partition", self._g, int(mode))
 
+    def SetSparse(self, enable):
+        """Count only the event bins when a histogram beyond LDS capacity is evaluated for lookup (default on)."""
+        capi.call("sxmc_group_set_sparse", self._g, int(bool(enable)))
+
     def SetPrebinning(self, enable):
         """Stream observables that no systematic writes as one pre-binned narrow column (default on)."""
         capi.call("sxmc_group_set_prebinning", self._g, int(bool(enable)))

@@ -279,18 +279,21 @@ def test_c5_shape_five_observables_hbm_resident_histograms():
     step against the oracle, bit for bit."""
     w = workloads.config5(3e-5, nevents=2000, nbins=(40, 40, 40, 4, 4))      # 1.0e6 bins per signal
     w.signals = w.signals[:4]
-    m = MCMC(w, seed=21, fused=True)
-    m.setup(sync_interval=8)
-    proposal = m.proposed_vector.get()
-    m.step(debug_mode=True)
-    rows, nacc = m.flush()
-    want, bins, norms, lut = oracle_nll_of_workload(w, proposal)
-    for j, p in enumerate(m.pdfs):
-        assert np.array_equal(p.GetBins(), bins[j])
-    assert np.array_equal(m.normalizations.get(), norms)
-    assert np.array_equal(m.lut.get().view(np.uint32), lut.ravel().view(np.uint32))
-    assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
-    assert nacc == 1
+    for sparse in (True, False):      # event-bin counters (default) and the dense HBM-resident histogram
+        m = MCMC(w, seed=21, fused=True)
+        m.group.SetSparse(sparse)
+        m.setup(sync_interval=8)
+        proposal = m.proposed_vector.get()
+        m.step(debug_mode=True)
+        rows, nacc = m.flush()
+        want, bins, norms, lut = oracle_nll_of_workload(w, proposal)
+        if not sparse:
+            for j, p in enumerate(m.pdfs):
+                assert np.array_equal(p.GetBins(), bins[j])
+        assert np.array_equal(m.normalizations.get(), norms)
+        assert np.array_equal(m.lut.get().view(np.uint32), lut.ravel().view(np.uint32))
+        assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
+        assert nacc == 1
 
 
 def test_concurrent_chains_share_one_sample_table():

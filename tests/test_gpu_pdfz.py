@@ -40,8 +40,18 @@ def gpu_eval(samples, nfields, lower, upper, nbins, systs, params, points=None, 
         ev.SetLaunchConfig(*launch)
     ev.EvalAsync(do_eval_pdf)
     ev.EvalFinished()
-    res = dict(bins=ev.GetBins(), norm=norm.get(), out=pdf_values.get(),
+    res = dict(norm=norm.get(), out=pdf_values.get(),
                read_bins=ev.GetReadBins() if points is not None else None, ev=ev)
+    try:
+        res["bins"] = ev.GetBins()
+    except capi.SxmcError:
+        # a histogram beyond LDS capacity evaluated for lookup counts only the event bins (sparse mode);
+        # the dense histogram comes from an evaluation with do_eval_pdf = False, as in CreateHistogram
+        ev.EvalAsync(False)
+        ev.EvalFinished()
+        res["bins"] = ev.GetBins()
+        res["sparse"] = True
+        assert np.array_equal(norm.get(), res["norm"])
     return res
 
 
@@ -198,8 +208,12 @@ def test_large_histogram_uses_global_atomics():
     samples = table(rng, 200003, 3, lo=-0.1, hi=1.1)
     nb = [300, 300]                                    # 90000 bins > LDS capacity
     pts = np.concatenate([table(rng, 1000, 2), np.zeros((1000, 1), np.float32)], axis=1)
-    compare(dict(samples=samples, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=nb,
-                 systs=[dict(type="shift", obs=0, pars=[0])], params=[0.01], points=pts))
+    g, o = compare(dict(samples=samples, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=nb,
+                        systs=[dict(type="shift", obs=0, pars=[0])], params=[0.01], points=pts))
+    assert g.get("sparse")                             # the lookup evaluation counted only the event bins
+    g, o = compare(dict(samples=samples, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=nb,
+                        systs=[dict(type="shift", obs=0, pars=[0])], params=[0.01]), do_eval_pdf=False)
+    assert not g.get("sparse")
 
 
 @pytest.mark.parametrize("launch", [(256, 1), (256, 4), (512, 2), (1024, 1), (1024, 2)])
@@ -401,3 +415,43 @@ def test_prebinned_column_edge_values():
     kw = dict(samples=tab, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=[4, 5], systs=systs, params=[0.05])
     g, o = compare(kw)
     assert o["norm"] == 3 * 6 and g["bins"].sum() == o["norm"]     # 0, nextbelow(1), -0, 0.5, 0.25, 0.999
+
+
+def test_sparse_counting_matches_dense_lookup():
+    """Histograms beyond LDS capacity, evaluated for lookup: only the distinct event bins are counted
+    (bit filter + hash table).  lut and norms must equal the dense evaluation's, bit for bit, including
+    events outside the domain (-1), of another dataset (-2), many events in one bin, and no usable event."""
+    rng = np.random.default_rng(16)
+    nb = [120, 110, 7]                                   # 92400 bins
+    sizes = [150001, 70001, 9]
+    pts = np.concatenate([table(rng, 4000, 3, lo=-0.2, hi=1.2), rng.integers(0, 2, size=(4000, 1)).astype(np.float32)],
+                         axis=1)
+    pts[:500, :3] = pts[0, :3]                           # 500 events share one bin
+    systs = [dict(type="scale", obs=0, pars=[0]), dict(type="resolution_scale", obs=1, true_obs=3, pars=[1, 0])]
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, nb, systs, [0.02, 0.1], nfields=5, points=pts)
+    group = nll.EvalGroup(evs)
+    out = {}
+    for sparse in (True, False):
+        group.SetSparse(sparse)
+        lut.set(np.full(lut.size, 777.0, np.float32))
+        group.EvalAsync(True)
+        group.EvalFinished()
+        out[sparse] = (lut.get(), norms.get())
+        if sparse:
+            with pytest.raises(capi.SxmcError):
+                evs[0].GetBins()
+    assert np.array_equal(out[True][0].view(np.uint32), out[False][0].view(np.uint32))
+    assert np.array_equal(out[True][1], out[False][1])
+    for j, t in enumerate(tabs):
+        o = oracle_eval(t, 5, [0.0] * 3, [1.0] * 3, nb, systs, [0.02, 0.1], points=pts, dataset=j % 2)
+        assert_same_bits(out[True][0].reshape(len(sizes), -1)[j], o["out"])
+        assert out[True][1][j] == o["norm"]
+        assert np.array_equal(evs[j].GetBins(), o["bins"])          # dense evaluation ran last
+    # no event inside the domain / of this dataset: nothing to count, everything NaN or 0
+    far = np.concatenate([np.full((5, 3), 7.0, np.float32), np.zeros((5, 1), np.float32)], axis=1)
+    for e in evs:
+        e.SetEvalPoints(far)
+    group.SetSparse(True)
+    group.EvalAsync(True)
+    group.EvalFinished()
+    assert np.all(np.isnan(lut.get()[:5]))
