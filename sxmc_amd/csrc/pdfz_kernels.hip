@@ -212,9 +212,8 @@ typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load 
 // counter slot.  Same counts at the bins that are read, same norm.
 typedef unsigned vuint2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void sparse_count(const SxSignalDesc& d, gptr<unsigned> counters, unsigned bin) {
-  const unsigned hb = (bin * 0x9E3779B1u) >> d.sparse_filter_shift;
-  if (!((to_global(d.sparse_filter)[hb >> 5] >> (hb & 31u)) & 1u)) return;
+// table part: the bit filter said "maybe"
+__device__ __forceinline__ void sparse_lookup(const SxSignalDesc& d, gptr<unsigned> counters, unsigned bin) {
   const unsigned mask = (1u << (32 - d.sparse_table_shift)) - 1u;
   unsigned hp = (bin * 0x85EBCA6Bu) >> d.sparse_table_shift;
   for (unsigned probe = 0; probe <= mask; probe++) {
@@ -226,6 +225,12 @@ __device__ __forceinline__ void sparse_count(const SxSignalDesc& d, gptr<unsigne
     if (e[0] == 0xFFFFFFFFu) return;
     hp = (hp + 1u) & mask;
   }
+}
+
+__device__ __forceinline__ void sparse_count(const SxSignalDesc& d, gptr<unsigned> counters, unsigned bin) {
+  const unsigned hb = (bin * 0x9E3779B1u) >> d.sparse_filter_shift;
+  if (!((to_global(d.sparse_filter)[hb >> 5] >> (hb & 31u)) & 1u)) return;
+  sparse_lookup(d, counters, bin);
 }
 
 // PRE-BINNING.  An observable that no systematic writes has the same value, hence the same bin index
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
                                                     const unsigned* __restrict__ blk_off,
                                                     unsigned hist_words, unsigned dbg) {
   extern __shared__ unsigned lds[];
+  constexpr int RING = NSLOT <= 4 ? 2 : 1;  // depth of the register ring of raw columns
   const unsigned tid = threadIdx.x;
   const unsigned nthreads = blockDim.x;
   const unsigned lane = tid & (kWave - 1);
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
       //   bit 1: every reload hits one cached address -> the kernel without its HBM stream
       //   bit 0: skip the arithmetic and the histogram -> the HBM stream alone
       //   bit 2: skip only the histogram update
-      const unsigned long long vl = vc + 2ull * step;
+      const unsigned long long vl = vc + (unsigned long long)RING * step;
       load_columns<NOBS, NSLOT, PREW, PROG>(buf, col, precol, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
       if (dbg & 1u) {
 #pragma unroll
@@ -419,6 +425,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
 
       // lanes past the end of the slice hold clamped duplicates: count them as failures
       const unsigned dead = (vc < v1) ? 0u : 1u;
+      unsigned okbin[SXMC_VEC];   // flat bin index of a sample to be counted, or all ones (non-LDS modes)
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
         // pdfz.cpp:388-398.  `bad` counts failed domain tests (each a vector compare feeding an
@@ -446,33 +453,57 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
         }
         const unsigned in_domain = (bad == 0u) ? 1u : 0u;
         cnt += in_domain;
+        // in domain but index out of range (the reference's one-past-the-end case) still counts in the
+        // norm; it and every failure are not histogrammed
+        const bool store = (bad == 0u) && ((unsigned)bin < B) && !(dbg & 4u);
         if (LDS_HIST) {
-          // in domain but index out of range (the reference's one-past-the-end case) still counts
-          // in the norm; it and every failure go to the lane's trash word
-          const bool store = (bad == 0u) && ((unsigned)bin < B) && !(dbg & 4u);
-          const unsigned slot = store ? (unsigned)bin : trash;
+          const unsigned slot = store ? (unsigned)bin : trash;   // failures go to the lane's trash word
           __hip_atomic_fetch_add(&hist[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-          if (bad == 0u && (unsigned)bin < B && !(dbg & 4u)) {
-            if (sparse) {
-              sparse_count(d, gbins, (unsigned)bin);
-            } else {
-              __hip_atomic_fetch_add(&gbins[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          okbin[q] = store ? (unsigned)bin : 0xFFFFFFFFu;
+        }
+      }
+      if (!LDS_HIST) {
+        if (sparse) {
+          // all four filter words are requested before any is tested: one L2 round trip, not four
+          unsigned hb[SXMC_VEC], word[SXMC_VEC];
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            hb[q] = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0x9E3779B1u) >> d.sparse_filter_shift : 0u;
+            word[q] = to_global(d.sparse_filter)[hb[q] >> 5];
+          }
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            if (okbin[q] != 0xFFFFFFFFu && ((word[q] >> (hb[q] & 31u)) & 1u)) sparse_lookup(d, gbins, okbin[q]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            if (okbin[q] != 0xFFFFFFFFu) {
+              __hip_atomic_fetch_add(&gbins[okbin[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
       }
     };
 
-    // wave-uniform trip count: every lane runs the same number of stage pairs
+    // wave-uniform trip count: every lane runs the same number of stages
     unsigned long long v = v0 + tid;
-    const unsigned long long npairs = (v1 - v0 + 2ull * step - 1) / (2ull * step);
-    Columns<NSLOT, PREW> bufA, bufB;
-    load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, v < v1 ? v : vlast);
-    load_columns<NOBS, NSLOT, PREW, PROG>(bufB, col, precol, v + step < v1 ? v + step : vlast);
-    for (unsigned long long it = 0; it < npairs; ++it, v += 2ull * step) {
-      stage(bufA, v);
-      stage(bufB, v + step);
+    if constexpr (RING == 2) {
+      const unsigned long long npairs = (v1 - v0 + 2ull * step - 1) / (2ull * step);
+      Columns<NSLOT, PREW> bufA, bufB;
+      load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, v < v1 ? v : vlast);
+      load_columns<NOBS, NSLOT, PREW, PROG>(bufB, col, precol, v + step < v1 ? v + step : vlast);
+      for (unsigned long long it = 0; it < npairs; ++it, v += 2ull * step) {
+        stage(bufA, v);
+        stage(bufB, v + step);
+      }
+    } else {
+      // wide shapes (5+ columns): one buffer, re-issued right after widening, keeps the registers in budget
+      const unsigned long long niter = (v1 - v0 + step - 1) / step;
+      Columns<NSLOT, PREW> bufA;
+      load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, v < v1 ? v : vlast);
+      for (unsigned long long it = 0; it < niter; ++it, v += step) stage(bufA, v);
     }
 
     // ---- in-domain count: lane registers -> wave -> workgroup -> one global atomic

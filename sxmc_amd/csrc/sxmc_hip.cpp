@@ -132,6 +132,7 @@ struct sxmc_hist {
   unsigned* d_filter = nullptr;
   unsigned* d_table = nullptr;
   int ntargets = 0, filter_shift = 0, table_shift = 0;
+  std::vector<unsigned> targets;   // sorted distinct event bins (host copy: members with equal sets share tables)
   bool bins_valid = true;          // false after a sparse evaluation: the dense histogram was not filled
 };
 
@@ -304,6 +305,7 @@ void free_sparse(sxmc_hist* h) {
   h->d_filter = nullptr;
   h->d_table = nullptr;
   h->ntargets = 0;
+  h->targets.clear();
 }
 
 int ceil_log2(size_t x) {
@@ -349,6 +351,7 @@ int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
   SX_HIP(hipMalloc((void**)&h->d_table, sizeof(unsigned) * table.size()));
   SX_HIP(hipMemcpy(h->d_table, table.data(), sizeof(unsigned) * table.size(), hipMemcpyHostToDevice));
   h->ntargets = (int)T;
+  h->targets = targets;
   h->filter_shift = 32 - fbits;
   h->table_shift = 32 - tbits;
   return SXMC_OK;
@@ -510,6 +513,16 @@ int group_rebuild(sxmc_group* g) {
     if (h->total_nbins > kLdsMaxBins) {
       if (h->has_points && h->d_table) {
         make_sparse_desc(h, sparse_descs[(size_t)i]);
+        // members that look up the same set of bins (the usual case: one data set, one binning) share ONE
+        // filter and table, so the probes of all signals hit the same few cache lines
+        for (int k = 0; k < i; k++) {
+          const sxmc_hist* o = g->members[k];
+          if (o->d_table && o->total_nbins == h->total_nbins && o->targets == h->targets) {
+            sparse_descs[(size_t)i].sparse_filter = o->d_filter;
+            sparse_descs[(size_t)i].sparse_table = o->d_table;
+            break;
+          }
+        }
         g->sparse_ready = true;
       } else {
         sparse_ok = false;
@@ -560,7 +573,11 @@ int group_rebuild(sxmc_group* g) {
     SX_HIP(hipMemcpy(c.d_descs, descs.data(), sizeof(SxSignalDesc) * descs.size(), hipMemcpyHostToDevice));
     if (g->sparse_ready && !c.shape.lds_hist) {
       std::vector<SxSignalDesc> sd = descs;
-      for (size_t q = 0; q < sd.size(); q++) make_sparse_desc(g->members[c.member_idx[q]], sd[q]);
+      for (size_t q = 0; q < sd.size(); q++) {
+        make_sparse_desc(g->members[c.member_idx[q]], sd[q]);
+        sd[q].sparse_filter = sparse_descs[(size_t)c.member_idx[q]].sparse_filter;  // shared tables
+        sd[q].sparse_table = sparse_descs[(size_t)c.member_idx[q]].sparse_table;
+      }
       SX_HIP(hipMalloc((void**)&c.d_descs_sparse, sizeof(SxSignalDesc) * sd.size()));
       SX_HIP(hipMemcpy(c.d_descs_sparse, sd.data(), sizeof(SxSignalDesc) * sd.size(), hipMemcpyHostToDevice));
     }
