@@ -314,6 +314,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
   const unsigned trash = hist_words + lane;
 
   bool lds_clean = false;
+  const unsigned* coarse_in_lds = nullptr;
   const unsigned seg_end = blk_off[blockIdx.x + 1];
 
   for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
@@ -333,6 +334,15 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
         for (unsigned b = tid; b < hist_words; b += nthreads) hist[b] = 0u;
       }
       if (tid == 0) *s_norm = 0u;
+      __syncthreads();
+    }
+    // sparse counting: stage the member's coarse bit filter in LDS (it rejects most samples without
+    // touching L2); members that share their tables share it, so it is reloaded only when it changes
+    const int cshift = sparse ? d.sparse_coarse_shift : 0;
+    if (sparse && d.sparse_coarse != coarse_in_lds) {
+      const unsigned cwords = 1u << (32 - cshift - 5);
+      for (unsigned b = tid; b < cwords && b < hist_words; b += nthreads) hist[b] = to_global(d.sparse_coarse)[b];
+      coarse_in_lds = d.sparse_coarse;
       __syncthreads();
     }
 
@@ -466,12 +476,20 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
       if (!LDS_HIST) {
         if (sparse) {
           // all four filter words are requested before any is tested: one L2 round trip, not four
+          // level 1: coarse filter in LDS (passes ~1 in 5 of the non-members at 1e5 event bins)
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            const unsigned hc = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0xC2B2AE35u) >> cshift : 0u;
+            if (!((hist[hc >> 5] >> (hc & 31u)) & 1u)) okbin[q] = 0xFFFFFFFFu;
+          }
+          // level 2: fine filter through L2; all four words are requested before any is tested
           unsigned hb[SXMC_VEC], word[SXMC_VEC];
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) {
             hb[q] = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0x9E3779B1u) >> d.sparse_filter_shift : 0u;
             word[q] = to_global(d.sparse_filter)[hb[q] >> 5];
           }
+          // level 3: the table, for the ~1 % that remain
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) {
             if (okbin[q] != 0xFFFFFFFFu && ((word[q] >> (hb[q] & 31u)) & 1u)) sparse_lookup(d, gbins, okbin[q]);
@@ -845,15 +863,16 @@ template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW = 0>
 hipError_t launch_fill_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                          const unsigned* blk_off, hipStream_t s) {
   auto k = fill_kernel<NOBS, NSLOT, LDS_HIST, PROG, PREW>;
-  if (LDS_HIST && sh.lds_bytes > 48 * 1024) {
+  if (sh.lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
     if (e != hipSuccess) return e;
   }
   // LDS: 4 header words + hist_words + 64 trash words
-  const unsigned hist_words = LDS_HIST ? (unsigned)(sh.lds_bytes / 4 - 4 - 64) : 0u;
-  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), LDS_HIST ? sh.lds_bytes : 64, s, descs, segs,
-                     blk_off, hist_words, (unsigned)sh.debug_mode);
+  // LDS-histogram launches: hist_words bins + 64 trash words; others: room for the sparse coarse filter
+  const unsigned hist_words = (unsigned)(sh.lds_bytes / 4 - 4 - (LDS_HIST ? 64 : 0));
+  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, hist_words,
+                     (unsigned)sh.debug_mode);
   return hipGetLastError();
 }
 
@@ -865,40 +884,50 @@ typedef hipError_t (*FillLauncher)(const SxLaunchShape&, const SxSignalDesc*, co
 struct StaticEntry {
   int nobs, nslot, nops;
   unsigned ops[4];
-  FillLauncher fn;         // all observables binned in the kernel
-  FillLauncher fn_pre[2];  // observables no systematic writes come pre-binned, 1 / 2 bytes per sample (with an
-                           // LDS-sized histogram the partial index of the table's programs is below 65535)
+  FillLauncher fn;           // LDS histogram, all observables binned in the kernel
+  FillLauncher fn_pre[2];    // LDS histogram, observables no systematic writes pre-binned, 1 / 2 bytes per sample
+                             // (with an LDS-sized histogram the partial index of the table's programs is < 65535)
+  FillLauncher fn_g;         // histogram beyond LDS capacity (dense global atomics or sparse event-bin counters)
+  FillLauncher fn_g_pre[2];
 };
 #define SX_SHIFT(o) sx_op(SXMC_SYST_SHIFT, o)
 #define SX_SCALE(o) sx_op(SXMC_SYST_SCALE, o)
 #define SX_CTSC(o) sx_op(SXMC_SYST_CTSCALE, o)
 #define SX_RES(o, e) sx_op(SXMC_SYST_RESOLUTION_SCALE, o, e)
 #define SX_NOPRE {nullptr, nullptr}
+#define SX_NOG nullptr, {nullptr, nullptr}
 #define SX_PRE(NO, NS, ...) \
   {launch_fill_k<NO, NS, true, StaticProg<__VA_ARGS__>, 1>, launch_fill_k<NO, NS, true, StaticProg<__VA_ARGS__>, 2>}
-#define SX_P1(NO, NS, PRE, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE}
-#define SX_P2(NO, NS, PRE, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE}
-#define SX_P3(NO, NS, PRE, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE}
+#define SX_G(NO, NS, ...) \
+  launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 0>, \
+  {launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 1>, launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 2>}
+#define SX_P1(NO, NS, PRE, G, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE, G}
+#define SX_P2(NO, NS, PRE, G, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE, G}
+#define SX_P3(NO, NS, PRE, G, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE, G}
 const StaticEntry kStaticPrograms[] = {
     // 1-D (bench_sxmc pdfz: one shift; config/example.json: scale + resolution_scale)
-    SX_P1(1, 1, SX_NOPRE, SX_SHIFT(0)),
-    SX_P1(1, 1, SX_NOPRE, SX_SCALE(0)),
-    SX_P2(1, 1, SX_NOPRE, SX_SHIFT(0), SX_SCALE(0)),
-    SX_P1(1, 2, SX_NOPRE, SX_RES(0, 1)),
-    SX_P2(1, 2, SX_NOPRE, SX_SCALE(0), SX_RES(0, 1)),
-    SX_P3(1, 2, SX_NOPRE, SX_SHIFT(0), SX_SCALE(0), SX_RES(0, 1)),
+    SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_SHIFT(0)),
+    SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_SCALE(0)),
+    SX_P2(1, 1, SX_NOPRE, SX_NOG, SX_SHIFT(0), SX_SCALE(0)),
+    SX_P1(1, 2, SX_NOPRE, SX_NOG, SX_RES(0, 1)),
+    SX_P2(1, 2, SX_NOPRE, SX_NOG, SX_SCALE(0), SX_RES(0, 1)),
+    SX_P3(1, 2, SX_NOPRE, SX_NOG, SX_SHIFT(0), SX_SCALE(0), SX_RES(0, 1)),
     // 2-D
-    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(0)), SX_SHIFT(0)),
-    SX_P1(2, 2, SX_PRE(2, 2, SX_SCALE(0)), SX_SCALE(0)),
-    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(1)), SX_SHIFT(1)),
-    SX_P2(2, 3, SX_PRE(2, 3, SX_SCALE(0), SX_RES(0, 2)), SX_SCALE(0), SX_RES(0, 2)),
-    SX_P3(2, 3, SX_NOPRE, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 2)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(0)), SX_NOG, SX_SHIFT(0)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SCALE(0)), SX_NOG, SX_SCALE(0)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(1)), SX_NOG, SX_SHIFT(1)),
+    SX_P2(2, 3, SX_PRE(2, 3, SX_SCALE(0), SX_RES(0, 2)), SX_NOG, SX_SCALE(0), SX_RES(0, 2)),
+    SX_P3(2, 3, SX_NOPRE, SX_NOG, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 2)),
     // 3-D (BASELINE config 3: shift(r) + scale(e) + resolution_scale(e | e_true))
-    SX_P1(3, 3, SX_PRE(3, 3, SX_SHIFT(0)), SX_SHIFT(0)),
-    SX_P1(3, 3, SX_PRE(3, 3, SX_SCALE(0)), SX_SCALE(0)),
-    SX_P1(3, 4, SX_PRE(3, 4, SX_RES(0, 3)), SX_RES(0, 3)),
-    SX_P2(3, 4, SX_PRE(3, 4, SX_SCALE(0), SX_RES(0, 3)), SX_SCALE(0), SX_RES(0, 3)),
-    SX_P3(3, 4, SX_PRE(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)), SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
+    SX_P1(3, 3, SX_PRE(3, 3, SX_SHIFT(0)), SX_NOG, SX_SHIFT(0)),
+    SX_P1(3, 3, SX_PRE(3, 3, SX_SCALE(0)), SX_NOG, SX_SCALE(0)),
+    SX_P1(3, 4, SX_PRE(3, 4, SX_RES(0, 3)), SX_NOG, SX_RES(0, 3)),
+    SX_P2(3, 4, SX_PRE(3, 4, SX_SCALE(0), SX_RES(0, 3)), SX_NOG, SX_SCALE(0), SX_RES(0, 3)),
+    SX_P3(3, 4, SX_PRE(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
+          SX_G(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)), SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
+    // 5-D (BASELINE config 5: the same three systematics, histograms beyond LDS capacity)
+    SX_P3(5, 6, SX_PRE(5, 6, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)),
+          SX_G(5, 6, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)), SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)),
 };
 constexpr int kNumStatic = (int)(sizeof(kStaticPrograms) / sizeof(kStaticPrograms[0]));
 
@@ -915,8 +944,12 @@ bool sx_fill_has_specialization(int nobs, int nslot) {
   return nobs >= 1 && nobs <= 5 && nslot >= nobs && nslot <= nobs + 2;
 }
 
-bool sx_fill_static_has_prebin(int prog) {
-  return prog >= 0 && prog < kNumStatic && kStaticPrograms[prog].fn_pre[0] != nullptr;
+// does static program `prog` have a kernel for this histogram mode, without / with a pre-binned column?
+bool sx_fill_static_supports(int prog, int lds_hist, int prebin) {
+  if (prog < 0 || prog >= kNumStatic) return false;
+  const StaticEntry& e = kStaticPrograms[prog];
+  if (prebin) return (lds_hist ? e.fn_pre[0] : e.fn_g_pre[0]) != nullptr;
+  return (lds_hist ? e.fn : e.fn_g) != nullptr;
 }
 
 hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,
@@ -942,15 +975,16 @@ int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* o
 hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                           const unsigned* blk_off, hipStream_t s) {
   if (sh.grid <= 0) return hipSuccess;
-  if (sh.lds_hist && sh.static_prog >= 0 && sh.static_prog < kNumStatic) {
+  if (sh.static_prog >= 0 && sh.static_prog < kNumStatic) {
     const StaticEntry& e = kStaticPrograms[sh.static_prog];
-    if (sh.pre_width) {
-      if (sh.pre_width != 1 && sh.pre_width != 2) return hipErrorInvalidValue;
-      const int w = sh.pre_width - 1;
-      if (!e.fn_pre[w]) return hipErrorInvalidValue;
-      return e.fn_pre[w](sh, descs, segs, blk_off, s);
+    FillLauncher fn = nullptr;
+    if (sh.pre_width == 0) {
+      fn = sh.lds_hist ? e.fn : e.fn_g;
+    } else if (sh.pre_width == 1 || sh.pre_width == 2) {
+      fn = sh.lds_hist ? e.fn_pre[sh.pre_width - 1] : e.fn_g_pre[sh.pre_width - 1];
     }
-    return e.fn(sh, descs, segs, blk_off, s);
+    if (!fn) return hipErrorInvalidValue;
+    return fn(sh, descs, segs, blk_off, s);
   }
 #define SX_CASE(NO, NS) \
   if (sh.nobs == NO && sh.nslot == NS) return launch_fill_dyn<NO, NS>(sh, descs, segs, blk_off, s);

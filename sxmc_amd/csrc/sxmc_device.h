@@ -60,7 +60,8 @@ struct SxSignalDesc {
   int sparse_filter_shift;       // hash >> shift selects a filter bit
   int sparse_table_shift;        // hash >> shift selects a table entry
   int sparse_real_nbins;         // the histogram's true bin count (total_nbins is the counter count here)
-  int pad1;
+  int sparse_coarse_shift;       // hash >> shift selects a bit of the coarse filter (staged in LDS)
+  const unsigned* sparse_coarse; // coarse one-hash bit filter, at most 64 KiB
   // --- evaluation at the data events
   const int* read_bins;
   unsigned long long npoints;
@@ -119,7 +120,7 @@ hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_desc
                           const unsigned* d_blk_off, hipStream_t s);
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
-bool sx_fill_static_has_prebin(int prog);
+bool sx_fill_static_supports(int prog, int lds_hist, int prebin);
 hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,
                             hipStream_t s);
 hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,

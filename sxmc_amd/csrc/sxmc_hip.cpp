@@ -131,7 +131,8 @@ struct sxmc_hist {
   int* d_read_slot = nullptr;      // [npoints]: counter slot of each event, or -1 / -2
   unsigned* d_filter = nullptr;
   unsigned* d_table = nullptr;
-  int ntargets = 0, filter_shift = 0, table_shift = 0;
+  unsigned* d_coarse = nullptr;    // coarse filter staged in LDS by the fill kernel
+  int ntargets = 0, filter_shift = 0, table_shift = 0, coarse_shift = 0;
   std::vector<unsigned> targets;   // sorted distinct event bins (host copy: members with equal sets share tables)
   bool bins_valid = true;          // false after a sparse evaluation: the dense histogram was not filled
 };
@@ -300,6 +301,8 @@ void free_sparse(sxmc_hist* h) {
   if (h->d_read_slot) (void)hipFree(h->d_read_slot);
   if (h->d_filter) (void)hipFree(h->d_filter);
   if (h->d_table) (void)hipFree(h->d_table);
+  if (h->d_coarse) (void)hipFree(h->d_coarse);
+  h->d_coarse = nullptr;
   h->d_cnt = nullptr;
   h->d_read_slot = nullptr;
   h->d_filter = nullptr;
@@ -330,6 +333,8 @@ int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
   }
   const int fbits = std::min(26, std::max(16, ceil_log2(64 * std::max<size_t>(T, 1))));  // <= 1.6 % false positives
   const int tbits = std::max(6, ceil_log2(2 * std::max<size_t>(T, 1)));                   // load <= 50 %
+  const int cbits = std::min(19, std::max(10, ceil_log2(8 * std::max<size_t>(T, 1))));   // <= 64 KiB of LDS
+  std::vector<unsigned> coarse((size_t)1 << (cbits - 5), 0u);
   std::vector<unsigned> filter((size_t)1 << (fbits - 5), 0u);
   std::vector<unsigned> table((size_t)2 << tbits, 0xFFFFFFFFu);
   const unsigned mask = (1u << tbits) - 1u;
@@ -337,6 +342,8 @@ int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
     const unsigned bin = targets[t];
     const unsigned hb = (bin * 0x9E3779B1u) >> (32 - fbits);
     filter[hb >> 5] |= 1u << (hb & 31u);
+    const unsigned hc = (bin * 0xC2B2AE35u) >> (32 - cbits);
+    coarse[hc >> 5] |= 1u << (hc & 31u);
     unsigned hp = (bin * 0x85EBCA6Bu) >> (32 - tbits);
     while (table[2 * (size_t)hp] != 0xFFFFFFFFu) hp = (hp + 1u) & mask;
     table[2 * (size_t)hp] = bin;
@@ -350,6 +357,9 @@ int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
   SX_HIP(hipMemcpy(h->d_filter, filter.data(), sizeof(unsigned) * filter.size(), hipMemcpyHostToDevice));
   SX_HIP(hipMalloc((void**)&h->d_table, sizeof(unsigned) * table.size()));
   SX_HIP(hipMemcpy(h->d_table, table.data(), sizeof(unsigned) * table.size(), hipMemcpyHostToDevice));
+  SX_HIP(hipMalloc((void**)&h->d_coarse, sizeof(unsigned) * coarse.size()));
+  SX_HIP(hipMemcpy(h->d_coarse, coarse.data(), sizeof(unsigned) * coarse.size(), hipMemcpyHostToDevice));
+  h->coarse_shift = 32 - cbits;
   h->ntargets = (int)T;
   h->targets = targets;
   h->filter_shift = 32 - fbits;
@@ -367,6 +377,8 @@ void make_sparse_desc(const sxmc_hist* h, SxSignalDesc& d) {
   d.sparse_table = h->d_table;
   d.sparse_filter_shift = h->filter_shift;
   d.sparse_table_shift = h->table_shift;
+  d.sparse_coarse = h->d_coarse;
+  d.sparse_coarse_shift = h->coarse_shift;
 }
 
 int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
@@ -448,19 +460,21 @@ int group_rebuild(sxmc_group* g) {
     const int key_nobs = spec ? d.nobs : 0, key_nslot = spec ? d.nslot : 0;
     // the member's program as static-table words (type | obs_slot << 4 | extra_slot << 8)
     std::vector<unsigned> prog;
-    bool prog_simple = spec && lds_hist && d.nsyst <= 4;
+    bool prog_simple = spec && d.nsyst <= 4;
     for (int q = 0; q < d.nsyst; q++) {
       if (d.syst[q].npars != 1) prog_simple = false;
       prog.push_back((unsigned)d.syst[q].type | ((unsigned)d.syst[q].obs_slot << 4) |
                      ((unsigned)d.syst[q].extra_slot << 8));
     }
     // pre-binning: observables that no systematic writes (static programs only)
-    const int static_prog = (prog_simple && !prog.empty())
-                                ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
-                                : -1;
+    int static_prog = (prog_simple && !prog.empty())
+                          ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
+                          : -1;
+    if (!sx_fill_static_supports(static_prog, lds_hist, 0)) static_prog = -1;
+    if (static_prog < 0) prog_simple = false;
     unsigned pre_mask = 0;
     int pre_width = 0;
-    if (g->cfg_prebin && sx_fill_static_has_prebin(static_prog)) {
+    if (g->cfg_prebin && sx_fill_static_supports(static_prog, lds_hist, 1)) {
       unsigned touched = 0;
       for (int q = 0; q < d.nsyst; q++) touched |= 1u << d.syst[q].obs_slot;
       long long bound = 0;  // largest value the partial index can take (index == nbins included)
@@ -520,6 +534,7 @@ int group_rebuild(sxmc_group* g) {
           if (o->d_table && o->total_nbins == h->total_nbins && o->targets == h->targets) {
             sparse_descs[(size_t)i].sparse_filter = o->d_filter;
             sparse_descs[(size_t)i].sparse_table = o->d_table;
+            sparse_descs[(size_t)i].sparse_coarse = o->d_coarse;
             break;
           }
         }
@@ -562,6 +577,11 @@ int group_rebuild(sxmc_group* g) {
     }
     c.total_vec = prefix;
     c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4 + 64) * 4 : 64;
+    if (!c.shape.lds_hist && g->sparse_ready) {
+      int cshift = 32;
+      for (int idx : c.member_idx) cshift = std::min(cshift, g->members[idx]->coarse_shift);
+      c.shape.lds_bytes = ((size_t)4 + ((size_t)1 << (32 - cshift - 5))) * 4;   // header + largest coarse filter
+    }
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, 1024 / threads);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
     bpc = std::min(bpc, lds_limit);
@@ -577,6 +597,7 @@ int group_rebuild(sxmc_group* g) {
         make_sparse_desc(g->members[c.member_idx[q]], sd[q]);
         sd[q].sparse_filter = sparse_descs[(size_t)c.member_idx[q]].sparse_filter;  // shared tables
         sd[q].sparse_table = sparse_descs[(size_t)c.member_idx[q]].sparse_table;
+        sd[q].sparse_coarse = sparse_descs[(size_t)c.member_idx[q]].sparse_coarse;
       }
       SX_HIP(hipMalloc((void**)&c.d_descs_sparse, sizeof(SxSignalDesc) * sd.size()));
       SX_HIP(hipMemcpy(c.d_descs_sparse, sd.data(), sizeof(SxSignalDesc) * sd.size(), hipMemcpyHostToDevice));
