@@ -130,6 +130,9 @@ def cpu_baseline(w, host_tables, vector, nevals, nthreads):
         norms = np.zeros(w.nsignals, np.uint32)
         all_bins = []
         for j, s in enumerate(w.signals):
+            if time.perf_counter() - t0 > 30:     # keep a long CPU leg visibly alive
+                print("cpu_baseline: signal %d/%d, %.0f s" % (j, w.nsignals, time.perf_counter() - t0),
+                      file=sys.stderr, flush=True)
             bins, norm = oracle.bin_samples(geom, host_tables[j], s.nfields, w.systematics,
                                             vector[w.nsources:], nthreads=nthreads)
             oracle.eval_pdf(rbs[j], bins, norm, geom.bin_volume, out=lut[j])
@@ -360,7 +363,9 @@ def main():
         gpu_nll = float(m.proposed_nll.get()[0])
         gpu_norms = m.normalizations.get()
         sec1, bins, norms, cpu_nll = cpu_baseline(w, host_tables, vector, args.cpu_evals, 1)
-        ncores = os.cpu_count() or 1
+        # all-core variant: private histograms per thread, so cap the threads where the histogram is huge
+        total_bins = int(np.prod(w.nbins))
+        ncores = max(1, min(os.cpu_count() or 1, int(4e9 // (4 * total_bins))))
         secn, bins_n, norms_n, _ = cpu_baseline(w, host_tables, vector, 1, ncores)
         exact = all(np.array_equal(a, b) for a, b in zip(gpu_bins, bins)) and np.array_equal(gpu_norms, norms)
         rel = abs(gpu_nll - cpu_nll) / abs(cpu_nll)
