@@ -109,7 +109,7 @@ def make_workload(args, torch, dev, seed):
         nb = tuple(int(x) for x in args.c5_bins.split(","))
         return make_c5_on_gpu(torch, dev, args.scale, seed, args.events, nb)
     makers = {"c1": workloads.config1, "c2": workloads.config2, "c5": workloads.config5,
-              "bench_pdfz": workloads.bench_pdfz}
+              "bench_pdfz": workloads.bench_pdfz, "bench_pdfz_group": workloads.bench_pdfz_group}
     w = makers[name](args.scale, seed=seed) if name == "c1" else makers[name](args.scale, seed=seed,
                                                                              nevents=args.events)
     tensors = [torch.from_numpy(s.samples).to(dev) for s in w.signals]
@@ -165,14 +165,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", help="c3 (default, the metric's config), c1, c2, c5, bench_pdfz")
+    ap.add_argument("--workload", default="c3", help="c3 (default, the metric's config), c1, c2, c5, bench_pdfz, bench_pdfz_group")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the sample counts (testing only)")
     ap.add_argument("--events", type=int, default=100000)
     ap.add_argument("--c5-bins", default="200,200,200,4,4", help="bins per observable for --workload c5")
-    ap.add_argument("--form", default="fused", choices=["step", "fused", "reference"],
+    ap.add_argument("--form", default="fused", choices=["step", "fused", "reference", "pdfz"],
                     help="fused (default): zero, fill, lookup+event sum, step end = 4 launches; step: the last two "
                          "merged (measured slower: every workgroup pays a release + ticket); reference: the "
-                         "reference's own sequence with the lut re-read")
+                         "reference's own sequence with the lut re-read; pdfz: only EvalAsync + EvalFinished of all evaluators "
+                         "per step, the loop of the reference's bench_sxmc (bench_sxmc.cpp:90-96, 193-200)")
     ap.add_argument("--launch", default="0,0", help="bin_threads,bin_blocks_per_cu (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=2)
@@ -222,7 +223,7 @@ def main():
     want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1
     host_tables = [t.cpu().numpy() for t in tensors] if want_cpu else None
 
-    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused={"step": "step", "fused": True, "reference": False}[args.form], samples_on_device=tensors)
+    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused={"step": "step", "fused": True, "reference": False, "pdfz": True}[args.form], samples_on_device=tensors)
     del tensors
     torch.cuda.empty_cache()
     threads, bpc = (int(x) for x in args.launch.split(","))
@@ -235,8 +236,15 @@ def main():
     m.setup(sync_interval=max(args.steps, args.warmup, 1))
 
     m.group.SetDebugMode(args.debug_mode)
+    def one_step():
+        if args.form == "pdfz":      # EvalAsync on all, EvalFinished on all (bench_sxmc.cpp:193-200)
+            m.group.EvalAsync(True, None)
+            m.group.EvalFinished()
+        else:
+            m.step()
+
     for _ in range(args.warmup):
-        m.step()
+        one_step()
     m.flush()
 
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
@@ -245,7 +253,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        m.step()
+        one_step()
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0)
@@ -253,6 +261,8 @@ def main():
     m.group.Profile(False, 0)
 
     chain, accepted = m.flush()
+    if chain.shape[0] == 0:
+        chain = np.zeros((1, w.nparameters + 1), np.float32)
     intervals = dist.gather_intervals(chain_intervals(chain, w.nparameters)[None], world, w.nparameters)
 
     # ---- ensemble leg (sxmc.cpp:59-145): whole fake experiments, experiment k on rank k mod N, the MC
@@ -260,7 +270,7 @@ def main():
     # timed region of the headline metric; reported beside it.
     experiments = None
     nexp = 3 * world if args.experiments < 0 else args.experiments
-    if nexp > 0 and not args.debug_mode:
+    if nexp > 0 and not args.debug_mode and args.form != "pdfz":
         from sxmc_amd import ensemble
         for s_ in w.signals:
             s_.nexpected_saved = s_.nexpected
@@ -268,7 +278,7 @@ def main():
         local = np.zeros((len(mine), w.nparameters, 4), np.float32)
         # chains for concurrent experiments: own non-blocking stream, own per-chain state, ONE copy of the tables
         nconc = max(1, min(args.exp_concurrent, len(mine)))
-        form = {"step": "step", "fused": True, "reference": False}[args.form]
+        form = {"step": "step", "fused": True, "reference": False, "pdfz": True}[args.form]
         pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m) for _ in range(nconc)]
         for c in pool:
             c.group.SetLaunchConfig(threads, bpc)

@@ -176,3 +176,22 @@ def bench_pdfz(scale=1.0, seed=7, nevents=100000):
     sig = [Signal(tab, 1, nexpected=100.0, source_id=0)]
     return Workload("bench_pdfz", 1, [-3.0], [3.0], [1000], sig, [dict(type="shift", obs=0, pars=[0])],
                     [0.1], ev, "bench_sxmc pdfz: N=1e7, 1-D, 1000 bins, 1 shift systematic")
+
+
+GROUP_SIZES = [1e3, 2e5, 1e4, 1e3, 1e3, 3e6, 5e5, 1e6, 8e4, 2e4] + [1e3] * 19    # bench_sxmc.cpp:121-151
+
+
+def bench_pdfz_group(scale=1.0, seed=8, nevents=100000):
+    """The reference's second benchmark shape (bench/bench_sxmc.cpp:105-225): 29 evaluators with 1e3 ... 3e6
+    N(0,1) samples each, 1-D, 1000 bins on [-3,3), one shift systematic per PDF, launched all-then-wait."""
+    rng = np.random.default_rng(seed)
+    signals = []
+    for j, n in enumerate(GROUP_SIZES):
+        tab = rng.normal(size=(max(1, int(n * scale)), 1)).astype(np.float32)
+        signals.append(Signal(tab, 1, nexpected=10.0 + j, source_id=j))
+    pts = rng.normal(size=nevents * 2).astype(np.float32)
+    pts = pts[(pts >= -3.0) & (pts < 3.0)][:nevents]
+    ev = np.zeros((pts.size, 2), dtype=np.float32)
+    ev[:, 0] = pts
+    return Workload("bench_pdfz_group", 1, [-3.0], [3.0], [1000], signals, [dict(type="shift", obs=0, pars=[0])],
+                    [0.1], ev, "bench_sxmc pdfz_group: 29 PDFs of 1e3..3e6 samples, 1-D, 1000 bins, 1 shift systematic")
