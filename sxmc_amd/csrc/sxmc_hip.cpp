@@ -93,12 +93,22 @@ int get_props(DeviceProps& p) {
 // chains / experiments on one GPU read ONE copy of the MC tables.
 struct SampleStore {
   float* d_cols = nullptr;
-  void* d_pre = nullptr;
-  unsigned pre_mask = 0;
-  int pre_width = 0;
+  // pre-binned columns built so far, one per (observable mask, width); kept until the table dies because
+  // descriptors of other groups may point at them
+  struct PreColumn {
+    unsigned mask;
+    int width;
+    void* ptr;
+  };
+  std::vector<PreColumn> pre;
+  void* find_pre(unsigned mask, int width) const {
+    for (const PreColumn& p : pre)
+      if (p.mask == mask && p.width == width) return p.ptr;
+    return nullptr;
+  }
   ~SampleStore() {
     if (d_cols) (void)hipFree(d_cols);
-    if (d_pre) (void)hipFree(d_pre);
+    for (PreColumn& p : pre) (void)hipFree(p.ptr);
   }
 };
 
@@ -558,17 +568,15 @@ int group_rebuild(sxmc_group* g) {
       if (c.shape.pre_width) {
         sxmc_hist* h = g->members[idx];
         SampleStore& st = *h->store;
-        if (!st.d_pre || st.pre_mask != c.pre_mask || st.pre_width != c.shape.pre_width) {
-          if (st.d_pre) SX_HIP(hipFree(st.d_pre));
-          st.d_pre = nullptr;
+        void* pre = st.find_pre(c.pre_mask, c.shape.pre_width);
+        if (!pre) {
           const size_t npad = h->nvec * SXMC_VEC;
-          SX_HIP(hipMalloc(&st.d_pre, std::max<size_t>(npad * (size_t)c.shape.pre_width, 16)));
-          SX_HIP(sx_launch_prebin(g->d_descs + idx, npad, c.pre_mask, c.shape.pre_width, st.d_pre, nullptr));
+          SX_HIP(hipMalloc(&pre, std::max<size_t>(npad * (size_t)c.shape.pre_width, 16)));
+          st.pre.push_back({c.pre_mask, c.shape.pre_width, pre});
+          SX_HIP(sx_launch_prebin(g->d_descs + idx, npad, c.pre_mask, c.shape.pre_width, pre, nullptr));
           SX_HIP(hipDeviceSynchronize());
-          st.pre_mask = c.pre_mask;
-          st.pre_width = c.shape.pre_width;
         }
-        d.pre = h->store->d_pre;
+        d.pre = pre;
       }
       d.vec_start = prefix;
       prefix += d.nvec;

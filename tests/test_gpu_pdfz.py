@@ -455,3 +455,33 @@ def test_sparse_counting_matches_dense_lookup():
     group.EvalAsync(True)
     group.EvalFinished()
     assert np.all(np.isnan(lut.get()[:5]))
+
+
+def test_shared_table_with_different_prebinned_columns():
+    """Two evaluators over one sample table whose systematics leave different observables untouched: each
+    group keeps its own pre-binned column, and evaluating one does not disturb the other."""
+    rng = np.random.default_rng(17)
+    nobs, nfields, nbins = 3, 5, [12, 9, 10]
+    t = table(rng, 250001, nfields)
+    sa = [dict(type="scale", obs=0, pars=[0])]                                     # untouched: 1, 2
+    sb = [dict(type="shift", obs=1, pars=[1]), dict(type="scale", obs=0, pars=[0]),
+          dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]              # untouched: 2
+    params = [0.03, -0.04, 0.2]
+    pbuf = DeviceArray(np.asarray(params, np.float64))
+    norms = DeviceArray.zeros(2, np.uint32)
+    base = pdfz.EvalHist(t, nfields, nobs, [0.0] * nobs, [1.0] * nobs, nbins)
+    ea, eb = pdfz.EvalHist.Shared(base), pdfz.EvalHist.Shared(base)
+    for e, systs in ((ea, sa), (eb, sb)):
+        for s in systs:
+            e.AddSystematic(make_systematic(s))
+    for j, e in enumerate((ea, eb)):
+        e.SetNormalizationBuffer(norms, j)
+        e.SetParameterBuffer(pbuf)
+    ga, gb = nll.EvalGroup([ea]), nll.EvalGroup([eb])
+    assert ga.AlgorithmicBytes()["fill_read"] < gb.AlgorithmicBytes()["fill_read"] < 4 * 4 * 250001 * 1.01
+    oa = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, sa, params)
+    ob = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, sb, params)
+    for g, e, o, j in ((ga, ea, oa, 0), (gb, eb, ob, 1), (ga, ea, oa, 0), (gb, eb, ob, 1)):
+        g.EvalAsync(False)
+        g.EvalFinished()
+        assert np.array_equal(e.GetBins(), o["bins"]) and norms.get()[j] == o["norm"]
