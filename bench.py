@@ -169,11 +169,13 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the sample counts (testing only)")
     ap.add_argument("--events", type=int, default=100000)
     ap.add_argument("--c5-bins", default="200,200,200,4,4", help="bins per observable for --workload c5")
-    ap.add_argument("--form", default="fused", choices=["step", "fused", "reference", "pdfz"],
-                    help="fused (default): zero, fill, lookup+event sum, step end = 4 launches; step: the last two "
+    ap.add_argument("--form", default="fused", choices=["step", "fused", "graph", "reference", "pdfz"],
+                    help="fused (default): zero, fill, lookup+event sum, step end = 4 launches; graph: the same "
+                         "launches replayed from a HIP graph of --graph-steps recorded steps; step: the last two "
                          "merged (measured slower: every workgroup pays a release + ticket); reference: the "
                          "reference's own sequence with the lut re-read; pdfz: only EvalAsync + EvalFinished of all evaluators "
                          "per step, the loop of the reference's bench_sxmc (bench_sxmc.cpp:90-96, 193-200)")
+    ap.add_argument("--graph-steps", type=int, default=10, help="steps recorded per HIP graph (--form graph)")
     ap.add_argument("--launch", default="0,0", help="bin_threads,bin_blocks_per_cu (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=2)
@@ -223,7 +225,9 @@ def main():
     want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1
     host_tables = [t.cpu().numpy() for t in tensors] if want_cpu else None
 
-    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused={"step": "step", "fused": True, "reference": False, "pdfz": True}[args.form], samples_on_device=tensors)
+    fused = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
+    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=fused, samples_on_device=tensors,
+             stream=capi.new_stream() if args.form == "graph" else None)
     del tensors
     torch.cuda.empty_cache()
     threads, bpc = (int(x) for x in args.launch.split(","))
@@ -233,7 +237,7 @@ def main():
     m.group.SetSparse(not args.no_sparse)
     if args.debug_mode:
         want_cpu = False
-    m.setup(sync_interval=max(args.steps, args.warmup, 1))
+    m.setup(sync_interval=max(args.steps, args.warmup + 1, 1))
 
     m.group.SetDebugMode(args.debug_mode)
     def one_step():
@@ -243,8 +247,17 @@ def main():
         else:
             m.step()
 
-    for _ in range(args.warmup):
-        one_step()
+    def run_steps(n):
+        if args.form == "graph":     # the fused sequence replayed from a HIP graph of --graph-steps steps
+            m.steps(n, args.graph_steps)
+        else:
+            for _ in range(n):
+                one_step()
+
+    if args.form == "graph":
+        m.step()                     # brings the launch plan up to date; recording cannot
+        m.flush()
+    run_steps(args.warmup)
     m.flush()
 
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
@@ -252,8 +265,7 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0)
@@ -261,8 +273,38 @@ def main():
     m.group.Profile(False, 0)
 
     chain, accepted = m.flush()
+    if args.form == "graph" and args.steps >= args.graph_steps:
+        # replayed launches carry no events: time the fill kernel on eager steps after the timed region
+        m.group.Profile(True, 64)
+        for _ in range(min(64, args.steps)):
+            one_step()
+        m.flush()
+        fill_ms_total, nfill = m.group.ProfileRead()
+        m.group.Profile(False, 0)
     if chain.shape[0] == 0:
         chain = np.zeros((1, w.nparameters + 1), np.float32)
+
+    # ---- the same steps replayed from a HIP graph, timed beside the headline number: replayed
+    # launches carry no events, so the headline and its roofline stay on the eagerly launched form above
+    graph_replay = None
+    if args.form == "fused" and args.graph_steps > 0 and args.steps >= args.graph_steps and not args.debug_mode:
+        gs = args.graph_steps
+        m.stream = capi.new_stream()
+        capi.synchronize()
+        m.steps(gs, gs)                                  # record + one replay
+        m.flush()
+        nrep = args.steps // gs
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.steps(nrep * gs, gs)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g_elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+        m.flush()
+        m.stream, m._graph = None, None
+        graph_replay = {"value": nrep * gs * world / g_elapsed, "unit": "evals/s", "ms_per_step": 1e3 * g_elapsed / (nrep * gs),
+                        "steps": nrep * gs, "steps_per_graph": gs}
     intervals = dist.gather_intervals(chain_intervals(chain, w.nparameters)[None], world, w.nparameters)
 
     # ---- ensemble leg (sxmc.cpp:59-145): whole fake experiments, experiment k on rank k mod N, the MC
@@ -346,7 +388,7 @@ def main():
             "workload": "%s: %s" % (w.name, w.description),
             "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
             "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
-            "step_form": args.form, "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
+            "step_form": args.form, "graph_steps": args.graph_steps if args.form == "graph" else 0, "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,
             "experiments_per_sec_at_1e5_steps": value / 1e5,
@@ -364,6 +406,7 @@ def main():
             "whole_step_frac": (fill_bytes + ab["event"]) * value / world / 1e9 / HBM_PEAK_GBS,
         },
         "cpu_baseline": None,
+        "graph_replay": graph_replay,
         "intervals_gathered": [int(x) for x in intervals.shape],
         "experiments": experiments,
     }

@@ -85,6 +85,21 @@ int sxmc_stream_create_nonblocking(sxmc_stream_t* s);
 int sxmc_stream_destroy(sxmc_stream_t s);
 int sxmc_stream_synchronize(sxmc_stream_t s);
 
+/* HIP-graph capture of a launch sequence (the per-step sequence of mcmc.cpp:264-348 is the
+ * same launches with the same arguments every step, so it can be recorded once and replayed).
+ * Between begin and end, every sxmc_group_* evaluation and sxmc_launch_* call given `s` is recorded
+ * instead of executed; `s` must be a created stream (the legacy default stream cannot be captured).
+ * The group must already have evaluated once with its current configuration (descriptor uploads cannot
+ * be recorded: SXMC_ERR_STATE otherwise), and a recorded graph is only valid until an evaluator of the
+ * group changes (systematics, evaluation points, bindings, launch configuration).  Kernel arguments are
+ * frozen at capture: device buffers are re-read at replay, scalar arguments are not. */
+typedef void* sxmc_graph_t;              /* hipGraphExec_t */
+int sxmc_graph_begin_capture(sxmc_stream_t s);
+int sxmc_graph_end_capture(sxmc_stream_t s, sxmc_graph_t* out);
+/* Replays the recorded sequence `times` times on `s` (asynchronous). */
+int sxmc_graph_launch(sxmc_graph_t graph, sxmc_stream_t s, int times);
+int sxmc_graph_destroy(sxmc_graph_t graph);
+
 int sxmc_event_create(sxmc_event_t* e);
 int sxmc_event_destroy(sxmc_event_t e);
 int sxmc_event_record(sxmc_event_t e, sxmc_stream_t s);

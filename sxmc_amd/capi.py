@@ -55,6 +55,10 @@ SIGNATURES = {
     "sxmc_stream_create_nonblocking": [_pvp],
     "sxmc_stream_destroy": [_vp],
     "sxmc_stream_synchronize": [_vp],
+    "sxmc_graph_begin_capture": [_vp],
+    "sxmc_graph_end_capture": [_vp, _pvp],
+    "sxmc_graph_launch": [_vp, _vp, _i],
+    "sxmc_graph_destroy": [_vp],
     "sxmc_event_create": [_pvp],
     "sxmc_event_destroy": [_vp],
     "sxmc_event_record": [_vp, _vp],
@@ -184,6 +188,44 @@ def new_stream(nonblocking=True):
     s = C.c_void_p(0)
     call("sxmc_stream_create_nonblocking" if nonblocking else "sxmc_stream_create", C.byref(s))
     return s.value
+
+
+class Graph:
+    """A recorded launch sequence (HIP graph).  `with Graph.capture(stream) as g: ...launches on stream...`
+    records instead of executing; g.launch(times) replays."""
+
+    def __init__(self, stream):
+        self.stream, self._g = stream, None
+
+    @classmethod
+    def capture(cls, stream):
+        return cls(stream)
+
+    def __enter__(self):
+        call("sxmc_graph_begin_capture", ptr(self.stream))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        g = C.c_void_p(0)
+        rc = load().sxmc_graph_end_capture(ptr(self.stream), C.byref(g))
+        if exc_type is None:
+            check(rc)
+            self._g = g
+        return False
+
+    def launch(self, times=1):
+        call("sxmc_graph_launch", self._g, ptr(self.stream), int(times))
+
+    def close(self):
+        if self._g:
+            load().sxmc_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceArray:

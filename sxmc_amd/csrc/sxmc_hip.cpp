@@ -36,6 +36,7 @@ hipError_t sx_nll_finish_combo(int, hipStream_t, size_t, const double*, size_t, 
 namespace {
 
 thread_local std::string g_last_error;
+thread_local bool t_capturing = false;  // this thread is recording a HIP graph (sxmc_graph_begin_capture)
 
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -639,6 +640,9 @@ int group_refresh(sxmc_group* g) {
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
   }
+  if (stale && t_capturing) {
+    return fail(SXMC_ERR_STATE, "the group's launch plan is out of date: evaluate once before recording a graph");
+  }
   return stale ? group_rebuild(g) : SXMC_OK;
 }
 
@@ -659,7 +663,7 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
     if (g->members[i]->total_nbins > kLdsMaxBins) g->members[i]->bins_valid = !sparse;
   }
   for (LaunchClass& c : g->classes) {
-    const bool rec = g->prof && g->prof_n < (int)g->ev0.size();
+    const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
     c.shape.debug_mode = g->debug_mode;
     SX_HIP(sx_launch_fill(c.shape, (sparse && c.d_descs_sparse) ? c.d_descs_sparse : c.d_descs, c.d_segs,
@@ -778,6 +782,38 @@ int sxmc_stream_synchronize(sxmc_stream_t s) {
   SX_HIP(hipStreamSynchronize((hipStream_t)s));
   return SXMC_OK;
 }
+int sxmc_graph_begin_capture(sxmc_stream_t s) {
+  SX_REQUIRE(s, "the legacy default stream cannot be captured: pass a created stream");
+  SX_REQUIRE(!t_capturing, "a capture is already in progress on this thread");
+  SX_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+  t_capturing = true;
+  return SXMC_OK;
+}
+int sxmc_graph_end_capture(sxmc_stream_t s, sxmc_graph_t* out) {
+  SX_REQUIRE(s && out, "null argument");
+  SX_REQUIRE(t_capturing, "no capture in progress on this thread");
+  t_capturing = false;
+  hipGraph_t graph = nullptr;
+  SX_HIP(hipStreamEndCapture((hipStream_t)s, &graph));
+  if (!graph) return fail(SXMC_ERR_HIP, "hipStreamEndCapture returned no graph (an error ended the capture)");
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(SXMC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  *out = exec;
+  return SXMC_OK;
+}
+int sxmc_graph_launch(sxmc_graph_t graph, sxmc_stream_t s, int times) {
+  SX_REQUIRE(graph, "null graph");
+  SX_REQUIRE(times >= 0, "negative repeat count");
+  for (int i = 0; i < times; i++) SX_HIP(hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)s));
+  return SXMC_OK;
+}
+int sxmc_graph_destroy(sxmc_graph_t graph) {
+  if (graph) SX_HIP(hipGraphExecDestroy((hipGraphExec_t)graph));
+  return SXMC_OK;
+}
+
 int sxmc_event_create(sxmc_event_t* e) {
   SX_REQUIRE(e, "null argument");
   hipEvent_t ev;

@@ -79,6 +79,7 @@ class MCMC:
         self.jump_buffer = None
         self.lut = None
         self.nevents = 0
+        self._graph, self._graph_steps = None, 0
 
     # mcmc.cpp:198-228 (keeps the reference's `i < nsignals` test at :217)
     def initial_jump_widths(self, fixed=None):
@@ -109,6 +110,7 @@ class MCMC:
         w = self.w
         data = w.events if data is None else data
         data = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        self._graph = None                      # recorded steps hold the old evaluation-point tables
         self.nevents = data.size // (w.nobs + 1)
         self.sync_interval = sync_interval
         self.jump_buffer = DeviceArray.zeros(sync_interval * (self.nparameters + 1), np.float32)
@@ -170,14 +172,47 @@ class MCMC:
         """Fresh generator states (a new experiment on the same evaluators)."""
         self.rngs = nll.make_rngs(self.nparameters, seed, self.stream)
 
-    def walk(self, data, nsteps, burnin_fraction, debug_mode=False, sync_interval=10000):
+    def walk(self, data, nsteps, burnin_fraction, debug_mode=False, sync_interval=10000, graph_steps=0):
         """MCMC::operator() (mcmc.cpp:143-387): start at the means, walk nsteps, re-tune the proposal
         widths from the chain's spread at burnin_steps and 2 * burnin_steps (dropping the steps so far
-        unless debug_mode).  Returns (chain [nkept, P + 1] float32, accepted)."""
+        unless debug_mode).  Returns (chain [nkept, P + 1] float32, accepted).
+        graph_steps = K > 0 replays a HIP graph of K recorded steps wherever K steps fit between two
+        points that need the host (re-tuning, jump-buffer flush); the chain is the same."""
         self.walk_begin(data, nsteps, burnin_fraction, debug_mode, sync_interval)
-        for i in range(nsteps):
-            self.walk_advance(i)
+        if graph_steps <= 0:
+            for i in range(nsteps):
+                self.walk_advance(i)
+            return self.walk_end()
+        b = self._burnin
+        flush_at = sorted({k for k in range(0, nsteps, sync_interval)} | {k for k in (nsteps - 1, b - 1, 2 * b - 1)
+                                                                          if 0 <= k < nsteps})
+        i = 0
+        for f in flush_at:                    # steps i..f: host work only before step i and after step f
+            self._retune_if_due(i)
+            self.steps(f - i + 1, graph_steps, self._debug)
+            self._flush_if_due(f)
+            i = f + 1
         return self.walk_end()
+
+    def capture_steps(self, k, debug_mode=False):
+        """Records k steps on this chain's stream as one HIP graph.  One step must have
+        run since the last change to the evaluators; the graph is dropped by setup()."""
+        if self.stream is None:
+            raise ValueError("graph capture needs a created stream (MCMC(stream=capi.new_stream()))")
+        with capi.Graph.capture(self.stream) as g:
+            for _ in range(k):
+                self.step(debug_mode)
+        return g
+
+    def steps(self, n, graph_steps=0, debug_mode=False):
+        """n steps in a row: graph replays of graph_steps recorded steps, the remainder launched one by one."""
+        if graph_steps > 0 and n >= graph_steps:
+            if self._graph is None or self._graph_steps != graph_steps:
+                self._graph, self._graph_steps = self.capture_steps(graph_steps, debug_mode), graph_steps
+            self._graph.launch(n // graph_steps)
+            n %= graph_steps
+        for _ in range(n):
+            self.step(debug_mode)
 
     # The same walk cut into per-step pieces, so that several chains can be advanced in turn and have
     # their kernels in flight together (one stream per chain).
@@ -192,7 +227,7 @@ class MCMC:
         self._scale_factor = np.float32(2.4 * 2.4 / self.nparameters)
         self._rows, self._accepted = [np.zeros((0, self.nparameters + 1), np.float32)], 0
 
-    def walk_advance(self, i):
+    def _retune_if_due(self, i):
         b = self._burnin
         if i == b or i == 2 * b:                                   # mcmc.cpp:274-311
             sofar = np.concatenate(self._rows, axis=0)
@@ -205,11 +240,18 @@ class MCMC:
             self.jump_width.set(jw)
             if not self._debug:
                 self._rows = [np.zeros((0, self.nparameters + 1), np.float32)]
-        self.step(self._debug)
+
+    def _flush_if_due(self, i):
+        b = self._burnin
         if i % self.sync_interval == 0 or i == self._nsteps - 1 or i == b - 1 or i == 2 * b - 1:
             r, nacc = self.flush(device_wide=False)                # mcmc.cpp:351-377
             self._rows.append(r)
             self._accepted += nacc
+
+    def walk_advance(self, i):
+        self._retune_if_due(i)
+        self.step(self._debug)
+        self._flush_if_due(i)
 
     def walk_end(self):
         return np.concatenate(self._rows, axis=0), self._accepted

@@ -317,3 +317,36 @@ def test_concurrent_chains_share_one_sample_table():
     for m, (chain, acc) in zip(chains, solo):
         got, nacc = m.flush()
         assert nacc == acc and np.array_equal(got, chain)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_graph_replayed_steps_walk_the_same_chain(fused):
+    """HIP-graph capture of the per-step sequence: a walk whose steps are replayed from a
+    recorded graph gives the chain of the walk launched step by step, bit for bit -- including across
+    the burn-in re-tuning points, the jump-buffer flushes and a second walk on other data."""
+    w = workloads.config3(0.004, nevents=3000)
+    eager = MCMC(w, seed=11, fused=fused)
+    want = eager.walk(w.events, 203, 0.2, sync_interval=50)
+    want2 = eager.walk(w.events[:2000], 90, 0.1, sync_interval=1000)
+    m = MCMC(w, seed=11, fused=fused, stream=capi.new_stream())
+    got = m.walk(w.events, 203, 0.2, sync_interval=50, graph_steps=8)
+    assert m._graph is not None
+    got2 = m.walk(w.events[:2000], 90, 0.1, sync_interval=1000, graph_steps=16)
+    for (a, na), (b, nb) in ((want, got), (want2, got2)):
+        assert na == nb and a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_graph_capture_refuses_a_stale_group_and_the_default_stream():
+    w = workloads.config1()
+    m = MCMC(w, seed=3, stream=capi.new_stream())
+    m.setup(sync_interval=16)                       # parameter buffers re-pointed: the launch plan is stale
+    with pytest.raises(capi.SxmcError):
+        m.capture_steps(2)
+    capi.synchronize()
+    m.step()                                        # one eager step brings it up to date
+    g = m.capture_steps(2)
+    g.launch(3)
+    rows, _ = m.flush()
+    assert rows.shape[0] == 7
+    with pytest.raises(capi.SxmcError):
+        capi.call("sxmc_graph_begin_capture", capi.ptr(None))
