@@ -36,6 +36,7 @@ class MCMC {
  public:
   bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
   bool verbose = false;
+  unsigned graph_steps = 0;     //!< > 0: replay the batched step from a HIP graph of this many recorded steps
   unsigned long long seed = 0;  //!< gRandom->GetSeed() in the reference (mcmc.cpp:125)
 
   MCMC(const std::vector<Source>& sources, const std::vector<Signal>& signals,
@@ -199,7 +200,72 @@ class MCMC {
     }
     const bool reevaluate = nsystematics > 0 && !systematics_fixed;
 
-    for (unsigned i = 0; i < nsteps; i++) {
+    // Recorded steps need a created stream (blocking: it still orders with the copies of the array
+    // accessors, which go through the legacy default stream) and the batched form.
+    const unsigned gsteps = (batched && reevaluate) ? graph_steps : 0;
+    sxmc_stream_t strm = nullptr;
+    sxmc_graph_t graph = nullptr;
+    if (gsteps > 0) check(sxmc_stream_create(&strm));
+
+    // Device pointers of one run of steps, resolved once per run: the accessors may copy (after the
+    // host wrote a counter or the widths), which must not happen while a graph is being recorded.
+    struct {
+      const float* lut;
+      const double *means, *sigmas, *nexpected;
+      const unsigned* n_mc;
+      const short* source_id;
+      const float* jump_width;
+      double *proposed, *current, *sums, *nll_current, *nll_proposed;
+      unsigned* norms;
+      int *accepted, *counter;
+      float* jump_buffer;
+      RNGState* rng;
+    } d;
+    auto resolve = [&]() {
+      d.lut = lut.readOnlyPtr();
+      d.means = parameter_means->readOnlyPtr();
+      d.sigmas = parameter_sigma->readOnlyPtr();
+      d.nexpected = nexpected->readOnlyPtr();
+      d.n_mc = n_mc->readOnlyPtr();
+      d.source_id = source_id->readOnlyPtr();
+      d.jump_width = jump_width.readOnlyPtr();
+      d.proposed = proposed_vector.ptr();
+      d.current = current_vector.ptr();
+      d.sums = event_partial_sums.ptr();
+      d.nll_current = current_nll.ptr();
+      d.nll_proposed = proposed_nll.ptr();
+      d.norms = normalizations.ptr();
+      d.accepted = accept_counter.ptr();
+      d.counter = jump_counter.ptr();
+      d.jump_buffer = jump_buffer.writeOnlyPtr();
+      d.rng = rngs->ptr();
+    };
+    auto one_step = [&]() {
+      int npartial = (int)nnllthreads;
+      if (batched && reevaluate) {
+        // zero, fill of all signals in one kernel, lookup fused with the event partial sums
+        check(sxmc_group_eval_nll_async(group, strm, d.proposed, d.nexpected, d.n_mc, d.source_id, d.norms, d.sums,
+                                        &npartial));
+      } else {
+        if (reevaluate) {
+          for (pdfz::Eval* p : pdfs) p->EvalAsync();
+          for (pdfz::Eval* p : pdfs) p->EvalFinished();
+        }
+        SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, strm, d.lut, d.proposed, nevents, nsignals,
+                           d.nexpected, d.n_mc, d.source_id, d.norms, d.sums);
+      }
+      SXMC_KERNEL_LAUNCH(finish_nll_jump_pick_combo, 1, nreducethreads, nreducethreads * sizeof(double), strm,
+                         (size_t)npartial, d.sums, nsignals, nsources, d.means, d.sigmas, d.rng, d.nll_current,
+                         d.nll_proposed, d.current, d.proposed, d.accepted, d.counter, d.jump_buffer,
+                         (int)nparameters, d.jump_width, d.nexpected, d.n_mc, d.source_id, d.norms, debug_mode);
+    };
+    // Steps after which the jump buffer is read back (mcmc.cpp:351-377)
+    auto flush_due = [&](unsigned i) {
+      return i % sync_interval == 0 || i == nsteps - 1 || i == burnin_steps - 1 || i == 2 * burnin_steps - 1;
+    };
+
+    unsigned i = 0;
+    while (i < nsteps) {
       // Re-tune the proposal from the burn-in samples (mcmc.cpp:274-311); the width becomes
       // scale_factor x the standard deviation of the parameter over the steps kept so far
       if (i == burnin_steps || i == 2 * burnin_steps) {
@@ -212,43 +278,44 @@ class MCMC {
         if (!debug_mode) chain.rows.clear();
       }
 
-      int npartial = (int)nnllthreads;
-      if (batched && reevaluate) {
-        // zero, fill of all signals in one kernel, lookup fused with the event partial sums
-        check(sxmc_group_eval_nll_async(group, nullptr, proposed_vector.readOnlyPtr(), nexpected->readOnlyPtr(),
-                                        n_mc->readOnlyPtr(), source_id->readOnlyPtr(),
-                                        normalizations.ptr(), event_partial_sums.ptr(), &npartial));
-      } else {
-        if (reevaluate) {
-          for (pdfz::Eval* p : pdfs) p->EvalAsync();
-          for (pdfz::Eval* p : pdfs) p->EvalFinished();
+      // steps i..f need the host only before the first and after the last
+      unsigned f = i;
+      while (!flush_due(f)) f++;
+      unsigned n = f - i + 1;
+      resolve();
+      if (gsteps > 0 && i > 0 && n >= gsteps) {
+        if (!graph) {  // record gsteps steps once; the launch plan is current after the eager step 0
+          check(sxmc_graph_begin_capture(strm));
+          try {
+            for (unsigned k = 0; k < gsteps; k++) one_step();
+          } catch (...) {
+            sxmc_graph_end_capture(strm, &graph);
+            throw;
+          }
+          check(sxmc_graph_end_capture(strm, &graph));
         }
-        SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, 0, lut.readOnlyPtr(),
-                           proposed_vector.readOnlyPtr(), nevents, nsignals, nexpected->readOnlyPtr(),
-                           n_mc->readOnlyPtr(), source_id->readOnlyPtr(), normalizations.readOnlyPtr(),
-                           event_partial_sums.ptr());
+        check(sxmc_graph_launch(graph, strm, (int)(n / gsteps)));
+        n %= gsteps;
       }
-      SXMC_KERNEL_LAUNCH(finish_nll_jump_pick_combo, 1, nreducethreads, nreducethreads * sizeof(double), 0,
-                         (size_t)npartial, event_partial_sums.ptr(), nsignals, nsources,
-                         parameter_means->readOnlyPtr(), parameter_sigma->readOnlyPtr(), rngs->ptr(),
-                         current_nll.ptr(), proposed_nll.ptr(), current_vector.ptr(), proposed_vector.ptr(),
-                         accept_counter.ptr(), jump_counter.ptr(), jump_buffer.writeOnlyPtr(), (int)nparameters,
-                         jump_width.readOnlyPtr(), nexpected->readOnlyPtr(), n_mc->readOnlyPtr(),
-                         source_id->readOnlyPtr(), normalizations.readOnlyPtr(), debug_mode);
+      for (unsigned k = 0; k < n; k++) one_step();
 
-      // Flush the jump buffer periodically (mcmc.cpp:351-377)
-      if (i % sync_interval == 0 || i == nsteps - 1 || i == burnin_steps - 1 || i == 2 * burnin_steps - 1) {
-        const int njumps = jump_counter.readOnlyHostPtr()[0];
-        const int naccepted = accept_counter.readOnlyHostPtr()[0];
-        if (verbose) {
-          std::printf("MCMC: Step %u/%u (%d in buffer, %d accepted)\n", i + 1, nsteps, njumps, naccepted);
-        }
-        const float* jb = jump_buffer.readOnlyHostPtr();
-        chain.rows.insert(chain.rows.end(), jb, jb + (size_t)njumps * ncol);
-        chain.accepted += (size_t)naccepted;
-        jump_counter.writeOnlyHostPtr()[0] = 0;
-        accept_counter.writeOnlyHostPtr()[0] = 0;
+      // Flush the jump buffer (mcmc.cpp:351-377); the host reads go through blocking copies
+      const int njumps = jump_counter.readOnlyHostPtr()[0];
+      const int naccepted = accept_counter.readOnlyHostPtr()[0];
+      if (verbose) {
+        std::printf("MCMC: Step %u/%u (%d in buffer, %d accepted)\n", f + 1, nsteps, njumps, naccepted);
       }
+      const float* jb = jump_buffer.readOnlyHostPtr();
+      chain.rows.insert(chain.rows.end(), jb, jb + (size_t)njumps * ncol);
+      chain.accepted += (size_t)naccepted;
+      jump_counter.writeOnlyHostPtr()[0] = 0;
+      accept_counter.writeOnlyHostPtr()[0] = 0;
+      i = f + 1;
+    }
+    if (graph) check(sxmc_graph_destroy(graph));
+    if (strm) {
+      check(sxmc_stream_synchronize(strm));
+      check(sxmc_stream_destroy(strm));
     }
     check(sxmc_device_synchronize());
     return chain;

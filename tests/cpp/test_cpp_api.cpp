@@ -422,6 +422,22 @@ TEST_F(SmallFit, MetropolisWalkWithBurnIn) {
   EXPECT_TRUE(mean_rate0 > 0.0 && mean_rate0 < 5.0);
 }
 
+TEST_F(SmallFit, GraphReplayedStepsWalkTheSameChain) {
+  // HIP-graph capture of the per-step sequence: same launches, same arguments, so the same chain
+  // bit for bit, across re-tuning points, jump-buffer flushes and a remainder shorter than the graph.
+  sxmc::MCMC a(sources, signals, systematics, observables, 7);
+  sxmc::Chain ca = a(data, 333, 0.2f, false, 100);
+  sxmc::MCMC b(sources, signals, systematics, observables, 7);
+  b.graph_steps = 8;
+  sxmc::Chain cb = b(data, 333, 0.2f, false, 100);
+  EXPECT_EQ(ca.nrows(), cb.nrows());
+  EXPECT_EQ(ca.accepted, cb.accepted);
+  EXPECT_TRUE(ca.accepted > 5);
+  bool same = ca.rows.size() == cb.rows.size();
+  for (size_t k = 0; same && k < ca.rows.size(); k++) same = ca.rows[k] == cb.rows[k];
+  EXPECT_TRUE(same);
+}
+
 TEST(NllLaunch, ReferenceSpelling) {
   // the launch macro with the reference's argument order (mcmc.cpp:396-414)
   const size_t ne = 5, ns = 2, np = 2;
