@@ -163,18 +163,20 @@ def value_per_gpu_hint(args, elapsed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="c3", help="c3 (default, the metric's config), c1, c2, c5, bench_pdfz, bench_pdfz_group")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the sample counts (testing only)")
     ap.add_argument("--events", type=int, default=100000)
     ap.add_argument("--c5-bins", default="200,200,200,4,4", help="bins per observable for --workload c5")
-    ap.add_argument("--form", default="fused", choices=["step", "fused", "graph", "reference", "pdfz"],
-                    help="fused (default): zero, fill, lookup+event sum, step end = 4 launches; graph: the same "
+    ap.add_argument("--form", default="graph", choices=["step", "fused", "graph", "reference", "pdfz"],
+                    help="fused: zero, fill, lookup+event sum, step end = 4 launches; graph (default): the same "
                          "launches replayed from a HIP graph of --graph-steps recorded steps; step: the last two "
                          "merged (measured slower: every workgroup pays a release + ticket); reference: the "
                          "reference's own sequence with the lut re-read; pdfz: only EvalAsync + EvalFinished of all evaluators "
                          "per step, the loop of the reference's bench_sxmc (bench_sxmc.cpp:90-96, 193-200)")
+    ap.add_argument("--prewarm", type=int, default=300,
+                    help="untimed steps before the --warmup steps (GPU clocks and graph replay settle)")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps recorded per HIP graph (--form graph)")
     ap.add_argument("--launch", default="0,0", help="bin_threads,bin_blocks_per_cu (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,15 +249,26 @@ def main():
         else:
             m.step()
 
+    # form "graph": the fused sequence replayed from a HIP graph of --graph-steps recorded steps.  Replayed
+    # launches carry no events, so the last steps of every run are launched one by one with HIP events
+    # around the fill kernel: the roofline figures come from those, inside the same timed region.
+    gs = args.graph_steps if args.form == "graph" else 0
+    def eager_share(n):          # about a tenth of the steps, and whatever does not fill a whole graph
+        return n if gs <= 0 or n < 2 * gs else n - ((n - n // 10) // gs) * gs
+
     def run_steps(n):
-        if args.form == "graph":     # the fused sequence replayed from a HIP graph of --graph-steps steps
-            m.steps(n, args.graph_steps)
-        else:
-            for _ in range(n):
-                one_step()
+        ne = eager_share(n)
+        if n > ne:
+            m.steps(n - ne, gs)
+        for _ in range(ne):
+            one_step()
 
     if args.form == "graph":
         m.step()                     # brings the launch plan up to date; recording cannot
+        m.flush()
+    # untimed: clocks and graph replay settle over the first few hundred steps, whatever --warmup says
+    for lo in range(0, args.prewarm, 100):
+        run_steps(min(100, args.prewarm - lo, args.steps))
         m.flush()
     run_steps(args.warmup)
     m.flush()
@@ -273,38 +286,8 @@ def main():
     m.group.Profile(False, 0)
 
     chain, accepted = m.flush()
-    if args.form == "graph" and args.steps >= args.graph_steps:
-        # replayed launches carry no events: time the fill kernel on eager steps after the timed region
-        m.group.Profile(True, 64)
-        for _ in range(min(64, args.steps)):
-            one_step()
-        m.flush()
-        fill_ms_total, nfill = m.group.ProfileRead()
-        m.group.Profile(False, 0)
     if chain.shape[0] == 0:
         chain = np.zeros((1, w.nparameters + 1), np.float32)
-
-    # ---- the same steps replayed from a HIP graph, timed beside the headline number: replayed
-    # launches carry no events, so the headline and its roofline stay on the eagerly launched form above
-    graph_replay = None
-    if args.form == "fused" and args.graph_steps > 0 and args.steps >= args.graph_steps and not args.debug_mode:
-        gs = args.graph_steps
-        m.stream = capi.new_stream()
-        capi.synchronize()
-        m.steps(gs, gs)                                  # record + one replay
-        m.flush()
-        nrep = args.steps // gs
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        m.steps(nrep * gs, gs)
-        torch.cuda.synchronize()
-        dist.barrier()
-        g_elapsed = dist.max_over_ranks(time.perf_counter() - t0)
-        m.flush()
-        m.stream, m._graph = None, None
-        graph_replay = {"value": nrep * gs * world / g_elapsed, "unit": "evals/s", "ms_per_step": 1e3 * g_elapsed / (nrep * gs),
-                        "steps": nrep * gs, "steps_per_graph": gs}
     intervals = dist.gather_intervals(chain_intervals(chain, w.nparameters)[None], world, w.nparameters)
 
     # ---- ensemble leg (sxmc.cpp:59-145): whole fake experiments, experiment k on rank k mod N, the MC
@@ -320,7 +303,8 @@ def main():
         local = np.zeros((len(mine), w.nparameters, 4), np.float32)
         # chains for concurrent experiments: own non-blocking stream, own per-chain state, ONE copy of the tables
         nconc = max(1, min(args.exp_concurrent, len(mine)))
-        form = {"step": "step", "fused": True, "reference": False, "pdfz": True}[args.form]
+        form = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
+        exp_graph = args.graph_steps if args.form in ("fused", "graph") else 0
         pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m) for _ in range(nconc)]
         for c in pool:
             c.group.SetLaunchConfig(threads, bpc)
@@ -331,7 +315,7 @@ def main():
             batch = mine[lo:lo + nconc]
             res = ensemble.run_experiments_concurrently(
                 w, [dist.experiment_seed(args.seed, k) for k in batch], args.exp_steps, pool[:len(batch)],
-                burnin_fraction=0.1, sync_interval=args.exp_steps)
+                burnin_fraction=0.1, sync_interval=args.exp_steps, graph_steps=exp_graph)
             for i, r in enumerate(res):
                 local[lo + i] = r[0]
         torch.cuda.synchronize()
@@ -340,6 +324,7 @@ def main():
         allint = dist.gather_intervals(local, nexp, w.nparameters)
         experiments = {
             "count": nexp, "steps_each": args.exp_steps, "seconds": exp_elapsed, "concurrent_per_gpu": nconc,
+            "steps_per_graph": exp_graph,
             "experiments_per_sec": nexp / exp_elapsed,
             "steps_per_sec_inside": nexp * args.exp_steps / exp_elapsed,
             "median_upper_limit_source0": dist.median(allint[:, 0, 2]),
@@ -388,7 +373,8 @@ def main():
             "workload": "%s: %s" % (w.name, w.description),
             "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
             "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
-            "step_form": args.form, "graph_steps": args.graph_steps if args.form == "graph" else 0, "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
+            "step_form": args.form, "steps_per_graph": gs, "prewarm_steps": args.prewarm,
+            "steps_launched_one_by_one_with_events": eager_share(args.steps), "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,
             "experiments_per_sec_at_1e5_steps": value / 1e5,
@@ -406,7 +392,6 @@ def main():
             "whole_step_frac": (fill_bytes + ab["event"]) * value / world / 1e9 / HBM_PEAK_GBS,
         },
         "cpu_baseline": None,
-        "graph_replay": graph_replay,
         "intervals_gathered": [int(x) for x in intervals.shape],
         "experiments": experiments,
     }
@@ -414,10 +399,10 @@ def main():
     if want_cpu:
         # same inputs, same parameter vector: time the oracle and assert parity in the same run
         vector = m.proposed_vector.get()
-        m.group.EvalAsync(False, None)          # histograms (dense, as CreateHistogram would)
+        m.group.EvalAsync(False, m.stream)      # histograms (dense, as CreateHistogram would)
         capi.synchronize()
         gpu_bins = [p.GetBins() for p in m.pdfs]
-        m.group.EvalAsync(True, None)           # lookup + NLL
+        m.group.EvalAsync(True, m.stream)       # lookup + NLL
         m.nll(m.proposed_vector, m.proposed_nll)
         capi.synchronize()
         gpu_nll = float(m.proposed_nll.get()[0])

@@ -160,7 +160,7 @@ def projection_interval(values, cl=0.9, nbins=100):
 
 # ------------------------------------------------------------------------------------ the ensemble
 def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_interval=10000, mcmc=None,
-                   form="fused"):
+                   form="fused", graph_steps=0):
     """One iteration of the loop in sxmc.cpp:59-145: fake data -> MCMC -> intervals.
     Reuses `mcmc` (evaluators with the MC tables resident in HBM) across experiments when given.
     Returns (intervals float32 [P, 4], chain, accepted)."""
@@ -170,14 +170,16 @@ def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_int
     else:
         mcmc.reseed(seed & 0xFFFFFFFF)
     data, _ = make_fake_dataset(rng, workload, mcmc.pdfs, poisson=True)
-    chain, accepted = mcmc.walk(data, nsteps, burnin_fraction, sync_interval=sync_interval)
+    chain, accepted = mcmc.walk(data, nsteps, burnin_fraction, sync_interval=sync_interval, graph_steps=graph_steps)
     return contour_intervals(chain, cl), chain, accepted
 
 
-def run_experiments_concurrently(workload, seeds, nsteps, chains, burnin_fraction=0.1, cl=0.9, sync_interval=10000):
+def run_experiments_concurrently(workload, seeds, nsteps, chains, burnin_fraction=0.1, cl=0.9, sync_interval=10000,
+                                 graph_steps=0):
     """len(chains) fake experiments at once on one GPU (BASELINE config 4: one experiment per stream):
     the chains share one resident copy of the MC tables (MCMC(..., share_with=...), own non-blocking
     streams) and are advanced in turn, so one experiment's small kernels overlap another's fill.
+    graph_steps = K > 0 advances each chain K recorded steps (one HIP-graph replay) per turn.
     Returns a list of (intervals, chain, accepted) in the order of `seeds`."""
     assert len(seeds) == len(chains)
     for m, seed in zip(chains, seeds):
@@ -185,9 +187,24 @@ def run_experiments_concurrently(workload, seeds, nsteps, chains, burnin_fractio
         m.reseed(seed & 0xFFFFFFFF)
         data, _ = make_fake_dataset(rng, workload, m.pdfs, poisson=True)
         m.walk_begin(data, nsteps, burnin_fraction, sync_interval=sync_interval)
-    for i in range(nsteps):
-        for m in chains:
-            m.walk_advance(i)
+    if graph_steps <= 0:
+        for i in range(nsteps):
+            for m in chains:
+                m.walk_advance(i)
+    else:
+        i = 0
+        for f in chains[0].flush_schedule():        # the same schedule for every chain
+            for m in chains:
+                m._retune_if_due(i)
+            n = f - i + 1
+            while n > 0:
+                k = graph_steps if n >= graph_steps else n
+                for m in chains:
+                    m.steps(k, graph_steps)
+                n -= k
+            for m in chains:
+                m._flush_if_due(f)
+            i = f + 1
     out = []
     for m in chains:
         chain, accepted = m.walk_end()

@@ -183,16 +183,19 @@ class MCMC:
             for i in range(nsteps):
                 self.walk_advance(i)
             return self.walk_end()
-        b = self._burnin
-        flush_at = sorted({k for k in range(0, nsteps, sync_interval)} | {k for k in (nsteps - 1, b - 1, 2 * b - 1)
-                                                                          if 0 <= k < nsteps})
         i = 0
-        for f in flush_at:                    # steps i..f: host work only before step i and after step f
+        for f in self.flush_schedule():       # steps i..f: host work only before step i and after step f
             self._retune_if_due(i)
             self.steps(f - i + 1, graph_steps, self._debug)
             self._flush_if_due(f)
             i = f + 1
         return self.walk_end()
+
+    def flush_schedule(self):
+        """Indices of the steps after which the jump buffer is read back (mcmc.cpp:351-377), ascending.  The
+        re-tuning points (burnin_steps, 2 * burnin_steps) each directly follow one of them."""
+        n, b = self._nsteps, self._burnin
+        return sorted({k for k in range(0, n, self.sync_interval)} | {k for k in (n - 1, b - 1, 2 * b - 1) if 0 <= k < n})
 
     def capture_steps(self, k, debug_mode=False):
         """Records k steps on this chain's stream as one HIP graph.  One step must have

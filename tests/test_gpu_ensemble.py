@@ -74,3 +74,19 @@ def test_run_config_end_to_end(tmp_path):
     with np.load(tmp_path / "fit_test_1.npz") as z:
         assert set(z.files) == set(names) and z["likelihood"].shape[0] == 400 - 80
         assert np.all(np.isfinite(z["likelihood"]))
+
+
+def test_concurrent_experiments_with_graph_replay_match_eager():
+    """Three experiments in flight, each advancing a HIP-graph replay of 8 steps per turn: the same chains and
+    intervals as the step-by-step schedule."""
+    from sxmc_amd import capi
+    from sxmc_amd.mcmc import MCMC
+    w = workloads.config3(0.003, nevents=2000)
+    seeds = [101, 102, 103]
+    base = MCMC(w, seed=1, stream=capi.new_stream())
+    pool = [base] + [MCMC(w, seed=1, stream=capi.new_stream(), share_with=base) for _ in range(2)]
+    eager = ensemble.run_experiments_concurrently(w, seeds, 150, pool, burnin_fraction=0.1, sync_interval=64)
+    graph = ensemble.run_experiments_concurrently(w, seeds, 150, pool, burnin_fraction=0.1, sync_interval=64,
+                                                  graph_steps=8)
+    for (ia, ca, na), (ib, cb, nb) in zip(eager, graph):
+        assert na == nb and np.array_equal(ca, cb) and np.array_equal(ia, ib)
