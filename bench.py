@@ -175,6 +175,9 @@ def main():
                          "merged (measured slower: every workgroup pays a release + ticket); reference: the "
                          "reference's own sequence with the lut re-read; pdfz: only EvalAsync + EvalFinished of all evaluators "
                          "per step, the loop of the reference's bench_sxmc (bench_sxmc.cpp:90-96, 193-200)")
+    ap.add_argument("--lut-output", action="store_true",
+                    help="materialise the lookup table in the fused step (default: it is an intermediate nobody reads, so "
+                         "the event sum runs over the distinct tuples of event bins weighted by multiplicity)")
     ap.add_argument("--prewarm", type=int, default=300,
                     help="untimed steps before the --warmup steps (GPU clocks and graph replay settle)")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps recorded per HIP graph (--form graph)")
@@ -229,7 +232,7 @@ def main():
 
     fused = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
     m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=fused, samples_on_device=tensors,
-             stream=capi.new_stream() if args.form == "graph" else None)
+             stream=capi.new_stream() if args.form == "graph" else None, lut_output=args.lut_output)
     del tensors
     torch.cuda.empty_cache()
     threads, bpc = (int(x) for x in args.launch.split(","))
@@ -305,7 +308,8 @@ def main():
         nconc = max(1, min(args.exp_concurrent, len(mine)))
         form = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
         exp_graph = args.graph_steps if args.form in ("fused", "graph") else 0
-        pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m) for _ in range(nconc)]
+        pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m, lut_output=args.lut_output)
+                for _ in range(nconc)]
         for c in pool:
             c.group.SetLaunchConfig(threads, bpc)
         dist.barrier()
@@ -374,6 +378,7 @@ def main():
             "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
             "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
             "step_form": args.form, "steps_per_graph": gs, "prewarm_steps": args.prewarm,
+            "lut_materialized": bool(args.lut_output or args.form in ("reference", "pdfz")),
             "steps_launched_one_by_one_with_events": eager_share(args.steps), "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,

@@ -187,6 +187,14 @@ int sxmc_group_set_sparse(sxmc_group_t g, int enable);
  * with the partial flat index of those observables and the fill streams it instead of their float
  * columns.  Results are identical; sxmc_group_algorithmic_bytes counts the bytes actually needed. */
 int sxmc_group_set_prebinning(sxmc_group_t g, int enable);
+/* 1 (default): sxmc_group_eval_nll_async / sxmc_group_mcmc_step_async write the lookup table
+ * (lut[j * E + i], the array eval_pdf produces at pdfz.cpp:411-436) as they consume it.  0: the table is
+ * an intermediate nobody reads (the MCMC loop, mcmc.cpp:264-348), so it is not written, and the event
+ * sum of nll_kernels.cpp:89-116 runs over the DISTINCT tuples of event bins, each log term weighted by
+ * the number of events sharing the tuple: sum_i log(s_i) = sum_k n_k log(s_k).  Same value up to
+ * rounding (the terms are added in another order); the work no longer grows with the number of
+ * events.  sxmc_group_eval_async always writes the table. */
+int sxmc_group_set_lut_output(sxmc_group_t g, int enable);
 /* Measurement hook for roofline analysis (RESULTS ARE WRONG when mode != 0; default 0):
  * bit 0 = histogram-fill kernel streams its columns but skips arithmetic and histogram,
  * bit 1 = arithmetic and histogram run but every reload hits one cached address,

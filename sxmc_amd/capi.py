@@ -89,6 +89,7 @@ SIGNATURES = {
     "sxmc_group_set_partition": [_vp, _i],
     "sxmc_group_set_sparse": [_vp, _i],
     "sxmc_group_set_prebinning": [_vp, _i],
+    "sxmc_group_set_lut_output": [_vp, _i],
     "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_group_eval_async": [_vp, _i, _vp],
     "sxmc_group_eval_nll_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi],

@@ -698,15 +698,39 @@ struct EvalMember {
 };
 
 // Body shared by eval_nll_kernel and eval_nll_finish_kernel: returns the workgroup's partial event sum
-// (valid in thread 0).
+// (valid in thread 0).  A row is an event -- or, with `weight`, a class of events that fall into the same
+// bin of every member (the descriptors then point at the class tables and carry no lookup-table output):
+// its log term counts weight[row] times.
 __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict__ descs, int nsig,
-                                                 unsigned long long npoints, const double* __restrict__ pars,
+                                                 unsigned long long npoints, const unsigned* __restrict__ weight,
+                                                 const double* __restrict__ pars,
                                                  const double* __restrict__ nexpected,
                                                  const unsigned* __restrict__ n_mc,
                                                  const short* __restrict__ source_id,
                                                  const unsigned* __restrict__ norms, double* sh) {
   double* s_wave = sh;  // [16] wave sums, then nsig EvalMember records
   EvalMember* s_mem = reinterpret_cast<EvalMember*>(sh + 16);
+
+  // The events' bin indices of the first members are requested before anything else: their addresses
+  // need only the descriptors (uniform, scalar loads), so the loads fly while the per-member factors
+  // below are fetched and staged.
+  constexpr int U = 16;
+  int rb[U];
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // (clamped indices, no branches: all U table addresses are fetched together, then all U loads issued)
+  auto load_read_bins = [&](unsigned long long ev, int j0) {
+    const unsigned long long evc = ev < npoints ? ev : npoints - 1;
+    gptr<const int> table[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) table[u] = to_global(descs[min(j0 + u, nsig - 1)].read_bins);
+#pragma unroll
+    for (int u = 0; u < U; u++) rb[u] = table[u][evc];
+#pragma unroll
+    for (int u = 0; u < U; u++) rb[u] = (j0 + u < nsig && ev < npoints) ? rb[u] : -2;
+  };
+  if (npoints == 0 || nsig <= 0) return 0.0;   // uniform: nothing to look up
+  load_read_bins(i, 0);
+
   for (int j = threadIdx.x; j < nsig; j += blockDim.x) {
     const SxSignalDesc& d = descs[j];
     s_mem[j].read_bins = d.read_bins;
@@ -719,16 +743,15 @@ __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict_
   }
   __syncthreads();
 
-  constexpr int U = 8;
   double sum = 0.0;
+  bool requested = true;
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < npoints; i += step) {
+  for (; i < npoints; i += step) {
     double s = 0.0;
     for (int j0 = 0; j0 < nsig; j0 += U) {
-      int rb[U];
+      if (!requested) load_read_bins(i, j0);
+      requested = false;
       unsigned count[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) rb[u] = (j0 + u < nsig) ? to_global(s_mem[j0 + u].read_bins)[i] : -2;
 #pragma unroll
       for (int u = 0; u < U; u++) count[u] = (rb[u] >= 0) ? to_global(s_mem[j0 + u].bins)[rb[u]] : 0u;
 #pragma unroll
@@ -739,12 +762,12 @@ __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict_
           if (rb[u] == -2) v = 0.0f;
           else if (rb[u] < 0) v = __int_as_float(0x7fc00000);
           else v = (float)((double)count[u] / s_mem[j0 + u].bin_norm);
-          to_global(s_mem[j0 + u].out)[s_mem[j0 + u].stride * (long)i] = v;
+          if (s_mem[j0 + u].out) to_global(s_mem[j0 + u].out)[s_mem[j0 + u].stride * (long)i] = v;
           s = s + s_mem[j0 + u].coef * (double)(!isnan(v) ? v : 0.0f);
         }
       }
     }
-    if (s > 0) sum += log(s);
+    if (s > 0) sum += weight ? (double)to_global(weight)[i] * log(s) : log(s);
   }
 
 #pragma unroll
@@ -761,6 +784,7 @@ __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict_
 
 __global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
                                                        unsigned long long npoints,
+                                                       const unsigned* __restrict__ weight,
                                                        const double* __restrict__ pars,
                                                        const double* __restrict__ nexpected,
                                                        const unsigned* __restrict__ n_mc,
@@ -768,7 +792,7 @@ __global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __res
                                                        const unsigned* __restrict__ norms,
                                                        double* __restrict__ sums) {
   extern __shared__ double sh[];
-  const double t = eval_nll_block(descs, nsig, npoints, pars, nexpected, n_mc, source_id, norms, sh);
+  const double t = eval_nll_block(descs, nsig, npoints, weight, pars, nexpected, n_mc, source_id, norms, sh);
   if (threadIdx.x == 0 && !isnan(t)) sums[blockIdx.x] = t;
 }
 
@@ -778,10 +802,12 @@ __global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __res
 // recipe for gfx950: partial stored, drained and released by lane 0 before its ticket; the last arriver
 // acquires (invalidating its CU's L1) before any of its lanes read the partials.
 __global__ __launch_bounds__(256) void eval_nll_finish_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
-                                                              unsigned long long npoints, double* sums,
+                                                              unsigned long long npoints,
+                                                              const unsigned* __restrict__ weight, double* sums,
                                                               unsigned* ticket, SxStepArgs a) {
   extern __shared__ double sh[];
-  const double t = eval_nll_block(descs, nsig, npoints, a.v_proposed, a.nexpected, a.n_mc, a.source_id, a.norms, sh);
+  const double t =
+      eval_nll_block(descs, nsig, npoints, weight, a.v_proposed, a.nexpected, a.n_mc, a.source_id, a.norms, sh);
   int* s_last = reinterpret_cast<int*>(sh + 15);  // last wave-sum slot: at most 4 waves are in use
   if (threadIdx.x == 0) {
     sums[blockIdx.x] = isnan(t) ? 0.0 : t;
@@ -1029,19 +1055,20 @@ hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned lo
 }
 
 hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
-                              const double* pars, const double* nexpected, const unsigned* n_mc,
+                              const unsigned* weight, const double* pars, const double* nexpected, const unsigned* n_mc,
                               const short* source_id, const unsigned* norms, double* sums,
                               int grid, int block, hipStream_t s) {
-  const size_t shmem = 16 * sizeof(double) + (size_t)nsig * sizeof(EvalMember);
-  hipLaunchKernelGGL(eval_nll_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, pars,
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
+  hipLaunchKernelGGL(eval_nll_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, weight, pars,
                      nexpected, n_mc, source_id, norms, sums);
   return hipGetLastError();
 }
 
-hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints, double* sums,
-                                      unsigned* ticket, const SxStepArgs& a, int grid, int block, hipStream_t s) {
-  const size_t shmem = 16 * sizeof(double) + (size_t)nsig * sizeof(EvalMember);
-  hipLaunchKernelGGL(eval_nll_finish_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, sums,
+hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
+                                      const unsigned* weight, double* sums, unsigned* ticket, const SxStepArgs& a,
+                                      int grid, int block, hipStream_t s) {
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
+  hipLaunchKernelGGL(eval_nll_finish_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, weight, sums,
                      ticket, a);
   return hipGetLastError();
 }

@@ -114,8 +114,9 @@ struct SxLaunchShape {
 };
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
-hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints, double* sums,
-                                      unsigned* ticket, const SxStepArgs& a, int grid, int block, hipStream_t s);
+hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
+                                      const unsigned* weight, double* sums, unsigned* ticket, const SxStepArgs& a,
+                                      int grid, int block, hipStream_t s);
 hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,
                           const unsigned* d_blk_off, hipStream_t s);
 bool sx_fill_has_specialization(int nobs, int nslot);
@@ -126,7 +127,7 @@ hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad,
 hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,
                               hipStream_t s);
 hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
-                              const double* pars, const double* nexpected, const unsigned* n_mc,
+                              const unsigned* weight, const double* pars, const double* nexpected, const unsigned* n_mc,
                               const short* source_id, const unsigned* norms, double* sums,
                               int grid, int block, hipStream_t s);
 hipError_t sx_launch_transpose(const float* aos, float* cols, unsigned long long nsamples,

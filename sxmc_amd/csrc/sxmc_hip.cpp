@@ -145,6 +145,9 @@ struct sxmc_hist {
   unsigned* d_coarse = nullptr;    // coarse filter staged in LDS by the fill kernel
   int ntargets = 0, filter_shift = 0, table_shift = 0, coarse_shift = 0;
   std::vector<unsigned> targets;   // sorted distinct event bins (host copy: members with equal sets share tables)
+  std::vector<int> h_read_bins;    // host copies of d_read_bins / d_read_slot: the group forms event classes from them
+  std::vector<int> h_read_slot;
+  unsigned long long points_version = 0;
   bool bins_valid = true;          // false after a sparse evaluation: the dense histogram was not filled
 };
 
@@ -276,6 +279,20 @@ struct sxmc_group {
   bool same_points = false;
   hipStream_t last_stream = nullptr;
   bool built = false;
+  // Events grouped by their tuple of bins over the members (used when the lookup table is not wanted,
+  // cfg_lut == 0): one row per distinct tuple, weighted by how many events share it.  One set per descriptor
+  // flavour (dense bins / sparse counter slots).
+  struct EventClasses {
+    int* d_rb = nullptr;             // [nmembers][K]
+    unsigned* d_weight = nullptr;    // [K]
+    SxSignalDesc* d_descs = nullptr; // member descriptors reading the class tables, no lookup-table output
+    size_t K = 0;
+    bool tables_valid = false, descs_valid = false;
+    std::vector<unsigned long long> seen_points;
+  };
+  EventClasses ec[2];               // [0] dense, [1] sparse flavour
+  std::vector<SxSignalDesc> h_descs_sparse;
+  int cfg_lut = 1;
   unsigned* d_ticket = nullptr;  // arrival counter of the fused step end, zeroed by the zero kernel
   double* d_step_sums = nullptr; // 1024 partial sums of the fused step
   // profiling of the fill kernel
@@ -320,6 +337,7 @@ void free_sparse(sxmc_hist* h) {
   h->d_table = nullptr;
   h->ntargets = 0;
   h->targets.clear();
+  h->h_read_slot.clear();
 }
 
 int ceil_log2(size_t x) {
@@ -370,6 +388,7 @@ int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
   SX_HIP(hipMemcpy(h->d_table, table.data(), sizeof(unsigned) * table.size(), hipMemcpyHostToDevice));
   SX_HIP(hipMalloc((void**)&h->d_coarse, sizeof(unsigned) * coarse.size()));
   SX_HIP(hipMemcpy(h->d_coarse, coarse.data(), sizeof(unsigned) * coarse.size(), hipMemcpyHostToDevice));
+  h->h_read_slot = slot;
   h->coarse_shift = 32 - cbits;
   h->ntargets = (int)T;
   h->targets = targets;
@@ -557,6 +576,8 @@ int group_rebuild(sxmc_group* g) {
     g->max_bins_sparse = std::max(g->max_bins_sparse, sparse_descs[(size_t)i].total_nbins);
   }
   g->sparse_ready = g->sparse_ready && sparse_ok;
+  g->h_descs_sparse = sparse_descs;
+  g->ec[0].descs_valid = g->ec[1].descs_valid = false;
   if (!g->d_descs_sparse) SX_HIP(hipMalloc((void**)&g->d_descs_sparse, sizeof(SxSignalDesc) * std::max(n, 1)));
   if (n) SX_HIP(hipMemcpy(g->d_descs_sparse, sparse_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
 
@@ -652,6 +673,108 @@ int group_check_bound(sxmc_group* g, bool need_pdf) {
     if (!h->systs.empty() && !h->params) return fail(SXMC_ERR_STATE, "evaluation before SetParameterBuffer");
     if (need_pdf && h->has_points && !h->pdf) return fail(SXMC_ERR_STATE, "evaluation before SetPDFValueBuffer");
   }
+  return SXMC_OK;
+}
+
+void free_event_classes(sxmc_group::EventClasses& ec) {
+  if (ec.d_rb) (void)hipFree(ec.d_rb);
+  if (ec.d_weight) (void)hipFree(ec.d_weight);
+  if (ec.d_descs) (void)hipFree(ec.d_descs);
+  ec = sxmc_group::EventClasses{};
+}
+
+// Event classes of one descriptor flavour, built on the host from the members' event-bin tables:
+// events with the same bin (counter slot) in every member contribute the same term to the event sum,
+// so the sum runs over the distinct tuples, each weighted by its multiplicity.  Tables are rebuilt when
+// evaluation points change, the descriptor copies whenever the group is rebuilt.
+int ensure_event_classes(sxmc_group* g, bool sparse) {
+  sxmc_group::EventClasses& ec = g->ec[sparse ? 1 : 0];
+  const size_t S = g->members.size();
+  bool tables_ok = ec.tables_valid && ec.seen_points.size() == S;
+  for (size_t j = 0; tables_ok && j < S; j++) tables_ok = ec.seen_points[j] == g->members[j]->points_version;
+  if (tables_ok && ec.descs_valid) return SXMC_OK;
+  if (t_capturing) {
+    return fail(SXMC_ERR_STATE, "the event classes are out of date: evaluate once before recording a graph");
+  }
+  SX_HIP(hipDeviceSynchronize());  // kernels in flight may still read the old tables
+  const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
+  if (!tables_ok) {
+    const size_t E = g->members[0]->npoints;
+    // the table each member's descriptor of this flavour reads
+    std::vector<const std::vector<int>*> arr(S);
+    for (size_t j = 0; j < S; j++) {
+      const sxmc_hist* h = g->members[j];
+      const bool slots = sparse && flavour[j].read_bins == h->d_read_slot && h->d_read_slot != nullptr;
+      arr[j] = slots ? &h->h_read_slot : &h->h_read_bins;
+      if (arr[j]->size() != E) return fail(SXMC_ERR_STATE, "event-bin table of a member is missing");
+    }
+    // members with identical tables (one binning, one data set: the usual case) count once in the key
+    std::vector<int> rep(S);
+    std::vector<int> distinct;
+    for (size_t j = 0; j < S; j++) {
+      rep[j] = -1;
+      for (size_t q = 0; q < distinct.size(); q++) {
+        if (*arr[(size_t)distinct[q]] == *arr[j]) {
+          rep[j] = (int)q;
+          break;
+        }
+      }
+      if (rep[j] < 0) {
+        rep[j] = (int)distinct.size();
+        distinct.push_back((int)j);
+      }
+    }
+    std::vector<unsigned> order(E);
+    for (size_t i = 0; i < E; i++) order[i] = (unsigned)i;
+    auto less = [&](unsigned a, unsigned b) {
+      for (int q : distinct) {
+        const int x = (*arr[(size_t)q])[a], y = (*arr[(size_t)q])[b];
+        if (x != y) return x < y;
+      }
+      return false;
+    };
+    auto same = [&](unsigned a, unsigned b) {
+      for (int q : distinct)
+        if ((*arr[(size_t)q])[a] != (*arr[(size_t)q])[b]) return false;
+      return true;
+    };
+    std::sort(order.begin(), order.end(), less);
+    std::vector<unsigned> first, weight;
+    for (size_t i = 0; i < E; i++) {
+      if (i > 0 && same(order[i - 1], order[i])) {
+        weight.back()++;
+      } else {
+        first.push_back(order[i]);
+        weight.push_back(1u);
+      }
+    }
+    const size_t K = first.size();
+    std::vector<int> tables(std::max<size_t>(S * K, 1));
+    for (size_t j = 0; j < S; j++)
+      for (size_t k = 0; k < K; k++) tables[j * K + k] = (*arr[j])[first[k]];
+    if (ec.d_rb) SX_HIP(hipFree(ec.d_rb));
+    if (ec.d_weight) SX_HIP(hipFree(ec.d_weight));
+    ec.d_rb = nullptr;
+    ec.d_weight = nullptr;
+    SX_HIP(hipMalloc((void**)&ec.d_rb, sizeof(int) * tables.size()));
+    SX_HIP(hipMemcpy(ec.d_rb, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
+    SX_HIP(hipMalloc((void**)&ec.d_weight, sizeof(unsigned) * std::max<size_t>(K, 1)));
+    if (K) SX_HIP(hipMemcpy(ec.d_weight, weight.data(), sizeof(unsigned) * K, hipMemcpyHostToDevice));
+    ec.K = K;
+    ec.seen_points.resize(S);
+    for (size_t j = 0; j < S; j++) ec.seen_points[j] = g->members[j]->points_version;
+    ec.tables_valid = true;
+    ec.descs_valid = false;
+  }
+  std::vector<SxSignalDesc> descs = flavour;
+  for (size_t j = 0; j < S; j++) {
+    descs[j].read_bins = ec.d_rb + j * ec.K;
+    descs[j].npoints = ec.K;
+    descs[j].pdf_out = nullptr;
+  }
+  if (!ec.d_descs) SX_HIP(hipMalloc((void**)&ec.d_descs, sizeof(SxSignalDesc) * std::max<size_t>(S, 1)));
+  SX_HIP(hipMemcpy(ec.d_descs, descs.data(), sizeof(SxSignalDesc) * S, hipMemcpyHostToDevice));
+  ec.descs_valid = true;
   return SXMC_OK;
 }
 
@@ -1059,6 +1182,8 @@ int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints
   h->npoints = n;
   h->has_points = true;
   h->version++;
+  h->points_version++;
+  h->h_read_bins = rb;
   if (h->total_nbins > kLdsMaxBins) {
     int rc = build_sparse(h, rb);
     if (rc) return rc;
@@ -1202,6 +1327,8 @@ int sxmc_group_destroy(sxmc_group_t g) {
   if (g->d_descs_sparse) (void)hipFree(g->d_descs_sparse);
   if (g->d_ticket) (void)hipFree(g->d_ticket);
   if (g->d_step_sums) (void)hipFree(g->d_step_sums);
+  free_event_classes(g->ec[0]);
+  free_event_classes(g->ec[1]);
   for (hipEvent_t e : g->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : g->ev1) (void)hipEventDestroy(e);
   delete g;
@@ -1234,6 +1361,12 @@ int sxmc_group_set_sparse(sxmc_group_t g, int enable) {
 int sxmc_group_set_prebinning(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_prebin = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_lut_output(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_lut = enable ? 1 : 0;
   return SXMC_OK;
 }
 
@@ -1275,14 +1408,29 @@ int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s, const double* d_p
   hipStream_t st = (hipStream_t)s;
   g->last_stream = st;
   const bool sparse = g->sparse_ready && g->cfg_sparse;
+  if (!g->cfg_lut) {
+    rc = ensure_event_classes(g, sparse);  // (may upload tables: before anything is launched)
+    if (rc) return rc;
+  }
   rc = group_fill(g, st, sparse);
   if (rc) return rc;
-  const unsigned long long ne = g->members[0]->npoints;
   SX_REQUIRE(g->members.size() <= 1024, "too many members for the fused evaluation");
+  // lookup table wanted: one pass over the events in order; otherwise over the distinct bin tuples
+  unsigned long long ne = g->members[0]->npoints;
+  const SxSignalDesc* descs = sparse ? g->d_descs_sparse : g->d_descs;
+  const unsigned* weight = nullptr;
+  if (!g->cfg_lut) {
+    rc = ensure_event_classes(g, sparse);
+    if (rc) return rc;
+    const sxmc_group::EventClasses& ec = g->ec[sparse ? 1 : 0];
+    ne = ec.K;
+    descs = ec.d_descs;
+    weight = ec.d_weight;
+  }
   const int block = 128;
-  int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
-  SX_HIP(sx_launch_eval_nll(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(), ne, d_pars,
-                            d_nexpected, d_n_mc, d_source_id, d_norms, d_sums, grid, block, st));
+  const int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
+  SX_HIP(sx_launch_eval_nll(descs, (int)g->members.size(), ne, weight, d_pars, d_nexpected, d_n_mc, d_source_id,
+                            d_norms, d_sums, grid, block, st));
   *npartial_out = grid;
   return SXMC_OK;
 }
@@ -1307,9 +1455,19 @@ int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_
   hipStream_t st = (hipStream_t)s;
   g->last_stream = st;
   const bool sparse = g->sparse_ready && g->cfg_sparse;
+  unsigned long long ne = g->members[0]->npoints;
+  const SxSignalDesc* descs = sparse ? g->d_descs_sparse : g->d_descs;
+  const unsigned* weight = nullptr;
+  if (!g->cfg_lut) {
+    rc = ensure_event_classes(g, sparse);
+    if (rc) return rc;
+    const sxmc_group::EventClasses& ec = g->ec[sparse ? 1 : 0];
+    ne = ec.K;
+    descs = ec.d_descs;
+    weight = ec.d_weight;
+  }
   rc = group_fill(g, st, sparse);  // zero (also clears the ticket) + fill
   if (rc) return rc;
-  const unsigned long long ne = g->members[0]->npoints;
   const int block = 128;
   const int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
   SxStepArgs a;
@@ -1332,8 +1490,8 @@ int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_
   a.n_mc = d_n_mc;
   a.source_id = d_source_id;
   a.norms = d_norms;
-  SX_HIP(sx_launch_eval_nll_finish(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(), ne,
-                                   g->d_step_sums, g->d_ticket, a, grid, block, st));
+  SX_HIP(sx_launch_eval_nll_finish(descs, (int)g->members.size(), ne, weight, g->d_step_sums, g->d_ticket, a, grid,
+                                   block, st));
   return SXMC_OK;
 }
 

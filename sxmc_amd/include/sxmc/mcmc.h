@@ -37,6 +37,8 @@ class MCMC {
   bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
   bool verbose = false;
   unsigned graph_steps = 0;     //!< > 0: replay the batched step from a HIP graph of this many recorded steps
+  bool lut_output = false;      //!< materialise the lookup table in the batched step (nothing reads it; when
+                                //!< false the event sum runs over distinct event-bin tuples, see sxmc_hip.h)
   unsigned long long seed = 0;  //!< gRandom->GetSeed() in the reference (mcmc.cpp:125)
 
   MCMC(const std::vector<Source>& sources, const std::vector<Signal>& signals,
@@ -197,6 +199,7 @@ class MCMC {
     if (batched) {
       // bindings must be current before the group reads them (proposal vector as parameter buffer)
       for (pdfz::Eval* p : pdfs) dynamic_cast<pdfz::EvalHist*>(p)->Bind();
+      check(sxmc_group_set_lut_output(group, lut_output ? 1 : 0));
     }
     const bool reevaluate = nsystematics > 0 && !systematics_fixed;
 

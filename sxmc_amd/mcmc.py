@@ -32,10 +32,13 @@ def make_systematic(desc):
 
 
 class MCMC:
-    def __init__(self, workload, seed=1234, stream=None, fused=True, samples_on_device=None, share_with=None):
+    def __init__(self, workload, seed=1234, stream=None, fused=True, samples_on_device=None, share_with=None,
+                 lut_output=True):
         """share_with: another MCMC over the same workload -- this one's evaluators then share its sample
         tables (one copy in HBM) and only the per-chain state is new; give each such chain its own
-        non-blocking `stream` to let their kernels overlap."""
+        non-blocking `stream` to let their kernels overlap.
+        lut_output=False: the fused step forms do not materialise the lookup table (self.lut then holds the
+        values of setup() only) and sum over distinct event-bin tuples (sxmc_group_set_lut_output)."""
         w = workload
         self.w = w
         self.stream = stream
@@ -56,6 +59,7 @@ class MCMC:
                 ev.AddSystematic(make_systematic(d))
             self.pdfs.append(ev)
         self.group = nll.EvalGroup(self.pdfs)
+        self.group.SetLutOutput(lut_output)
 
         # mcmc.cpp:53-98
         self.parameter_means = DeviceArray(w.parameter_means().astype(np.float64))

@@ -86,6 +86,11 @@ class EvalGroup:
         """Stream observables that no systematic writes as one pre-binned narrow column (default on)."""
         capi.call("sxmc_group_set_prebinning", self._g, int(bool(enable)))
 
+    def SetLutOutput(self, enable):
+        """False: EvalNllAsync / McmcStepAsync do not write the lookup table and sum over the distinct tuples
+        of event bins, weighted by multiplicity (see include/sxmc_hip.h).  Default True."""
+        capi.call("sxmc_group_set_lut_output", self._g, int(bool(enable)))
+
     def SetDebugMode(self, mode):
         """Measurement hook (results are wrong when mode != 0), see include/sxmc_hip.h."""
         capi.call("sxmc_group_set_debug_mode", self._g, int(mode))

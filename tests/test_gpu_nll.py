@@ -350,3 +350,63 @@ def test_graph_capture_refuses_a_stale_group_and_the_default_stream():
     assert rows.shape[0] == 7
     with pytest.raises(capi.SxmcError):
         capi.call("sxmc_graph_begin_capture", capi.ptr(None))
+
+
+@pytest.mark.parametrize("make,scale,nevents", [(workloads.config1, 1.0, None), (workloads.config2, 0.02, 5000),
+                                                (workloads.config3, 0.004, 5000)])
+@pytest.mark.parametrize("fused", [True, "step"])
+def test_event_classes_give_the_same_nll_without_the_lookup_table(make, scale, nevents, fused):
+    """lut_output=False: the event sum runs over distinct tuples of event bins weighted by multiplicity.
+    NLL of each step against the oracle (which walks the events one by one), histograms and norms bit for
+    bit; the lookup table keeps the values of setup()."""
+    w = make(scale) if nevents is None else make(scale, nevents=nevents)
+    w.events[:40] = w.events[0]                      # many events in one bin
+    w.events[40:45, :w.nobs] = 1e9                   # outside the domain
+    m = MCMC(w, seed=99, fused=fused, lut_output=False)
+    m.setup(sync_interval=16)
+    capi.synchronize()
+    lut_setup = m.lut.get().copy()
+    proposals = []
+    for _ in range(3):
+        proposals.append(m.proposed_vector.get())
+        m.step(debug_mode=True)
+    rows, nacc = m.flush()
+    assert nacc == 3
+    for k, v in enumerate(proposals):
+        want, bins, norms, lut = oracle_nll_of_workload(w, v)
+        assert abs(rows[k, -1] - want) <= 1e-6 * abs(want)
+    assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
+    for j, p in enumerate(m.pdfs):
+        assert np.array_equal(p.GetBins(), bins[j])
+    assert np.array_equal(m.normalizations.get(), norms)
+    assert np.array_equal(m.lut.get().view(np.uint32), lut_setup.view(np.uint32))
+    # new evaluation points: the classes are rebuilt
+    m.setup(data=w.events[: max(3, w.events.shape[0] // 2)], sync_interval=16)
+    v = m.proposed_vector.get()
+    m.step(debug_mode=True)
+    rows, _ = m.flush()
+    w2 = workloads.Workload.__new__(workloads.Workload)
+    w2.__dict__.update(w.__dict__)
+    w2.events = w.events[: max(3, w.events.shape[0] // 2)]
+    want, _, _, _ = oracle_nll_of_workload(w2, v)
+    assert abs(rows[0, -1] - want) <= 1e-6 * abs(want)
+
+
+def test_event_classes_with_sparse_counters_and_two_datasets():
+    """Members of two data sets (their event-bin tables differ) and histograms beyond LDS capacity (sparse
+    counter slots): class keys are tuples over the distinct tables."""
+    w = workloads.config5(3e-5, nevents=2000, nbins=(40, 40, 40, 4, 4))
+    w.signals = w.signals[:4]
+    w.signals[1].dataset = 1
+    w.signals[3].dataset = 1
+    w.events[::3, -1] = 1.0
+    for sparse in (True, False):
+        m = MCMC(w, seed=21, fused=True, lut_output=False)
+        m.group.SetSparse(sparse)
+        m.setup(sync_interval=8)
+        proposal = m.proposed_vector.get()
+        m.step(debug_mode=True)
+        rows, nacc = m.flush()
+        want, bins, norms, lut = oracle_nll_of_workload(w, proposal)
+        assert np.array_equal(m.normalizations.get(), norms)
+        assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
