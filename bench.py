@@ -298,7 +298,8 @@ def main():
     # timed region of the headline metric; reported beside it.
     experiments = None
     nexp = 3 * world if args.experiments < 0 else args.experiments
-    if nexp > 0 and not args.debug_mode and args.form != "pdfz":
+    # (fake data sets are drawn from 1-3 D histograms only, as in the reference: pdfz.cpp:499-501)
+    if nexp > 0 and not args.debug_mode and args.form != "pdfz" and w.nobs <= 3:
         from sxmc_amd import ensemble
         for s_ in w.signals:
             s_.nexpected_saved = s_.nexpected
