@@ -48,6 +48,11 @@ void oracle_set_eval_points(size_t npoints, const float* points, int nobs,
       }
       bin_id += (int)((element - lower[iobs]) * bin_scale[iobs]) * bin_stride[iobs];
     }
+    /* deviation: an index rounded up past the end (header) would make eval_pdf read
+     * one-past-the-end; such a point is treated as outside the domain */
+    if (in_pdf_domain && (unsigned)bin_id >= (unsigned)(bin_stride[0] * nbins[0])) {
+      in_pdf_domain = 0;
+    }
     /* dataset test overwrites bin_id, then out-of-domain wins (pdfz.cpp:289-300) */
     if (points[(size_t)(nobs + 1) * ipoint + nobs] != dataset) {
       bin_id = -2;

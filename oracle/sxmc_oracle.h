@@ -28,6 +28,8 @@
  *     makes the reference write one-past-the-end (pdfz.cpp:396-402): here the index
  *     arithmetic is kept unclamped exactly as written, the sample still counts in `norm`,
  *     and the bin increment is dropped iff the flat index falls outside [0, total_nbins).
+ *     An evaluation point whose flat index falls outside that range (the reference would read
+ *     one-past-the-end in eval_pdf) is treated as outside the domain (-1 -> NaN).
  */
 #ifndef SXMC_ORACLE_H
 #define SXMC_ORACLE_H

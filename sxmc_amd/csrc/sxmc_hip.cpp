@@ -1168,6 +1168,8 @@ int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints
       }
       bin_id += (int)((element - h->lower[(size_t)k]) * h->scale[(size_t)k]) * h->stride[(size_t)k];
     }
+    // an index rounded up past the end (the reference would read one-past-the-end in eval_pdf): outside
+    if (in_domain && (unsigned)bin_id >= (unsigned)h->total_nbins) in_domain = false;
     if (points[row * ip + (size_t)D] != (float)h->dataset) bin_id = -2;  // pdfz.cpp:289-293
     rb[ip] = in_domain ? bin_id : -1;
   }
