@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -102,6 +103,7 @@ struct SampleStore {
     void* ptr;
   };
   std::vector<PreColumn> pre;
+  std::mutex pre_mutex;  // evaluators sharing the table may be set up from different host threads
   void* find_pre(unsigned mask, int width) const {
     for (const PreColumn& p : pre)
       if (p.mask == mask && p.width == width) return p.ptr;
@@ -590,6 +592,7 @@ int group_rebuild(sxmc_group* g) {
       if (c.shape.pre_width) {
         sxmc_hist* h = g->members[idx];
         SampleStore& st = *h->store;
+        std::lock_guard<std::mutex> lock(st.pre_mutex);
         void* pre = st.find_pre(c.pre_mask, c.shape.pre_width);
         if (!pre) {
           const size_t npad = h->nvec * SXMC_VEC;

@@ -28,6 +28,16 @@ inline void check(int rc) {
   if (rc != SXMC_OK) throw HipError(std::string("libsxmc_hip: ") + sxmc_last_error());
 }
 
+/** The stream the calling thread's array transfers are ordered on.  Default (null): blocking copies
+ *  through the legacy default stream, which wait for every blocking stream of the device -- the
+ *  reference's single-chain behaviour.  A thread that drives its own chain on a non-blocking stream sets
+ *  this to that stream: its transfers are then enqueued there and waited for there, and do not touch
+ *  the chains of other threads. */
+inline sxmc_stream_t& transfer_stream() {
+  static thread_local sxmc_stream_t s = nullptr;
+  return s;
+}
+
 template <typename T>
 class DeviceArray {
  public:
@@ -105,14 +115,26 @@ class DeviceArray {
   }
   void toHost() {
     allocHost();
-    if (!host_valid_ && dev_valid_) check(sxmc_memcpy_d2h(host_, dev_, n_ * sizeof(T)));
+    if (!host_valid_ && dev_valid_) {
+      if (sxmc_stream_t s = transfer_stream()) {
+        check(sxmc_memcpy_d2h_async(host_, dev_, n_ * sizeof(T), s));
+        check(sxmc_stream_synchronize(s));
+      } else {
+        check(sxmc_memcpy_d2h(host_, dev_, n_ * sizeof(T)));
+      }
+    }
     host_valid_ = true;
   }
   void toDevice() {
     allocDevice();
     if (!dev_valid_) {
       allocHost();  // a never-written array uploads zeros
-      check(sxmc_memcpy_h2d(dev_, host_, n_ * sizeof(T)));
+      if (sxmc_stream_t s = transfer_stream()) {
+        check(sxmc_memcpy_h2d_async(dev_, host_, n_ * sizeof(T), s));
+        check(sxmc_stream_synchronize(s));  // the host side may be rewritten as soon as this returns
+      } else {
+        check(sxmc_memcpy_h2d(dev_, host_, n_ * sizeof(T)));
+      }
     }
     dev_valid_ = true;
   }

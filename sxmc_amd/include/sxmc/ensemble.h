@@ -17,8 +17,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <exception>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mcmc.h"
@@ -151,29 +153,91 @@ struct ExperimentResult {
 
 /** The experiment loop of sxmc.cpp:59-145 over the given experiment indices (all of them on one GPU,
  *  or this rank's share).  Evaluators (and their MC tables in HBM) are reused by every experiment. */
+/** Per-experiment seed (the reference's single sequential gRandom stream cannot be sharded). */
+inline unsigned long long experiment_seed(unsigned long long base_seed, unsigned k) {
+  unsigned long long x = base_seed * 0x9E3779B97F4A7C15ull + (k + 1ull) * 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 31;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 29;
+  return x;
+}
+
+/** One iteration of sxmc.cpp:59-145: fake data -> MCMC -> intervals, on `stream` (null: default). */
+inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed, std::vector<Source>& sources,
+                                       std::vector<Signal>& signals, std::vector<Systematic>& systematics,
+                                       std::vector<Observable>& observables, unsigned nsteps, float burnin_fraction,
+                                       float cl, unsigned sync_interval, unsigned graph_steps = 0,
+                                       sxmc_stream_t stream = nullptr) {
+  const unsigned long long x = experiment_seed(base_seed, k);
+  std::mt19937_64 rng(x);
+  std::vector<float> data = make_fake_dataset(rng, signals, systematics, observables, true);
+  MCMC mcmc(sources, signals, systematics, observables, x, stream);
+  mcmc.graph_steps = graph_steps;
+  Chain chain = mcmc(data, nsteps, burnin_fraction, false, sync_interval);
+  ExperimentResult r;
+  r.index = k;
+  r.intervals = contour_intervals(chain, cl);
+  r.accepted = chain.accepted;
+  r.nevents = data.size() / (observables.size() + 1);
+  return r;
+}
+
 inline std::vector<ExperimentResult> ensemble(const std::vector<unsigned>& experiments, unsigned long long base_seed,
                                               std::vector<Source>& sources, std::vector<Signal>& signals,
                                               std::vector<Systematic>& systematics,
                                               std::vector<Observable>& observables, unsigned nsteps,
-                                              float burnin_fraction, float cl = 0.9f, unsigned sync_interval = 10000) {
+                                              float burnin_fraction, float cl = 0.9f, unsigned sync_interval = 10000,
+                                              unsigned graph_steps = 0) {
   std::vector<ExperimentResult> out;
   for (unsigned k : experiments) {
-    // per-experiment seed (the reference's single sequential gRandom stream cannot be sharded)
-    unsigned long long x = base_seed * 0x9E3779B97F4A7C15ull + (k + 1ull) * 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 31;
-    x *= 0x94D049BB133111EBull;
-    x ^= x >> 29;
-    std::mt19937_64 rng(x);
-    std::vector<float> data = make_fake_dataset(rng, signals, systematics, observables, true);
-    MCMC mcmc(sources, signals, systematics, observables, x);
-    Chain chain = mcmc(data, nsteps, burnin_fraction, false, sync_interval);
-    ExperimentResult r;
-    r.index = k;
-    r.intervals = contour_intervals(chain, cl);
-    r.accepted = chain.accepted;
-    r.nevents = data.size() / (observables.size() + 1);
-    out.push_back(r);
+    out.push_back(run_experiment(k, base_seed, sources, signals, systematics, observables, nsteps, burnin_fraction,
+                                 cl, sync_interval, graph_steps));
   }
+  return out;
+}
+
+/** The same loop with `nconcurrent` experiments in flight on this GPU (BASELINE config 4's per-GPU shape:
+ *  one experiment per stream).  Each lane is a host thread with its own non-blocking stream and its own
+ *  evaluators, which share the resident sample tables of `signals` (share_pdfz); lane t runs experiments
+ *  t, t + nconcurrent, ...  Results come back in the order of `experiments` and are the ones `ensemble`
+ *  gives (every experiment is seeded by its index). */
+inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsigned>& experiments,
+                                                         unsigned long long base_seed, std::vector<Source>& sources,
+                                                         std::vector<Signal>& signals,
+                                                         std::vector<Systematic>& systematics,
+                                                         std::vector<Observable>& observables, unsigned nsteps,
+                                                         float burnin_fraction, unsigned nconcurrent, float cl = 0.9f,
+                                                         unsigned sync_interval = 10000, unsigned graph_steps = 0) {
+  const size_t lanes = std::max<size_t>(1, std::min<size_t>(nconcurrent, experiments.size()));
+  std::vector<ExperimentResult> out(experiments.size());
+  std::vector<std::exception_ptr> errors(lanes);
+  std::vector<std::thread> threads;
+  for (size_t t = 0; t < lanes; t++) {
+    threads.emplace_back([&, t]() {
+      sxmc_stream_t strm = nullptr;
+      std::vector<Signal> mine;
+      try {
+        check(sxmc_stream_create_nonblocking(&strm));
+        transfer_stream() = strm;
+        for (const Signal& s : signals) mine.push_back(share_pdfz(s));
+        std::vector<Source> src = sources;
+        std::vector<Systematic> sys = systematics;
+        std::vector<Observable> obs = observables;
+        for (size_t i = t; i < experiments.size(); i += lanes) {
+          out[i] = run_experiment(experiments[i], base_seed, src, mine, sys, obs, nsteps, burnin_fraction, cl,
+                                  sync_interval, graph_steps, strm);
+        }
+      } catch (...) {
+        errors[t] = std::current_exception();
+      }
+      for (Signal& s : mine) delete s.histogram;
+      transfer_stream() = nullptr;
+      if (strm) sxmc_stream_destroy(strm);
+    });
+  }
+  for (std::thread& th : threads) th.join();
+  for (std::exception_ptr& e : errors)
+    if (e) std::rethrow_exception(e);
   return out;
 }
 

@@ -89,6 +89,14 @@ inline void build_pdfz(Signal& sig, const std::vector<float>& samples, int nfiel
   }
 }
 
+/** A copy of `base` whose evaluator shares base's sample table (pdfz::EvalHist::SharedSamples): what each
+ *  additional concurrent chain on a GPU works with.  The caller deletes .histogram, as for build_pdfz. */
+inline Signal share_pdfz(const Signal& base) {
+  Signal s = base;
+  s.histogram = new pdfz::EvalHist(*dynamic_cast<pdfz::EvalHist*>(base.histogram), pdfz::EvalHist::SharedSamples{});
+  return s;
+}
+
 /** Signal::get_efficiency (signal.cpp:172-199): fraction of the MC samples inside the PDF domain with
  *  every systematic at its mean. */
 inline double get_efficiency(Signal& sig, const std::vector<Systematic>& systematics) {

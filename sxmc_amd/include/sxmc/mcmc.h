@@ -43,8 +43,9 @@ class MCMC {
 
   MCMC(const std::vector<Source>& sources, const std::vector<Signal>& signals,
        const std::vector<Systematic>& systematics, const std::vector<Observable>& observables,
-       unsigned long long _seed = 1)
+       unsigned long long _seed = 1, sxmc_stream_t _stream = nullptr)
       : seed(_seed),
+        stream(_stream),
         nsources(sources.size()),
         nsignals(signals.size()),
         nsystematics(systematics.size()),
@@ -97,7 +98,7 @@ class MCMC {
     rngs.reset(new pdfz::Array<RNGState>(nparameters, true));
     const int bs = 128;
     const int nb = (int)(nparameters / bs + 1);
-    SXMC_KERNEL_LAUNCH(init_device_rngs, nb, bs, 0, 0, (int)nparameters, seed, rngs->writeOnlyPtr());
+    SXMC_KERNEL_LAUNCH(init_device_rngs, nb, bs, 0, stream, (int)nparameters, seed, rngs->writeOnlyPtr());
 
     // the batched form needs every evaluator to be a histogram evaluator of this library
     std::vector<sxmc_hist_t> handles;
@@ -146,6 +147,15 @@ class MCMC {
   /** MCMC::operator() (mcmc.cpp:143-387).  data: rows of nobservables+1 floats (last = dataset id). */
   Chain operator()(std::vector<float>& data, unsigned nsteps, float burnin_fraction,
                    const bool debug_mode = false, unsigned sync_interval = 10000) {
+    // array transfers of this walk are ordered on the chain's stream (a blocking copy through the legacy
+    // default stream would neither wait for a non-blocking stream nor leave other chains alone)
+    struct TransferGuard {
+      sxmc_stream_t prev;
+      explicit TransferGuard(sxmc_stream_t s) : prev(transfer_stream()) {
+        if (s) transfer_stream() = s;
+      }
+      ~TransferGuard() { transfer_stream() = prev; }
+    } transfer_guard(stream);
     const unsigned burnin_steps = nsteps * burnin_fraction;
     Chain chain;
     chain.names = parameter_names;
@@ -192,7 +202,7 @@ class MCMC {
 
     nll(lut.readOnlyPtr(), nevents, current_vector.readOnlyPtr(), current_nll.writeOnlyPtr(),
         normalizations.readOnlyPtr(), event_partial_sums.ptr(), event_total_sum.ptr());
-    SXMC_KERNEL_LAUNCH(pick_new_vector, 1, 64, 0, 0, (int)nparameters, rngs->ptr(), jump_width.readOnlyPtr(),
+    SXMC_KERNEL_LAUNCH(pick_new_vector, 1, 64, 0, stream, (int)nparameters, rngs->ptr(), jump_width.readOnlyPtr(),
                        current_vector.readOnlyPtr(), proposed_vector.writeOnlyPtr());
 
     const bool batched = group != nullptr && !reference_form;
@@ -206,9 +216,10 @@ class MCMC {
     // Recorded steps need a created stream (blocking: it still orders with the copies of the array
     // accessors, which go through the legacy default stream) and the batched form.
     const unsigned gsteps = (batched && reevaluate) ? graph_steps : 0;
-    sxmc_stream_t strm = nullptr;
+    sxmc_stream_t strm = stream;
     sxmc_graph_t graph = nullptr;
-    if (gsteps > 0) check(sxmc_stream_create(&strm));
+    const bool own_stream = gsteps > 0 && !strm;
+    if (own_stream) check(sxmc_stream_create(&strm));
 
     // Device pointers of one run of steps, resolved once per run: the accessors may copy (after the
     // host wrote a counter or the widths), which must not happen while a graph is being recorded.
@@ -316,11 +327,13 @@ class MCMC {
       i = f + 1;
     }
     if (graph) check(sxmc_graph_destroy(graph));
-    if (strm) {
-      check(sxmc_stream_synchronize(strm));
-      check(sxmc_stream_destroy(strm));
+    if (strm) check(sxmc_stream_synchronize(strm));
+    if (own_stream) check(sxmc_stream_destroy(strm));
+    if (stream) {
+      check(sxmc_stream_synchronize(stream));  // this chain only: others may be running beside it
+    } else {
+      check(sxmc_device_synchronize());
     }
-    check(sxmc_device_synchronize());
     return chain;
   }
 
@@ -330,12 +343,12 @@ class MCMC {
   /** MCMC::nll (mcmc.cpp:390-415): three launches over an evaluated lookup table. */
   void nll(const float* lut, size_t nevents, const double* v, double* out, const unsigned* norms,
            double* event_partial_sums, double* event_total_sum) {
-    SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, 0, lut, v, nevents, nsignals,
+    SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, stream, lut, v, nevents, nsignals,
                        nexpected->readOnlyPtr(), n_mc->readOnlyPtr(), source_id->readOnlyPtr(), norms,
                        event_partial_sums);
-    SXMC_KERNEL_LAUNCH(nll_event_reduce, 1, nreducethreads, nreducethreads * sizeof(double), 0,
+    SXMC_KERNEL_LAUNCH(nll_event_reduce, 1, nreducethreads, nreducethreads * sizeof(double), stream,
                        (size_t)nnllthreads, event_partial_sums, event_total_sum);
-    SXMC_KERNEL_LAUNCH(nll_total, 1, 1, 0, 0, nparameters, v, nsignals, nsources,
+    SXMC_KERNEL_LAUNCH(nll_total, 1, 1, 0, stream, nparameters, v, nsignals, nsources,
                        parameter_means->readOnlyPtr(), parameter_sigma->readOnlyPtr(), event_total_sum,
                        nexpected->readOnlyPtr(), n_mc->readOnlyPtr(), source_id->readOnlyPtr(), norms, out);
   }
@@ -354,6 +367,8 @@ class MCMC {
   }
 
  private:
+  sxmc_stream_t stream;  //!< every launch of this chain goes here (null: the legacy default stream, as the
+                         //!< reference; one non-blocking stream per chain when several run on one GPU)
   size_t nsources, nsignals, nsystematics, nobservables;
   size_t nparameters = 0, nfloat = 0;
   bool systematics_fixed = true;

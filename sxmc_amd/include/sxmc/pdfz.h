@@ -83,6 +83,11 @@ class Eval {
       : nfields(_nfields), nobservables(_nobservables), dataset(_dataset) {}
   virtual ~Eval() {}
 
+ protected:
+  Eval(int _nfields, int _nobservables, unsigned _dataset)
+      : nfields(_nfields), nobservables(_nobservables), dataset(_dataset) {}
+
+ public:
   virtual void SetEvalPoints(const std::vector<float>& points) = 0;
   virtual void SetPDFValueBuffer(Array<float>* output, int offset = 0, int stride = 1) {
     pdf_buffer = output;
@@ -127,6 +132,12 @@ class EvalHist : public Eval {
     throw_on(sxmc_hist_create(samples.data(), samples.size(), 0, nfields, nobservables, lower.data(),
                               lower.size(), upper.data(), upper.size(), nbins.data(), nbins.size(), dataset,
                               &handle));
+  }
+  /** A second evaluator over the SAME sample table as `base` (nothing copied; own histogram, event bins
+   *  and bindings; systematics as attached to `base` so far): one per concurrent chain on a GPU. */
+  struct SharedSamples {};
+  EvalHist(const EvalHist& base, SharedSamples) : Eval(base.nfields, base.nobservables, base.dataset) {
+    throw_on(sxmc_hist_create_shared(base.handle, &handle));
   }
   EvalHist(const EvalHist&) = delete;
   EvalHist& operator=(const EvalHist&) = delete;

@@ -531,6 +531,27 @@ TEST_F(SmallFit, FakeDatasetAndWholeExperiments) {
   EXPECT_TRUE(res[0].intervals[0].upper != res[1].intervals[0].upper);  // different data sets
 }
 
+TEST_F(SmallFit, ConcurrentExperimentsMatchSequential) {
+  // three experiments in flight (a host thread, a non-blocking stream and evaluators sharing the sample
+  // tables each; steps replayed from HIP graphs): the intervals of the one-at-a-time loop, exactly
+  const std::vector<unsigned> ks = {0u, 3u, 5u, 6u, 9u};
+  std::vector<sxmc::ExperimentResult> seq =
+      sxmc::ensemble(ks, 11, sources, signals, systematics, observables, 400, 0.2f, 0.9f, 100);
+  std::vector<sxmc::ExperimentResult> par = sxmc::ensemble_concurrent(ks, 11, sources, signals, systematics,
+                                                                      observables, 400, 0.2f, 3, 0.9f, 100, 8);
+  EXPECT_EQ(seq.size(), par.size());
+  for (size_t i = 0; i < seq.size(); i++) {
+    EXPECT_EQ(seq[i].index, par[i].index);
+    EXPECT_EQ(seq[i].accepted, par[i].accepted);
+    EXPECT_EQ(seq[i].nevents, par[i].nevents);
+    for (size_t p = 0; p < seq[i].intervals.size(); p++) {
+      EXPECT_EQ(seq[i].intervals[p].lower, par[i].intervals[p].lower);
+      EXPECT_EQ(seq[i].intervals[p].upper, par[i].intervals[p].upper);
+      EXPECT_EQ(seq[i].intervals[p].point_estimate, par[i].intervals[p].point_estimate);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   int ndev = 0;
   if (sxmc_device_count(&ndev) != SXMC_OK || ndev < 1) {
