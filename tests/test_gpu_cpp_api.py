@@ -33,3 +33,17 @@ def test_cpp_api_on_gpu():
     print(r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:]
     assert " 0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_bench_driver_on_gpu():
+    """tests/cpp/bench_cpp.cpp: BASELINE config 3's shape built and walked entirely through the C++ host layer
+    (build_pdfz, sxmc::MCMC on its own stream, graph-replayed steps), here at 1 % of the samples."""
+    import json
+    build()
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "bench_cpp"), "0.01", "300", "8"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["steps"] == 300 and out["nsignals"] == 12 and out["steps_per_sec"] > 100
+    assert 0 < out["accepted"] < 300
