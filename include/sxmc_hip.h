@@ -64,6 +64,8 @@ int sxmc_set_device(int device);
 int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes,
                      int* lds_bytes_per_cu, int* clock_khz);
 int sxmc_device_synchronize(void);
+/* Free and total device memory in bytes (hipMemGetInfo). */
+int sxmc_mem_info(size_t* free_bytes, size_t* total_bytes);
 
 /* Device side of hemi::Array<T>: allocation and the two copy directions
  * its accessors perform implicitly. */

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sxmc_set_device": [_i],
     "sxmc_device_info": [_i, C.c_char_p, _pi, _psz, _pi, _pi],
     "sxmc_device_synchronize": [],
+    "sxmc_mem_info": [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "sxmc_malloc": [_pvp, _sz],
     "sxmc_free": [_vp],
     "sxmc_host_alloc": [_pvp, _sz],

@@ -843,6 +843,12 @@ int sxmc_device_synchronize(void) {
   return SXMC_OK;
 }
 
+int sxmc_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  SX_REQUIRE(free_bytes && total_bytes, "null argument");
+  SX_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return SXMC_OK;
+}
+
 int sxmc_malloc(void** d_ptr, size_t bytes) {
   SX_REQUIRE(d_ptr, "null argument");
   SX_HIP(hipMalloc(d_ptr, bytes ? bytes : 4));

@@ -410,3 +410,44 @@ def test_event_classes_with_sparse_counters_and_two_datasets():
         want, bins, norms, lut = oracle_nll_of_workload(w, proposal)
         assert np.array_equal(m.normalizations.get(), norms)
         assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
+
+
+def test_no_device_memory_is_leaked_by_chains_and_graphs():
+    """Evaluators, groups (launch plans, sparse structures, event classes, pre-binned columns), chains and
+    recorded graphs give their device memory back."""
+    import ctypes as C
+    w = workloads.config3(0.002, nevents=2000)
+    w5 = workloads.config5(2e-5, nevents=500, nbins=(40, 40, 40, 4, 4))
+    w5.signals = w5.signals[:3]
+
+    def cycle():
+        for wl in (w, w5):
+            m = MCMC(wl, seed=3, stream=capi.new_stream(), lut_output=False)
+            m.walk(wl.events, 40, 0.1, sync_interval=16, graph_steps=4)
+            other = MCMC(wl, seed=4, share_with=m)
+            other.setup(sync_interval=8)
+            other.step()
+            other.flush()
+            for p in other.pdfs + m.pdfs:
+                p.close()
+            other.group.close()
+            m.group.close()
+            if m._graph is not None:
+                m._graph.close()
+            capi.call("sxmc_stream_destroy", capi.ptr(m.stream))
+            del m, other
+        import gc
+        gc.collect()
+        capi.synchronize()
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        capi.call("sxmc_mem_info", C.byref(f), C.byref(t))
+        return f.value
+
+    cycle()                                          # first cycle may grow pools (code objects, streams)
+    free0 = free_bytes()
+    for _ in range(3):
+        cycle()
+    free1 = free_bytes()
+    assert free0 - free1 < 8 << 20, (free0, free1)
