@@ -94,7 +94,12 @@ int sxmc_stream_synchronize(sxmc_stream_t s);
  * The group must already have evaluated once with its current configuration (descriptor uploads cannot
  * be recorded: SXMC_ERR_STATE otherwise), and a recorded graph is only valid until an evaluator of the
  * group changes (systematics, evaluation points, bindings, launch configuration).  Kernel arguments are
- * frozen at capture: device buffers are re-read at replay, scalar arguments are not. */
+ * frozen at capture: device buffers are re-read at replay, scalar arguments are not.
+ * Host threads: while one thread records, no other thread may allocate, free, copy through the legacy
+ * default stream or synchronise the device (the ROCm runtime refuses those calls and fails the
+ * recording); launching, and waiting on or copying through its own non-blocking stream, is fine.  A
+ * program with one chain per host thread serialises set-up, recording and tear-down with a mutex
+ * (sxmc::MCMC::exclusive, sxmc::ensemble_concurrent). */
 typedef void* sxmc_graph_t;              /* hipGraphExec_t */
 int sxmc_graph_begin_capture(sxmc_stream_t s);
 int sxmc_graph_end_capture(sxmc_stream_t s, sxmc_graph_t* out);

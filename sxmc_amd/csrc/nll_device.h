@@ -141,9 +141,15 @@ __device__ __forceinline__ double block_sum(size_t n, const double* sums, double
 
 // The fused end of an MCMC step (nll_kernels.cpp:230-271): reduce the event partial sums, total the
 // NLL at the proposed vector, Metropolis accept/reject + append to the jump buffer, draw the next
-// proposal.  One workgroup.  Every small array is staged into LDS by all lanes at once and the
-// vector copy / buffer append / proposal run one parameter per lane: the kernel is a handful of
-// memory latencies long instead of one per element.
+// proposal.  One workgroup, one launch per step, so it is built to be a few memory latencies long:
+//   phase A (all lanes): everything that does not depend on the accept decision -- every input is
+//     loaded once, lane j forms signal j's expected-rate term and lane i parameter i's constraint term
+//     (the divisions), lane i draws its proposal deviate (lane 0 its uniform first: same consumption
+//     order of generator 0 as jump_decider followed by pick_new_vector), the partial sums are reduced;
+//   phase B (lane 0): the terms are added in the reference's order (so the value is the sequential
+//     loop's, bit for bit), accept or reject;
+//   phase C (all lanes): vector copy, jump-buffer append and next proposal, one parameter per lane.
+// Vectors longer than kStage fall back to the plain sequential form.
 constexpr int kStage = 256;
 
 __device__ __forceinline__ void finish_step_device(size_t npartial_sums, const double* sums, size_t nsignals,
@@ -156,71 +162,100 @@ __device__ __forceinline__ void finish_step_device(size_t npartial_sums, const d
                                                    const short* source_id, const unsigned* norms,
                                                    bool debug_mode) {
   __shared__ double s_wave[17];
-  __shared__ double s_vprop[kStage], s_means[kStage], s_sigmas[kStage], s_nexp[kStage];
-  __shared__ unsigned s_nmc[kStage], s_norms[kStage];
-  __shared__ short s_sid[kStage];
+  __shared__ double s_vprop[kStage], s_vcur[kStage], s_pen[kStage], s_z[kStage], s_term[kStage];
+  __shared__ float s_jw[kStage];
+  __shared__ unsigned char s_flag[kStage];  // bit 0: constraint term present, bit 1: negative source rate
   __shared__ int s_accept, s_count;
-  __shared__ double s_nllcur;
+  __shared__ double s_nllcur, s_u;
 
   const bool staged = nparameters <= kStage && nsignals <= (size_t)kStage;
-  if (staged) {
-    for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
-      s_vprop[i] = v_proposed[i];
-      s_means[i] = means[i];
-      s_sigmas[i] = sigmas[i];
-    }
-    for (int i = threadIdx.x; i < (int)nsignals; i += blockDim.x) {
-      s_nexp[i] = nexpected[i];
-      s_nmc[i] = n_mc[i];
-      s_norms[i] = norms[i];
-      s_sid[i] = source_id[i];
-    }
-  }
-  double total_sum = block_sum(npartial_sums, sums, s_wave);  // barriers inside: staging is visible after
-
-  if (threadIdx.x == 0) {
-    if (staged) {
-      nll_total_device(nparameters, nsignals, nsources, s_vprop, s_means, s_sigmas, &total_sum, s_nexp, s_nmc,
-                       s_sid, s_norms, nll_proposed);
-    } else {
+  if (!staged) {
+    double total_sum = block_sum(npartial_sums, sums, s_wave);
+    if (threadIdx.x == 0) {
       nll_total_device(nparameters, nsignals, nsources, v_proposed, means, sigmas, &total_sum, nexpected, n_mc,
                        source_id, norms, nll_proposed);
+      jump_decider_device(rng, nll_current, nll_proposed, v_current, v_proposed, nparameters, accepted, counter,
+                          jump_buffer, debug_mode);
     }
-    // jump_decider_device (nll_kernels.cpp:56-86), scalar part
-    const double u = rng_uniform(&rng[0]);
-    const double np = nll_proposed[0];
-    const double nc = nll_current[0];
-    const bool accept = debug_mode || (np < nc || u <= exp(nc - np));
+    __threadfence_block();
+    __syncthreads();
+    pick_new_vector_device(nparameters, rng, jump_width, v_current, v_proposed);
+    return;
+  }
+
+  // ---- phase A
+  double nc = 0.0;
+  int count = 0;
+  if (threadIdx.x == 0) {
+    nc = nll_current[0];
+    count = counter[0];
+  }
+  for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
+    const double p = v_proposed[i], mean = means[i], sigma = sigmas[i];
+    const float jw = jump_width[i];
+    s_vprop[i] = p;
+    s_vcur[i] = v_current[i];
+    s_jw[i] = jw;
+    unsigned char flag = 0;
+    double pen = 0.0;
+    if (sigma > 0) {  // nll_kernels.cpp:181-184
+      const double x = (p - mean) / sigma;
+      pen = 0.5 * x * x;
+      flag |= 1;
+    }
+    if ((size_t)i < nsources && p < 0) flag |= 2;  // :176-179
+    s_pen[i] = pen;
+    s_flag[i] = flag;
+    if (i == 0 || jw > 0) {
+      sxmc_rng_state st = rng[i];
+      if (i == 0) s_u = rng_uniform(&st);            // jump_decider's draw (nll_kernels.cpp:63)
+      s_z[i] = (jw > 0) ? rng_normal(&st) : 0.0;     // pick_new_vector's draw (:42), free parameters only
+      rng[i].offset = st.offset;
+    }
+  }
+  for (int j = threadIdx.x; j < (int)nsignals; j += blockDim.x) {
+    s_term[j] = v_proposed[source_id[j]] * nexpected[j] * norms[j] / n_mc[j];  // :169-172
+  }
+  const double total_sum = block_sum(npartial_sums, sums, s_wave);  // barriers inside: LDS is visible after
+
+  // ---- phase B
+  if (threadIdx.x == 0) {
+    double sum = -total_sum;
+    bool bad = isnan(sum);
+    if (!bad) {
+      for (unsigned j = 0; j < nsignals; j++) sum += s_term[j];
+      for (int i = 0; i < nparameters; i++) {
+        if (s_flag[i] & 2) {
+          bad = true;
+          break;
+        }
+        if (s_flag[i] & 1) sum += s_pen[i];
+      }
+    }
+    const double np = bad ? 1e18 : sum;
+    nll_proposed[0] = np;
+    const bool accept = debug_mode || (np < nc || s_u <= exp(nc - np));  // Metropolis, :69-77
     if (accept) {
       nll_current[0] = np;
       accepted[0] += 1;
     }
-    const int count = counter[0];
     counter[0] = count + 1;
     s_accept = accept ? 1 : 0;
     s_count = count;
     s_nllcur = accept ? np : nc;
   }
-  __threadfence_block();
   __syncthreads();
 
+  // ---- phase C
   const bool accept = s_accept != 0;
   const size_t row = (size_t)s_count * (size_t)(nparameters + 1);
   for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
-    // accepted: v_current <- v_proposed; every step: append v_current (as float) to the jump buffer
-    const double cur = accept ? (staged ? s_vprop[i] : v_proposed[i]) : v_current[i];
+    const double cur = accept ? s_vprop[i] : s_vcur[i];
     if (accept) v_current[i] = cur;
     jump_buffer[row + i] = (float)cur;
-    // pick_new_vector_device (nll_kernels.cpp:30-53): next proposal around the (new) current vector
-    if (jump_width[i] > 0) {
-      const double z = rng_normal(&rng[i]);
-      v_proposed[i] = cur + jump_width[i] * z;
-    } else {
-      v_proposed[i] = cur;
-    }
+    v_proposed[i] = (s_jw[i] > 0) ? cur + s_jw[i] * s_z[i] : cur;  // :40-47
   }
   if (threadIdx.x == 0) jump_buffer[row + nparameters] = (float)s_nllcur;
 }
-
 
 }  // namespace sxdev

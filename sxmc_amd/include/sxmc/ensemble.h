@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <cmath>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <random>
 #include <string>
 #include <thread>
@@ -167,13 +169,22 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
                                        std::vector<Signal>& signals, std::vector<Systematic>& systematics,
                                        std::vector<Observable>& observables, unsigned nsteps, float burnin_fraction,
                                        float cl, unsigned sync_interval, unsigned graph_steps = 0,
-                                       sxmc_stream_t stream = nullptr) {
+                                       sxmc_stream_t stream = nullptr, std::mutex* exclusive = nullptr) {
   const unsigned long long x = experiment_seed(base_seed, k);
   std::mt19937_64 rng(x);
+  // `exclusive` (one chain per host thread): held over everything that allocates, copies through the
+  // legacy stream or synchronises the device -- see MCMC::exclusive
+  std::unique_lock<std::mutex> lock;
+  if (exclusive) lock = std::unique_lock<std::mutex>(*exclusive);
   std::vector<float> data = make_fake_dataset(rng, signals, systematics, observables, true);
-  MCMC mcmc(sources, signals, systematics, observables, x, stream);
-  mcmc.graph_steps = graph_steps;
-  Chain chain = mcmc(data, nsteps, burnin_fraction, false, sync_interval);
+  std::unique_ptr<MCMC> mcmc(new MCMC(sources, signals, systematics, observables, x, stream));
+  mcmc->graph_steps = graph_steps;
+  mcmc->exclusive = exclusive;
+  if (exclusive) lock.unlock();   // the walk takes it itself
+  Chain chain = (*mcmc)(data, nsteps, burnin_fraction, false, sync_interval);
+  if (exclusive) lock.lock();
+  mcmc.reset();
+  if (exclusive) lock.unlock();
   ExperimentResult r;
   r.index = k;
   r.intervals = contour_intervals(chain, cl);
@@ -211,28 +222,35 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
   const size_t lanes = std::max<size_t>(1, std::min<size_t>(nconcurrent, experiments.size()));
   std::vector<ExperimentResult> out(experiments.size());
   std::vector<std::exception_ptr> errors(lanes);
+  std::mutex exclusive;  // set-up, graph recording and tear-down of the lanes, one at a time
   std::vector<std::thread> threads;
   for (size_t t = 0; t < lanes; t++) {
     threads.emplace_back([&, t]() {
       sxmc_stream_t strm = nullptr;
       std::vector<Signal> mine;
       try {
-        check(sxmc_stream_create_nonblocking(&strm));
-        transfer_stream() = strm;
-        for (const Signal& s : signals) mine.push_back(share_pdfz(s));
+        {
+          std::lock_guard<std::mutex> lock(exclusive);
+          check(sxmc_stream_create_nonblocking(&strm));
+          transfer_stream() = strm;
+          for (const Signal& s : signals) mine.push_back(share_pdfz(s));
+        }
         std::vector<Source> src = sources;
         std::vector<Systematic> sys = systematics;
         std::vector<Observable> obs = observables;
         for (size_t i = t; i < experiments.size(); i += lanes) {
           out[i] = run_experiment(experiments[i], base_seed, src, mine, sys, obs, nsteps, burnin_fraction, cl,
-                                  sync_interval, graph_steps, strm);
+                                  sync_interval, graph_steps, strm, &exclusive);
         }
       } catch (...) {
         errors[t] = std::current_exception();
       }
-      for (Signal& s : mine) delete s.histogram;
-      transfer_stream() = nullptr;
-      if (strm) sxmc_stream_destroy(strm);
+      {
+        std::lock_guard<std::mutex> lock(exclusive);
+        for (Signal& s : mine) delete s.histogram;
+        transfer_stream() = nullptr;
+        if (strm) sxmc_stream_destroy(strm);
+      }
     });
   }
   for (std::thread& th : threads) th.join();

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,10 @@ class MCMC {
   bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
   bool verbose = false;
   unsigned graph_steps = 0;     //!< > 0: replay the batched step from a HIP graph of this many recorded steps
+  std::mutex* exclusive = nullptr;  //!< with one chain per host thread: the mutex this walk holds while it
+                                    //!< allocates, uploads, rebuilds launch plans, records its graph and frees
+                                    //!< (calls the runtime refuses beside another thread's recording); it is
+                                    //!< released while the walk only launches and waits on its own stream
   bool lut_output = false;      //!< materialise the lookup table in the batched step (nothing reads it; when
                                 //!< false the event sum runs over distinct event-bin tuples, see sxmc_hip.h)
   unsigned long long seed = 0;  //!< gRandom->GetSeed() in the reference (mcmc.cpp:125)
@@ -147,6 +152,8 @@ class MCMC {
   /** MCMC::operator() (mcmc.cpp:143-387).  data: rows of nobservables+1 floats (last = dataset id). */
   Chain operator()(std::vector<float>& data, unsigned nsteps, float burnin_fraction,
                    const bool debug_mode = false, unsigned sync_interval = 10000) {
+    std::unique_lock<std::mutex> excl;  // (first local: released last, after the arrays below are freed)
+    if (exclusive) excl = std::unique_lock<std::mutex>(*exclusive);
     // array transfers of this walk are ordered on the chain's stream (a blocking copy through the legacy
     // default stream would neither wait for a non-blocking stream nor leave other chains alone)
     struct TransferGuard {
@@ -311,6 +318,8 @@ class MCMC {
         check(sxmc_graph_launch(graph, strm, (int)(n / gsteps)));
         n %= gsteps;
       }
+      // set-up is over once the first run of steps after step 0 has its graph (or needs none)
+      if (i > 0 && excl.owns_lock()) excl.unlock();
       for (unsigned k = 0; k < n; k++) one_step();
 
       // Flush the jump buffer (mcmc.cpp:351-377); the host reads go through blocking copies
@@ -326,8 +335,9 @@ class MCMC {
       accept_counter.writeOnlyHostPtr()[0] = 0;
       i = f + 1;
     }
-    if (graph) check(sxmc_graph_destroy(graph));
     if (strm) check(sxmc_stream_synchronize(strm));
+    if (exclusive && !excl.owns_lock()) excl.lock();  // tear-down frees device memory
+    if (graph) check(sxmc_graph_destroy(graph));
     if (own_stream) check(sxmc_stream_destroy(strm));
     if (stream) {
       check(sxmc_stream_synchronize(stream));  // this chain only: others may be running beside it
