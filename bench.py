@@ -259,10 +259,20 @@ def main():
     def eager_share(n):          # about a tenth of the steps, and whatever does not fill a whole graph
         return n if gs <= 0 or n < 2 * gs else n - ((n - n // 10) // gs) * gs
 
+    graph_state = {"steps_per_graph": gs, "fallback": None}
+
     def run_steps(n):
         ne = eager_share(n)
-        if n > ne:
-            m.steps(n - ne, gs)
+        if n > ne and graph_state["steps_per_graph"] > 0:
+            try:
+                m.steps(n - ne, graph_state["steps_per_graph"])
+            except capi.SxmcError as exc:
+                # recording refused (nothing was launched): same launches one by one, said so in the output
+                graph_state["steps_per_graph"], graph_state["fallback"] = 0, str(exc)
+                m._graph = None
+                ne = n
+        elif n > ne:
+            ne = n
         for _ in range(ne):
             one_step()
 
@@ -308,7 +318,7 @@ def main():
         # chains for concurrent experiments: own non-blocking stream, own per-chain state, ONE copy of the tables
         nconc = max(1, min(args.exp_concurrent, len(mine)))
         form = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
-        exp_graph = args.graph_steps if args.form in ("fused", "graph") else 0
+        exp_graph = args.graph_steps if args.form in ("fused", "graph") and graph_state["fallback"] is None else 0
         pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m, lut_output=args.lut_output)
                 for _ in range(nconc)]
         for c in pool:
@@ -378,9 +388,10 @@ def main():
             "workload": "%s: %s" % (w.name, w.description),
             "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
             "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
-            "step_form": args.form, "steps_per_graph": gs, "prewarm_steps": args.prewarm,
+            "step_form": args.form, "steps_per_graph": graph_state["steps_per_graph"], "graph_fallback": graph_state["fallback"],
+            "prewarm_steps": args.prewarm,
             "lut_materialized": bool(args.lut_output or args.form in ("reference", "pdfz")),
-            "steps_launched_one_by_one_with_events": eager_share(args.steps), "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
+            "steps_launched_one_by_one_with_events": eager_share(args.steps) if graph_state["steps_per_graph"] else args.steps, "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,
             "experiments_per_sec_at_1e5_steps": value / 1e5,

@@ -1,0 +1,46 @@
+"""GPU: HIP-graph recording beside a live RCCL communicator.
+
+bench.py records its step graph in a process that has joined a torch.distributed "nccl" (= RCCL) group, whose
+watchdog threads talk to the HIP runtime in the background.  The ROCm runtime refuses some calls made by OTHER
+threads while a stream is being recorded, so this is rehearsed here with a one-rank RCCL group on the single GPU
+of the test box: barrier and all-reduce, record and replay steps, all-gather of the intervals."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import numpy as np, torch, torch.distributed as dist
+from sxmc_amd import capi, workloads
+from sxmc_amd.mcmc import MCMC
+torch.cuda.set_device(0)
+capi.call("sxmc_set_device", 0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+w = workloads.config3(0.003, nevents=2000)
+eager = MCMC(w, seed=5, lut_output=False)
+want = eager.walk(w.events, 120, 0.1, sync_interval=50)
+m = MCMC(w, seed=5, stream=capi.new_stream(), lut_output=False)
+dist.barrier()
+t = torch.ones(1, device="cuda")
+dist.all_reduce(t)                      # leaves work for the watchdog to poll
+got = m.walk(w.events, 120, 0.1, sync_interval=50, graph_steps=8)
+dist.barrier()
+out = torch.empty(4, device="cuda")
+dist.all_gather_into_tensor(out, torch.arange(4, dtype=torch.float32, device="cuda"))
+torch.cuda.synchronize()
+assert want[1] == got[1] and np.array_equal(want[0], got[0])
+assert out.cpu().tolist() == [0.0, 1.0, 2.0, 3.0]
+dist.destroy_process_group()
+print("rccl-graph-ok")
+"""
+
+
+@pytest.mark.gpu
+def test_graph_recording_beside_an_rccl_communicator():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-graph-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
