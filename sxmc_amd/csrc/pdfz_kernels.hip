@@ -476,11 +476,12 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
       if (!LDS_HIST) {
         if (sparse) {
           // all four filter words are requested before any is tested: one L2 round trip, not four
-          // level 1: coarse filter in LDS (passes ~1 in 5 of the non-members at 1e5 event bins)
+          // level 1: coarse filter in LDS, two bits per bin (passes ~3 % of the non-members at 1e5 event bins)
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) {
             const unsigned hc = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0xC2B2AE35u) >> cshift : 0u;
-            if (!((hist[hc >> 5] >> (hc & 31u)) & 1u)) okbin[q] = 0xFFFFFFFFu;
+            const unsigned hd = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0x27D4EB2Fu) >> cshift : 0u;
+            if (!((hist[hc >> 5] >> (hc & 31u)) & (hist[hd >> 5] >> (hd & 31u)) & 1u)) okbin[q] = 0xFFFFFFFFu;
           }
           // level 2: fine filter through L2; all four words are requested before any is tested
           unsigned hb[SXMC_VEC], word[SXMC_VEC];

@@ -60,8 +60,8 @@ struct SxSignalDesc {
   int sparse_filter_shift;       // hash >> shift selects a filter bit
   int sparse_table_shift;        // hash >> shift selects a table entry
   int sparse_real_nbins;         // the histogram's true bin count (total_nbins is the counter count here)
-  int sparse_coarse_shift;       // hash >> shift selects a bit of the coarse filter (staged in LDS)
-  const unsigned* sparse_coarse; // coarse one-hash bit filter, at most 64 KiB
+  int sparse_coarse_shift;       // hash >> shift selects a bit of the coarse filter (staged in LDS; two hashes per bin)
+  const unsigned* sparse_coarse; // coarse two-hash bit filter, at most 128 KiB
   // --- evaluation at the data events
   const int* read_bins;
   unsigned long long npoints;

@@ -364,7 +364,9 @@ int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
   }
   const int fbits = std::min(26, std::max(16, ceil_log2(64 * std::max<size_t>(T, 1))));  // <= 1.6 % false positives
   const int tbits = std::max(6, ceil_log2(2 * std::max<size_t>(T, 1)));                   // load <= 50 %
-  const int cbits = std::min(19, std::max(10, ceil_log2(8 * std::max<size_t>(T, 1))));   // <= 64 KiB of LDS
+  // coarse filter: two hashes per bin, >= 8 bits per bin up to 2^20 bits (128 KiB of LDS): ~3 % false
+  // positives at 1e5 event bins (one hash in 64 KiB let 19 % through, and every survivor costs L2 probes)
+  const int cbits = std::min(20, std::max(10, ceil_log2(16 * std::max<size_t>(T, 1))));
   std::vector<unsigned> coarse((size_t)1 << (cbits - 5), 0u);
   std::vector<unsigned> filter((size_t)1 << (fbits - 5), 0u);
   std::vector<unsigned> table((size_t)2 << tbits, 0xFFFFFFFFu);
@@ -373,8 +375,9 @@ int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
     const unsigned bin = targets[t];
     const unsigned hb = (bin * 0x9E3779B1u) >> (32 - fbits);
     filter[hb >> 5] |= 1u << (hb & 31u);
-    const unsigned hc = (bin * 0xC2B2AE35u) >> (32 - cbits);
+    const unsigned hc = (bin * 0xC2B2AE35u) >> (32 - cbits), hd = (bin * 0x27D4EB2Fu) >> (32 - cbits);
     coarse[hc >> 5] |= 1u << (hc & 31u);
+    coarse[hd >> 5] |= 1u << (hd & 31u);
     unsigned hp = (bin * 0x85EBCA6Bu) >> (32 - tbits);
     while (table[2 * (size_t)hp] != 0xFFFFFFFFu) hp = (hp + 1u) & mask;
     table[2 * (size_t)hp] = bin;
@@ -614,7 +617,10 @@ int group_rebuild(sxmc_group* g) {
       int cshift = 32;
       for (int idx : c.member_idx) cshift = std::min(cshift, g->members[idx]->coarse_shift);
       c.shape.lds_bytes = ((size_t)4 + ((size_t)1 << (32 - cshift - 5))) * 4;   // header + largest coarse filter
+      // a filter of more than half the LDS leaves room for one workgroup per CU: make it a full one
+      if (g->cfg_threads <= 0 && c.shape.lds_bytes * 2 > (size_t)props.lds_per_cu) c.shape.threads = 1024;
     }
+    const int threads = c.shape.threads;  // (shadows the group-wide default above)
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, 1024 / threads);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
     bpc = std::min(bpc, lds_limit);
