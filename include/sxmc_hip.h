@@ -210,7 +210,8 @@ int sxmc_group_set_debug_mode(sxmc_group_t g, int mode);
 int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s);
 /* As sxmc_group_eval_async(g, 1, s) followed by nll_event_chunks (nll_kernels.cpp:89-116) over
  * the members' lookup table, with the table lookup and the event sum fused in one kernel: the
- * lut is still written (it is the API contract, mcmc.cpp:232-236) but not re-read.  Requires
+ * lut is still written (it is the API contract, mcmc.cpp:232-236; unless sxmc_group_set_lut_output
+ * switched that off) but not re-read.  Requires
  * all members to share the same number of evaluation points.  Writes one partial sum per
  * block: d_sums[0 .. *npartial_out).  d_sums must hold at least 1024 doubles. */
 int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s,
