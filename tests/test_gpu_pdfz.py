@@ -485,3 +485,65 @@ def test_shared_table_with_different_prebinned_columns():
         g.EvalAsync(False)
         g.EvalFinished()
         assert np.array_equal(e.GetBins(), o["bins"]) and norms.get()[j] == o["norm"]
+
+
+def test_maximum_sizes_of_the_interface():
+    """MAX_NFIELDS = 10 fields (pdfz.cpp:17), SXMC_MAX_SYST = 16 systematics on one evaluator, 8 polynomial
+    coefficients in one systematic; one more of each is refused."""
+    rng = np.random.default_rng(18)
+    nfields, nobs = 10, 4
+    samples = table(rng, 30011, nfields, lo=0.05, hi=0.95)
+    kinds = ["shift", "scale", "ctscale", "resolution_scale"]
+    systs = []
+    for q in range(15):
+        s = dict(type=kinds[q % 4], obs=q % nobs, pars=[q % 5])
+        if s["type"] == "resolution_scale":
+            s["true_obs"] = 4 + (q % 6)                      # every extra field gets referenced
+        systs.append(s)
+    systs.append(dict(type="shift", obs=1, pars=[0, 1, 2, 3, 4, 0, 1, 2]))   # 8 coefficients
+    params = [0.004, -0.003, 0.002, 0.001, -0.002]
+    pts = np.concatenate([table(rng, 300, nobs), np.zeros((300, 1), np.float32)], axis=1)
+    kw = dict(samples=samples, nfields=nfields, lower=[0.0] * nobs, upper=[1.0] * nobs, nbins=[5, 4, 3, 6],
+              systs=systs, params=params, points=pts)
+    g, o = compare(kw)
+    assert o["norm"] > 1000
+    ev = g["ev"]
+    with pytest.raises(pdfz.Error):
+        ev.AddSystematic(make_systematic(dict(type="shift", obs=0, pars=[0])))          # a 17th
+    with pytest.raises(pdfz.Error):
+        pdfz.EvalHist(np.zeros((3, 11), np.float32), 11, 2, [0.0, 0.0], [1.0, 1.0], [2, 2])   # 11 fields
+    e2 = pdfz.EvalHist(samples, nfields, nobs, [0.0] * nobs, [1.0] * nobs, [5, 4, 3, 6])
+    with pytest.raises(pdfz.Error):
+        e2.AddSystematic(make_systematic(dict(type="shift", obs=0, pars=[0] * 9)))      # 9 coefficients
+
+
+@pytest.mark.parametrize("nbins", [[40832], [40833], [232, 176], [232, 177]])
+def test_histograms_at_the_lds_capacity_boundary(nbins):
+    """40 832 bins is the largest LDS-private histogram; one more bin switches to the HBM-resident modes."""
+    rng = np.random.default_rng(19)
+    nobs = len(nbins)
+    samples = table(rng, 150001, nobs + 1, lo=-0.05, hi=1.05)
+    pts = np.concatenate([table(rng, 500, nobs), np.zeros((500, 1), np.float32)], axis=1)
+    kw = dict(samples=samples, nfields=nobs + 1, lower=[0.0] * nobs, upper=[1.0] * nobs, nbins=nbins,
+              systs=[dict(type="scale", obs=0, pars=[0])], params=[0.01], points=pts)
+    compare(kw)                                       # lookup evaluation (sparse counters beyond the boundary)
+    kw.pop("points")
+    compare(kw, do_eval_pdf=False)                    # dense histogram only
+
+
+@pytest.mark.parametrize("lut_output", [True, False])
+def test_fused_evaluation_without_events(lut_output):
+    """No data events at all: the fused evaluation still fills the histograms and returns a zero event sum."""
+    rng = np.random.default_rng(20)
+    evs, tabs, lut, norms, pbuf = build_group(rng, [5001, 7003], 2, [6, 5], [dict(type="shift", obs=0, pars=[0])],
+                                              [0.02], points=np.zeros((0, 3), np.float32))
+    group = nll.EvalGroup(evs)
+    group.SetLutOutput(lut_output)
+    sums = DeviceArray(np.full(1024, 7.0))
+    n = group.EvalNllAsync(None, pbuf, DeviceArray(np.ones(2)), DeviceArray(np.array([5001, 7003], np.uint32)),
+                           DeviceArray(np.zeros(2, np.int16)), norms, sums)
+    group.EvalFinished()
+    assert n >= 1 and np.all(sums.get()[:n] == 0.0)
+    for j, t in enumerate(tabs):
+        o = oracle_eval(t, 3, [0.0] * 2, [1.0] * 2, [6, 5], [dict(type="shift", obs=0, pars=[0])], [0.02])
+        assert np.array_equal(evs[j].GetBins(), o["bins"]) and norms.get()[j] == o["norm"]
