@@ -176,8 +176,10 @@ def main():
                          "reference's own sequence with the lut re-read; pdfz: only EvalAsync + EvalFinished of all evaluators "
                          "per step, the loop of the reference's bench_sxmc (bench_sxmc.cpp:90-96, 193-200)")
     ap.add_argument("--lut-output", action="store_true",
-                    help="materialise the lookup table in the fused step (default: it is an intermediate nobody reads, so "
-                         "the event sum runs over the distinct tuples of event bins weighted by multiplicity)")
+                    help="keep the step's intermediates readable between steps: lookup table written, histograms and "
+                         "normalisations left in place (4 launches per step).  Default: the walk reads none of them, so "
+                         "the event sum runs over the distinct tuples of event bins weighted by multiplicity and the step "
+                         "end also clears histograms and normalisations for the next step (3 launches per step)")
     ap.add_argument("--prewarm", type=int, default=300,
                     help="untimed steps before the --warmup steps (GPU clocks and graph replay settle)")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps recorded per HIP graph (--form graph)")
@@ -232,7 +234,8 @@ def main():
 
     fused = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
     m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=fused, samples_on_device=tensors,
-             stream=capi.new_stream() if args.form == "graph" else None, lut_output=args.lut_output)
+             stream=capi.new_stream() if args.form == "graph" else None, lut_output=args.lut_output,
+             consume=not args.lut_output)
     del tensors
     torch.cuda.empty_cache()
     threads, bpc = (int(x) for x in args.launch.split(","))
@@ -319,8 +322,8 @@ def main():
         nconc = max(1, min(args.exp_concurrent, len(mine)))
         form = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
         exp_graph = args.graph_steps if args.form in ("fused", "graph") and graph_state["fallback"] is None else 0
-        pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m, lut_output=args.lut_output)
-                for _ in range(nconc)]
+        pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m, lut_output=args.lut_output,
+                     consume=not args.lut_output) for _ in range(nconc)]
         for c in pool:
             c.group.SetLaunchConfig(threads, bpc)
         dist.barrier()
@@ -391,6 +394,7 @@ def main():
             "step_form": args.form, "steps_per_graph": graph_state["steps_per_graph"], "graph_fallback": graph_state["fallback"],
             "prewarm_steps": args.prewarm,
             "lut_materialized": bool(args.lut_output or args.form in ("reference", "pdfz")),
+            "launches_per_step": 3 if m.consume else (1 if args.form == "pdfz" else 4),
             "steps_launched_one_by_one_with_events": eager_share(args.steps) if graph_state["steps_per_graph"] else args.steps, "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,

@@ -231,6 +231,20 @@ int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_
                                float* d_jump_buffer, int nparameters, size_t nsources,
                                const float* d_jump_width, const double* d_nexpected, const unsigned* d_n_mc,
                                const short* d_source_id, const unsigned* d_norms, int debug_mode);
+/* finish_nll_jump_pick_combo (nll_kernels.cpp:230-271; arguments as sxmc_launch_finish_nll_jump_pick_combo,
+ * one workgroup of 128) launched TOGETHER with the zeroing the group's next evaluation would start with:
+ * that evaluation then skips its zero launch (3 launches per MCMC step instead of 4).  For a walk that does
+ * not look at them between steps: the group's histograms and the members' normalisation slots are CLEARED
+ * when this returns (sxmc_hist_get_bins gives SXMC_ERR_STATE until an evaluation with do_eval_pdf = 0).
+ * Must follow an evaluation of the group on the same stream; d_norms is the array the members'
+ * normalisations are bound into. */
+int sxmc_group_finish_step_async(sxmc_group_t g, sxmc_stream_t s, size_t npartial_sums, const double* d_sums,
+                                 const double* d_means, const double* d_sigmas, sxmc_rng_state* d_rng,
+                                 double* d_nll_current, double* d_nll_proposed, double* d_v_current,
+                                 double* d_v_proposed, int* d_accepted, int* d_counter, float* d_jump_buffer,
+                                 int nparameters, size_t nsources, const float* d_jump_width,
+                                 const double* d_nexpected, const unsigned* d_n_mc, const short* d_source_id,
+                                 const unsigned* d_norms, int debug_mode);
 int sxmc_group_synchronize(sxmc_group_t g);
 /* Live timing of the dominant kernel (the histogram fill) with HIP events on the stream it is
  * launched on.  enable!=0 starts recording (at most `capacity` launches are kept). */

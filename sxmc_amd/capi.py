@@ -96,6 +96,8 @@ SIGNATURES = {
     "sxmc_group_eval_nll_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi],
     "sxmc_group_mcmc_step_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp,
                                    _vp, _vp, _vp, _vp, _i],
+    "sxmc_group_finish_step_async": [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz,
+                                     _vp, _vp, _vp, _vp, _vp, _i],
     "sxmc_group_synchronize": [_vp],
     "sxmc_group_profile": [_vp, _i, _i],
     "sxmc_group_profile_read": [_vp, _pd, _pi],

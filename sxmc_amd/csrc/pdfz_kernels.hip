@@ -832,6 +832,35 @@ __global__ __launch_bounds__(256) void eval_nll_finish_kernel(const SxSignalDesc
                             a.debug_mode != 0);
 }
 
+// finish_nll_jump_pick_combo (workgroup 0) and, beside it in the same launch, what zero_kernel does for
+// the NEXT evaluation (all other workgroups): a walk that does not look at histograms or normalisations
+// between steps saves a launch per step.  Workgroup 0 clears the normalisations itself, after it has read
+// them; the other workgroups touch only the histograms (counters), which nothing reads at this point.
+__global__ __launch_bounds__(256) void finish_zero_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                          unsigned zblocks, size_t npartial, const double* sums,
+                                                          unsigned* ticket, SxStepArgs a) {
+  if (blockIdx.x == 0) {
+    sxdev::finish_step_device(npartial, sums, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                              a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                              a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
+                              a.debug_mode != 0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nsig; j += blockDim.x) *descs[j].norm = 0u;
+    if (threadIdx.x == 0 && ticket) *ticket = 0u;
+    return;
+  }
+  const unsigned b = blockIdx.x - 1u;
+  const SxSignalDesc& d = descs[b / zblocks];
+  const unsigned chunk = b % zblocks;
+  unsigned* bins = d.bins;
+  const unsigned n = (unsigned)d.total_nbins;
+  const unsigned n4 = n >> 2;
+  uint4* b4 = reinterpret_cast<uint4*>(bins);
+  const unsigned stride = zblocks * blockDim.x;
+  for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
+}
+
 // ------------------------------------------------------------------------------------ pre-binning
 // Builds the pre-binned column of one evaluator: for every sample, sum_k idx_k * stride_k over the
 // observables in `mask` with the fill kernel's arithmetic (pdfz.cpp:388-398), or all ones when one of
@@ -1071,6 +1100,16 @@ hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsi
   const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
   hipLaunchKernelGGL(eval_nll_finish_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, weight, sums,
                      ticket, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,
+                                 const double* sums, unsigned* ticket, const SxStepArgs& a, int block, hipStream_t s) {
+  int zb = (max_bins / 4 + block - 1) / block;
+  if (zb < 1) zb = 1;
+  if (zb > 1024) zb = 1024;
+  hipLaunchKernelGGL(finish_zero_kernel, dim3(1 + (unsigned)zb * (unsigned)nsig), dim3(block), 0, s, d_descs, nsig,
+                     (unsigned)zb, npartial, sums, ticket, a);
   return hipGetLastError();
 }
 

@@ -114,6 +114,8 @@ struct SxLaunchShape {
 };
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
+hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,
+                                 const double* sums, unsigned* ticket, const SxStepArgs& a, int block, hipStream_t s);
 hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
                                       const unsigned* weight, double* sums, unsigned* ticket, const SxStepArgs& a,
                                       int grid, int block, hipStream_t s);

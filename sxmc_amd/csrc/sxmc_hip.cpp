@@ -38,6 +38,8 @@ namespace {
 
 thread_local std::string g_last_error;
 thread_local bool t_capturing = false;  // this thread is recording a HIP graph (sxmc_graph_begin_capture)
+thread_local unsigned long long t_capture_epoch = 0;   // one per recording
+thread_local std::vector<struct sxmc_group*> t_capture_groups;  // groups launched in the current recording
 
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -151,6 +153,8 @@ struct sxmc_hist {
   std::vector<int> h_read_slot;
   unsigned long long points_version = 0;
   bool bins_valid = true;          // false after a sparse evaluation: the dense histogram was not filled
+  const sxmc_group* cleared_by = nullptr;  // the group whose finish_step cleared this histogram and nothing has
+                                           // counted into it since (any group's fill resets it)
 };
 
 namespace {
@@ -295,6 +299,11 @@ struct sxmc_group {
   EventClasses ec[2];               // [0] dense, [1] sparse flavour
   std::vector<SxSignalDesc> h_descs_sparse;
   int cfg_lut = 1;
+  // sxmc_group_finish_step_async zeroes histograms and normalisations for the next evaluation: that
+  // evaluation then skips its zero kernel.  0 = nothing pre-zeroed, 1 = dense flavour, 2 = sparse flavour.
+  int prezeroed = 0;
+  bool last_sparse = false;
+  unsigned long long capture_epoch = 0;  // last recording this group launched in
   unsigned* d_ticket = nullptr;  // arrival counter of the fused step end, zeroed by the zero kernel
   double* d_step_sums = nullptr; // 1024 partial sums of the fused step
   // profiling of the fill kernel
@@ -583,6 +592,7 @@ int group_rebuild(sxmc_group* g) {
   g->sparse_ready = g->sparse_ready && sparse_ok;
   g->h_descs_sparse = sparse_descs;
   g->ec[0].descs_valid = g->ec[1].descs_valid = false;
+  g->prezeroed = 0;
   if (!g->d_descs_sparse) SX_HIP(hipMalloc((void**)&g->d_descs_sparse, sizeof(SxSignalDesc) * std::max(n, 1)));
   if (n) SX_HIP(hipMemcpy(g->d_descs_sparse, sparse_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
 
@@ -789,10 +799,27 @@ int ensure_event_classes(sxmc_group* g, bool sparse) {
 
 int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
   sparse = sparse && g->sparse_ready && g->cfg_sparse;
-  SX_HIP(sx_launch_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
-                        sparse ? g->max_bins_sparse : g->max_bins, g->d_ticket, s));
+  // Recorded launches do not run now, so what a recording "pre-zeroed" is not zero yet: the first
+  // evaluation of every recording zeroes explicitly, and sxmc_graph_end_capture drops the flag.
+  bool first_in_recording = false;
+  if (t_capturing && g->capture_epoch != t_capture_epoch) {
+    g->capture_epoch = t_capture_epoch;
+    t_capture_groups.push_back(g);
+    first_in_recording = true;
+  }
+  bool skip_zero = g->prezeroed == (sparse ? 2 : 1) && !first_in_recording;
+  for (sxmc_hist* h : g->members) {  // (an evaluator may also be evaluated alone or through another group)
+    skip_zero = skip_zero && h->cleared_by == g;
+    h->cleared_by = nullptr;
+  }
+  g->prezeroed = 0;
+  g->last_sparse = sparse;
+  if (!skip_zero) {
+    SX_HIP(sx_launch_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
+                          sparse ? g->max_bins_sparse : g->max_bins, g->d_ticket, s));
+  }
   for (size_t i = 0; i < g->members.size(); i++) {
-    if (g->members[i]->total_nbins > kLdsMaxBins) g->members[i]->bins_valid = !sparse;
+    g->members[i]->bins_valid = g->members[i]->total_nbins > kLdsMaxBins ? !sparse : true;
   }
   for (LaunchClass& c : g->classes) {
     const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
@@ -925,12 +952,16 @@ int sxmc_graph_begin_capture(sxmc_stream_t s) {
   SX_REQUIRE(!t_capturing, "a capture is already in progress on this thread");
   SX_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
   t_capturing = true;
+  t_capture_epoch++;
+  t_capture_groups.clear();
   return SXMC_OK;
 }
 int sxmc_graph_end_capture(sxmc_stream_t s, sxmc_graph_t* out) {
   SX_REQUIRE(s && out, "null argument");
   SX_REQUIRE(t_capturing, "no capture in progress on this thread");
   t_capturing = false;
+  for (sxmc_group* g : t_capture_groups) g->prezeroed = 0;  // nothing recorded has run yet
+  t_capture_groups.clear();
   hipGraph_t graph = nullptr;
   SX_HIP(hipStreamEndCapture((hipStream_t)s, &graph));
   if (!graph) return fail(SXMC_ERR_HIP, "hipStreamEndCapture returned no graph (an error ended the capture)");
@@ -1277,8 +1308,8 @@ int sxmc_hist_get_bins(sxmc_hist_t h, unsigned* out, size_t n) {
   SX_REQUIRE(n == (size_t)h->total_nbins, "bins buffer size mismatch");
   if (!h->bins_valid) {
     return fail(SXMC_ERR_STATE,
-                "the last evaluation counted only the event bins (sparse mode): evaluate with do_eval_pdf = 0 "
-                "to fill the histogram");
+                "the histogram is not filled (the last evaluation counted only the event bins, or "
+                "sxmc_group_finish_step_async cleared it): evaluate with do_eval_pdf = 0");
   }
   SX_HIP(hipMemcpy(out, h->d_bins, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
   return SXMC_OK;
@@ -1509,6 +1540,51 @@ int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_
   a.norms = d_norms;
   SX_HIP(sx_launch_eval_nll_finish(descs, (int)g->members.size(), ne, weight, g->d_step_sums, g->d_ticket, a, grid,
                                    block, st));
+  return SXMC_OK;
+}
+
+int sxmc_group_finish_step_async(sxmc_group_t g, sxmc_stream_t s, size_t npartial_sums, const double* d_sums,
+                                 const double* d_means, const double* d_sigmas, sxmc_rng_state* d_rng,
+                                 double* d_nll_current, double* d_nll_proposed, double* d_v_current,
+                                 double* d_v_proposed, int* d_accepted, int* d_counter, float* d_jump_buffer,
+                                 int nparameters, size_t nsources, const float* d_jump_width,
+                                 const double* d_nexpected, const unsigned* d_n_mc, const short* d_source_id,
+                                 const unsigned* d_norms, int debug_mode) {
+  SX_REQUIRE(g && d_sums && d_means && d_sigmas && d_rng && d_nll_current && d_nll_proposed && d_v_current &&
+                 d_v_proposed && d_accepted && d_counter && d_jump_buffer && d_jump_width && d_nexpected &&
+                 d_n_mc && d_source_id && d_norms,
+             "null argument");
+  SX_REQUIRE(nparameters > 0, "nparameters must be positive");
+  if (!g->built) return fail(SXMC_ERR_STATE, "finish_step before any evaluation of the group");
+  SxStepArgs a;
+  a.nsignals = g->members.size();
+  a.nsources = nsources;
+  a.means = d_means;
+  a.sigmas = d_sigmas;
+  a.rng = d_rng;
+  a.nll_current = d_nll_current;
+  a.nll_proposed = d_nll_proposed;
+  a.v_current = d_v_current;
+  a.v_proposed = d_v_proposed;
+  a.accepted = d_accepted;
+  a.counter = d_counter;
+  a.jump_buffer = d_jump_buffer;
+  a.nparameters = nparameters;
+  a.debug_mode = debug_mode;
+  a.jump_width = d_jump_width;
+  a.nexpected = d_nexpected;
+  a.n_mc = d_n_mc;
+  a.source_id = d_source_id;
+  a.norms = d_norms;
+  const bool sparse = g->last_sparse;
+  SX_HIP(sx_launch_finish_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
+                               sparse ? g->max_bins_sparse : g->max_bins, npartial_sums, d_sums, g->d_ticket, a, 128,
+                               (hipStream_t)s));
+  g->prezeroed = sparse ? 2 : 1;
+  for (sxmc_hist* h : g->members) {
+    h->bins_valid = false;
+    h->cleared_by = g;
+  }
   return SXMC_OK;
 }
 

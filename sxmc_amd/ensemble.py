@@ -167,7 +167,7 @@ def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_int
     rng = np.random.default_rng(seed)
     if mcmc is None:
         mcmc = MCMC(workload, seed=seed & 0xFFFFFFFF, fused={"fused": True, "step": "step", "reference": False}[form],
-                    lut_output=False)
+                    lut_output=False, consume=True)
     else:
         mcmc.reseed(seed & 0xFFFFFFFF)
     data, _ = make_fake_dataset(rng, workload, mcmc.pdfs, poisson=True)

@@ -38,6 +38,9 @@ class MCMC {
   bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
   bool verbose = false;
   unsigned graph_steps = 0;     //!< > 0: replay the batched step from a HIP graph of this many recorded steps
+  bool consume = true;          //!< batched form: the step end also clears histograms and normalisations for the
+                                //!< next step (sxmc_group_finish_step_async: 3 launches per step; nothing reads them
+                                //!< between the steps of a walk)
   std::mutex* exclusive = nullptr;  //!< with one chain per host thread: the mutex this walk holds while it
                                     //!< allocates, uploads, rebuilds launch plans, records its graph and frees
                                     //!< (calls the runtime refuses beside another thread's recording); it is
@@ -274,6 +277,13 @@ class MCMC {
         }
         SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, strm, d.lut, d.proposed, nevents, nsignals,
                            d.nexpected, d.n_mc, d.source_id, d.norms, d.sums);
+      }
+      if (batched && reevaluate && consume) {
+        check(sxmc_group_finish_step_async(group, strm, (size_t)npartial, d.sums, d.means, d.sigmas, d.rng,
+                                           d.nll_current, d.nll_proposed, d.current, d.proposed, d.accepted,
+                                           d.counter, d.jump_buffer, (int)nparameters, nsources, d.jump_width,
+                                           d.nexpected, d.n_mc, d.source_id, d.norms, debug_mode ? 1 : 0));
+        return;
       }
       SXMC_KERNEL_LAUNCH(finish_nll_jump_pick_combo, 1, nreducethreads, nreducethreads * sizeof(double), strm,
                          (size_t)npartial, d.sums, nsignals, nsources, d.means, d.sigmas, d.rng, d.nll_current,

@@ -258,7 +258,7 @@ def run_config(path, out_dir=None, nexperiments=None, nsteps=None):
     from .mcmc import MCMC
     fc = load_config(path)
     w = build_workload(fc)
-    m = MCMC(w, seed=fc.seed & 0xFFFFFFFF, fused=True, lut_output=False)
+    m = MCMC(w, seed=fc.seed & 0xFFFFFFFF, fused=True, lut_output=False, consume=True)
     nexp = nexperiments or fc.nexperiments
     nsteps = nsteps or fc.nsteps
     data = load_data(fc, w)

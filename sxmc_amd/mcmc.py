@@ -33,16 +33,19 @@ def make_systematic(desc):
 
 class MCMC:
     def __init__(self, workload, seed=1234, stream=None, fused=True, samples_on_device=None, share_with=None,
-                 lut_output=True):
+                 lut_output=True, consume=False):
         """share_with: another MCMC over the same workload -- this one's evaluators then share its sample
         tables (one copy in HBM) and only the per-chain state is new; give each such chain its own
         non-blocking `stream` to let their kernels overlap.
         lut_output=False: the fused step forms do not materialise the lookup table (self.lut then holds the
-        values of setup() only) and sum over distinct event-bin tuples (sxmc_group_set_lut_output)."""
+        values of setup() only) and sum over distinct event-bin tuples (sxmc_group_set_lut_output).
+        consume=True (fused form): the step end also clears histograms and normalisations for the next step
+        (3 launches per step; they cannot be read between steps: sxmc_group_finish_step_async)."""
         w = workload
         self.w = w
         self.stream = stream
         self.fused = fused
+        self.consume = bool(consume) and fused is True
         self.nsources, self.nsignals = w.nsources, w.nsignals
         self.nparameters = w.nparameters
         self.nnllthreads = NLL_BLOCKS * NLL_BLOCK_SIZE
@@ -164,6 +167,14 @@ class MCMC:
                                  self.nevents, self.nsignals, self.nexpected, self.n_mc, self.source_id,
                                  self.normalizations, self.event_partial_sums)
             npartial = self.nnllthreads
+        if self.consume:
+            self.group.FinishStepAsync(self.stream, npartial, self.event_partial_sums, self.parameter_means,
+                                       self.parameter_sigma, self.rngs, self.current_nll, self.proposed_nll,
+                                       self.current_vector, self.proposed_vector, self.accept_counter,
+                                       self.jump_counter, self.jump_buffer, self.nparameters, self.nsources,
+                                       self.jump_width, self.nexpected, self.n_mc, self.source_id,
+                                       self.normalizations, debug_mode)
+            return
         nll.finish_nll_jump_pick_combo(1, REDUCE_THREADS, self.stream, npartial, self.event_partial_sums,
                                        self.nsignals, self.nsources, self.parameter_means,
                                        self.parameter_sigma, self.rngs, self.current_nll, self.proposed_nll,

@@ -114,6 +114,16 @@ class EvalGroup:
                   ptr(counter), ptr(jump_buffer), int(nparameters), int(nsources), ptr(jump_width),
                   ptr(nexpected), ptr(n_mc), ptr(source_id), ptr(norms), int(bool(debug_mode)))
 
+    def FinishStepAsync(self, stream, npartial_sums, sums, means, sigmas, rng, nll_current, nll_proposed, v_current,
+                        v_proposed, accepted, counter, jump_buffer, nparameters, nsources, jump_width, nexpected,
+                        n_mc, source_id, norms, debug_mode=False):
+        """finish_nll_jump_pick_combo launched together with the zeroing the next evaluation would start with
+        (histograms and normalisations are cleared afterwards; see include/sxmc_hip.h)."""
+        capi.call("sxmc_group_finish_step_async", self._g, ptr(stream), int(npartial_sums), ptr(sums), ptr(means),
+                  ptr(sigmas), ptr(rng), ptr(nll_current), ptr(nll_proposed), ptr(v_current), ptr(v_proposed),
+                  ptr(accepted), ptr(counter), ptr(jump_buffer), int(nparameters), int(nsources), ptr(jump_width),
+                  ptr(nexpected), ptr(n_mc), ptr(source_id), ptr(norms), int(bool(debug_mode)))
+
     def EvalFinished(self):
         capi.call("sxmc_group_synchronize", self._g)
 

@@ -451,3 +451,67 @@ def test_no_device_memory_is_leaked_by_chains_and_graphs():
         cycle()
     free1 = free_bytes()
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+@pytest.mark.parametrize("make,scale,nevents,sparse", [(workloads.config3, 0.004, 3000, True),
+                                                       (workloads.config1, 1.0, None, True),
+                                                       (workloads.config5, 3e-5, 1500, True),
+                                                       (workloads.config5, 3e-5, 1500, False)])
+def test_step_end_that_clears_for_the_next_step_walks_the_same_chain(make, scale, nevents, sparse):
+    """consume=True: finish_nll_jump_pick_combo and the next step's zeroing in one launch (3 launches per
+    step).  Same chain bit for bit, step by step and replayed from graphs; histograms and normalisations are
+    cleared between steps and come back with an ordinary evaluation."""
+    kw = {} if nevents is None else dict(nevents=nevents)
+    if make is workloads.config5:
+        kw["nbins"] = (40, 40, 40, 4, 4)
+    w = make(scale, **kw)
+    if make is workloads.config5:
+        w.signals = w.signals[:3]
+    plain = MCMC(w, seed=17, lut_output=False)
+    plain.group.SetSparse(sparse)
+    want = plain.walk(w.events, 90, 0.1, sync_interval=40)
+    for graph_steps in (0, 8):
+        m = MCMC(w, seed=17, lut_output=False, consume=True, stream=capi.new_stream())
+        m.group.SetSparse(sparse)
+        got = m.walk(w.events, 90, 0.1, sync_interval=40, graph_steps=graph_steps)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        # between steps nothing is left to read ...
+        assert np.all(m.normalizations.get() == 0)
+        with pytest.raises(capi.SxmcError):
+            m.pdfs[0].GetBins()
+        # ... and an ordinary evaluation at the same vector brings both back
+        m.group.EvalAsync(False, m.stream)
+        m.group.EvalFinished()
+        vec = m.proposed_vector.get()
+        _, bins, norms, _ = oracle_nll_of_workload(w, vec)
+        assert np.array_equal(m.normalizations.get(), norms)
+        for j, p in enumerate(m.pdfs):
+            assert np.array_equal(p.GetBins(), bins[j])
+        # one more consuming step after that evaluation still starts from cleared histograms
+        v = m.proposed_vector.get()
+        m.step(debug_mode=True)
+        rows, _ = m.flush(device_wide=False)
+        wantv, _, _, _ = oracle_nll_of_workload(w, v)
+        assert abs(rows[-1, -1] - wantv) <= 1e-6 * abs(wantv)
+
+
+def test_cleared_histograms_are_not_trusted_after_another_evaluation_of_a_member():
+    """After a consuming step the group skips its next zero launch -- unless a member was evaluated on its own
+    (or through another group) in between, which leaves counts behind."""
+    w = workloads.config3(0.003, nevents=2000)
+    m = MCMC(w, seed=23, lut_output=False, consume=True)
+    m.setup(sync_interval=16)
+    m.step(debug_mode=True)
+    capi.synchronize()
+    # a member evaluated alone, with other parameters, between two steps of the walk
+    alone = DeviceArray(np.array([0.3, 0.1, -0.2]))
+    keep = m.pdfs[4]
+    keep.SetParameterBuffer(alone)
+    keep.EvalAsync(False)
+    keep.EvalFinished()
+    keep.SetParameterBuffer(m.proposed_vector, m.nsources)
+    v = m.proposed_vector.get()
+    m.step(debug_mode=True)
+    rows, _ = m.flush()
+    want, _, norms, _ = oracle_nll_of_workload(w, v)
+    assert abs(rows[-1, -1] - want) <= 1e-6 * abs(want)
