@@ -328,6 +328,41 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     const unsigned B = sparse ? (unsigned)d.sparse_real_nbins : (unsigned)d.total_nbins;
     gptr<unsigned> gbins = to_global(d.bins);
 
+    // ---- the member's systematics: coefficients (and, for the dynamic program, the op words into
+    // lane-indexed registers).  Requested FIRST: loads return in order, so waiting for a coefficient that
+    // was asked for after the columns below would drain those too.
+    const int nsyst = d.nsyst;
+    unsigned opword = 0u;
+    double coef = 0.0;
+    double craw[PROG::n > 0 ? PROG::n : 1];
+    if constexpr (PROG::dynamic) {
+      if ((int)lane < nsyst) opword = pack_opword(d.syst[lane]);
+      if ((int)lane < d.ncoef) coef = to_global(d.params)[(long)d.coef_par[lane] * d.param_stride];
+    } else {
+      // one coefficient per systematic: its parameter index comes with the descriptor (scalar), the value is
+      // one uniform load each
+#pragma unroll
+      for (int q = 0; q < PROG::n; q++) craw[q] = to_global(d.params)[(long)d.coef_par[q] * d.param_stride];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the first units' columns are requested before anything else is set up: their addresses need
+    // only the descriptor, and the loads fly while LDS is cleared and the geometry arrives
+    gptr<const vfloat4> col[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
+    }
+    gptr<const typename PreVec<PREW>::type> precol =
+        to_global(reinterpret_cast<const typename PreVec<PREW>::type*>(d.pre));
+    const unsigned long long vlast = v1 - 1;
+    const unsigned long long vfirst = v0 + tid;
+    Columns<NSLOT, PREW> bufA, bufB;
+    load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, vfirst < v1 ? vfirst : vlast);
+    if constexpr (RING == 2) {
+      load_columns<NOBS, NSLOT, PREW, PROG>(bufB, col, precol, vfirst + step < v1 ? vfirst + step : vlast);
+    }
+
     if (!lds_clean) {
       // whole LDS histogram (sized for the largest member), once per workgroup
       if (LDS_HIST) {
@@ -356,25 +391,10 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
       sc[k] = d.scale[k];
       st[k] = d.bin_stride[k];
     }
-    gptr<const vfloat4> col[NSLOT];
-#pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
-      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
-    }
-    gptr<const typename PreVec<PREW>::type> precol =
-        to_global(reinterpret_cast<const typename PreVec<PREW>::type*>(d.pre));
-
-    // ---- the member's systematics: coefficients (and, for the dynamic program, the op words)
-    // into lane-indexed registers
-    const int nsyst = d.nsyst;
-    unsigned opword = 0u;
-    double coef = 0.0;
-    if (PROG::dynamic && (int)lane < nsyst) opword = pack_opword(d.syst[lane]);
-    if ((int)lane < d.ncoef) coef = to_global(d.params)[(long)d.coef_par[lane] * d.param_stride];
     // static program: p_s = 0 + c_s * pow(x, 0) = 0 + c_s * 1 (pdfz.cpp:310-314), wave-uniform
     double pc[PROG::n > 0 ? PROG::n : 1];
 #pragma unroll
-    for (int s = 0; s < PROG::n; s++) pc[s] = 0.0 + readlane_d(coef, s) * 1.0;
+    for (int s = 0; s < PROG::n; s++) pc[s] = 0.0 + craw[s] * 1.0;
 
     unsigned cnt = 0;
 
@@ -383,7 +403,6 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     // then do the arithmetic: two units (2 x NSLOT KiB per wave) stay in flight under the
     // compute.  Loads are unconditional (index clamped into the slice) so the wait counters stay
     // exact; lanes past the end of the slice are treated like out-of-domain samples.
-    const unsigned long long vlast = v1 - 1;
     auto stage = [&](Columns<NSLOT, PREW>& buf, const unsigned long long vc) {
       double f[NSLOT][SXMC_VEC];
 #pragma unroll
@@ -507,12 +526,9 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     };
 
     // wave-uniform trip count: every lane runs the same number of stages
-    unsigned long long v = v0 + tid;
+    unsigned long long v = vfirst;
     if constexpr (RING == 2) {
       const unsigned long long npairs = (v1 - v0 + 2ull * step - 1) / (2ull * step);
-      Columns<NSLOT, PREW> bufA, bufB;
-      load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, v < v1 ? v : vlast);
-      load_columns<NOBS, NSLOT, PREW, PROG>(bufB, col, precol, v + step < v1 ? v + step : vlast);
       for (unsigned long long it = 0; it < npairs; ++it, v += 2ull * step) {
         stage(bufA, v);
         stage(bufB, v + step);
@@ -520,8 +536,6 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
     } else {
       // wide shapes (5+ columns): one buffer, re-issued right after widening, keeps the registers in budget
       const unsigned long long niter = (v1 - v0 + step - 1) / step;
-      Columns<NSLOT, PREW> bufA;
-      load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, v < v1 ? v : vlast);
       for (unsigned long long it = 0; it < niter; ++it, v += step) stage(bufA, v);
     }
 
