@@ -375,7 +375,9 @@ def main():
         pass
 
     result = {
-        "metric": "NLL evals/sec (10^8 samples, 3 obs, 12 signals)",
+        # BASELINE.json's metric string; `value` is its first half (NLL evaluations per second, whole job), the
+        # second half (experiments per second) is the "experiments" object below
+        "metric": "NLL evals/sec (10^8 samples, 3 obs, 12 signals) + experiments/sec at 1/2/4/8 GPUs",
         "value": value,
         "unit": "evals/s",
         "n_gpus": world,
