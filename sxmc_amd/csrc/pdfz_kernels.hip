@@ -304,7 +304,6 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
                                                     const unsigned* __restrict__ blk_off,
                                                     unsigned hist_words, unsigned dbg) {
   extern __shared__ unsigned lds[];
-  constexpr int RING = NSLOT <= 4 ? 2 : 1;  // depth of the register ring of raw columns
   const unsigned tid = threadIdx.x;
   const unsigned nthreads = blockDim.x;
   const unsigned lane = tid & (kWave - 1);
@@ -357,11 +356,8 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
         to_global(reinterpret_cast<const typename PreVec<PREW>::type*>(d.pre));
     const unsigned long long vlast = v1 - 1;
     const unsigned long long vfirst = v0 + tid;
-    Columns<NSLOT, PREW> bufA, bufB;
+    Columns<NSLOT, PREW> bufA;
     load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, vfirst < v1 ? vfirst : vlast);
-    if constexpr (RING == 2) {
-      load_columns<NOBS, NSLOT, PREW, PROG>(bufB, col, precol, vfirst + step < v1 ? vfirst + step : vlast);
-    }
 
     if (!lds_clean) {
       // whole LDS histogram (sized for the largest member), once per workgroup
@@ -398,11 +394,14 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
 
     unsigned cnt = 0;
 
-    // ---- the sample loop: a two-deep ring of raw column registers.  One stage = wait for a
-    // buffer, widen it to double, immediately re-issue the buffer's loads for two units ahead,
-    // then do the arithmetic: two units (2 x NSLOT KiB per wave) stay in flight under the
-    // compute.  Loads are unconditional (index clamped into the slice) so the wait counters stay
-    // exact; lanes past the end of the slice are treated like out-of-domain samples.
+    // ---- the sample loop.  One stage = wait for the unit's raw columns, widen them to double,
+    // immediately re-issue the loads for the next unit into the same registers, then do the arithmetic
+    // under them.  ONE unit in flight per lane, on purpose: HBM delivers most when a CU keeps about 32 KiB
+    // of loads in flight (tools/hbm_probe.hip: 7.1 TB/s there, 5.5-6.5 TB/s at twice that), and 512 lanes
+    // per CU x 3-4 columns x 16 bytes is that much; a second unit in flight (tried: a two-deep register
+    // ring) or more waves per CU only queue up behind the memory system (-8 %).  Loads are unconditional
+    // (index clamped into the slice) so the wait counters stay exact; lanes past the end of the slice
+    // are treated like out-of-domain samples.
     auto stage = [&](Columns<NSLOT, PREW>& buf, const unsigned long long vc) {
       double f[NSLOT][SXMC_VEC];
 #pragma unroll
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
       //   bit 1: every reload hits one cached address -> the kernel without its HBM stream
       //   bit 0: skip the arithmetic and the histogram -> the HBM stream alone
       //   bit 2: skip only the histogram update
-      const unsigned long long vl = vc + (unsigned long long)RING * step;
+      const unsigned long long vl = vc + step;
       load_columns<NOBS, NSLOT, PREW, PROG>(buf, col, precol, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
       if (dbg & 1u) {
 #pragma unroll
@@ -527,17 +526,8 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
 
     // wave-uniform trip count: every lane runs the same number of stages
     unsigned long long v = vfirst;
-    if constexpr (RING == 2) {
-      const unsigned long long npairs = (v1 - v0 + 2ull * step - 1) / (2ull * step);
-      for (unsigned long long it = 0; it < npairs; ++it, v += 2ull * step) {
-        stage(bufA, v);
-        stage(bufB, v + step);
-      }
-    } else {
-      // wide shapes (5+ columns): one buffer, re-issued right after widening, keeps the registers in budget
-      const unsigned long long niter = (v1 - v0 + step - 1) / step;
-      for (unsigned long long it = 0; it < niter; ++it, v += step) stage(bufA, v);
-    }
+    const unsigned long long niter = (v1 - v0 + step - 1) / step;
+    for (unsigned long long it = 0; it < niter; ++it, v += step) stage(bufA, v);
 
     // ---- in-domain count: lane registers -> wave -> workgroup -> one global atomic
 #pragma unroll

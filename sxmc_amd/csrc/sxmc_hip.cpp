@@ -631,7 +631,15 @@ int group_rebuild(sxmc_group* g) {
       if (g->cfg_threads <= 0 && c.shape.lds_bytes * 2 > (size_t)props.lds_per_cu) c.shape.threads = 1024;
     }
     const int threads = c.shape.threads;  // (shadows the group-wide default above)
-    int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, 1024 / threads);
+    // Waves per CU.  The fill is a stream: HBM delivers most with about 32 KiB of loads in flight per CU,
+    // which is 512 lanes with one unit (3-4 columns x 16 bytes) each; more waves only queue up (measured
+    // -8 % at BASELINE config 3).  Members whose per-sample arithmetic is long (a run-time decoded program
+    // of two or more systematics, the shape-agnostic kernel) or that probe L2 per sample (histograms
+    // beyond LDS) need the second set of waves to hide it.
+    int cls_nsyst = 0;
+    for (int idx : c.member_idx) cls_nsyst = std::max(cls_nsyst, g->h_descs[(size_t)idx].nsyst);
+    const bool light = c.shape.lds_hist && c.shape.nobs > 0 && (c.shape.static_prog >= 0 || cls_nsyst <= 1);
+    int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
     bpc = std::min(bpc, lds_limit);
     unsigned long long grid = (unsigned long long)props.cus * bpc;
