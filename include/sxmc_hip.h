@@ -168,7 +168,7 @@ int sxmc_hist_get_samples(sxmc_hist_t h, float* h_out, size_t n);
 int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s);
 
 /* Replaces EvalHist::Optimize/OptimizeBin/OptimizeEval (pdfz.cpp:622-814): the launch shape
- * is sized analytically from the device; 0 keeps the default.  threads: 256, 512 or 1024. */
+ * is sized analytically from the device; 0 keeps the default.  threads: a multiple of 64 up to 1024. */
 int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_per_cu);
 
 /* ---------------------------------------------------------------- evaluator group ----------- */

@@ -489,7 +489,7 @@ int group_rebuild(sxmc_group* g) {
   g->same_points = n > 0;
 
   int threads = g->cfg_threads > 0 ? g->cfg_threads : 512;
-  if (threads != 256 && threads != 512 && threads != 1024) threads = 512;
+  if (threads < 64 || threads > 1024 || threads % 64) threads = 512;
 
   for (int i = 0; i < n; i++) {
     sxmc_hist* h = g->members[i];
@@ -638,7 +638,9 @@ int group_rebuild(sxmc_group* g) {
     // beyond LDS) need the second set of waves to hide it.
     int cls_nsyst = 0;
     for (int idx : c.member_idx) cls_nsyst = std::max(cls_nsyst, g->h_descs[(size_t)idx].nsyst);
-    const bool light = c.shape.lds_hist && c.shape.nobs > 0 && (c.shape.static_prog >= 0 || cls_nsyst <= 1);
+    const double stream_bytes = (double)c.total_vec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot);
+    const bool light = c.shape.lds_hist && c.shape.nobs > 0 && (c.shape.static_prog >= 0 || cls_nsyst <= 1) &&
+                       stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
     bpc = std::min(bpc, lds_limit);
@@ -1349,8 +1351,8 @@ int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s) {
 }
 int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_per_cu) {
   SX_REQUIRE(h, "null evaluator");
-  SX_REQUIRE(bin_threads == 0 || bin_threads == 256 || bin_threads == 512 || bin_threads == 1024,
-             "bin_threads must be 0, 256, 512 or 1024");
+  SX_REQUIRE(bin_threads == 0 || (bin_threads >= 64 && bin_threads <= 1024 && bin_threads % 64 == 0),
+             "bin_threads must be 0 or a multiple of 64 up to 1024");
   SX_REQUIRE(bin_blocks_per_cu >= 0 && bin_blocks_per_cu <= 16, "bin_blocks_per_cu out of range");
   h->cfg_threads = bin_threads;
   h->cfg_bpc = bin_blocks_per_cu;
@@ -1393,8 +1395,8 @@ int sxmc_group_destroy(sxmc_group_t g) {
 
 int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks_per_cu) {
   SX_REQUIRE(g, "null group");
-  SX_REQUIRE(bin_threads == 0 || bin_threads == 256 || bin_threads == 512 || bin_threads == 1024,
-             "bin_threads must be 0, 256, 512 or 1024");
+  SX_REQUIRE(bin_threads == 0 || (bin_threads >= 64 && bin_threads <= 1024 && bin_threads % 64 == 0),
+             "bin_threads must be 0 or a multiple of 64 up to 1024");
   SX_REQUIRE(bin_blocks_per_cu >= 0 && bin_blocks_per_cu <= 16, "bin_blocks_per_cu out of range");
   g->cfg_threads = bin_threads;
   g->cfg_bpc = bin_blocks_per_cu;
