@@ -180,6 +180,8 @@ def main():
                          "normalisations left in place (4 launches per step).  Default: the walk reads none of them, so "
                          "the event sum runs over the distinct tuples of event bins weighted by multiplicity and the step "
                          "end also clears histograms and normalisations for the next step (3 launches per step)")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the analytic launch shape instead of timing a few lane counts per CU at set-up")
     ap.add_argument("--prewarm", type=int, default=300,
                     help="untimed steps before the --warmup steps (GPU clocks and graph replay settle)")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps recorded per HIP graph (--form graph)")
@@ -248,6 +250,12 @@ def main():
     m.setup(sync_interval=max(args.steps, args.warmup + 1, 1))
 
     m.group.SetDebugMode(args.debug_mode)
+    # EvalHist::Optimize's role (pdfz.cpp:622-727): a few trial launches pick the lane count per CU for this box
+    tuned_threads = 0
+    if not args.no_autotune and threads == 0 and bpc == 0:
+        tuned_threads = m.group.Optimize(m.stream)
+        capi.synchronize()
+
     def one_step():
         if args.form == "pdfz":      # EvalAsync on all, EvalFinished on all (bench_sxmc.cpp:193-200)
             m.group.EvalAsync(True, None)
@@ -397,7 +405,7 @@ def main():
             "prewarm_steps": args.prewarm,
             "lut_materialized": bool(args.lut_output or args.form in ("reference", "pdfz")),
             "launches_per_step": 3 if m.consume else (1 if args.form == "pdfz" else 4),
-            "steps_launched_one_by_one_with_events": eager_share(args.steps) if graph_state["steps_per_graph"] else args.steps, "debug_mode": args.debug_mode, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
+            "steps_launched_one_by_one_with_events": eager_share(args.steps) if graph_state["steps_per_graph"] else args.steps, "debug_mode": args.debug_mode, "autotuned_lanes_per_cu": tuned_threads, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,
             "experiments_per_sec_at_1e5_steps": value / 1e5,

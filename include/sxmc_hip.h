@@ -178,6 +178,13 @@ int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_p
 int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* out);
 int sxmc_group_destroy(sxmc_group_t g);
 int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks_per_cu);
+/* EvalHist::Optimize / OptimizeBin (pdfz.cpp:622-727) for the batched launch: times the fill with a few
+ * lane counts per CU on stream `s` and keeps the fastest (the analytic default is within a few per cent;
+ * which count wins differs from one box to the next).  Only acts when every member is a pure stream and no
+ * launch configuration was set by hand; results never depend on the shape.  The members' histograms and
+ * normalisation slots hold counts of the trial runs afterwards (the next evaluation zeroes them as usual).
+ * *chosen_threads (optional): the lane count kept, 0 when nothing was tried. */
+int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads);
 /* How the fill kernel's work is cut over workgroups: 0 = automatic, 1 = sliced (each workgroup one
  * contiguous slice of the concatenated members), 2 = interleaved (each member's workgroups stride
  * through it chunk by chunk, like a grid-stride copy). */

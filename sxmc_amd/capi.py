@@ -87,6 +87,7 @@ SIGNATURES = {
     "sxmc_group_create": [_vp, _i, _pvp],
     "sxmc_group_destroy": [_vp],
     "sxmc_group_set_launch_config": [_vp, _i, _i],
+    "sxmc_group_optimize": [_vp, _vp, _pi],
     "sxmc_group_set_partition": [_vp, _i],
     "sxmc_group_set_sparse": [_vp, _i],
     "sxmc_group_set_prebinning": [_vp, _i],

@@ -170,6 +170,7 @@ struct LaunchClass {
   unsigned* d_blk_off = nullptr;
   unsigned long long total_vec = 0;
   int partition = 0;  // 1 sliced, 2 interleaved (what build_partition chose)
+  bool light = false; // a pure stream: runs best with few waves per CU (see group_rebuild)
 };
 
 void free_class(LaunchClass& c) {
@@ -641,6 +642,7 @@ int group_rebuild(sxmc_group* g) {
     const double stream_bytes = (double)c.total_vec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot);
     const bool light = c.shape.lds_hist && c.shape.nobs > 0 && (c.shape.static_prog >= 0 || cls_nsyst <= 1) &&
                        stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
+    c.light = light;
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
     bpc = std::min(bpc, lds_limit);
@@ -1401,6 +1403,58 @@ int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks
   g->cfg_threads = bin_threads;
   g->cfg_bpc = bin_blocks_per_cu;
   return SXMC_OK;
+}
+
+int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
+  SX_REQUIRE(g, "null group");
+  SX_REQUIRE(!t_capturing, "not while recording a graph");
+  if (chosen_threads) *chosen_threads = 0;
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  rc = group_check_bound(g, false);
+  if (rc) return rc;
+  // only the pure-stream launches have anything to choose: how many lanes per CU keep HBM busiest differs
+  // by a few per cent from one box to the next
+  if (g->classes.empty() || g->cfg_threads > 0 || g->cfg_bpc > 0) return SXMC_OK;
+  for (const LaunchClass& c : g->classes)
+    if (!c.light) return SXMC_OK;
+  hipStream_t st = (hipStream_t)s;
+  hipEvent_t e0, e1;
+  SX_HIP(hipEventCreate(&e0));
+  SX_HIP(hipEventCreate(&e1));
+  const int candidates[] = {512, 448, 576, 640, 768};
+  int best_threads = 0;
+  float best_ms = 0;
+  int failure = SXMC_OK;
+  for (int cand : candidates) {
+    g->cfg_threads = cand;
+    g->cfg_bpc = 1;
+    if ((failure = group_refresh(g)) != SXMC_OK) break;
+    float ms = 1e30f;
+    for (int rep = 0; rep < 4 && failure == SXMC_OK; rep++) {  // first repetition warms up
+      hipError_t e = hipEventRecord(e0, st);
+      if (e == hipSuccess) failure = group_fill(g, st, false);
+      if (failure == SXMC_OK && e == hipSuccess) e = hipEventRecord(e1, st);
+      if (failure == SXMC_OK && e == hipSuccess) e = hipEventSynchronize(e1);
+      float t = 0;
+      if (failure == SXMC_OK && e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+      if (failure == SXMC_OK && e != hipSuccess) failure = fail(SXMC_ERR_HIP, std::string("optimize: ") + hipGetErrorString(e));
+      if (rep > 0 && t < ms) ms = t;
+    }
+    if (failure != SXMC_OK) break;
+    if (best_threads == 0 || ms < best_ms) {
+      best_threads = cand;
+      best_ms = ms;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  // the default shape is what 0, 0 means: keep the configuration "automatic" when it won
+  g->cfg_threads = (failure == SXMC_OK && best_threads != 512) ? best_threads : 0;
+  g->cfg_bpc = (failure == SXMC_OK && best_threads != 512) ? 1 : 0;
+  if (failure != SXMC_OK) return failure;
+  if (chosen_threads) *chosen_threads = best_threads;
+  return group_refresh(g);
 }
 
 int sxmc_group_set_partition(sxmc_group_t g, int mode) {

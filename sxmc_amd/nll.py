@@ -74,6 +74,13 @@ class EvalGroup:
     def SetLaunchConfig(self, bin_threads=0, bin_blocks_per_cu=0):
         capi.call("sxmc_group_set_launch_config", self._g, int(bin_threads), int(bin_blocks_per_cu))
 
+    def Optimize(self, stream=None):
+        """Times the fill with a few lane counts per CU and keeps the fastest (EvalHist::Optimize for the batched
+        launch).  Returns the lane count kept (0: nothing to choose)."""
+        n = C.c_int(0)
+        capi.call("sxmc_group_optimize", self._g, ptr(stream), C.byref(n))
+        return n.value
+
     def SetPartition(self, mode):
         """0 automatic, 1 sliced, 2 interleaved (see include/sxmc_hip.h)."""
         capi.call("sxmc_group_set_partition", self._g, int(mode))

@@ -547,3 +547,26 @@ def test_fused_evaluation_without_events(lut_output):
     for j, t in enumerate(tabs):
         o = oracle_eval(t, 3, [0.0] * 2, [1.0] * 2, [6, 5], [dict(type="shift", obs=0, pars=[0])], [0.02])
         assert np.array_equal(evs[j].GetBins(), o["bins"]) and norms.get()[j] == o["norm"]
+
+
+def test_optimize_keeps_results_and_only_acts_on_pure_streams():
+    """sxmc_group_optimize (EvalHist::Optimize for the batched launch): trial launches pick a lane count per CU;
+    histograms afterwards are those of any other shape; groups with a hand-set shape, a long run-time program
+    or little work are left alone."""
+    rng = np.random.default_rng(21)
+    systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+             dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]
+    params = [0.02, -0.01, 0.07]
+    sizes = [2000003] * 8                                               # 16e6 samples x 16 B: a long stream
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], systs, params, nfields=5)
+    group = nll.EvalGroup(evs)
+    chosen = group.Optimize()
+    assert chosen in (448, 512, 576, 640, 768)
+    group.EvalAsync(False)
+    group.EvalFinished()
+    o = oracle_eval(tabs[3], 5, [0.0] * 3, [1.0] * 3, [20, 20, 20], systs, params)
+    assert np.array_equal(evs[3].GetBins(), o["bins"]) and norms.get()[3] == o["norm"]
+    group.SetLaunchConfig(256, 2)
+    assert group.Optimize() == 0                                        # shape set by hand: untouched
+    small = build_group(rng, [5000, 7000], 2, [9, 7], [dict(type="shift", obs=0, pars=[0])], [0.01])
+    assert nll.EvalGroup(small[0]).Optimize() == 0                      # short launches take all the waves
