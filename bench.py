@@ -333,7 +333,10 @@ def main():
         pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m, lut_output=args.lut_output,
                      consume=not args.lut_output) for _ in range(nconc)]
         for c in pool:
-            c.group.SetLaunchConfig(threads, bpc)
+            if tuned_threads not in (0, 512):
+                c.group.SetLaunchConfig(tuned_threads, 1)       # what the trial launches chose for this box
+            else:
+                c.group.SetLaunchConfig(threads, bpc)
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
