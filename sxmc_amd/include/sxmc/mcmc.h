@@ -38,6 +38,8 @@ class MCMC {
   bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
   bool verbose = false;
   unsigned graph_steps = 0;     //!< > 0: replay the batched step from a HIP graph of this many recorded steps
+  bool optimize = true;         //!< EvalHist's `optimize` constructor flag for the batched launch: a few trial
+                                //!< launches at the start of a walk pick the lane count per CU (sxmc_group_optimize)
   bool consume = true;          //!< batched form: the step end also clears histograms and normalisations for the
                                 //!< next step (sxmc_group_finish_step_async: 3 launches per step; nothing reads them
                                 //!< between the steps of a walk)
@@ -220,6 +222,10 @@ class MCMC {
       // bindings must be current before the group reads them (proposal vector as parameter buffer)
       for (pdfz::Eval* p : pdfs) dynamic_cast<pdfz::EvalHist*>(p)->Bind();
       check(sxmc_group_set_lut_output(group, lut_output ? 1 : 0));
+      if (optimize && !optimized) {
+        check(sxmc_group_optimize(group, stream, nullptr));
+        optimized = true;
+      }
     }
     const bool reevaluate = nsystematics > 0 && !systematics_fixed;
 
@@ -401,6 +407,7 @@ class MCMC {
   std::vector<bool> parameter_fixed;
   std::vector<pdfz::Eval*> pdfs;
   sxmc_group_t group = nullptr;
+  bool optimized = false;
 };
 
 }  // namespace sxmc
