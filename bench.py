@@ -407,7 +407,7 @@ def main():
             "step_form": args.form, "steps_per_graph": graph_state["steps_per_graph"], "graph_fallback": graph_state["fallback"],
             "prewarm_steps": args.prewarm,
             "lut_materialized": bool(args.lut_output or args.form in ("reference", "pdfz")),
-            "launches_per_step": 3 if m.consume else (1 if args.form == "pdfz" else 4),
+            "launches_per_step": 3 if (args.form in ("pdfz", "step") or m.consume) else 4,
             "steps_launched_one_by_one_with_events": eager_share(args.steps) if graph_state["steps_per_graph"] else args.steps, "debug_mode": args.debug_mode, "autotuned_lanes_per_cu": tuned_threads, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
             "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
             "samples_per_sec": value * w.nsamples_total,
