@@ -116,34 +116,35 @@ def make_workload(args, torch, dev, seed):
     return w, tensors
 
 
-def cpu_baseline(w, host_tables, vector, nevals, nthreads):
-    """The oracle (CPU restatement of the reference loop) timed on this box's host cores, same
-    workload, same inputs.  Returns (seconds per evaluation, bins, norms, nll)."""
+def oracle_eval(w, tables, vector, which, nthreads):
+    """One oracle evaluation (pdfz.cpp:349-436) of the signals `which` at `vector`.  tables[j]: host
+    float32 [n, F] of signal j.  Returns (seconds, {j: bins}, {j: norm}, {j: lut row})."""
     from oracle import oracle
     geom = oracle.HistGeometry(w.lower, w.upper, w.nbins)
     ne = w.events.shape[0]
-    rbs = [oracle.set_eval_points(geom, w.events, s.dataset) for s in w.signals]
-    best = None
-    for _ in range(nevals):
-        t0 = time.perf_counter()
-        lut = np.zeros((w.nsignals, ne), np.float32)
-        norms = np.zeros(w.nsignals, np.uint32)
-        all_bins = []
-        for j, s in enumerate(w.signals):
-            if time.perf_counter() - t0 > 30:     # keep a long CPU leg visibly alive
-                print("cpu_baseline: signal %d/%d, %.0f s" % (j, w.nsignals, time.perf_counter() - t0),
-                      file=sys.stderr, flush=True)
-            bins, norm = oracle.bin_samples(geom, host_tables[j], s.nfields, w.systematics,
-                                            vector[w.nsources:], nthreads=nthreads)
-            oracle.eval_pdf(rbs[j], bins, norm, geom.bin_volume, out=lut[j])
-            norms[j] = norm
-            all_bins.append(bins)
-        val, _ = oracle.full_nll(lut, vector, ne, w.nsignals, w.nsources, w.parameter_means(),
-                                 w.parameter_sigmas(), [s.nexpected for s in w.signals],
-                                 [s.n_mc for s in w.signals], [s.source_id for s in w.signals], norms)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return best, all_bins, norms, val
+    t0 = time.perf_counter()
+    bins_of, norm_of, lut_of = {}, {}, {}
+    for j in which:
+        s = w.signals[j]
+        if time.perf_counter() - t0 > 30:     # keep a long CPU leg visibly alive
+            print("oracle: signal %d, %.0f s" % (j, time.perf_counter() - t0), file=sys.stderr, flush=True)
+        rb = oracle.set_eval_points(geom, w.events, s.dataset)
+        bins, norm = oracle.bin_samples(geom, tables[j], s.nfields, w.systematics, vector[w.nsources:],
+                                        nthreads=nthreads)
+        row = np.zeros(ne, np.float32)
+        oracle.eval_pdf(rb, bins, norm, geom.bin_volume, out=row)
+        bins_of[j], norm_of[j], lut_of[j] = bins, norm, row
+    return time.perf_counter() - t0, bins_of, norm_of, lut_of
+
+
+def oracle_nll(w, vector, lut, norms):
+    """MCMC::nll on the CPU (nll_kernels.cpp:89-188) over a lookup table [S, E] and the norms."""
+    from oracle import oracle
+    ne = w.events.shape[0]
+    val, _ = oracle.full_nll(lut, vector, ne, w.nsignals, w.nsources, w.parameter_means(), w.parameter_sigmas(),
+                             [s.nexpected for s in w.signals], [s.n_mc for s in w.signals],
+                             [s.source_id for s in w.signals], norms)
+    return val
 
 
 def chain_intervals(chain, nparameters):
@@ -156,8 +157,277 @@ def chain_intervals(chain, nparameters):
     return out
 
 
-def value_per_gpu_hint(args, elapsed):
-    return args.steps / elapsed
+FORMS = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}
+
+
+class Leg:
+    """One measured workload: tables resident in HBM, a chain walking it, the timed region, the roofline
+    figures of its fill kernel and the parity check against the oracle."""
+
+    def __init__(self, args, torch, dev, name, form, lut_output, seed, exp_seed, scale=None, events=None,
+                 keep_host="none"):
+        from sxmc_amd import capi
+        from sxmc_amd.mcmc import MCMC
+        self.args, self.torch, self.name, self.form, self.lut_output = args, torch, name, form, lut_output
+        a = argparse.Namespace(**vars(args))
+        a.workload = name
+        if scale is not None:
+            a.scale = scale
+        if events is not None:
+            a.events = events
+        self.scale = a.scale
+        w, tensors = make_workload(a, torch, dev, seed)
+        if args.nsyst >= 0:
+            w.systematics = w.systematics[:args.nsyst]
+            w.description += " [first %d systematics only]" % args.nsyst
+        rng = np.random.default_rng(exp_seed)
+        w.events = w.events[rng.permutation(w.events.shape[0])]
+        self.w = w
+        # host copies for the oracle: every signal, or the first and the last (the largest workloads)
+        if keep_host == "all":
+            self.host_signals = list(range(w.nsignals))
+        elif keep_host == "ends":
+            self.host_signals = sorted({0, w.nsignals - 1})
+        else:
+            self.host_signals = []
+        self.host_tables = {j: tensors[j].cpu().numpy() for j in self.host_signals}
+        self.m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=FORMS[form], samples_on_device=tensors,
+                      stream=capi.new_stream() if form == "graph" else None, lut_output=lut_output,
+                      consume=not lut_output)
+        del tensors
+        torch.cuda.empty_cache()
+        threads, bpc = (int(x) for x in args.launch.split(","))
+        m = self.m
+        m.group.SetLaunchConfig(threads, bpc)
+        m.group.SetPartition(args.partition)
+        m.group.SetPrebinning(not args.no_prebin)
+        m.group.SetSparse(not args.no_sparse)
+        self.graph_state = {"steps_per_graph": args.graph_steps if form == "graph" else 0, "fallback": None}
+        self.tuned_threads = 0
+
+    def setup(self, steps, warmup):
+        from sxmc_amd import capi
+        args, m = self.args, self.m
+        m.setup(sync_interval=max(steps, warmup + 1, min(args.prewarm, 100) + 1, 1))
+        m.group.SetDebugMode(args.debug_mode)
+        # EvalHist::Optimize's role (pdfz.cpp:622-727): a few trial launches pick the lane count per CU for this box
+        if not args.no_autotune and args.launch == "0,0":
+            self.tuned_threads = m.group.Optimize(m.stream)
+            capi.synchronize()
+        if self.form == "graph":
+            m.step()                     # brings the launch plan up to date; recording cannot
+            m.flush()
+        # untimed: clocks and graph replay settle over the first few hundred steps, whatever --warmup says
+        for lo in range(0, args.prewarm, 100):
+            self.run_steps(min(100, args.prewarm - lo, max(steps, 1)))
+            m.flush()
+        self.run_steps(warmup)
+        m.flush()
+
+    def one_step(self):
+        m = self.m
+        if self.form == "pdfz":      # EvalAsync on all, EvalFinished on all (bench_sxmc.cpp:193-200)
+            m.group.EvalAsync(True, None)
+            m.group.EvalFinished()
+        else:
+            m.step()
+
+    # form "graph": the fused sequence replayed from a HIP graph of --graph-steps recorded steps.  Replayed
+    # launches carry no events, so the last steps of every run are launched one by one with HIP events
+    # around the fill kernel: the roofline figures come from those, inside the same timed region.
+    def eager_share(self, n):          # about a tenth of the steps, and whatever does not fill a whole graph
+        gs = self.graph_state["steps_per_graph"]
+        return n if gs <= 0 or n < 2 * gs else n - ((n - n // 10) // gs) * gs
+
+    def run_steps(self, n):
+        from sxmc_amd import capi
+        m, gstate = self.m, self.graph_state
+        ne = self.eager_share(n)
+        if n > ne and gstate["steps_per_graph"] > 0:
+            try:
+                m.steps(n - ne, gstate["steps_per_graph"])
+            except capi.SxmcError as exc:
+                # recording refused (nothing was launched): same launches one by one, said so in the output
+                gstate["steps_per_graph"], gstate["fallback"] = 0, str(exc)
+                m._graph = None
+                ne = n
+        elif n > ne:
+            ne = n
+        for _ in range(ne):
+            self.one_step()
+
+    def timed(self, steps, collective=True):
+        """Exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        from sxmc_amd import dist
+        m, torch = self.m, self.torch
+        m.group.Profile(True, steps)
+        if collective:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.run_steps(steps)
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if collective:
+            elapsed = dist.max_over_ranks(elapsed)
+        self.fill_ms_total, self.nfill = m.group.ProfileRead()
+        m.group.Profile(False, 0)
+        self.elapsed, self.steps = elapsed, steps
+        return elapsed
+
+    def launches_per_step(self):
+        return 3 if (self.form in ("pdfz", "step") or self.m.consume) else 4
+
+    def roofline(self, world=1):
+        args, w, m = self.args, self.w, self.m
+        ab = m.group.AlgorithmicBytes()
+        fill_bytes = ab["fill_read"] + ab["hist"]
+        fill_ms = self.fill_ms_total / max(self.nfill, 1)
+        achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
+        value = self.steps * world / self.elapsed
+        # SURVEY.md 8(d) counts 4 bytes for every column the computation needs (observables + referenced truth
+        # fields); `fill_bytes` is smaller when untouched observables are not streamed as float columns.
+        # `achieved` uses the smaller figure (what the kernel must move); the survey's figure is reported beside it.
+        extra_fields = {s["true_obs"] for s in w.systematics if s.get("true_obs", -1) >= w.nobs}
+        survey_bytes = 4.0 * (w.nobs + len(extra_fields)) * w.nsamples_total + ab["hist"]
+        # HBM bytes of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc
+        # passes (tools/profile_on_gpu.sh), corrected as MI355X_MICROARCH.md prescribes, kept per workload
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else ""))
+            if t and self.scale == 1.0 and args.nsyst < 0:
+                traffic = t["bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
+        return {
+            "bound": "hbm", "kernel": "fill_kernel (histogram fill, all signals batched)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
+            "avg_launch_ms": fill_ms, "launches_timed": self.nfill,
+            "survey_bytes_per_launch": survey_bytes,
+            "achieved_at_survey_bytes": survey_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0,
+            "whole_step_algorithmic_bytes": fill_bytes + ab["event"],
+            "whole_step_frac": (fill_bytes + ab["event"]) * value / world / 1e9 / HBM_PEAK_GBS,
+        }
+
+    def config(self):
+        w, args, m = self.w, self.args, self.m
+        return {
+            "workload": "%s: %s" % (w.name, w.description),
+            "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
+            "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
+            "step_form": self.form, "steps_per_graph": self.graph_state["steps_per_graph"],
+            "graph_fallback": self.graph_state["fallback"],
+            "lut_materialized": bool(self.lut_output or self.form in ("reference", "pdfz")),
+            "launches_per_step": self.launches_per_step(),
+            "steps_launched_one_by_one_with_events":
+                self.eager_share(self.steps) if self.graph_state["steps_per_graph"] else self.steps,
+            "autotuned_lanes_per_cu": self.tuned_threads, "scale": self.scale,
+        }
+
+    def parity(self, time_evals=0):
+        """GPU against the oracle at the chain's current proposal, on the signals whose tables were kept on
+        the host: every bin count and norm (dense evaluation, what CreateHistogram reads), the lookup-table
+        rows the walk's own evaluation form produces (sparse event-bin counters where histograms exceed LDS)
+        bit for bit, and the NLL.  When only some signals went through the oracle, the oracle's NLL chain runs
+        on their oracle rows plus the GPU's rows of the others.  time_evals > 0 also times the oracle
+        (single thread, best of time_evals) -> cpu_baseline.  Raises SystemExit on a mismatch."""
+        from sxmc_amd import capi
+        m, w = self.m, self.w
+        which = self.host_signals
+        if not which:
+            return None, None
+        m.flush()                               # (room in the jump buffer for the step below)
+        vector = m.proposed_vector.get()
+        m.group.EvalAsync(False, m.stream)      # histograms (dense, as CreateHistogram would)
+        capi.synchronize()
+        ncores = max(1, min(os.cpu_count() or 1, int(4e9 // (4 * int(np.prod(w.nbins))))))
+        secn, bins, norms, rows = oracle_eval(w, self.host_tables, vector, which, ncores)
+        exact_bins = True
+        for j in which:
+            exact_bins = exact_bins and np.array_equal(m.pdfs[j].GetBins(), bins[j])
+            bins[j] = None
+        m.group.EvalAsync(True, m.stream)       # lookup (+ NLL below) in the evaluation form of the walk
+        m.nll(m.proposed_vector, m.proposed_nll)
+        capi.synchronize()
+        gpu_nll = float(m.proposed_nll.get()[0])
+        gpu_norms = m.normalizations.get()
+        gpu_lut = m.lut.get().reshape(w.nsignals, -1)
+        exact_norms = all(int(gpu_norms[j]) == int(norms[j]) for j in which)
+        exact_lut = all(np.array_equal(gpu_lut[j].view(np.uint32), rows[j].view(np.uint32)) for j in which)
+        lut = gpu_lut.copy()
+        for j in which:
+            lut[j] = rows[j]
+        cpu_nll = oracle_nll(w, vector, lut, gpu_norms)
+        rel = abs(gpu_nll - cpu_nll) / abs(cpu_nll)
+        # the walk's own step form (event classes / fused lookup) at the same vector
+        m.step(debug_mode=True)
+        chain, _ = m.flush()
+        step_nll = float(chain[-1, -1])
+        step_rel = abs(step_nll - np.float32(cpu_nll)) / abs(cpu_nll)
+        par = {"bins_and_norms_bit_exact": bool(exact_bins and exact_norms), "lut_bit_exact": bool(exact_lut),
+               "signals_checked": [int(j) for j in which], "signals_total": w.nsignals,
+               "samples_checked": int(sum(self.host_tables[j].shape[0] for j in which)),
+               "nll_gpu": gpu_nll, "nll_cpu": cpu_nll, "nll_rel_diff": rel, "nll_tolerance": 1e-6,
+               "nll_of_walk_step_form_float32": step_nll, "nll_of_walk_step_form_rel_diff": step_rel,
+               "nll_oracle_inputs": "oracle lookup rows for every signal" if len(which) == w.nsignals else
+                                    "oracle lookup rows for the checked signals, GPU rows for the others"}
+        cpu = None
+        if time_evals > 0:
+            nchecked = par["samples_checked"]
+            best = min(oracle_eval(w, self.host_tables, vector, which, 1)[0] for _ in range(time_evals))
+            frac = nchecked / float(w.nsamples_total)
+            cpu = {"value": frac / best, "unit": "evals/s", "cores": 1, "kind": "port",
+                   "sample": "%d oracle evaluations (zero + fill + lookup) of %d of the %d signals = %d of the %d samples, "
+                             "%d events, best of %d, oracle/libsxmc_oracle.so single thread (the reference's CPU mode "
+                             "is a serial loop)%s"
+                             % (time_evals, len(which), w.nsignals, nchecked, w.nsamples_total, w.events.shape[0],
+                                time_evals, "" if frac == 1.0 else "; value scaled to the whole workload by sample count"),
+                   "all_cores": {"value": frac / secn, "cores": ncores,
+                                 "note": "same oracle, pthreads over sample chunks with private histograms"}}
+        ok = par["bins_and_norms_bit_exact"] and exact_lut and rel <= 1e-6 and step_rel <= 2e-6
+        par["ok"] = bool(ok)
+        return par, cpu
+
+    def close(self):
+        from sxmc_amd import capi
+        m = self.m
+        capi.synchronize()
+        if m._graph is not None:
+            m._graph.close()
+        for p in m.pdfs:
+            p.close()
+        m.group.close()
+        self.host_tables = {}
+        self.m = None
+        import gc
+        gc.collect()
+        self.torch.cuda.empty_cache()
+
+
+def also_record(args, torch, dev, name, form, lut_output, steps, warmup, exp_seed, keep_host, share=None):
+    """A sub-record of the default run: another workload (or another step form of the headline workload)
+    measured the same way -- evals/s, the fill kernel's time and roofline fraction, parity."""
+    t0 = time.perf_counter()
+    leg = Leg(args, torch, dev, name, form, lut_output, args.seed, exp_seed, scale=1.0, keep_host=keep_host)
+    leg.setup(steps, warmup)
+    elapsed = leg.timed(steps, collective=False)
+    rf = leg.roofline()
+    par, cpu = leg.parity(time_evals=1)
+    rec = {"value": steps / elapsed, "unit": "evals/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * elapsed / steps, "fill_kernel_us": 1e3 * rf["avg_launch_ms"], "frac": rf["frac"],
+           "config": leg.config(), "roofline": rf, "parity": par, "cpu_baseline": cpu,
+           "leg_seconds": None}
+    leg.close()
+    rec["leg_seconds"] = time.perf_counter() - t0
+    if par is not None and not par["ok"]:
+        print(json.dumps({name: rec}))
+        raise SystemExit("PARITY FAILURE (%s): GPU result differs from the CPU oracle" % name)
+    return rec
 
 
 def main():
@@ -186,7 +456,7 @@ def main():
                     help="untimed steps before the --warmup steps (GPU clocks and graph replay settle)")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps recorded per HIP graph (--form graph)")
     ap.add_argument("--launch", default="0,0", help="bin_threads,bin_blocks_per_cu (0 = default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (timing AND parity)")
     ap.add_argument("--cpu-evals", type=int, default=2)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--experiments", type=int, default=-1,
@@ -195,6 +465,10 @@ def main():
     ap.add_argument("--exp-steps", type=int, default=2000, help="MCMC steps per fake experiment in the ensemble leg")
     ap.add_argument("--exp-concurrent", type=int, default=3,
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
+    ap.add_argument("--also", default="auto",
+                    help="sub-records measured after the headline: comma list of c3_lut_materialized, c2, c5; "
+                         "auto = all three when the headline is the full-size C3 on one GPU; none = skip")
+    ap.add_argument("--also-steps", type=int, default=200, help="timed steps of each sub-record (C5: a quarter)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
     ap.add_argument("--no-sparse", action="store_true", help="fill HBM-resident histograms densely (global atomics)")
     ap.add_argument("--no-prebin", action="store_true", help="bin every observable in the kernel (no pre-binned column)")
@@ -223,91 +497,19 @@ def main():
     info = capi.device_info(device_index)
 
     # ---- inputs: same MC tables on every rank (replica), own data events + chain seed per rank
-    w, tensors = make_workload(args, torch, dev, args.seed)
-    if args.nsyst >= 0:
-        w.systematics = w.systematics[:args.nsyst]
-        w.description += " [first %d systematics only]" % args.nsyst
     exp_seed = dist.experiment_seed(args.seed, rank)
-    rng = np.random.default_rng(exp_seed)
-    w.events = w.events[rng.permutation(w.events.shape[0])]
-
-    want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1
-    host_tables = [t.cpu().numpy() for t in tensors] if want_cpu else None
-
-    fused = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
-    m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=fused, samples_on_device=tensors,
-             stream=capi.new_stream() if args.form == "graph" else None, lut_output=args.lut_output,
-             consume=not args.lut_output)
-    del tensors
-    torch.cuda.empty_cache()
+    want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1 and not args.debug_mode
+    big = args.workload.lower() == "c5" and args.scale >= 0.2
+    leg = Leg(args, torch, dev, args.workload, args.form, args.lut_output, args.seed, exp_seed,
+              keep_host=("ends" if big else "all") if want_cpu else "none")
+    w, m = leg.w, leg.m
+    leg.setup(args.steps, args.warmup)
+    tuned_threads = leg.tuned_threads
+    graph_state = leg.graph_state
     threads, bpc = (int(x) for x in args.launch.split(","))
-    m.group.SetLaunchConfig(threads, bpc)
-    m.group.SetPartition(args.partition)
-    m.group.SetPrebinning(not args.no_prebin)
-    m.group.SetSparse(not args.no_sparse)
-    if args.debug_mode:
-        want_cpu = False
-    m.setup(sync_interval=max(args.steps, args.warmup + 1, 1))
-
-    m.group.SetDebugMode(args.debug_mode)
-    # EvalHist::Optimize's role (pdfz.cpp:622-727): a few trial launches pick the lane count per CU for this box
-    tuned_threads = 0
-    if not args.no_autotune and threads == 0 and bpc == 0:
-        tuned_threads = m.group.Optimize(m.stream)
-        capi.synchronize()
-
-    def one_step():
-        if args.form == "pdfz":      # EvalAsync on all, EvalFinished on all (bench_sxmc.cpp:193-200)
-            m.group.EvalAsync(True, None)
-            m.group.EvalFinished()
-        else:
-            m.step()
-
-    # form "graph": the fused sequence replayed from a HIP graph of --graph-steps recorded steps.  Replayed
-    # launches carry no events, so the last steps of every run are launched one by one with HIP events
-    # around the fill kernel: the roofline figures come from those, inside the same timed region.
-    gs = args.graph_steps if args.form == "graph" else 0
-    def eager_share(n):          # about a tenth of the steps, and whatever does not fill a whole graph
-        return n if gs <= 0 or n < 2 * gs else n - ((n - n // 10) // gs) * gs
-
-    graph_state = {"steps_per_graph": gs, "fallback": None}
-
-    def run_steps(n):
-        ne = eager_share(n)
-        if n > ne and graph_state["steps_per_graph"] > 0:
-            try:
-                m.steps(n - ne, graph_state["steps_per_graph"])
-            except capi.SxmcError as exc:
-                # recording refused (nothing was launched): same launches one by one, said so in the output
-                graph_state["steps_per_graph"], graph_state["fallback"] = 0, str(exc)
-                m._graph = None
-                ne = n
-        elif n > ne:
-            ne = n
-        for _ in range(ne):
-            one_step()
-
-    if args.form == "graph":
-        m.step()                     # brings the launch plan up to date; recording cannot
-        m.flush()
-    # untimed: clocks and graph replay settle over the first few hundred steps, whatever --warmup says
-    for lo in range(0, args.prewarm, 100):
-        run_steps(min(100, args.prewarm - lo, args.steps))
-        m.flush()
-    run_steps(args.warmup)
-    m.flush()
 
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
-    m.group.Profile(True, args.steps)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
-    fill_ms_total, nfill = m.group.ProfileRead()
-    m.group.Profile(False, 0)
+    elapsed = leg.timed(args.steps)
 
     chain, accepted = m.flush()
     if chain.shape[0] == 0:
@@ -322,13 +524,11 @@ def main():
     # (fake data sets are drawn from 1-3 D histograms only, as in the reference: pdfz.cpp:499-501)
     if nexp > 0 and not args.debug_mode and args.form != "pdfz" and w.nobs <= 3:
         from sxmc_amd import ensemble
-        for s_ in w.signals:
-            s_.nexpected_saved = s_.nexpected
         mine = dist.experiments_of_rank(nexp, rank, world)
         local = np.zeros((len(mine), w.nparameters, 4), np.float32)
         # chains for concurrent experiments: own non-blocking stream, own per-chain state, ONE copy of the tables
         nconc = max(1, min(args.exp_concurrent, len(mine)))
-        form = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}[args.form]
+        form = FORMS[args.form]
         exp_graph = args.graph_steps if args.form in ("fused", "graph") and graph_state["fallback"] is None else 0
         pool = [MCMC(w, seed=1, fused=form, stream=capi.new_stream(), share_with=m, lut_output=args.lut_output,
                      consume=not args.lut_output) for _ in range(nconc)]
@@ -359,32 +559,28 @@ def main():
             "median_upper_limit_source0": dist.median(allint[:, 0, 2]),
             "gathered_shape": [int(x) for x in allint.shape],
             "note": "fake data set + MCMC walk with burn-in re-tuning + contour intervals per experiment; "
-                    "projected to 1e5-step chains: %.4f experiments/s" % (value_per_gpu_hint(args, elapsed) * world / 1e5),
+                    "projected to 1e5-step chains: %.4f experiments/s" % (args.steps / elapsed * world / 1e5),
         }
+        for c in pool:
+            capi.synchronize()
+            if c._graph is not None:
+                c._graph.close()
+            for p in c.pdfs:
+                p.close()
+            c.group.close()
+        del pool
 
-    total_steps = args.steps * world
-    value = total_steps / elapsed
-    ab = m.group.AlgorithmicBytes()
-    fill_bytes = ab["fill_read"] + ab["hist"]
-    fill_ms = fill_ms_total / max(nfill, 1)
-    achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
-    # SURVEY.md 8(d) counts 4 bytes for every column the computation needs (observables + referenced truth
-    # fields); `fill_bytes` above is smaller when untouched observables are streamed as a pre-binned column.
-    # `achieved` uses the smaller figure (what the kernel must move); the survey's figure is reported beside it.
-    extra_fields = {s["true_obs"] for s in w.systematics if s.get("true_obs", -1) >= w.nobs}
-    survey_bytes = 4.0 * (w.nobs + len(extra_fields)) * w.nsamples_total + ab["hist"]
-
-    # HBM bytes of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc
-    # passes (tools/profile_on_gpu.sh), corrected as MI355X_MICROARCH.md prescribes, kept per workload
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else ""))
-        if t and args.scale == 1.0 and args.nsyst < 0:
-            traffic = t["bytes_per_launch"]
-    except (OSError, ValueError):
-        pass
-
+    value = args.steps * world / elapsed
+    cfg = leg.config()
+    cfg.update({
+        "prewarm_steps": args.prewarm, "debug_mode": args.debug_mode, "partition": args.partition,
+        "prebinning": not args.no_prebin, "launch": args.launch,
+        "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
+        "samples_per_sec": value * w.nsamples_total,
+        "experiments_per_sec_at_1e5_steps": value / 1e5,
+        "accepted_fraction_rank0": accepted / max(args.steps, 1),
+        "device": info["name"], "compute_units": info["compute_units"],
+    })
     result = {
         # BASELINE.json's metric string; `value` is its first half (NLL evaluations per second, whole job), the
         # second half (experiments per second) is the "experiments" object below
@@ -400,67 +596,43 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {
-            "workload": "%s: %s" % (w.name, w.description),
-            "nsamples_total": int(w.nsamples_total), "nsignals": w.nsignals, "nobservables": w.nobs,
-            "nbins": w.nbins, "nevents": int(w.events.shape[0]), "nparameters": w.nparameters,
-            "step_form": args.form, "steps_per_graph": graph_state["steps_per_graph"], "graph_fallback": graph_state["fallback"],
-            "prewarm_steps": args.prewarm,
-            "lut_materialized": bool(args.lut_output or args.form in ("reference", "pdfz")),
-            "launches_per_step": 3 if (args.form in ("pdfz", "step") or m.consume) else 4,
-            "steps_launched_one_by_one_with_events": eager_share(args.steps) if graph_state["steps_per_graph"] else args.steps, "debug_mode": args.debug_mode, "autotuned_lanes_per_cu": tuned_threads, "partition": args.partition, "prebinning": not args.no_prebin, "launch": args.launch, "scale": args.scale,
-            "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
-            "samples_per_sec": value * w.nsamples_total,
-            "experiments_per_sec_at_1e5_steps": value / 1e5,
-            "accepted_fraction_rank0": accepted / max(args.steps, 1),
-            "device": info["name"], "compute_units": info["compute_units"],
-        },
-        "roofline": {
-            "bound": "hbm", "kernel": "fill_kernel (histogram fill, all signals batched)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": fill_ms, "launches_timed": nfill,
-            "survey_bytes_per_launch": survey_bytes,
-            "achieved_at_survey_bytes": survey_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0,
-            "whole_step_algorithmic_bytes": fill_bytes + ab["event"],
-            "whole_step_frac": (fill_bytes + ab["event"]) * value / world / 1e9 / HBM_PEAK_GBS,
-        },
+        "config": cfg,
+        "roofline": leg.roofline(world),
         "cpu_baseline": None,
+        "parity": None,
         "intervals_gathered": [int(x) for x in intervals.shape],
         "experiments": experiments,
+        "also": None,
     }
 
     if want_cpu:
-        # same inputs, same parameter vector: time the oracle and assert parity in the same run
-        vector = m.proposed_vector.get()
-        m.group.EvalAsync(False, m.stream)      # histograms (dense, as CreateHistogram would)
-        capi.synchronize()
-        gpu_bins = [p.GetBins() for p in m.pdfs]
-        m.group.EvalAsync(True, m.stream)       # lookup + NLL
-        m.nll(m.proposed_vector, m.proposed_nll)
-        capi.synchronize()
-        gpu_nll = float(m.proposed_nll.get()[0])
-        gpu_norms = m.normalizations.get()
-        sec1, bins, norms, cpu_nll = cpu_baseline(w, host_tables, vector, args.cpu_evals, 1)
-        # all-core variant: private histograms per thread, so cap the threads where the histogram is huge
-        total_bins = int(np.prod(w.nbins))
-        ncores = max(1, min(os.cpu_count() or 1, int(4e9 // (4 * total_bins))))
-        secn, bins_n, norms_n, _ = cpu_baseline(w, host_tables, vector, 1, ncores)
-        exact = all(np.array_equal(a, b) for a, b in zip(gpu_bins, bins)) and np.array_equal(gpu_norms, norms)
-        rel = abs(gpu_nll - cpu_nll) / abs(cpu_nll)
-        result["cpu_baseline"] = {
-            "value": 1.0 / sec1, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": "%d full NLL evaluations of the same workload (all %d samples, %d events), best of %d, "
-                      "oracle/libsxmc_oracle.so single thread (the reference's CPU mode is a serial loop)"
-                      % (args.cpu_evals, w.nsamples_total, w.events.shape[0], args.cpu_evals),
-            "all_cores": {"value": 1.0 / secn, "cores": ncores,
-                          "note": "same oracle, pthreads over sample chunks with private histograms"},
-        }
-        result["parity"] = {"bins_and_norms_bit_exact": bool(exact), "nll_gpu": gpu_nll, "nll_cpu": cpu_nll,
-                            "nll_rel_diff": rel, "nll_tolerance": 1e-6}
-        if not exact or not rel <= 1e-6:
+        # same inputs, same parameter vector: parity asserted for every workload, the oracle timed beside it
+        par, cpu = leg.parity(time_evals=args.cpu_evals)
+        result["parity"], result["cpu_baseline"] = par, cpu
+        if not par["ok"]:
             print(json.dumps(result))
             raise SystemExit("PARITY FAILURE: GPU result differs from the CPU oracle")
+
+    # ---- sub-records: the other single-GPU configurations and the lookup-table-materialising step form,
+    # measured in the same run so that their numbers carry the driver's clock too
+    also = args.also
+    if also == "auto":
+        full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and world == 1 and not args.debug_mode
+        also = "c3_lut_materialized,c2,c5" if full_c3 and want_cpu and args.form == "graph" else "none"
+    if also != "none" and rank == 0:
+        leg.close()
+        recs = {}
+        for name in [x.strip() for x in also.split(",") if x.strip()]:
+            if name == "c3_lut_materialized":
+                recs[name] = also_record(args, torch, dev, "c3", "graph", True, args.also_steps, 20, exp_seed, "all")
+            elif name == "c2":
+                recs[name] = also_record(args, torch, dev, "c2", "graph", False, args.also_steps, 20, exp_seed, "all")
+            elif name == "c5":
+                recs[name] = also_record(args, torch, dev, "c5", "graph", False, max(10, args.also_steps // 4), 10,
+                                         exp_seed, "ends")
+            else:
+                raise SystemExit("unknown --also entry %r" % name)
+        result["also"] = recs
 
     if rank == 0:
         print(json.dumps(result))

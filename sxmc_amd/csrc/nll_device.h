@@ -124,9 +124,16 @@ __device__ __forceinline__ void nll_total_device(size_t nparameters, size_t nsig
 __device__ __forceinline__ double block_sum(size_t n, const double* sums, double* s_wave /*[17]*/) {
   double t = 0.0;
   for (size_t i = threadIdx.x; i < n; i += blockDim.x) t += sums[i];
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off, kWave);
+  // a block size that is not a multiple of 64 leaves the last wave partly empty: what a shuffle reads from
+  // a lane that does not exist is undefined, so those contributions are replaced by zero
   const int wave = threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int live = min(kWave, (int)blockDim.x - wave * kWave);
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const double o = __shfl_down(t, off, kWave);
+    t += (lane + off < live) ? o : 0.0;
+  }
   const int nwaves = (blockDim.x + kWave - 1) / kWave;
   if ((threadIdx.x & (kWave - 1)) == 0) s_wave[wave] = t;
   __syncthreads();

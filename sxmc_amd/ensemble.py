@@ -28,9 +28,12 @@ INTERVAL_FIELDS = ("point_estimate", "lower", "upper", "coverage")
 
 
 # ------------------------------------------------------------------------------------ fake data
-def get_efficiency(ev, nsyst_pars, syst_means):
-    """Signal::get_efficiency: fraction of the MC samples inside the PDF domain with every systematic
-    at its mean.  Leaves the evaluator bound to scratch buffers; returns (efficiency, bins)."""
+def get_efficiency(ev, nsyst_pars, syst_means, n_mc=None):
+    """Signal::get_efficiency (signal.cpp:172-199): in-domain count with every systematic at its mean,
+    divided by the signal's n_mc -- the number of simulated events BEFORE cuts (signal.cpp:198), which is
+    what the NLL kernels divide by too.  n_mc=None: the evaluator's row count (no cuts were applied).
+    Leaves the evaluator bound to scratch buffers (kept alive by the evaluator until it is re-bound);
+    returns (efficiency, bins, in-domain count)."""
     params = DeviceArray(np.asarray(syst_means, dtype=np.float64) if nsyst_pars else np.zeros(1))
     norm = DeviceArray.zeros(1, np.uint32)
     ev.SetNormalizationBuffer(norm)
@@ -38,7 +41,7 @@ def get_efficiency(ev, nsyst_pars, syst_means):
     ev.EvalAsync(False)
     ev.EvalFinished()
     n = int(norm.get()[0])
-    return n / float(ev.nsamples), ev.GetBins(), n
+    return n / float(ev.nsamples if n_mc is None else n_mc), ev.GetBins(), n
 
 
 def random_sample(rng, bins, lower, upper, nbins, nobserved):
@@ -67,7 +70,7 @@ def make_fake_dataset(rng, workload, evaluators, poisson=True):
     syst_means = w.parameter_means()[w.nsources:]
     rows, observed = [], []
     for sig, ev in zip(w.signals, evaluators):
-        eff, bins, _ = get_efficiency(ev, w.nsyst_pars, syst_means)
+        eff, bins, _ = get_efficiency(ev, w.nsyst_pars, syst_means, sig.n_mc)
         nevents = sig.nexpected * eff
         n = int(rng.poisson(nevents)) if poisson else int(math.floor(nevents + 0.5))
         pts = random_sample(rng, bins, w.lower, w.upper, w.nbins, n)

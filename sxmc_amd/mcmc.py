@@ -242,7 +242,9 @@ class MCMC:
         self.jump_counter.set(np.zeros(1, np.int32))
         self.accept_counter.set(np.zeros(1, np.int32))
         self.setup(data, sync_interval=sync_interval)
-        self._scale_factor = np.float32(2.4 * 2.4 / self.nparameters)
+        # mcmc.cpp:199: nfloat = the parameters that are not fixed (a fixed one carries jump width <= 0)
+        nfloat = max(1, int(np.count_nonzero(self.jump_width.get() > 0)))
+        self._scale_factor = np.float32(2.4 * 2.4 / nfloat)
         self._rows, self._accepted = [np.zeros((0, self.nparameters + 1), np.float32)], 0
 
     def _retune_if_due(self, i):

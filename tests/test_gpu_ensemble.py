@@ -38,6 +38,22 @@ def test_efficiency_and_fake_dataset_follow_the_histograms():
     assert start == data.shape[0]
 
 
+def test_efficiency_divides_by_the_count_before_cuts():
+    """signal.cpp:198: efficiency = in-domain count / n_mc, the number of simulated events BEFORE cuts -- the
+    same n_mc the NLL kernels divide the norms by -- not the number of rows that survived the cuts."""
+    w = workloads.config2(0.01, nevents=100)
+    for j, s in enumerate(w.signals):
+        s.nexpected = 20000.0
+        s.n_mc_total = 2 * s.samples.shape[0] + 17 * j          # cuts removed more than half of the rows
+    m = MCMC(w, seed=1)
+    _, observed = ensemble.make_fake_dataset(np.random.default_rng(2), w, m.pdfs, poisson=False)
+    geom = oracle.HistGeometry(w.lower, w.upper, w.nbins)
+    for j, s in enumerate(w.signals):
+        _, norm = oracle.bin_samples(geom, s.samples, s.nfields, [], np.zeros(1))
+        assert observed[j] == int(np.floor(s.nexpected * norm / s.n_mc_total + 0.5))
+        assert observed[j] < int(np.floor(s.nexpected * norm / s.samples.shape[0] + 0.5))
+
+
 def test_one_fake_experiment_end_to_end():
     w = workloads.config3(0.003, nevents=100)
     for s in w.signals:

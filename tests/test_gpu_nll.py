@@ -60,7 +60,8 @@ def test_nll_chain_matches_oracle(ne, ns, nsources):
     assert np.all(np.abs(sums) < 1e299)
 
 
-@pytest.mark.parametrize("grid,block,red", [(1, 64, 64), (3, 192, 256), (64, 256, 128), (16, 1024, 1024)])
+@pytest.mark.parametrize("grid,block,red", [(1, 64, 64), (3, 192, 256), (64, 256, 128), (16, 1024, 1024),
+                                            (5, 96, 96), (2, 33, 1)])   # partly filled waves in the reduction
 def test_nll_launch_shapes(grid, block, red):
     rng = np.random.default_rng(3)
     x = random_nll_inputs(rng, 5003, 6, 6)
