@@ -201,6 +201,7 @@ class Leg:
         m.group.SetLaunchConfig(threads, bpc)
         m.group.SetPartition(args.partition)
         m.group.SetPrebinning(not args.no_prebin)
+        m.group.SetBucketing(not args.no_bucket)
         m.group.SetSparse(not args.no_sparse)
         self.graph_state = {"steps_per_graph": args.graph_steps if form == "graph" else 0, "fallback": None}
         self.tuned_threads = 0
@@ -297,7 +298,7 @@ class Leg:
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else ""))
+                t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else ""))
             if t and self.scale == 1.0 and args.nsyst < 0:
                 traffic = t["bytes_per_launch"]
         except (OSError, ValueError):
@@ -472,6 +473,8 @@ def main():
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
     ap.add_argument("--no-sparse", action="store_true", help="fill HBM-resident histograms densely (global atomics)")
     ap.add_argument("--no-prebin", action="store_true", help="bin every observable in the kernel (no pre-binned column)")
+    ap.add_argument("--no-bucket", action="store_true",
+                    help="stream the table in the caller's row order (no copy grouped by the untouched observables' bins)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
     ap.add_argument("--debug-mode", type=int, default=0,
                     help="roofline measurement hook (wrong results): 1 stream only, 2 compute only, 4 no histogram")
@@ -574,7 +577,7 @@ def main():
     cfg = leg.config()
     cfg.update({
         "prewarm_steps": args.prewarm, "debug_mode": args.debug_mode, "partition": args.partition,
-        "prebinning": not args.no_prebin, "launch": args.launch,
+        "prebinning": not args.no_prebin, "bucketing": not args.no_bucket, "launch": args.launch,
         "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
         "samples_per_sec": value * w.nsamples_total,
         "experiments_per_sec_at_1e5_steps": value / 1e5,

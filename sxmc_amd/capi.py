@@ -91,6 +91,7 @@ SIGNATURES = {
     "sxmc_group_set_partition": [_vp, _i],
     "sxmc_group_set_sparse": [_vp, _i],
     "sxmc_group_set_prebinning": [_vp, _i],
+    "sxmc_group_set_bucketing": [_vp, _i],
     "sxmc_group_set_lut_output": [_vp, _i],
     "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_group_eval_async": [_vp, _i, _vp],

@@ -1,0 +1,139 @@
+// layout_kernels.hip -- one-off device work that builds the BUCKETED copy of an evaluator's sample table.
+//
+// An observable that no systematic writes has the same bin index at every evaluation (the reference
+// recomputes it per sample per step, pdfz.cpp:388-398).  Samples are therefore grouped, once, by the
+// tuple of bin indices of those observables ("bucket"): inside a bucket their contribution to the flat
+// bin index is one constant, so the fill streams only the columns that do change (the observables some
+// systematic writes + the truth fields they reference) and reads one word per 256 samples ("granule")
+// for the rest.  Samples outside the domain in an untouched observable can never be counted and are
+// dropped from the copy.  Counters are integers, so the order in which samples are visited does not
+// change a single count: results stay bit-identical (the parity tests compare with the
+// unbucketed evaluation and with the CPU restatement of the reference).
+//
+// Steps (host side: sxmc_hip.cpp build_bucketed): key per sample -> stable radix sort of (key, row) ->
+// first row of every key -> host lays the granules out -> gather of the streamed columns.
+#include "sxmc_device.h"
+
+#include <hipcub/hipcub.hpp>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// key = sum over the observables in `mask` of idx_k * radix_k, idx_k = (int)((x - lo) * scale) exactly as
+// the fill computes it (pdfz.cpp:388-398; idx_k == nbins_k can happen one ulp below the upper edge and is
+// a bucket of its own: radix bases are nbins_k + 1); `outside` for rows outside the domain (NaN included).
+struct KeyPlan {
+  unsigned mask;
+  unsigned outside;
+  unsigned radix[SXMC_MAX_NFIELDS];
+};
+
+__global__ __launch_bounds__(256) void bucket_key_kernel(const SxSignalDesc* __restrict__ dp, KeyPlan plan,
+                                                         unsigned* __restrict__ keys, unsigned* __restrict__ rows) {
+  const SxSignalDesc& d = *dp;
+  const unsigned long long n = d.nsamples;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    bool ok = true;
+    unsigned key = 0;
+    for (int k = 0; k < d.nobs; k++) {
+      if (!((plan.mask >> k) & 1u)) continue;
+      const double x = (double)d.cols[(unsigned long long)k * d.col_pitch + i];
+      ok = ok && (x >= d.lower[k]) && (x < d.upper[k]);
+      key += (unsigned)(int)((x - d.lower[k]) * d.scale[k]) * plan.radix[k];
+    }
+    keys[i] = ok ? key : plan.outside;
+    rows[i] = (unsigned)i;
+  }
+}
+
+// first[k] = position of the first row with key k in the sorted order (first[] pre-filled with all ones)
+__global__ __launch_bounds__(256) void bucket_first_kernel(const unsigned* __restrict__ sorted_keys,
+                                                           unsigned long long n, unsigned* __restrict__ first) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const unsigned k = sorted_keys[i];
+    if (i == 0 || sorted_keys[i - 1] != k) first[k] = (unsigned)i;
+  }
+}
+
+// One workgroup per granule per pass: row i of granule p comes from sorted position src[p] + i when
+// i < valid[p]; the rest of the granule is padding (NaN: outside every domain).
+struct GatherCols {
+  int ncols;
+  int col[SXMC_MAX_NFIELDS];
+};
+
+__global__ __launch_bounds__(256) void bucket_gather_kernel(const float* __restrict__ cols, unsigned long long pitch,
+                                                            GatherCols gc, const unsigned* __restrict__ sorted_rows,
+                                                            const unsigned* __restrict__ src,
+                                                            const unsigned* __restrict__ valid,
+                                                            unsigned long long ngranules, float* __restrict__ out,
+                                                            unsigned long long out_pitch) {
+  for (unsigned long long p = blockIdx.x; p < ngranules; p += gridDim.x) {
+    const unsigned i = threadIdx.x;
+    const bool live = i < valid[p];
+    const unsigned row = live ? sorted_rows[(unsigned long long)src[p] + i] : 0u;
+    for (int c = 0; c < gc.ncols; c++) {
+      out[(unsigned long long)c * out_pitch + p * 256ull + i] =
+          live ? cols[(unsigned long long)gc.col[c] * pitch + row] : __int_as_float(0x7fc00000);
+    }
+  }
+}
+
+unsigned grid_for(unsigned long long n, unsigned cap) {
+  unsigned long long b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+hipError_t sx_bucket_keys(const SxSignalDesc* d_desc, unsigned long long nsamples, unsigned mask, const unsigned* radix,
+                          unsigned outside, unsigned* d_keys, unsigned* d_rows, hipStream_t s) {
+  if (nsamples == 0) return hipSuccess;
+  KeyPlan plan;
+  plan.mask = mask;
+  plan.outside = outside;
+  for (int k = 0; k < SXMC_MAX_NFIELDS; k++) plan.radix[k] = radix[k];
+  hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_for(nsamples, 16384)), dim3(256), 0, s, d_desc, plan, d_keys, d_rows);
+  return hipGetLastError();
+}
+
+// stable sort of (key, row) pairs on the low `bits` bits of the key
+hipError_t sx_bucket_sort(const unsigned* keys_in, unsigned* keys_out, const unsigned* rows_in, unsigned* rows_out,
+                          unsigned long long n, int bits, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (n > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  size_t temp_bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, rows_in, rows_out, (int)n, 0,
+                                                    bits, s);
+  if (e != hipSuccess) return e;
+  void* temp = nullptr;
+  e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
+  if (e != hipSuccess) return e;
+  e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, rows_in, rows_out, (int)n, 0, bits, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(temp);
+  return e != hipSuccess ? e : e2;
+}
+
+hipError_t sx_bucket_first(const unsigned* sorted_keys, unsigned long long n, unsigned* d_first, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(bucket_first_kernel, dim3(grid_for(n, 16384)), dim3(256), 0, s, sorted_keys, n, d_first);
+  return hipGetLastError();
+}
+
+hipError_t sx_bucket_gather(const float* cols, unsigned long long pitch, int ncols, const int* col_list,
+                            const unsigned* sorted_rows, const unsigned* d_src, const unsigned* d_valid,
+                            unsigned long long ngranules, float* out, unsigned long long out_pitch, hipStream_t s) {
+  if (ngranules == 0 || ncols == 0) return hipSuccess;
+  GatherCols gc;
+  gc.ncols = ncols;
+  for (int c = 0; c < SXMC_MAX_NFIELDS; c++) gc.col[c] = c < ncols ? col_list[c] : 0;
+  const unsigned grid = (unsigned)(ngranules > 65536ull * 4 ? 65536ull * 4 : ngranules);
+  hipLaunchKernelGGL(bucket_gather_kernel, dim3(grid), dim3(256), 0, s, cols, pitch, gc, sorted_rows, d_src, d_valid,
+                     ngranules, out, out_pitch);
+  return hipGetLastError();
+}

@@ -238,6 +238,14 @@ __device__ __forceinline__ void sparse_count(const SxSignalDesc& d, gptr<unsigne
 // a narrow column holding sum_k idx_k * stride_k over those observables (all ones = outside the domain)
 // with exactly the arithmetic below, and the fill streams that column (PREW = 1, 2 or 4 bytes per
 // sample) instead of the float columns it replaces.  PREW = 0: every observable is read and binned here.
+//
+// BUCKETING (PREW = kPreGranule).  The same fact taken further (layout_kernels.hip): the evaluator keeps a
+// copy of the table sorted by the bin indices of the untouched observables, holding only the columns that
+// change (samples outside the domain in an untouched observable are not in it at all).  The kernel then
+// sees a lower-dimensional problem -- every observable it is given is binned here -- plus ONE word per
+// 256-sample granule: the granule's constant contribution to the flat bin index.  A wave reads exactly one
+// granule per step (units are 4 samples, a wave covers 64 consecutive units), so that word is wave-uniform.
+constexpr int kPreGranule = 3;
 template <int PREW> struct PreVec { typedef unsigned type; };
 template <> struct PreVec<2> { typedef unsigned type __attribute__((ext_vector_type(2))); };
 template <> struct PreVec<4> { typedef unsigned type __attribute__((ext_vector_type(4))); };
@@ -251,7 +259,7 @@ struct Columns {
 // slot k is streamed unless it is an observable that the pre-binned column covers
 template <int NOBS, int PREW, typename PROG>
 constexpr bool slot_loaded(int k) {
-  return PREW == 0 || k >= NOBS || ((PROG::touched >> k) & 1u);
+  return PREW == 0 || PREW == kPreGranule || k >= NOBS || ((PROG::touched >> k) & 1u);
 }
 
 template <int PREW>
@@ -259,6 +267,7 @@ __device__ __forceinline__ unsigned pre_value(const typename PreVec<PREW>::type&
   if constexpr (PREW == 1) return (p >> (8 * q)) & 0xFFu;
   if constexpr (PREW == 2) return (p[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
   if constexpr (PREW == 4) return p[q];
+  if constexpr (PREW == kPreGranule) return p;
   return 0u;
 }
 template <int PREW>
@@ -282,7 +291,10 @@ __device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr
       }
     }
   }
-  if constexpr (PREW != 0) {
+  if constexpr (PREW == kPreGranule) {
+    c.pre = pre[v >> 6];   // one word per granule: every lane of the wave asks for the same address
+    __builtin_amdgcn_sched_barrier(0);
+  } else if constexpr (PREW != 0) {
     c.pre = __builtin_nontemporal_load(&pre[v]);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
         int bin = 0;
         if constexpr (PREW != 0) {
           const unsigned pv = pre_value<PREW>(prebits, q);
-          bad += (pv == pre_sentinel<PREW>()) ? 1u : 0u;
+          if constexpr (PREW != kPreGranule) bad += (pv == pre_sentinel<PREW>()) ? 1u : 0u;
           bin = (int)pv;
         }
 #pragma unroll
@@ -474,7 +486,8 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
           const int idx = (int)((x - lo[k]) * sc[k]);
           if (LDS_HIST) {
             // histogram fits LDS => every index and stride is far below 2^23
-            bin = (k == NOBS - 1) ? bin + idx : __mul24(idx, st[k]) + bin;
+            // (the last observable of a full-dimensional problem has stride 1; a bucketed one need not)
+            bin = (k == NOBS - 1 && PREW != kPreGranule) ? bin + idx : __mul24(idx, st[k]) + bin;
           } else {
             bin += idx * st[k];
           }
@@ -949,6 +962,7 @@ struct StaticEntry {
                              // (with an LDS-sized histogram the partial index of the table's programs is < 65535)
   FillLauncher fn_g;         // histogram beyond LDS capacity (dense global atomics or sparse event-bin counters)
   FillLauncher fn_g_pre[2];
+  FillLauncher fn_gran[2];   // bucketed table (every observable given is binned, + one offset per granule): LDS / beyond LDS
 };
 #define SX_SHIFT(o) sx_op(SXMC_SYST_SHIFT, o)
 #define SX_SCALE(o) sx_op(SXMC_SYST_SCALE, o)
@@ -961,33 +975,41 @@ struct StaticEntry {
 #define SX_G(NO, NS, ...) \
   launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 0>, \
   {launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 1>, launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 2>}
-#define SX_P1(NO, NS, PRE, G, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE, G}
-#define SX_P2(NO, NS, PRE, G, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE, G}
-#define SX_P3(NO, NS, PRE, G, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE, G}
+#define SX_NOGRAN {nullptr, nullptr}
+#define SX_GRAN(NO, NS, ...) \
+  {launch_fill_k<NO, NS, true, StaticProg<__VA_ARGS__>, kPreGranule>, launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, kPreGranule>}
+#define SX_P1(NO, NS, PRE, G, GR, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE, G, GR}
+#define SX_P2(NO, NS, PRE, G, GR, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE, G, GR}
+#define SX_P3(NO, NS, PRE, G, GR, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE, G, GR}
 const StaticEntry kStaticPrograms[] = {
-    // 1-D (bench_sxmc pdfz: one shift; config/example.json: scale + resolution_scale)
-    SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_SHIFT(0)),
-    SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_SCALE(0)),
-    SX_P2(1, 1, SX_NOPRE, SX_NOG, SX_SHIFT(0), SX_SCALE(0)),
-    SX_P1(1, 2, SX_NOPRE, SX_NOG, SX_RES(0, 1)),
-    SX_P2(1, 2, SX_NOPRE, SX_NOG, SX_SCALE(0), SX_RES(0, 1)),
-    SX_P3(1, 2, SX_NOPRE, SX_NOG, SX_SHIFT(0), SX_SCALE(0), SX_RES(0, 1)),
+    // 1-D (bench_sxmc pdfz: one shift; config/example.json: scale + resolution_scale).  These are also what a
+    // bucketed higher-dimensional table with ONE observable written by systematics reduces to.
+    SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_GRAN(1, 1, SX_SHIFT(0)), SX_SHIFT(0)),
+    SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_GRAN(1, 1, SX_SCALE(0)), SX_SCALE(0)),
+    SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_GRAN(1, 1, SX_CTSC(0)), SX_CTSC(0)),
+    SX_P2(1, 1, SX_NOPRE, SX_NOG, SX_GRAN(1, 1, SX_SHIFT(0), SX_SCALE(0)), SX_SHIFT(0), SX_SCALE(0)),
+    SX_P1(1, 2, SX_NOPRE, SX_NOG, SX_GRAN(1, 2, SX_RES(0, 1)), SX_RES(0, 1)),
+    SX_P2(1, 2, SX_NOPRE, SX_NOG, SX_GRAN(1, 2, SX_SCALE(0), SX_RES(0, 1)), SX_SCALE(0), SX_RES(0, 1)),
+    SX_P3(1, 2, SX_NOPRE, SX_NOG, SX_GRAN(1, 2, SX_SHIFT(0), SX_SCALE(0), SX_RES(0, 1)), SX_SHIFT(0), SX_SCALE(0),
+          SX_RES(0, 1)),
     // 2-D
-    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(0)), SX_NOG, SX_SHIFT(0)),
-    SX_P1(2, 2, SX_PRE(2, 2, SX_SCALE(0)), SX_NOG, SX_SCALE(0)),
-    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(1)), SX_NOG, SX_SHIFT(1)),
-    SX_P2(2, 3, SX_PRE(2, 3, SX_SCALE(0), SX_RES(0, 2)), SX_NOG, SX_SCALE(0), SX_RES(0, 2)),
-    SX_P3(2, 3, SX_NOPRE, SX_NOG, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 2)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(0)), SX_NOG, SX_NOGRAN, SX_SHIFT(0)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SCALE(0)), SX_NOG, SX_NOGRAN, SX_SCALE(0)),
+    SX_P1(2, 2, SX_PRE(2, 2, SX_SHIFT(1)), SX_NOG, SX_NOGRAN, SX_SHIFT(1)),
+    SX_P2(2, 3, SX_PRE(2, 3, SX_SCALE(0), SX_RES(0, 2)), SX_NOG, SX_NOGRAN, SX_SCALE(0), SX_RES(0, 2)),
+    // (also what BASELINE configs 3 and 5 reduce to once bucketed: e and r are written, the rest is not)
+    SX_P3(2, 3, SX_NOPRE, SX_NOG, SX_GRAN(2, 3, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 2)), SX_SHIFT(1), SX_SCALE(0),
+          SX_RES(0, 2)),
     // 3-D (BASELINE config 3: shift(r) + scale(e) + resolution_scale(e | e_true))
-    SX_P1(3, 3, SX_PRE(3, 3, SX_SHIFT(0)), SX_NOG, SX_SHIFT(0)),
-    SX_P1(3, 3, SX_PRE(3, 3, SX_SCALE(0)), SX_NOG, SX_SCALE(0)),
-    SX_P1(3, 4, SX_PRE(3, 4, SX_RES(0, 3)), SX_NOG, SX_RES(0, 3)),
-    SX_P2(3, 4, SX_PRE(3, 4, SX_SCALE(0), SX_RES(0, 3)), SX_NOG, SX_SCALE(0), SX_RES(0, 3)),
+    SX_P1(3, 3, SX_PRE(3, 3, SX_SHIFT(0)), SX_NOG, SX_NOGRAN, SX_SHIFT(0)),
+    SX_P1(3, 3, SX_PRE(3, 3, SX_SCALE(0)), SX_NOG, SX_NOGRAN, SX_SCALE(0)),
+    SX_P1(3, 4, SX_PRE(3, 4, SX_RES(0, 3)), SX_NOG, SX_NOGRAN, SX_RES(0, 3)),
+    SX_P2(3, 4, SX_PRE(3, 4, SX_SCALE(0), SX_RES(0, 3)), SX_NOG, SX_NOGRAN, SX_SCALE(0), SX_RES(0, 3)),
     SX_P3(3, 4, SX_PRE(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
-          SX_G(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)), SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
+          SX_G(3, 4, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)), SX_NOGRAN, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 3)),
     // 5-D (BASELINE config 5: the same three systematics, histograms beyond LDS capacity)
     SX_P3(5, 6, SX_PRE(5, 6, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)),
-          SX_G(5, 6, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)), SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)),
+          SX_G(5, 6, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)), SX_NOGRAN, SX_SHIFT(1), SX_SCALE(0), SX_RES(0, 5)),
 };
 constexpr int kNumStatic = (int)(sizeof(kStaticPrograms) / sizeof(kStaticPrograms[0]));
 
@@ -1004,10 +1026,12 @@ bool sx_fill_has_specialization(int nobs, int nslot) {
   return nobs >= 1 && nobs <= 5 && nslot >= nobs && nslot <= nobs + 2;
 }
 
-// does static program `prog` have a kernel for this histogram mode, without / with a pre-binned column?
+// does static program `prog` have a kernel for this histogram mode, without / with a pre-binned column
+// (prebin = 1) / for a bucketed table (prebin = 3)?
 bool sx_fill_static_supports(int prog, int lds_hist, int prebin) {
   if (prog < 0 || prog >= kNumStatic) return false;
   const StaticEntry& e = kStaticPrograms[prog];
+  if (prebin == kPreGranule) return e.fn_gran[lds_hist ? 0 : 1] != nullptr;
   if (prebin) return (lds_hist ? e.fn_pre[0] : e.fn_g_pre[0]) != nullptr;
   return (lds_hist ? e.fn : e.fn_g) != nullptr;
 }
@@ -1040,6 +1064,8 @@ hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, co
     FillLauncher fn = nullptr;
     if (sh.pre_width == 0) {
       fn = sh.lds_hist ? e.fn : e.fn_g;
+    } else if (sh.pre_width == kPreGranule) {
+      fn = e.fn_gran[sh.lds_hist ? 0 : 1];
     } else if (sh.pre_width == 1 || sh.pre_width == 2) {
       fn = sh.lds_hist ? e.fn_pre[sh.pre_width - 1] : e.fn_g_pre[sh.pre_width - 1];
     }

@@ -51,7 +51,8 @@ struct SxSignalDesc {
   double scale[SXMC_MAX_NFIELDS];  // nbins / (upper - lower), computed on the host in double
   SxSystOp syst[SXMC_MAX_SYST];
   short coef_par[64];            // coefficient lane -> parameter index
-  const void* pre;               // pre-binned column of the observables no systematic writes (or null)
+  const void* pre;               // pre-binned column of the observables no systematic writes (or null); for a
+                                 // bucketed table: one bin offset per 256-sample granule
   // --- sparse counting (histograms too large for LDS, evaluation for lookup only): `bins` then points
   //     at one counter per DISTINCT EVENT BIN, `read_bins` at the events' counter slots, and the fill maps
   //     a sample's flat bin index to its slot through a one-hash bit filter and an open-addressing table
@@ -110,7 +111,8 @@ struct SxLaunchShape {
   size_t lds_bytes;
   int debug_mode;   // measurement hook, see fill_kernel
   int static_prog;  // index into the static program table, or -1: decode the program at run time
-  int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none
+  int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none, 3 = bucketed table (one
+                    // bin offset per 256-sample granule)
 };
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
@@ -126,6 +128,15 @@ int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* o
 bool sx_fill_static_supports(int prog, int lds_hist, int prebin);
 hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,
                             hipStream_t s);
+// bucketed copy of a sample table (layout_kernels.hip)
+hipError_t sx_bucket_keys(const SxSignalDesc* d_desc, unsigned long long nsamples, unsigned mask, const unsigned* radix,
+                          unsigned outside, unsigned* d_keys, unsigned* d_rows, hipStream_t s);
+hipError_t sx_bucket_sort(const unsigned* keys_in, unsigned* keys_out, const unsigned* rows_in, unsigned* rows_out,
+                          unsigned long long n, int bits, hipStream_t s);
+hipError_t sx_bucket_first(const unsigned* sorted_keys, unsigned long long n, unsigned* d_first, hipStream_t s);
+hipError_t sx_bucket_gather(const float* cols, unsigned long long pitch, int ncols, const int* col_list,
+                            const unsigned* sorted_rows, const unsigned* d_src, const unsigned* d_valid,
+                            unsigned long long ngranules, float* out, unsigned long long out_pitch, hipStream_t s);
 hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,
                               hipStream_t s);
 hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,

@@ -111,9 +111,38 @@ struct SampleStore {
       if (p.mask == mask && p.width == width) return p.ptr;
     return nullptr;
   }
+  // Bucketed copies built so far (layout_kernels.hip), one per (untouched-observable mask, streamed fields,
+  // runs); kept until the table dies for the same reason.  `rejected`: building it was tried and the padding
+  // of the granules would have outweighed the columns saved (tiny tables with many buckets).
+  struct Bucketed {
+    unsigned mask = 0;
+    std::vector<int> fields;        // streamed fields, in the order of the compacted slots
+    int runs = 1;                   // granule order transposed for this many runs (1 = sorted order)
+    bool rejected = false;
+    float* d_cols = nullptr;        // [fields.size()][pitch]
+    size_t pitch = 0;
+    unsigned* d_gpre = nullptr;     // [ngranules] bin offset of the granule
+    unsigned* d_gkey = nullptr;     // [ngranules] dense bucket key of the granule
+    size_t ngranules = 0;           // physical granules (with the runs' padding)
+    size_t nkept = 0;               // samples in the copy (inside the domain of every untouched observable)
+    std::vector<unsigned> keys;     // bucket keys present, ascending (host copy)
+    std::vector<unsigned> key_pre;  // bin offset of each of them
+    unsigned nkeys_total = 0;       // size of the key space
+  };
+  std::vector<std::unique_ptr<Bucketed>> bucketed;
+  Bucketed* find_bucketed(unsigned mask, const std::vector<int>& fields, int runs) const {
+    for (const auto& b : bucketed)
+      if (b->mask == mask && b->fields == fields && b->runs == runs) return b.get();
+    return nullptr;
+  }
   ~SampleStore() {
     if (d_cols) (void)hipFree(d_cols);
     for (PreColumn& p : pre) (void)hipFree(p.ptr);
+    for (auto& b : bucketed) {
+      if (b->d_cols) (void)hipFree(b->d_cols);
+      if (b->d_gpre) (void)hipFree(b->d_gpre);
+      if (b->d_gkey) (void)hipFree(b->d_gkey);
+    }
   }
 };
 
@@ -191,7 +220,8 @@ void free_class(LaunchClass& c) {
 //  sliced: workgroup b owns the contiguous slice [total*b/G, total*(b+1)/G) of the concatenated
 //    members: perfectly balanced, used when members outnumber workgroups or are tiny.
 void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threads, int want_mode,
-                     std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off, int& mode_out) {
+                     std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off, int& mode_out,
+                     unsigned long long align = 1) {
   segs.clear();
   blk_off.assign(1, 0u);
   unsigned long long total = 0;
@@ -245,8 +275,9 @@ void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threa
     return;
   }
   for (int b = 0; b < grid; b++) {
-    unsigned long long r0 = total * (unsigned long long)b / grid;
-    const unsigned long long r1 = total * (unsigned long long)(b + 1) / grid;
+    // (bucketed tables: slices start on granule boundaries; every member's unit count is a multiple of `align`)
+    unsigned long long r0 = total * (unsigned long long)b / grid / align * align;
+    const unsigned long long r1 = b + 1 == grid ? total : total * (unsigned long long)(b + 1) / grid / align * align;
     unsigned long long start = 0;
     for (size_t j = 0; j < descs.size() && r0 < r1; j++) {
       const unsigned long long s0 = start, s1 = start + descs[j].nvec;
@@ -280,6 +311,8 @@ struct sxmc_group {
   int cfg_seen_threads = -1, cfg_seen_bpc = -1;
   int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
   int cfg_prebin = 1, cfg_seen_prebin = -1;        // pre-bin the observables no systematic writes
+  int cfg_bucket = 1, cfg_seen_bucket = -1;        // stream a bucketed copy of the table where that pays
+  std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
   int debug_mode = 0;
   int max_bins = 0;
   unsigned long long max_points = 0;
@@ -473,6 +506,160 @@ int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
   return SXMC_OK;
 }
 
+struct DevBuf {  // device temporary, freed on scope exit
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+// The bucketed copy of member `h`'s table (layout_kernels.hip): samples grouped by their bin indices in the
+// observables of `mask` (those no systematic writes), holding the columns `fields`; granule order transposed
+// for `runs` runs.  Fetched from the table's cache or built; *out = nullptr when it does not pay for this table
+// (the granules' padding would outweigh the columns saved).  d_full_desc: the member's descriptor on the device.
+int get_bucketed(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask, const std::vector<int>& fields,
+                 int runs, const SampleStore::Bucketed** out) {
+  *out = nullptr;
+  SampleStore& st = *h->store;
+  std::lock_guard<std::mutex> lock(st.pre_mutex);
+  if (SampleStore::Bucketed* have = st.find_bucketed(mask, fields, runs)) {
+    *out = have->rejected ? nullptr : have;
+    return SXMC_OK;
+  }
+  st.bucketed.push_back(std::make_unique<SampleStore::Bucketed>());
+  SampleStore::Bucketed* b = st.bucketed.back().get();
+  b->mask = mask;
+  b->fields = fields;
+  b->runs = runs;
+  b->rejected = true;  // until it is complete
+  const size_t n = h->nsamples;
+  if (n == 0 || n > 0x7FFFFF00ull || fields.empty() || runs < 1) return SXMC_OK;
+
+  // key space: mixed radix over the untouched observables, last one fastest, bases nbins + 1 (an index can
+  // come out as nbins one ulp below the upper edge; such samples form buckets of their own)
+  unsigned radix[SXMC_MAX_NFIELDS] = {0};
+  unsigned long long nkeys = 1;
+  for (int k = h->nobs - 1; k >= 0; k--) {
+    if (!((mask >> k) & 1u)) continue;
+    radix[k] = (unsigned)nkeys;
+    nkeys *= (unsigned long long)h->nbins[(size_t)k] + 1ull;
+    if (nkeys > (1ull << 20)) return SXMC_OK;
+  }
+  const unsigned outside = (unsigned)nkeys;
+  const int bits = ceil_log2((size_t)nkeys + 1);
+
+  DevBuf keys0, keys1, rows0, rows1, dfirst, dsrc, dvalid;
+  SX_HIP(keys0.alloc(n * 4));
+  SX_HIP(keys1.alloc(n * 4));
+  SX_HIP(rows0.alloc(n * 4));
+  SX_HIP(rows1.alloc(n * 4));
+  SX_HIP(dfirst.alloc((nkeys + 1) * 4));
+  SX_HIP(hipMemset(dfirst.p, 0xFF, (nkeys + 1) * 4));
+  SX_HIP(sx_bucket_keys(d_full_desc, n, mask, radix, outside, keys0.as<unsigned>(), rows0.as<unsigned>(), nullptr));
+  SX_HIP(sx_bucket_sort(keys0.as<unsigned>(), keys1.as<unsigned>(), rows0.as<unsigned>(), rows1.as<unsigned>(), n, bits,
+                        nullptr));
+  SX_HIP(sx_bucket_first(keys1.as<unsigned>(), n, dfirst.as<unsigned>(), nullptr));
+  std::vector<unsigned> first((size_t)nkeys + 1);
+  SX_HIP(hipMemcpy(first.data(), dfirst.p, first.size() * 4, hipMemcpyDeviceToHost));
+
+  const size_t kept = first[outside] != 0xFFFFFFFFu ? first[outside] : n;
+  std::vector<unsigned> present;
+  for (unsigned k = 0; k < outside; k++)
+    if (first[k] != 0xFFFFFFFFu) present.push_back(k);
+  // logical granules: bucket by bucket, each bucket padded to whole granules
+  std::vector<unsigned> lsrc, lvalid, lwhich;
+  for (size_t i = 0; i < present.size(); i++) {
+    const size_t lo = first[present[i]], hi = i + 1 < present.size() ? first[present[i + 1]] : kept;
+    for (size_t at = lo; at < hi; at += 256) {
+      lsrc.push_back((unsigned)at);
+      lvalid.push_back((unsigned)std::min<size_t>(256, hi - at));
+      lwhich.push_back((unsigned)i);
+    }
+  }
+  const size_t L = lsrc.size();
+  if ((double)L * 256.0 > 1.3 * (double)kept + 16384.0) return SXMC_OK;  // mostly padding: not worth it
+
+  b->keys = present;
+  b->nkeys_total = outside;
+  b->key_pre.resize(present.size());
+  for (size_t i = 0; i < present.size(); i++) {
+    long long pre = 0;
+    for (int k = 0; k < h->nobs; k++) {
+      if (!((mask >> k) & 1u)) continue;
+      const unsigned idx = (present[i] / radix[k]) % ((unsigned)h->nbins[(size_t)k] + 1u);
+      pre += (long long)idx * h->stride[(size_t)k];
+    }
+    b->key_pre[i] = (unsigned)pre;
+  }
+  // physical order: run r holds logical granules [r * T, (r + 1) * T), and the runs are interleaved granule by
+  // granule (physical p = t * runs + r), so that `runs` consumers that each walk one run read neighbouring
+  // addresses at the same time.  runs = 1: the sorted order itself.
+  const size_t T = (L + (size_t)runs - 1) / (size_t)runs, P = T * (size_t)runs;
+  std::vector<unsigned> psrc(std::max<size_t>(P, 1), 0u), pvalid(std::max<size_t>(P, 1), 0u),
+      ppre(std::max<size_t>(P, 1), 0u), pkey(std::max<size_t>(P, 1), outside);
+  for (size_t p = 0; p < P; p++) {
+    const size_t r = p % (size_t)runs, t = p / (size_t)runs, l = r * T + t;
+    if (l < L) {
+      psrc[p] = lsrc[l];
+      pvalid[p] = lvalid[l];
+      ppre[p] = b->key_pre[lwhich[l]];
+      pkey[p] = present[lwhich[l]];
+    } else {  // padding granule at the end of the last runs: no samples, stays in the last bucket
+      pkey[p] = L ? present[lwhich[L - 1]] : outside;
+    }
+  }
+  b->ngranules = P;
+  b->nkept = kept;
+  b->pitch = std::max<size_t>(64, P * 256);
+  SX_HIP(hipMalloc((void**)&b->d_cols, sizeof(float) * b->pitch * fields.size()));
+  SX_HIP(hipMalloc((void**)&b->d_gpre, sizeof(unsigned) * psrc.size()));
+  SX_HIP(hipMalloc((void**)&b->d_gkey, sizeof(unsigned) * psrc.size()));
+  SX_HIP(hipMemcpy(b->d_gpre, ppre.data(), sizeof(unsigned) * psrc.size(), hipMemcpyHostToDevice));
+  SX_HIP(hipMemcpy(b->d_gkey, pkey.data(), sizeof(unsigned) * psrc.size(), hipMemcpyHostToDevice));
+  SX_HIP(dsrc.alloc(psrc.size() * 4));
+  SX_HIP(dvalid.alloc(psrc.size() * 4));
+  SX_HIP(hipMemcpy(dsrc.p, psrc.data(), psrc.size() * 4, hipMemcpyHostToDevice));
+  SX_HIP(hipMemcpy(dvalid.p, pvalid.data(), psrc.size() * 4, hipMemcpyHostToDevice));
+  SX_HIP(sx_bucket_gather(st.d_cols, h->pitch, (int)fields.size(), fields.data(), rows1.as<unsigned>(),
+                          dsrc.as<unsigned>(), dvalid.as<unsigned>(), P, b->d_cols, b->pitch, nullptr));
+  SX_HIP(hipDeviceSynchronize());
+  b->rejected = false;
+  *out = b;
+  return SXMC_OK;
+}
+
+// The member's problem as the fill sees it once its table is bucketed: only the observables some systematic
+// writes (+ the extra fields), slots renumbered, columns = the bucketed copy.  `keep`: full slot -> new slot or -1.
+void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, SxSignalDesc& cd) {
+  cd = full;
+  int nobs = 0, nslot = 0;
+  for (int k = 0; k < full.nslot; k++) {
+    if (keep[(size_t)k] < 0) continue;
+    const int q = keep[(size_t)k];
+    cd.slot_col[q] = q;  // the copy holds exactly the streamed fields, in slot order
+    if (k < full.nobs) {
+      cd.bin_stride[q] = full.bin_stride[k];
+      cd.lower[q] = full.lower[k];
+      cd.upper[q] = full.upper[k];
+      cd.scale[q] = full.scale[k];
+      nobs++;
+    }
+    nslot++;
+  }
+  cd.nobs = nobs;
+  cd.nslot = nslot;
+  for (int q = 0; q < full.nsyst; q++) {
+    cd.syst[q].obs_slot = (short)keep[(size_t)full.syst[q].obs_slot];
+    cd.syst[q].extra_slot =
+        (short)(full.syst[q].type == SXMC_SYST_RESOLUTION_SCALE ? keep[(size_t)full.syst[q].extra_slot] : 0);
+  }
+}
+
 int group_rebuild(sxmc_group* g) {
   // Descriptors may still be read by kernels in flight on another stream: rebuilds are rare
   // (bindings change only during setup), so a device-wide sync is the simple safe choice.
@@ -492,47 +679,113 @@ int group_rebuild(sxmc_group* g) {
   int threads = g->cfg_threads > 0 ? g->cfg_threads : 512;
   if (threads < 64 || threads > 1024 || threads % 64) threads = 512;
 
+  for (int i = 0; i < n; i++) fill_desc(g->members[i], g->h_descs[i]);
+  if (!g->d_descs) SX_HIP(hipMalloc((void**)&g->d_descs, sizeof(SxSignalDesc) * std::max(n, 1)));
+  if (n) SX_HIP(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
+
+  std::vector<SxSignalDesc> fill_descs((size_t)n);  // each member as its fill launch sees it
+  g->member_bucket.assign((size_t)n, nullptr);
   for (int i = 0; i < n; i++) {
     sxmc_hist* h = g->members[i];
-    SxSignalDesc& d = g->h_descs[i];
-    fill_desc(h, d);
+    const SxSignalDesc& d = g->h_descs[i];
+    fill_descs[(size_t)i] = d;
     g->max_bins = std::max(g->max_bins, h->total_nbins);
     g->max_points = std::max<unsigned long long>(g->max_points, d.npoints);
     if (!h->has_points || h->npoints != g->members[0]->npoints) g->same_points = false;
 
     const int lds_hist = h->total_nbins <= kLdsMaxBins ? 1 : 0;
-    const bool spec = sx_fill_has_specialization(d.nobs, d.nslot) && d.ncoef <= 64;
-    const int key_nobs = spec ? d.nobs : 0, key_nslot = spec ? d.nslot : 0;
-    // the member's program as static-table words (type | obs_slot << 4 | extra_slot << 8)
-    std::vector<unsigned> prog;
-    bool prog_simple = spec && d.nsyst <= 4;
-    for (int q = 0; q < d.nsyst; q++) {
-      if (d.syst[q].npars != 1) prog_simple = false;
-      prog.push_back((unsigned)d.syst[q].type | ((unsigned)d.syst[q].obs_slot << 4) |
-                     ((unsigned)d.syst[q].extra_slot << 8));
-    }
-    // pre-binning: observables that no systematic writes (static programs only)
-    int static_prog = (prog_simple && !prog.empty())
-                          ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
-                          : -1;
-    if (!sx_fill_static_supports(static_prog, lds_hist, 0)) static_prog = -1;
-    if (static_prog < 0) prog_simple = false;
+    int key_nobs = 0, key_nslot = 0, static_prog = -1, pre_width = 0;
     unsigned pre_mask = 0;
-    int pre_width = 0;
-    if (g->cfg_prebin && sx_fill_static_supports(static_prog, lds_hist, 1)) {
+    std::vector<unsigned> prog;
+    bool prog_simple = false;
+
+    // ---- bucketed table: the observables no systematic writes become a per-granule bin offset and the
+    // fill sees the lower-dimensional problem of the ones that are written
+    bool bucketed = false;
+    if (g->cfg_bucket && d.nsyst > 0 && d.nsyst <= 4 && d.ncoef <= 64) {
       unsigned touched = 0;
-      for (int q = 0; q < d.nsyst; q++) touched |= 1u << d.syst[q].obs_slot;
-      long long bound = 0;  // largest value the partial index can take (index == nbins included)
-      for (int k = 0; k < d.nobs; k++) {
-        if (!((touched >> k) & 1u)) {
-          pre_mask |= 1u << k;
-          bound += (long long)h->nbins[(size_t)k] * h->stride[(size_t)k];
+      bool one_coef = true;
+      for (int q = 0; q < d.nsyst; q++) {
+        touched |= 1u << d.syst[q].obs_slot;
+        one_coef = one_coef && d.syst[q].npars == 1;
+      }
+      unsigned mask = 0;
+      std::vector<int> keep((size_t)d.nslot, -1), fields;
+      int nobs2 = 0;
+      for (int k = 0; k < d.nslot; k++) {
+        if (k < d.nobs && !((touched >> k) & 1u)) {
+          mask |= 1u << k;
+          continue;
+        }
+        keep[(size_t)k] = (int)fields.size();
+        fields.push_back(d.slot_col[k]);
+        if (k < d.nobs) nobs2++;
+      }
+      if (mask && nobs2 >= 1 && one_coef && sx_fill_has_specialization(nobs2, (int)fields.size())) {
+        SxSignalDesc cd;
+        compact_desc(d, keep, cd);
+        std::vector<unsigned> prog2;
+        for (int q = 0; q < cd.nsyst; q++) {
+          prog2.push_back((unsigned)cd.syst[q].type | ((unsigned)cd.syst[q].obs_slot << 4) |
+                          ((unsigned)cd.syst[q].extra_slot << 8));
+        }
+        const int sp = sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
+        if (sx_fill_static_supports(sp, lds_hist, 3)) {
+          const SampleStore::Bucketed* bk = nullptr;
+          rc = get_bucketed(h, g->d_descs + i, mask, fields, 1, &bk);
+          if (rc) return rc;
+          if (bk) {
+            cd.cols = bk->d_cols;
+            cd.col_pitch = bk->pitch;
+            cd.nsamples = bk->ngranules * 256;
+            cd.nvec = bk->ngranules * 64;
+            cd.pre = bk->d_gpre;
+            fill_descs[(size_t)i] = cd;
+            g->member_bucket[(size_t)i] = bk;
+            bucketed = true;
+            key_nobs = cd.nobs;
+            key_nslot = cd.nslot;
+            prog = prog2;
+            prog_simple = true;
+            static_prog = sp;
+            pre_mask = mask;
+            pre_width = 3;
+          }
         }
       }
-      pre_width = bound < 0xFF ? 1 : 2;
-      if (!pre_mask || bound >= 0xFFFF) {
-        pre_mask = 0;
-        pre_width = 0;
+    }
+    if (!bucketed) {
+      const bool spec = sx_fill_has_specialization(d.nobs, d.nslot) && d.ncoef <= 64;
+      key_nobs = spec ? d.nobs : 0;
+      key_nslot = spec ? d.nslot : 0;
+      // the member's program as static-table words (type | obs_slot << 4 | extra_slot << 8)
+      prog_simple = spec && d.nsyst <= 4;
+      for (int q = 0; q < d.nsyst; q++) {
+        if (d.syst[q].npars != 1) prog_simple = false;
+        prog.push_back((unsigned)d.syst[q].type | ((unsigned)d.syst[q].obs_slot << 4) |
+                       ((unsigned)d.syst[q].extra_slot << 8));
+      }
+      // pre-binning: observables that no systematic writes (static programs only)
+      static_prog = (prog_simple && !prog.empty())
+                        ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
+                        : -1;
+      if (!sx_fill_static_supports(static_prog, lds_hist, 0)) static_prog = -1;
+      if (static_prog < 0) prog_simple = false;
+      if (g->cfg_prebin && sx_fill_static_supports(static_prog, lds_hist, 1)) {
+        unsigned touched = 0;
+        for (int q = 0; q < d.nsyst; q++) touched |= 1u << d.syst[q].obs_slot;
+        long long bound = 0;  // largest value the partial index can take (index == nbins included)
+        for (int k = 0; k < d.nobs; k++) {
+          if (!((touched >> k) & 1u)) {
+            pre_mask |= 1u << k;
+            bound += (long long)h->nbins[(size_t)k] * h->stride[(size_t)k];
+          }
+        }
+        pre_width = bound < 0xFF ? 1 : 2;
+        if (!pre_mask || bound >= 0xFFFF) {
+          pre_mask = 0;
+          pre_width = 0;
+        }
       }
     }
     LaunchClass* cls = nullptr;
@@ -560,8 +813,6 @@ int group_rebuild(sxmc_group* g) {
     cls->member_idx.push_back(i);
   }
 
-  if (!g->d_descs) SX_HIP(hipMalloc((void**)&g->d_descs, sizeof(SxSignalDesc) * std::max(n, 1)));
-  if (n) SX_HIP(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
   // sparse flavour: members whose histogram exceeds LDS count into per-event-bin counters
   std::vector<SxSignalDesc> sparse_descs = g->h_descs;
   g->sparse_ready = false;
@@ -602,8 +853,8 @@ int group_rebuild(sxmc_group* g) {
     unsigned long long prefix = 0;
     int cls_max_bins = 0;
     for (int idx : c.member_idx) {
-      SxSignalDesc d = g->h_descs[idx];
-      if (c.shape.pre_width) {
+      SxSignalDesc d = fill_descs[(size_t)idx];
+      if (c.shape.pre_width == 1 || c.shape.pre_width == 2) {
         sxmc_hist* h = g->members[idx];
         SampleStore& st = *h->store;
         std::lock_guard<std::mutex> lock(st.pre_mutex);
@@ -666,7 +917,8 @@ int group_rebuild(sxmc_group* g) {
     if (c.shape.grid > 0) {
       std::vector<SxSegment> segs;
       std::vector<unsigned> blk_off;
-      build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition);
+      build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition,
+                      c.shape.pre_width == 3 ? 64 : 1);
       SX_HIP(hipMalloc((void**)&c.d_segs, sizeof(SxSegment) * std::max<size_t>(segs.size(), 1)));
       SX_HIP(hipMalloc((void**)&c.d_blk_off, sizeof(unsigned) * blk_off.size()));
       if (!segs.empty()) {
@@ -682,13 +934,15 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_bpc = g->cfg_bpc;
   g->cfg_seen_partition = g->cfg_partition;
   g->cfg_seen_prebin = g->cfg_prebin;
+  g->cfg_seen_bucket = g->cfg_bucket;
   g->built = true;
   return SXMC_OK;
 }
 
 int group_refresh(sxmc_group* g) {
   bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc ||
-               g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_prebin != g->cfg_prebin;
+               g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_prebin != g->cfg_prebin ||
+               g->cfg_seen_bucket != g->cfg_bucket;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
   }
@@ -1476,6 +1730,12 @@ int sxmc_group_set_prebinning(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_bucketing(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_bucket = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
 int sxmc_group_set_lut_output(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_lut = enable ? 1 : 0;
@@ -1707,7 +1967,13 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
         }
       }
     }
-    fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
+    if (const SampleStore::Bucketed* bk = i < g->member_bucket.size() ? g->member_bucket[i] : nullptr) {
+      // bucketed table: the columns that change, for the samples inside the domain of the untouched observables,
+      // + one word per granule
+      fr += (double)bk->nkept * 4.0 * (double)bk->fields.size() + 4.0 * (double)bk->ngranules;
+    } else {
+      fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
+    }
     if (h->total_nbins <= kLdsMaxBins) {
       hb += 4.0 * (double)h->total_nbins;                       // LDS-private, flushed once
     } else if (g->sparse_ready && g->cfg_sparse) {

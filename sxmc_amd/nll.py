@@ -93,6 +93,10 @@ class EvalGroup:
         """Stream observables that no systematic writes as one pre-binned narrow column (default on)."""
         capi.call("sxmc_group_set_prebinning", self._g, int(bool(enable)))
 
+    def SetBucketing(self, enable):
+        """Stream a copy of the table grouped by the bins of the observables no systematic writes (default on)."""
+        capi.call("sxmc_group_set_bucketing", self._g, int(bool(enable)))
+
     def SetLutOutput(self, enable):
         """False: EvalNllAsync / McmcStepAsync do not write the lookup table and sum over the distinct tuples
         of event bins, weighted by multiplicity (see include/sxmc_hip.h).  Default True."""

@@ -389,6 +389,7 @@ def test_prebinned_observables_give_identical_histograms(nobs, nbins, systs, par
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=nfields)
     # edge cases in the pre-binned columns: NaN, exact edges, out of domain
     group = nll.EvalGroup(evs)
+    group.SetBucketing(False)          # (bucketing would take precedence: test_bucketed_table_* covers it)
     results = []
     for prebin in (True, False):
         group.SetPrebinning(prebin)
@@ -402,6 +403,81 @@ def test_prebinned_observables_give_identical_histograms(nobs, nbins, systs, par
         o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, systs, params)
         for bins, nrm, _ in results:
             assert np.array_equal(bins[j], o["bins"]) and nrm[j] == o["norm"]
+
+
+C5_LIKE = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+           dict(type="resolution_scale", obs=0, true_obs=5, pars=[2])]
+
+
+@pytest.mark.parametrize("nobs,nbins,systs,params,nfields", [
+    (3, [20, 20, 20], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+                       dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])], [0.02, -0.01, 0.07], 5),  # C3
+    (3, [10, 30, 40], [dict(type="scale", obs=0, pars=[0])], [0.03], 5),        # 1271 buckets: small tables fall back
+    (3, [4, 3, 5], [dict(type="resolution_scale", obs=0, true_obs=3, pars=[0])], [0.2], 5),
+    (2, [200, 200], [dict(type="shift", obs=1, pars=[0])], [-0.02], 4),         # the written observable is the last one
+    (2, [9, 7], [dict(type="scale", obs=0, pars=[0]), dict(type="resolution_scale", obs=0, true_obs=2, pars=[1])],
+     [0.01, 0.1], 4),
+    (3, [5, 5, 8], [dict(type="ctscale", obs=2, pars=[0])], [0.04], 4),
+    (3, [6, 7, 8], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=1, pars=[1])], [0.01, -0.02], 4),
+    (5, [6, 5, 4, 3, 2], C5_LIKE, [0.02, -0.01, 0.07], 7),                      # C5's shape, histogram in LDS
+    (5, [60, 50, 8, 3, 2], C5_LIKE, [0.02, -0.01, 0.07], 7),                    # ... and beyond LDS (144000 bins)
+])
+def test_bucketed_table_gives_identical_histograms(nobs, nbins, systs, params, nfields):
+    """Samples grouped by the bins of the observables no systematic writes; the fill streams only the columns
+    that change + one bin offset per 256-sample granule.  Histograms and norms must be those of the oracle and
+    of the same launch with bucketing off (pre-binned column) and with both off."""
+    rng = np.random.default_rng(15)
+    sizes = [70001, 3, 123457, 0, 255, 257]
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=nfields)
+    group = nll.EvalGroup(evs)
+    results = []
+    for bucket, prebin in ((True, True), (False, True), (False, False)):
+        group.SetBucketing(bucket)
+        group.SetPrebinning(prebin)
+        for partition in ((0, 1, 2) if bucket else (0,)):
+            group.SetPartition(partition)
+            group.EvalAsync(False)
+            group.EvalFinished()
+            results.append(([e.GetBins() for e in evs], norms.get(), group.AlgorithmicBytes()["fill_read"]))
+    group.SetPartition(0)
+    assert results[0][2] < results[-1][2]                  # fewer bytes to stream
+    for j, t in enumerate(tabs):
+        o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, systs, params)
+        for bins, nrm, _ in results:
+            assert np.array_equal(bins[j], o["bins"]) and nrm[j] == o["norm"]
+    # the caller's row order is untouched (GetSamples reads the original table, pdfz.h:542-556)
+    got = evs[0].GetSamples().reshape(-1, nobs + 1)
+    assert np.array_equal(got[:, :nobs].view(np.uint32), tabs[0][:, :nobs].view(np.uint32))
+
+
+def test_bucketed_table_edge_values():
+    """The untouched observables carry NaN / inf / exact edges / -0.0 / values one float below an edge (the bucket
+    keys are formed with the fill's own arithmetic, pdfz.cpp:388-398): the bucketed evaluation must count
+    exactly what the oracle counts."""
+    rng = np.random.default_rng(19)
+    n = 40000
+    tab = table(rng, n, 4)
+    edge = np.array([np.nan, np.inf, -np.inf, 0.0, 1.0, np.nextafter(np.float32(1), np.float32(0)), -0.0, 0.5,
+                     np.nextafter(np.float32(0.5), np.float32(0)), 0.999], np.float32)
+    tab[:, 1] = np.where(rng.uniform(size=n) < 0.3, rng.choice(edge, size=n), tab[:, 1])
+    tab[:, 2] = np.where(rng.uniform(size=n) < 0.3, rng.choice(edge, size=n), tab[:, 2])
+    lower, upper, nbins = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [7, 3, 3]
+    geom = oracle.HistGeometry(lower, upper, nbins)
+    systs = [dict(type="shift", obs=0, pars=[0])]
+    for bucket in (True, False):
+        ev = pdfz.EvalHist(tab, 4, 3, lower, upper, nbins)
+        ev.AddSystematic(make_systematic(systs[0]))
+        norm, pbuf = DeviceArray.zeros(1, np.uint32), DeviceArray(np.array([0.013]))
+        ev.SetNormalizationBuffer(norm)
+        ev.SetParameterBuffer(pbuf)
+        group = nll.EvalGroup([ev])
+        group.SetBucketing(bucket)
+        group.EvalAsync(False)
+        group.EvalFinished()
+        bins, nrm = oracle.bin_samples(geom, tab, 4, systs, np.array([0.013]))
+        assert np.array_equal(ev.GetBins(), bins) and norm.get()[0] == nrm
+        group.close()
+        ev.close()
 
 
 def test_prebinned_column_edge_values():
