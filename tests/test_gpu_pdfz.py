@@ -633,8 +633,8 @@ def test_optimize_keeps_results_and_only_acts_on_pure_streams():
     systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
              dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]
     params = [0.02, -0.01, 0.07]
-    sizes = [2000003] * 8                                               # 16e6 samples x 16 B: a long stream
-    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], systs, params, nfields=5)
+    sizes = [3000003] * 12                # 36e6 samples, half of them inside the untouched observable's domain,
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], systs, params, nfields=5)   # x 12 B: long
     group = nll.EvalGroup(evs)
     chosen = group.Optimize()
     assert chosen in (448, 512, 576, 640, 768)
