@@ -570,6 +570,220 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
   }
 }
 
+// SPARSE COUNTING OVER A BUCKETED TABLE, WALKED IN RUNS.  Histograms beyond LDS capacity, evaluated for lookup
+// (BASELINE config 5).  The table is bucketed (layout_kernels.hip) and laid out so that every WAVE walks its own
+// run of consecutive granules of the sorted order: a wave stays inside one bucket -- one tuple of bin indices of
+// the untouched observables -- for many steps.  The event bins are grouped by the same buckets on the host, each
+// bucket with a small open-addressing table keyed by the index contribution of the WRITTEN observables.  On
+// entering a bucket a wave copies that table into its private slice of LDS; a sample then costs one LDS probe
+// (no L2 filter, no global table, no global atomic), hits are counted in LDS beside the keys, and the counts go to
+// the global event-bin counters once, when the wave leaves the bucket.  Counts are integers: same counters as
+// every other evaluation form, bit for bit.
+// Left to the global table (sparse_lookup): buckets with more event bins than a wave's slice holds, buckets whose
+// key contains an index equal to nbins, and single samples whose written observable's index comes out as nbins
+// (pdfz.cpp:388-398 lets such an index alias into the next row of the flat index; the bucket tables assume the
+// canonical decomposition, the global table is keyed by the flat index itself).
+typedef unsigned vuint2g __attribute__((ext_vector_type(2)));
+
+template <int NOBS, int NSLOT, typename PROG>
+__global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* __restrict__ descs,
+                                                           const SxSegment* __restrict__ segs,
+                                                           const unsigned* __restrict__ blk_off, unsigned smax,
+                                                           unsigned dbg) {
+  static_assert(!PROG::dynamic, "static programs only");
+  extern __shared__ unsigned lds[];
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & (kWave - 1);
+  const unsigned wave = tid / kWave;
+  unsigned* wkeys = lds + (size_t)wave * 2u * smax;   // this wave's table keys ...
+  unsigned* wcnt = wkeys + smax;                      // ... and the hit counts beside them
+  for (unsigned b = lane; b < smax; b += kWave) wcnt[b] = 0u;
+
+  const unsigned seg_end = blk_off[blockIdx.x + 1];
+  for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
+    const SxSegment& sg = segs[si];
+    const SxSignalDesc& d = descs[sg.sig];
+    const unsigned long long v0 = sg.v0;
+    const unsigned long long v1 = sg.v1;
+    const unsigned long long step = sg.step;
+    const unsigned B = (unsigned)d.sparse_real_nbins;
+    gptr<unsigned> gcnt = to_global(d.bins);
+    gptr<const unsigned> tkeys = to_global(d.sparse_tkeys);
+    gptr<const unsigned> tslot = to_global(d.sparse_tslot);
+    gptr<const vuint2g> dir = to_global(reinterpret_cast<const vuint2g*>(d.sparse_dir));
+
+    double craw[PROG::n > 0 ? PROG::n : 1];
+#pragma unroll
+    for (int q = 0; q < PROG::n; q++) craw[q] = to_global(d.params)[(long)d.coef_par[q] * d.param_stride];
+    __builtin_amdgcn_sched_barrier(0);
+
+    gptr<const vfloat4> col[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
+    }
+    gptr<const vuint2g> gkp = to_global(reinterpret_cast<const vuint2g*>(d.pre));  // {bucket key, bin offset} per granule
+    const unsigned long long vlast = v1 - 1;
+    const unsigned long long vfirst = v0 + tid;
+
+    vfloat4 raw[NSLOT];
+    vuint2g kp;
+    auto load = [&](unsigned long long v) {
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+        raw[k] = __builtin_nontemporal_load(&col[k][v]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      kp = gkp[v >> 6];
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    load(vfirst < v1 ? vfirst : vlast);
+
+    double lo[NOBS], hi[NOBS], sc[NOBS];
+    int st[NOBS];
+    unsigned nb[NOBS];
+#pragma unroll
+    for (int k = 0; k < NOBS; k++) {
+      lo[k] = d.lower[k];
+      hi[k] = d.upper[k];
+      sc[k] = d.scale[k];
+      st[k] = d.bin_stride[k];
+      nb[k] = (unsigned)d.nbins[k];
+    }
+    double pc[PROG::n > 0 ? PROG::n : 1];
+#pragma unroll
+    for (int s = 0; s < PROG::n; s++) pc[s] = 0.0 + craw[s] * 1.0;
+
+    unsigned cnt = 0;
+    // the bucket this wave is in: its table sits in wkeys[0 .. 1 << cur_log2), counts in wcnt
+    unsigned cur_key = 0xFFFFFFFFu, cur_off = 0u, cur_info = SXMC_SPARSE_EMPTY;
+
+    auto flush = [&]() {
+      if (cur_info <= SXMC_SPARSE_SMAX_LOG2) {
+        const unsigned S = 1u << cur_info;
+        for (unsigned b = lane; b < S; b += kWave) {
+          const unsigned c = wcnt[b];
+          if (c != 0u) {
+            __hip_atomic_fetch_add(&gcnt[tslot[cur_off + b]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wcnt[b] = 0u;
+          }
+        }
+      }
+    };
+
+    unsigned long long v = vfirst;
+    const unsigned long long niter = (v1 - v0 + step - 1) / step;
+    for (unsigned long long it = 0; it < niter; ++it, v += step) {
+      double f[NSLOT][SXMC_VEC];
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+        f[k][0] = (double)raw[k].x;
+        f[k][1] = (double)raw[k].y;
+        f[k][2] = (double)raw[k].z;
+        f[k][3] = (double)raw[k].w;
+      }
+      const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane((int)kp[0]);
+      const unsigned pre = (unsigned)__builtin_amdgcn_readfirstlane((int)kp[1]);
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f[k][q]));
+      }
+      const unsigned long long vl = v + step;
+      load(vl < v1 ? vl : vlast);
+      if (dbg & 1u) {
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) cnt += (f[k][q] == 12345.678) ? 1u : 0u;
+        }
+        continue;
+      }
+
+      // ---- a new bucket: counts of the old one go to the global counters, the new table comes into LDS
+      if (key != cur_key) {
+        flush();
+        const vuint2g e = dir[key];
+        cur_key = key;
+        cur_off = (unsigned)__builtin_amdgcn_readfirstlane((int)e[0]);
+        cur_info = (unsigned)__builtin_amdgcn_readfirstlane((int)e[1]) & 0xFFu;
+        if (cur_info <= SXMC_SPARSE_SMAX_LOG2) {
+          const unsigned S = 1u << cur_info;
+          for (unsigned b = lane; b < S; b += kWave) wkeys[b] = tkeys[cur_off + b];
+        }
+      }
+
+      run_static<NSLOT>(f, pc, PROG{}, std::make_index_sequence<(size_t)PROG::n>{});
+
+      const unsigned dead = (v < v1) ? 0u : 1u;
+      unsigned p2[SXMC_VEC];
+      bool fast[SXMC_VEC], slow[SXMC_VEC];
+      const bool table_here = cur_info <= SXMC_SPARSE_SMAX_LOG2;
+      const bool all_slow = cur_info == SXMC_SPARSE_SLOW;
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        unsigned bad = dead, alias = 0u;
+        int bin = 0;
+#pragma unroll
+        for (int k = 0; k < NOBS; k++) {
+          const double x = f[k][q];
+          bad += !(x >= lo[k]) ? 1u : 0u;
+          bad += !(x < hi[k]) ? 1u : 0u;
+          const int idx = (int)((x - lo[k]) * sc[k]);
+          alias += ((unsigned)idx >= nb[k]) ? 1u : 0u;
+          bin += idx * st[k];
+        }
+        const bool in_domain = bad == 0u;
+        cnt += in_domain ? 1u : 0u;
+        p2[q] = (unsigned)bin;
+        const bool count_it = in_domain && !(dbg & 4u);
+        fast[q] = count_it && table_here && alias == 0u;
+        slow[q] = count_it && (all_slow || alias != 0u);
+      }
+      if (table_here) {
+        const unsigned hshift = 32u - cur_info, hmask = (1u << cur_info) - 1u;
+        unsigned h[SXMC_VEC], k0[SXMC_VEC];
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          h[q] = cur_info ? (p2[q] * 0x9E3779B1u) >> hshift : 0u;
+          k0[q] = wkeys[h[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          bool pend = fast[q];
+          unsigned hh = h[q], kk = k0[q];
+          while (pend) {
+            if (kk == p2[q]) {
+              __hip_atomic_fetch_add(&wcnt[hh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              pend = false;
+            } else if (kk == 0xFFFFFFFFu) {
+              pend = false;
+            } else {
+              hh = (hh + 1u) & hmask;
+              kk = wkeys[hh];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        if (slow[q]) {
+          const unsigned flat = pre + p2[q];
+          if (flat < B) sparse_lookup(d, gcnt, flat);
+        }
+      }
+    }
+    flush();
+    cur_info = SXMC_SPARSE_EMPTY;
+
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
+    if (lane == 0 && cnt != 0u) {
+      __hip_atomic_fetch_add(to_global(d.norm), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // Shape-agnostic fallback (any nobs/nslot up to SXMC_MAX_NFIELDS): one sample per lane per
 // iteration, fields in a dynamically indexed array.  Correctness path for shapes without a
 // specialization; same arithmetic.
@@ -952,6 +1166,22 @@ hipError_t launch_fill_k(const SxLaunchShape& sh, const SxSignalDesc* descs, con
 typedef hipError_t (*FillLauncher)(const SxLaunchShape&, const SxSignalDesc*, const SxSegment*, const unsigned*,
                                    hipStream_t);
 
+template <int NOBS, int NSLOT, typename PROG>
+hipError_t launch_fill_sparse_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
+                                const unsigned* blk_off, hipStream_t s) {
+  auto k = fill_sparse_kernel<NOBS, NSLOT, PROG>;
+  if (sh.sparse_lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sh.sparse_lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  const unsigned nwaves = (unsigned)sh.threads / 64u;
+  const unsigned smax = (unsigned)(sh.sparse_lds_bytes / 4 / nwaves / 2);   // entries per wave (keys + counts)
+  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.sparse_lds_bytes, s, descs, segs, blk_off, smax,
+                     (unsigned)sh.debug_mode);
+  return hipGetLastError();
+}
+
 // Static programs (LDS-histogram launches only).  Slots: observables 0..nobs-1, then the
 // referenced extra fields in ascending order.
 struct StaticEntry {
@@ -963,6 +1193,7 @@ struct StaticEntry {
   FillLauncher fn_g;         // histogram beyond LDS capacity (dense global atomics or sparse event-bin counters)
   FillLauncher fn_g_pre[2];
   FillLauncher fn_gran[2];   // bucketed table (every observable given is binned, + one offset per granule): LDS / beyond LDS
+  FillLauncher fn_sruns;     // bucketed table walked in runs, event bins counted in per-wave LDS tables
 };
 #define SX_SHIFT(o) sx_op(SXMC_SYST_SHIFT, o)
 #define SX_SCALE(o) sx_op(SXMC_SYST_SCALE, o)
@@ -975,9 +1206,10 @@ struct StaticEntry {
 #define SX_G(NO, NS, ...) \
   launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 0>, \
   {launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 1>, launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, 2>}
-#define SX_NOGRAN {nullptr, nullptr}
+#define SX_NOGRAN {nullptr, nullptr}, nullptr
 #define SX_GRAN(NO, NS, ...) \
-  {launch_fill_k<NO, NS, true, StaticProg<__VA_ARGS__>, kPreGranule>, launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, kPreGranule>}
+  {launch_fill_k<NO, NS, true, StaticProg<__VA_ARGS__>, kPreGranule>, launch_fill_k<NO, NS, false, StaticProg<__VA_ARGS__>, kPreGranule>}, \
+  launch_fill_sparse_k<NO, NS, StaticProg<__VA_ARGS__>>
 #define SX_P1(NO, NS, PRE, G, GR, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE, G, GR}
 #define SX_P2(NO, NS, PRE, G, GR, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE, G, GR}
 #define SX_P3(NO, NS, PRE, G, GR, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE, G, GR}
@@ -1034,6 +1266,17 @@ bool sx_fill_static_supports(int prog, int lds_hist, int prebin) {
   if (prebin == kPreGranule) return e.fn_gran[lds_hist ? 0 : 1] != nullptr;
   if (prebin) return (lds_hist ? e.fn_pre[0] : e.fn_g_pre[0]) != nullptr;
   return (lds_hist ? e.fn : e.fn_g) != nullptr;
+}
+
+bool sx_fill_static_supports_sparse_runs(int prog) {
+  return prog >= 0 && prog < kNumStatic && kStaticPrograms[prog].fn_sruns != nullptr;
+}
+
+hipError_t sx_launch_fill_sparse_runs(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
+                                      const unsigned* blk_off, hipStream_t s) {
+  if (sh.grid <= 0) return hipSuccess;
+  if (!sx_fill_static_supports_sparse_runs(sh.static_prog)) return hipErrorInvalidValue;
+  return kStaticPrograms[sh.static_prog].fn_sruns(sh, descs, segs, blk_off, s);
 }
 
 hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,

@@ -63,6 +63,12 @@ struct SxSignalDesc {
   int sparse_real_nbins;         // the histogram's true bin count (total_nbins is the counter count here)
   int sparse_coarse_shift;       // hash >> shift selects a bit of the coarse filter (staged in LDS; two hashes per bin)
   const unsigned* sparse_coarse; // coarse two-hash bit filter, at most 128 KiB
+  // --- sparse counting over a bucketed table walked in runs (fill_sparse_kernel): the event bins are grouped by
+  //     bucket (the bin indices of the untouched observables), each bucket with its own small hash table
+  const unsigned* sparse_dir;    // pairs {first table entry, log2(table size) | flags}, indexed by bucket key
+  const unsigned* sparse_tkeys;  // table entries: the event bin's index contribution of the written observables
+  const unsigned* sparse_tslot;  // ... and its counter slot
+  int nbins[SXMC_MAX_NFIELDS];   // bins per observable (an index that comes out as nbins is the aliasing case)
   // --- evaluation at the data events
   const int* read_bins;
   unsigned long long npoints;
@@ -111,6 +117,8 @@ struct SxLaunchShape {
   size_t lds_bytes;
   int debug_mode;   // measurement hook, see fill_kernel
   int static_prog;  // index into the static program table, or -1: decode the program at run time
+  int sparse_runs;  // 1: the sparse flavour of this launch runs fill_sparse_kernel (bucketed table laid out in runs)
+  size_t sparse_lds_bytes;
   int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none, 3 = bucketed table (one
                     // bin offset per 256-sample granule)
 };
@@ -123,6 +131,12 @@ hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsi
                                       int grid, int block, hipStream_t s);
 hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,
                           const unsigned* d_blk_off, hipStream_t s);
+hipError_t sx_launch_fill_sparse_runs(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,
+                                      const unsigned* d_blk_off, hipStream_t s);
+bool sx_fill_static_supports_sparse_runs(int prog);
+#define SXMC_SPARSE_EMPTY 0xFFu   /* directory flag: the bucket holds no event bin */
+#define SXMC_SPARSE_SLOW 0xFEu    /* directory flag: look every sample up in the global table (see the kernel) */
+#define SXMC_SPARSE_SMAX_LOG2 10  /* largest per-wave table: 1024 entries */
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
 bool sx_fill_static_supports(int prog, int lds_hist, int prebin);

@@ -111,25 +111,42 @@ struct SampleStore {
       if (p.mask == mask && p.width == width) return p.ptr;
     return nullptr;
   }
-  // Bucketed copies built so far (layout_kernels.hip), one per (untouched-observable mask, streamed fields,
-  // runs); kept until the table dies for the same reason.  `rejected`: building it was tried and the padding
-  // of the granules would have outweighed the columns saved (tiny tables with many buckets).
+  // Bucketing (layout_kernels.hip).  The SORT of the rows by the untouched observables' bin indices is done once
+  // per set of untouched observables (`mask`) and kept; `rejected`: it was tried and the padding of the granules
+  // would have outweighed the columns saved (tiny tables with many buckets).
+  struct BucketSort {
+    unsigned mask = 0;
+    bool rejected = true;
+    unsigned* d_rows = nullptr;     // [nsamples] row numbers in sorted order (rows outside the domain last)
+    size_t nkept = 0;               // rows inside the domain of every untouched observable
+    unsigned nkeys_total = 0;       // size of the key space (= the key of "outside")
+    unsigned radix[SXMC_MAX_NFIELDS] = {0};
+    std::vector<unsigned> keys;     // bucket keys present, ascending
+    std::vector<unsigned> key_pre;  // bin offset of each of them
+    std::vector<unsigned> lsrc, lvalid, lwhich;  // logical granules: first sorted position, rows, index into keys
+  };
+  // ... and the COPIES laid out from it, one per (mask, streamed fields, runs); kept until the table dies because
+  // descriptors of other groups may point at them.
   struct Bucketed {
     unsigned mask = 0;
     std::vector<int> fields;        // streamed fields, in the order of the compacted slots
     int runs = 1;                   // granule order transposed for this many runs (1 = sorted order)
-    bool rejected = false;
+    bool complete = false;
+    const BucketSort* sort = nullptr;
     float* d_cols = nullptr;        // [fields.size()][pitch]
     size_t pitch = 0;
     unsigned* d_gpre = nullptr;     // [ngranules] bin offset of the granule
-    unsigned* d_gkey = nullptr;     // [ngranules] dense bucket key of the granule
+    unsigned* d_gkp = nullptr;      // [ngranules] pairs {bucket key, bin offset}
     size_t ngranules = 0;           // physical granules (with the runs' padding)
-    size_t nkept = 0;               // samples in the copy (inside the domain of every untouched observable)
-    std::vector<unsigned> keys;     // bucket keys present, ascending (host copy)
-    std::vector<unsigned> key_pre;  // bin offset of each of them
-    unsigned nkeys_total = 0;       // size of the key space
+    size_t nkept = 0;               // samples in the copy
   };
+  std::vector<std::unique_ptr<BucketSort>> sorts;
   std::vector<std::unique_ptr<Bucketed>> bucketed;
+  BucketSort* find_sort(unsigned mask) const {
+    for (const auto& b : sorts)
+      if (b->mask == mask) return b.get();
+    return nullptr;
+  }
   Bucketed* find_bucketed(unsigned mask, const std::vector<int>& fields, int runs) const {
     for (const auto& b : bucketed)
       if (b->mask == mask && b->fields == fields && b->runs == runs) return b.get();
@@ -141,8 +158,10 @@ struct SampleStore {
     for (auto& b : bucketed) {
       if (b->d_cols) (void)hipFree(b->d_cols);
       if (b->d_gpre) (void)hipFree(b->d_gpre);
-      if (b->d_gkey) (void)hipFree(b->d_gkey);
+      if (b->d_gkp) (void)hipFree(b->d_gkp);
     }
+    for (auto& b : sorts)
+      if (b->d_rows) (void)hipFree(b->d_rows);
   }
 };
 
@@ -177,6 +196,13 @@ struct sxmc_hist {
   unsigned* d_table = nullptr;
   unsigned* d_coarse = nullptr;    // coarse filter staged in LDS by the fill kernel
   int ntargets = 0, filter_shift = 0, table_shift = 0, coarse_shift = 0;
+  // the event bins grouped by bucket, for sparse counting over a bucketed table walked in runs (fill_sparse_kernel)
+  unsigned* d_bdir = nullptr;      // [nkeys + 1] pairs {first table entry, log2 size | flag}
+  unsigned* d_btkeys = nullptr;
+  unsigned* d_btslot = nullptr;
+  unsigned btab_mask = 0;
+  unsigned long long btab_points_version = 0;
+  bool btab_valid = false;
   std::vector<unsigned> targets;   // sorted distinct event bins (host copy: members with equal sets share tables)
   std::vector<int> h_read_bins;    // host copies of d_read_bins / d_read_slot: the group forms event classes from them
   std::vector<int> h_read_slot;
@@ -200,6 +226,7 @@ struct LaunchClass {
   unsigned long long total_vec = 0;
   int partition = 0;  // 1 sliced, 2 interleaved (what build_partition chose)
   bool light = false; // a pure stream: runs best with few waves per CU (see group_rebuild)
+  bool runs_mode = false;  // bucketed tables laid out in per-wave runs; the sparse flavour runs fill_sparse_kernel
 };
 
 void free_class(LaunchClass& c) {
@@ -219,6 +246,54 @@ void free_class(LaunchClass& c) {
 //    neighbouring chunks at the same time and every workgroup flushes one histogram once.
 //  sliced: workgroup b owns the contiguous slice [total*b/G, total*(b+1)/G) of the concatenated
 //    members: perfectly balanced, used when members outnumber workgroups or are tiny.
+// Largest-remainder apportionment of `grid` workgroups over members of `sizes` units: at least one per
+// non-empty member and never more than the member has chunks of `threads` units.  false: they do not fit.
+bool apportion_workgroups(const std::vector<unsigned long long>& sizes, int grid, int threads, std::vector<int>& K) {
+  K.assign(sizes.size(), 0);
+  unsigned long long total = 0;
+  for (unsigned long long n : sizes) total += n;
+  if (total == 0) return true;
+  int used = 0;
+  std::vector<std::pair<double, int>> frac;
+  for (size_t j = 0; j < sizes.size(); j++) {
+    if (!sizes[j]) continue;
+    const double share = (double)grid * (double)sizes[j] / (double)total;
+    const unsigned long long chunks = (sizes[j] + threads - 1) / threads;
+    K[j] = (int)std::min<unsigned long long>(chunks, std::max<unsigned long long>(1, (unsigned long long)share));
+    used += K[j];
+    frac.push_back({share - std::floor(share), (int)j});
+  }
+  std::sort(frac.begin(), frac.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  for (size_t i = 0; used < grid && !frac.empty() && i < 4 * frac.size(); i++) {
+    const int j = frac[i % frac.size()].second;
+    const unsigned long long chunks = (sizes[(size_t)j] + threads - 1) / threads;
+    if ((unsigned long long)K[(size_t)j] < chunks) {
+      K[(size_t)j]++;
+      used++;
+    }
+  }
+  return used <= grid;
+}
+
+// Workgroup i of member j takes chunks i, i + K_j, ... of `threads` units of the member.
+void interleaved_segments(const std::vector<SxSignalDesc>& descs, const std::vector<int>& K, int threads, int grid,
+                          std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off) {
+  segs.clear();
+  blk_off.assign(1, 0u);
+  for (size_t j = 0; j < descs.size(); j++) {
+    for (int i = 0; i < K[j]; i++) {
+      SxSegment sg{};
+      sg.sig = (int)j;
+      sg.v0 = (unsigned long long)i * threads;
+      sg.v1 = descs[j].nvec;
+      sg.step = (unsigned long long)K[j] * threads;
+      segs.push_back(sg);
+      blk_off.push_back((unsigned)segs.size());
+    }
+  }
+  while ((int)blk_off.size() < grid + 1) blk_off.push_back((unsigned)segs.size());  // idle workgroups
+}
+
 void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threads, int want_mode,
                      std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off, int& mode_out,
                      unsigned long long align = 1) {
@@ -233,44 +308,14 @@ void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threa
   bool interleave = want_mode == 2 || (want_mode == 0 && nonempty > 0 && grid >= 2 * nonempty &&
                                        total >= (unsigned long long)grid * threads * 8ull);
   if (want_mode == 2 && (nonempty == 0 || grid < nonempty)) interleave = false;
-  std::vector<int> K(descs.size(), 0);
+  std::vector<int> K;
   if (interleave) {
-    // largest-remainder apportionment of the workgroups, at least one per non-empty member and never
-    // more than the member has chunks
-    int used = 0;
-    std::vector<std::pair<double, int>> frac;
-    for (size_t j = 0; j < descs.size(); j++) {
-      if (!descs[j].nvec) continue;
-      const double share = (double)grid * (double)descs[j].nvec / (double)total;
-      const unsigned long long chunks = (descs[j].nvec + threads - 1) / threads;
-      K[j] = (int)std::min<unsigned long long>(chunks, std::max<unsigned long long>(1, (unsigned long long)share));
-      used += K[j];
-      frac.push_back({share - std::floor(share), (int)j});
-    }
-    std::sort(frac.begin(), frac.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-    for (size_t i = 0; used < grid && !frac.empty() && i < 4 * frac.size(); i++) {
-      const int j = frac[i % frac.size()].second;
-      const unsigned long long chunks = (descs[j].nvec + threads - 1) / threads;
-      if ((unsigned long long)K[j] < chunks) {
-        K[j]++;
-        used++;
-      }
-    }
-    if (used > grid) interleave = false;  // more non-empty members than workgroups
+    std::vector<unsigned long long> sizes;
+    for (const SxSignalDesc& d : descs) sizes.push_back(d.nvec);
+    interleave = apportion_workgroups(sizes, grid, threads, K);  // false: more non-empty members than workgroups
   }
   if (interleave) {
-    for (size_t j = 0; j < descs.size(); j++) {
-      for (int i = 0; i < K[j]; i++) {
-        SxSegment sg{};
-        sg.sig = (int)j;
-        sg.v0 = (unsigned long long)i * threads;
-        sg.v1 = descs[j].nvec;
-        sg.step = (unsigned long long)K[j] * threads;
-        segs.push_back(sg);
-        blk_off.push_back((unsigned)segs.size());
-      }
-    }
-    while ((int)blk_off.size() < grid + 1) blk_off.push_back((unsigned)segs.size());  // idle workgroups
+    interleaved_segments(descs, K, threads, grid, segs, blk_off);
     mode_out = 2;
     return;
   }
@@ -369,7 +414,16 @@ int slot_of(const std::vector<int>& slot_col, int field) {
   return 0;
 }
 
+void free_bucket_tables(sxmc_hist* h) {
+  if (h->d_bdir) (void)hipFree(h->d_bdir);
+  if (h->d_btkeys) (void)hipFree(h->d_btkeys);
+  if (h->d_btslot) (void)hipFree(h->d_btslot);
+  h->d_bdir = h->d_btkeys = h->d_btslot = nullptr;
+  h->btab_valid = false;
+}
+
 void free_sparse(sxmc_hist* h) {
+  free_bucket_tables(h);
   if (h->d_cnt) (void)hipFree(h->d_cnt);
   if (h->d_read_slot) (void)hipFree(h->d_read_slot);
   if (h->d_filter) (void)hipFree(h->d_filter);
@@ -477,6 +531,7 @@ int fill_desc(const sxmc_hist* h, SxSignalDesc& d) {
   d.params = h->params ? h->params + h->par_off : nullptr;
   for (int k = 0; k < d.nslot; k++) d.slot_col[k] = slot_col[k];
   for (int k = 0; k < h->nobs; k++) {
+    d.nbins[k] = h->nbins[(size_t)k];
     d.bin_stride[k] = h->stride[k];
     d.lower[k] = h->lower[k];
     d.upper[k] = h->upper[k];
@@ -518,51 +573,44 @@ struct DevBuf {  // device temporary, freed on scope exit
   }
 };
 
-// The bucketed copy of member `h`'s table (layout_kernels.hip): samples grouped by their bin indices in the
-// observables of `mask` (those no systematic writes), holding the columns `fields`; granule order transposed
-// for `runs` runs.  Fetched from the table's cache or built; *out = nullptr when it does not pay for this table
-// (the granules' padding would outweigh the columns saved).  d_full_desc: the member's descriptor on the device.
-int get_bucketed(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask, const std::vector<int>& fields,
-                 int runs, const SampleStore::Bucketed** out) {
+// The rows of member `h`'s table sorted by their bin indices in the observables of `mask` (those no systematic
+// writes) and cut into 256-row granules, bucket by bucket.  Fetched from the table's cache or built; *out =
+// nullptr when bucketing does not pay for this table.  d_full_desc: the member's descriptor on the device.
+int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask, const SampleStore::BucketSort** out) {
   *out = nullptr;
   SampleStore& st = *h->store;
   std::lock_guard<std::mutex> lock(st.pre_mutex);
-  if (SampleStore::Bucketed* have = st.find_bucketed(mask, fields, runs)) {
+  if (SampleStore::BucketSort* have = st.find_sort(mask)) {
     *out = have->rejected ? nullptr : have;
     return SXMC_OK;
   }
-  st.bucketed.push_back(std::make_unique<SampleStore::Bucketed>());
-  SampleStore::Bucketed* b = st.bucketed.back().get();
+  st.sorts.push_back(std::make_unique<SampleStore::BucketSort>());
+  SampleStore::BucketSort* b = st.sorts.back().get();
   b->mask = mask;
-  b->fields = fields;
-  b->runs = runs;
-  b->rejected = true;  // until it is complete
   const size_t n = h->nsamples;
-  if (n == 0 || n > 0x7FFFFF00ull || fields.empty() || runs < 1) return SXMC_OK;
+  if (n == 0 || n > 0x7FFFFF00ull) return SXMC_OK;
 
   // key space: mixed radix over the untouched observables, last one fastest, bases nbins + 1 (an index can
   // come out as nbins one ulp below the upper edge; such samples form buckets of their own)
-  unsigned radix[SXMC_MAX_NFIELDS] = {0};
   unsigned long long nkeys = 1;
   for (int k = h->nobs - 1; k >= 0; k--) {
     if (!((mask >> k) & 1u)) continue;
-    radix[k] = (unsigned)nkeys;
+    b->radix[k] = (unsigned)nkeys;
     nkeys *= (unsigned long long)h->nbins[(size_t)k] + 1ull;
     if (nkeys > (1ull << 20)) return SXMC_OK;
   }
   const unsigned outside = (unsigned)nkeys;
   const int bits = ceil_log2((size_t)nkeys + 1);
 
-  DevBuf keys0, keys1, rows0, rows1, dfirst, dsrc, dvalid;
+  DevBuf keys0, keys1, rows0, dfirst;
   SX_HIP(keys0.alloc(n * 4));
   SX_HIP(keys1.alloc(n * 4));
   SX_HIP(rows0.alloc(n * 4));
-  SX_HIP(rows1.alloc(n * 4));
+  SX_HIP(hipMalloc((void**)&b->d_rows, n * 4));
   SX_HIP(dfirst.alloc((nkeys + 1) * 4));
   SX_HIP(hipMemset(dfirst.p, 0xFF, (nkeys + 1) * 4));
-  SX_HIP(sx_bucket_keys(d_full_desc, n, mask, radix, outside, keys0.as<unsigned>(), rows0.as<unsigned>(), nullptr));
-  SX_HIP(sx_bucket_sort(keys0.as<unsigned>(), keys1.as<unsigned>(), rows0.as<unsigned>(), rows1.as<unsigned>(), n, bits,
-                        nullptr));
+  SX_HIP(sx_bucket_keys(d_full_desc, n, mask, b->radix, outside, keys0.as<unsigned>(), rows0.as<unsigned>(), nullptr));
+  SX_HIP(sx_bucket_sort(keys0.as<unsigned>(), keys1.as<unsigned>(), rows0.as<unsigned>(), b->d_rows, n, bits, nullptr));
   SX_HIP(sx_bucket_first(keys1.as<unsigned>(), n, dfirst.as<unsigned>(), nullptr));
   std::vector<unsigned> first((size_t)nkeys + 1);
   SX_HIP(hipMemcpy(first.data(), dfirst.p, first.size() * 4, hipMemcpyDeviceToHost));
@@ -572,64 +620,169 @@ int get_bucketed(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask, c
   for (unsigned k = 0; k < outside; k++)
     if (first[k] != 0xFFFFFFFFu) present.push_back(k);
   // logical granules: bucket by bucket, each bucket padded to whole granules
-  std::vector<unsigned> lsrc, lvalid, lwhich;
   for (size_t i = 0; i < present.size(); i++) {
     const size_t lo = first[present[i]], hi = i + 1 < present.size() ? first[present[i + 1]] : kept;
     for (size_t at = lo; at < hi; at += 256) {
-      lsrc.push_back((unsigned)at);
-      lvalid.push_back((unsigned)std::min<size_t>(256, hi - at));
-      lwhich.push_back((unsigned)i);
+      b->lsrc.push_back((unsigned)at);
+      b->lvalid.push_back((unsigned)std::min<size_t>(256, hi - at));
+      b->lwhich.push_back((unsigned)i);
     }
   }
-  const size_t L = lsrc.size();
-  if ((double)L * 256.0 > 1.3 * (double)kept + 16384.0) return SXMC_OK;  // mostly padding: not worth it
-
+  if ((double)b->lsrc.size() * 256.0 > 1.3 * (double)kept + 16384.0) {  // mostly padding: not worth it
+    (void)hipFree(b->d_rows);
+    b->d_rows = nullptr;
+    b->lsrc.clear();
+    b->lvalid.clear();
+    b->lwhich.clear();
+    return SXMC_OK;
+  }
   b->keys = present;
   b->nkeys_total = outside;
+  b->nkept = kept;
   b->key_pre.resize(present.size());
   for (size_t i = 0; i < present.size(); i++) {
     long long pre = 0;
     for (int k = 0; k < h->nobs; k++) {
       if (!((mask >> k) & 1u)) continue;
-      const unsigned idx = (present[i] / radix[k]) % ((unsigned)h->nbins[(size_t)k] + 1u);
+      const unsigned idx = (present[i] / b->radix[k]) % ((unsigned)h->nbins[(size_t)k] + 1u);
       pre += (long long)idx * h->stride[(size_t)k];
     }
     b->key_pre[i] = (unsigned)pre;
   }
-  // physical order: run r holds logical granules [r * T, (r + 1) * T), and the runs are interleaved granule by
-  // granule (physical p = t * runs + r), so that `runs` consumers that each walk one run read neighbouring
-  // addresses at the same time.  runs = 1: the sorted order itself.
-  const size_t T = (L + (size_t)runs - 1) / (size_t)runs, P = T * (size_t)runs;
-  std::vector<unsigned> psrc(std::max<size_t>(P, 1), 0u), pvalid(std::max<size_t>(P, 1), 0u),
-      ppre(std::max<size_t>(P, 1), 0u), pkey(std::max<size_t>(P, 1), outside);
+  b->rejected = false;
+  *out = b;
+  return SXMC_OK;
+}
+
+// The bucketed COPY of the table for a sort: the columns `fields`, granule order transposed for `runs` runs --
+// run r holds logical granules [r * T, (r + 1) * T), and the runs are interleaved granule by granule (physical
+// p = t * runs + r), so that `runs` consumers that each walk one run read neighbouring addresses at the same
+// time.  runs = 1: the sorted order itself.
+int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vector<int>& fields, int runs,
+                 const SampleStore::Bucketed** out) {
+  *out = nullptr;
+  SampleStore& st = *h->store;
+  std::lock_guard<std::mutex> lock(st.pre_mutex);
+  if (SampleStore::Bucketed* have = st.find_bucketed(bs->mask, fields, runs)) {
+    if (!have->complete) return fail(SXMC_ERR_HIP, "an earlier attempt to lay this table out failed");
+    *out = have;
+    return SXMC_OK;
+  }
+  SX_REQUIRE(!fields.empty() && runs >= 1, "bad bucketed layout request");
+  st.bucketed.push_back(std::make_unique<SampleStore::Bucketed>());
+  SampleStore::Bucketed* b = st.bucketed.back().get();
+  b->mask = bs->mask;
+  b->fields = fields;
+  b->runs = runs;
+  b->sort = bs;
+  const size_t L = bs->lsrc.size();
+  const unsigned outside = bs->nkeys_total;
+  const size_t T = (L + (size_t)runs - 1) / (size_t)runs, P = T * (size_t)runs, A = std::max<size_t>(P, 1);
+  std::vector<unsigned> psrc(A, 0u), pvalid(A, 0u), ppre(A, 0u), pkp(2 * A, 0u);
   for (size_t p = 0; p < P; p++) {
     const size_t r = p % (size_t)runs, t = p / (size_t)runs, l = r * T + t;
     if (l < L) {
-      psrc[p] = lsrc[l];
-      pvalid[p] = lvalid[l];
-      ppre[p] = b->key_pre[lwhich[l]];
-      pkey[p] = present[lwhich[l]];
+      psrc[p] = bs->lsrc[l];
+      pvalid[p] = bs->lvalid[l];
+      ppre[p] = bs->key_pre[bs->lwhich[l]];
+      pkp[2 * p] = bs->keys[bs->lwhich[l]];
     } else {  // padding granule at the end of the last runs: no samples, stays in the last bucket
-      pkey[p] = L ? present[lwhich[L - 1]] : outside;
+      pkp[2 * p] = L ? bs->keys[bs->lwhich[L - 1]] : outside;
     }
+    pkp[2 * p + 1] = ppre[p];
   }
   b->ngranules = P;
-  b->nkept = kept;
+  b->nkept = bs->nkept;
   b->pitch = std::max<size_t>(64, P * 256);
+  DevBuf dsrc, dvalid;
   SX_HIP(hipMalloc((void**)&b->d_cols, sizeof(float) * b->pitch * fields.size()));
-  SX_HIP(hipMalloc((void**)&b->d_gpre, sizeof(unsigned) * psrc.size()));
-  SX_HIP(hipMalloc((void**)&b->d_gkey, sizeof(unsigned) * psrc.size()));
-  SX_HIP(hipMemcpy(b->d_gpre, ppre.data(), sizeof(unsigned) * psrc.size(), hipMemcpyHostToDevice));
-  SX_HIP(hipMemcpy(b->d_gkey, pkey.data(), sizeof(unsigned) * psrc.size(), hipMemcpyHostToDevice));
-  SX_HIP(dsrc.alloc(psrc.size() * 4));
-  SX_HIP(dvalid.alloc(psrc.size() * 4));
-  SX_HIP(hipMemcpy(dsrc.p, psrc.data(), psrc.size() * 4, hipMemcpyHostToDevice));
-  SX_HIP(hipMemcpy(dvalid.p, pvalid.data(), psrc.size() * 4, hipMemcpyHostToDevice));
-  SX_HIP(sx_bucket_gather(st.d_cols, h->pitch, (int)fields.size(), fields.data(), rows1.as<unsigned>(),
-                          dsrc.as<unsigned>(), dvalid.as<unsigned>(), P, b->d_cols, b->pitch, nullptr));
+  SX_HIP(hipMalloc((void**)&b->d_gpre, sizeof(unsigned) * A));
+  SX_HIP(hipMalloc((void**)&b->d_gkp, sizeof(unsigned) * 2 * A));
+  SX_HIP(hipMemcpy(b->d_gpre, ppre.data(), sizeof(unsigned) * A, hipMemcpyHostToDevice));
+  SX_HIP(hipMemcpy(b->d_gkp, pkp.data(), sizeof(unsigned) * 2 * A, hipMemcpyHostToDevice));
+  SX_HIP(dsrc.alloc(A * 4));
+  SX_HIP(dvalid.alloc(A * 4));
+  SX_HIP(hipMemcpy(dsrc.p, psrc.data(), A * 4, hipMemcpyHostToDevice));
+  SX_HIP(hipMemcpy(dvalid.p, pvalid.data(), A * 4, hipMemcpyHostToDevice));
+  SX_HIP(sx_bucket_gather(st.d_cols, h->pitch, (int)fields.size(), fields.data(), bs->d_rows, dsrc.as<unsigned>(),
+                          dvalid.as<unsigned>(), P, b->d_cols, b->pitch, nullptr));
   SX_HIP(hipDeviceSynchronize());
-  b->rejected = false;
+  b->complete = true;
   *out = b;
+  return SXMC_OK;
+}
+
+// The evaluator's event bins grouped by the buckets of a sort (fill_sparse_kernel): per bucket key an
+// open-addressing table keyed by the event bin's index contribution of the WRITTEN observables (flat index minus
+// the bucket's offset, canonical decomposition), value = the event bin's counter slot (its rank among the sorted
+// distinct event bins, as in build_sparse).  Rebuilt when the evaluation points or the untouched set change.
+int build_bucket_tables(sxmc_hist* h, const SampleStore::BucketSort* bs) {
+  if (h->btab_valid && h->btab_mask == bs->mask && h->btab_points_version == h->points_version) return SXMC_OK;
+  free_bucket_tables(h);
+  const unsigned nkeys = bs->nkeys_total;
+  const int D = h->nobs;
+  std::vector<unsigned> dir(2 * ((size_t)nkeys + 1), 0u);
+  for (size_t k = 0; k <= nkeys; k++) dir[2 * k + 1] = SXMC_SPARSE_EMPTY;
+  // bucket keys with an index equal to nbins: their samples alias into other rows of the flat index
+  for (unsigned key = 0; key < nkeys; key++) {
+    for (int k = 0; k < D; k++) {
+      if (!((bs->mask >> k) & 1u)) continue;
+      if ((key / bs->radix[k]) % ((unsigned)h->nbins[(size_t)k] + 1u) == (unsigned)h->nbins[(size_t)k]) {
+        dir[2 * (size_t)key + 1] = SXMC_SPARSE_SLOW;
+      }
+    }
+  }
+  // event bins by bucket
+  std::vector<std::vector<std::pair<unsigned, unsigned>>> by_key;   // only for keys that have some
+  std::vector<int> where((size_t)nkeys, -1);
+  for (size_t t = 0; t < h->targets.size(); t++) {
+    const unsigned flat = h->targets[t];
+    unsigned key = 0, pre = 0;
+    for (int k = 0; k < D; k++) {
+      if (!((bs->mask >> k) & 1u)) continue;
+      const unsigned idx = (flat / (unsigned)h->stride[(size_t)k]) % (unsigned)h->nbins[(size_t)k];
+      key += idx * bs->radix[k];
+      pre += idx * (unsigned)h->stride[(size_t)k];
+    }
+    if (where[key] < 0) {
+      where[key] = (int)by_key.size();
+      by_key.emplace_back();
+    }
+    by_key[(size_t)where[key]].push_back({flat - pre, (unsigned)t});
+  }
+  std::vector<unsigned> tkeys, tslot;
+  for (unsigned key = 0; key < nkeys; key++) {
+    if (where[key] < 0) continue;
+    const auto& list = by_key[(size_t)where[key]];
+    int lg = std::max(1, ceil_log2(4 * list.size()));                 // load <= 25 %: a miss is ~1.2 probes
+    if (lg > SXMC_SPARSE_SMAX_LOG2) lg = std::max(1, ceil_log2(2 * list.size()));
+    if (lg > SXMC_SPARSE_SMAX_LOG2) {                                  // more event bins than a wave's slice holds
+      dir[2 * (size_t)key + 1] = SXMC_SPARSE_SLOW;
+      continue;
+    }
+    const size_t off = tkeys.size(), S = (size_t)1 << lg;
+    tkeys.resize(off + S, 0xFFFFFFFFu);
+    tslot.resize(off + S, 0u);
+    for (const auto& e : list) {
+      size_t hp = (size_t)((e.first * 0x9E3779B1u) >> (32 - lg));
+      while (tkeys[off + hp] != 0xFFFFFFFFu) hp = (hp + 1) & (S - 1);
+      tkeys[off + hp] = e.first;
+      tslot[off + hp] = e.second;
+    }
+    dir[2 * (size_t)key] = (unsigned)off;
+    dir[2 * (size_t)key + 1] = (unsigned)lg;
+  }
+  SX_HIP(hipMalloc((void**)&h->d_bdir, sizeof(unsigned) * dir.size()));
+  SX_HIP(hipMemcpy(h->d_bdir, dir.data(), sizeof(unsigned) * dir.size(), hipMemcpyHostToDevice));
+  SX_HIP(hipMalloc((void**)&h->d_btkeys, sizeof(unsigned) * std::max<size_t>(tkeys.size(), 4)));
+  SX_HIP(hipMalloc((void**)&h->d_btslot, sizeof(unsigned) * std::max<size_t>(tkeys.size(), 4)));
+  if (!tkeys.empty()) {
+    SX_HIP(hipMemcpy(h->d_btkeys, tkeys.data(), sizeof(unsigned) * tkeys.size(), hipMemcpyHostToDevice));
+    SX_HIP(hipMemcpy(h->d_btslot, tslot.data(), sizeof(unsigned) * tslot.size(), hipMemcpyHostToDevice));
+  }
+  h->btab_mask = bs->mask;
+  h->btab_points_version = h->points_version;
+  h->btab_valid = true;
   return SXMC_OK;
 }
 
@@ -644,6 +797,7 @@ void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, SxSign
     cd.slot_col[q] = q;  // the copy holds exactly the streamed fields, in slot order
     if (k < full.nobs) {
       cd.bin_stride[q] = full.bin_stride[k];
+      cd.nbins[q] = full.nbins[k];
       cd.lower[q] = full.lower[k];
       cd.upper[q] = full.upper[k];
       cd.scale[q] = full.scale[k];
@@ -684,6 +838,11 @@ int group_rebuild(sxmc_group* g) {
   if (n) SX_HIP(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
 
   std::vector<SxSignalDesc> fill_descs((size_t)n);  // each member as its fill launch sees it
+  struct BucketPlan {                               // bucketed members: what to lay out once the class's shape is known
+    const SampleStore::BucketSort* sort = nullptr;
+    std::vector<int> fields;
+  };
+  std::vector<BucketPlan> plans((size_t)n);
   g->member_bucket.assign((size_t)n, nullptr);
   for (int i = 0; i < n; i++) {
     sxmc_hist* h = g->members[i];
@@ -696,6 +855,7 @@ int group_rebuild(sxmc_group* g) {
     const int lds_hist = h->total_nbins <= kLdsMaxBins ? 1 : 0;
     int key_nobs = 0, key_nslot = 0, static_prog = -1, pre_width = 0;
     unsigned pre_mask = 0;
+    bool runs_mode = false;
     std::vector<unsigned> prog;
     bool prog_simple = false;
 
@@ -731,18 +891,20 @@ int group_rebuild(sxmc_group* g) {
         }
         const int sp = sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
         if (sx_fill_static_supports(sp, lds_hist, 3)) {
-          const SampleStore::Bucketed* bk = nullptr;
-          rc = get_bucketed(h, g->d_descs + i, mask, fields, 1, &bk);
+          const SampleStore::BucketSort* bs = nullptr;
+          rc = get_bucket_sort(h, g->d_descs + i, mask, &bs);
           if (rc) return rc;
-          if (bk) {
-            cd.cols = bk->d_cols;
-            cd.col_pitch = bk->pitch;
-            cd.nsamples = bk->ngranules * 256;
-            cd.nvec = bk->ngranules * 64;
-            cd.pre = bk->d_gpre;
-            fill_descs[(size_t)i] = cd;
-            g->member_bucket[(size_t)i] = bk;
+          if (bs) {
+            fill_descs[(size_t)i] = cd;     // (columns, unit count and granule table: once the layout is chosen)
+            plans[(size_t)i].sort = bs;
+            plans[(size_t)i].fields = fields;
             bucketed = true;
+            // histograms beyond LDS, evaluated at data events: per-wave runs + event bins grouped by bucket
+            runs_mode = !lds_hist && h->has_points && h->d_table && sx_fill_static_supports_sparse_runs(sp);
+            if (runs_mode) {
+              rc = build_bucket_tables(h, bs);
+              if (rc) return rc;
+            }
             key_nobs = cd.nobs;
             key_nslot = cd.nslot;
             prog = prog2;
@@ -792,7 +954,7 @@ int group_rebuild(sxmc_group* g) {
     for (LaunchClass& c : g->classes) {
       if (c.shape.nobs == key_nobs && c.shape.nslot == key_nslot && c.shape.lds_hist == lds_hist &&
           c.prog_simple == prog_simple && (!prog_simple || c.prog == prog) && c.pre_mask == pre_mask &&
-          c.shape.pre_width == pre_width) {
+          c.shape.pre_width == pre_width && c.runs_mode == runs_mode) {
         cls = &c;
       }
     }
@@ -809,6 +971,7 @@ int group_rebuild(sxmc_group* g) {
       cls->shape.static_prog = static_prog;
       cls->shape.pre_width = pre_width;
       cls->pre_mask = pre_mask;
+      cls->runs_mode = runs_mode;
     }
     cls->member_idx.push_back(i);
   }
@@ -849,13 +1012,49 @@ int group_rebuild(sxmc_group* g) {
   if (n) SX_HIP(hipMemcpy(g->d_descs_sparse, sparse_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
 
   for (LaunchClass& c : g->classes) {
+    const bool bucketed = c.shape.pre_width == 3;
+    // ---- threads per workgroup, LDS
+    int cls_max_bins = 0, cls_nsyst = 0;
+    for (int idx : c.member_idx) {
+      cls_max_bins = std::max(cls_max_bins, g->h_descs[(size_t)idx].total_nbins);
+      cls_nsyst = std::max(cls_nsyst, g->h_descs[(size_t)idx].nsyst);
+    }
+    c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4 + 64) * 4 : 64;
+    c.shape.sparse_runs = 0;
+    c.shape.sparse_lds_bytes = 0;
+    std::vector<int> K;   // runs mode: workgroups per member
+    if (c.runs_mode) {
+      // one full workgroup per CU; every wave owns 2 x 1024 words of LDS (table keys + counts) and walks its own
+      // run of consecutive granules: member j gets K_j workgroups (in proportion to its granules) = K_j x waves runs
+      const int rthreads = g->cfg_threads > 0 ? c.shape.threads : 1024;
+      const size_t need = (size_t)(rthreads / 64) * 2u * ((size_t)4 << SXMC_SPARSE_SMAX_LOG2);
+      std::vector<unsigned long long> sizes;
+      for (int idx : c.member_idx) sizes.push_back((unsigned long long)plans[(size_t)idx].sort->lsrc.size() * 64ull);
+      const int rbpc = std::min(g->cfg_bpc > 0 ? g->cfg_bpc : 1, std::max(1, (int)((size_t)props.lds_per_cu / need)));
+      if (need > (size_t)props.lds_per_cu || !apportion_workgroups(sizes, props.cus * rbpc, rthreads, K)) {
+        c.runs_mode = false;   // (more such members than workgroups: the table stays in sorted order)
+      } else {
+        c.shape.threads = rthreads;
+        c.shape.sparse_lds_bytes = need;
+      }
+    }
+    if (!c.shape.lds_hist && g->sparse_ready && !c.runs_mode) {
+      int cshift = 32;
+      for (int idx : c.member_idx) cshift = std::min(cshift, g->members[idx]->coarse_shift);
+      c.shape.lds_bytes = ((size_t)4 + ((size_t)1 << (32 - cshift - 5))) * 4;   // header + largest coarse filter
+      // a filter of more than half the LDS leaves room for one workgroup per CU: make it a full one
+      if (g->cfg_threads <= 0 && c.shape.lds_bytes * 2 > (size_t)props.lds_per_cu) c.shape.threads = 1024;
+    }
+    const int threads = c.shape.threads;  // (shadows the group-wide default above)
+
+    // ---- the members' descriptors; bucketed members: lay the table out now that the shape is known
     std::vector<SxSignalDesc> descs;
     unsigned long long prefix = 0;
-    int cls_max_bins = 0;
-    for (int idx : c.member_idx) {
+    for (size_t q = 0; q < c.member_idx.size(); q++) {
+      const int idx = c.member_idx[q];
       SxSignalDesc d = fill_descs[(size_t)idx];
+      sxmc_hist* h = g->members[idx];
       if (c.shape.pre_width == 1 || c.shape.pre_width == 2) {
-        sxmc_hist* h = g->members[idx];
         SampleStore& st = *h->store;
         std::lock_guard<std::mutex> lock(st.pre_mutex);
         void* pre = st.find_pre(c.pre_mask, c.shape.pre_width);
@@ -868,48 +1067,72 @@ int group_rebuild(sxmc_group* g) {
         }
         d.pre = pre;
       }
+      if (bucketed) {
+        const int runs = c.runs_mode ? std::max(1, K[q]) * (threads / 64) : 1;
+        const SampleStore::Bucketed* bk = nullptr;
+        rc = get_bucketed(h, plans[(size_t)idx].sort, plans[(size_t)idx].fields, runs, &bk);
+        if (rc) return rc;
+        d.cols = bk->d_cols;
+        d.col_pitch = bk->pitch;
+        d.nsamples = bk->ngranules * 256;
+        d.nvec = bk->ngranules * 64;
+        d.pre = bk->d_gpre;
+        g->member_bucket[(size_t)idx] = bk;
+      }
       d.vec_start = prefix;
       prefix += d.nvec;
-      cls_max_bins = std::max(cls_max_bins, d.total_nbins);
       descs.push_back(d);
     }
     c.total_vec = prefix;
-    c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4 + 64) * 4 : 64;
-    if (!c.shape.lds_hist && g->sparse_ready) {
-      int cshift = 32;
-      for (int idx : c.member_idx) cshift = std::min(cshift, g->members[idx]->coarse_shift);
-      c.shape.lds_bytes = ((size_t)4 + ((size_t)1 << (32 - cshift - 5))) * 4;   // header + largest coarse filter
-      // a filter of more than half the LDS leaves room for one workgroup per CU: make it a full one
-      if (g->cfg_threads <= 0 && c.shape.lds_bytes * 2 > (size_t)props.lds_per_cu) c.shape.threads = 1024;
-    }
-    const int threads = c.shape.threads;  // (shadows the group-wide default above)
     // Waves per CU.  The fill is a stream: HBM delivers most with about 32 KiB of loads in flight per CU,
     // which is 512 lanes with one unit (3-4 columns x 16 bytes) each; more waves only queue up (measured
     // -8 % at BASELINE config 3).  Members whose per-sample arithmetic is long (a run-time decoded program
     // of two or more systematics, the shape-agnostic kernel) or that probe L2 per sample (histograms
     // beyond LDS) need the second set of waves to hide it.
-    int cls_nsyst = 0;
-    for (int idx : c.member_idx) cls_nsyst = std::max(cls_nsyst, g->h_descs[(size_t)idx].nsyst);
     const double stream_bytes = (double)c.total_vec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot);
     const bool light = c.shape.lds_hist && c.shape.nobs > 0 && (c.shape.static_prog >= 0 || cls_nsyst <= 1) &&
                        stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
     c.light = light;
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
-    const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(c.shape.lds_bytes, 1)));
+    const size_t lds_need = std::max(c.shape.lds_bytes, c.shape.sparse_lds_bytes);
+    const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(lds_need, 1)));
     bpc = std::min(bpc, lds_limit);
     unsigned long long grid = (unsigned long long)props.cus * bpc;
     const unsigned long long want = (c.total_vec + threads - 1) / threads;  // >= 1 unit per lane
     grid = std::max<unsigned long long>(1, std::min(grid, want));
     c.shape.grid = c.total_vec ? (int)grid : 0;
+    if (c.runs_mode) {
+      int used = 0;
+      for (int k : K) used += k;
+      c.shape.grid = used;
+      c.shape.sparse_runs = 1;
+    }
     SX_HIP(hipMalloc((void**)&c.d_descs, sizeof(SxSignalDesc) * descs.size()));
     SX_HIP(hipMemcpy(c.d_descs, descs.data(), sizeof(SxSignalDesc) * descs.size(), hipMemcpyHostToDevice));
     if (g->sparse_ready && !c.shape.lds_hist) {
       std::vector<SxSignalDesc> sd = descs;
       for (size_t q = 0; q < sd.size(); q++) {
-        make_sparse_desc(g->members[c.member_idx[q]], sd[q]);
+        sxmc_hist* h = g->members[c.member_idx[q]];
+        make_sparse_desc(h, sd[q]);
         sd[q].sparse_filter = sparse_descs[(size_t)c.member_idx[q]].sparse_filter;  // shared tables
         sd[q].sparse_table = sparse_descs[(size_t)c.member_idx[q]].sparse_table;
         sd[q].sparse_coarse = sparse_descs[(size_t)c.member_idx[q]].sparse_coarse;
+        if (c.runs_mode) {
+          // members that look up the same set of bins share ONE set of bucket tables (one data set, one binning)
+          const sxmc_hist* owner = h;
+          for (size_t k = 0; k < q; k++) {
+            const sxmc_hist* o = g->members[c.member_idx[k]];
+            if (o->btab_valid && o->btab_mask == h->btab_mask && o->total_nbins == h->total_nbins &&
+                o->targets == h->targets) {
+              owner = o;
+              break;
+            }
+          }
+          sd[q].sparse_dir = owner->d_bdir;
+          sd[q].sparse_tkeys = owner->d_btkeys;
+          sd[q].sparse_tslot = owner->d_btslot;
+          sd[q].pre = g->member_bucket[(size_t)c.member_idx[q]]->d_gkp;   // {bucket key, bin offset} per granule
+        }
       }
       SX_HIP(hipMalloc((void**)&c.d_descs_sparse, sizeof(SxSignalDesc) * sd.size()));
       SX_HIP(hipMemcpy(c.d_descs_sparse, sd.data(), sizeof(SxSignalDesc) * sd.size(), hipMemcpyHostToDevice));
@@ -917,8 +1140,12 @@ int group_rebuild(sxmc_group* g) {
     if (c.shape.grid > 0) {
       std::vector<SxSegment> segs;
       std::vector<unsigned> blk_off;
-      build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition,
-                      c.shape.pre_width == 3 ? 64 : 1);
+      if (c.runs_mode) {
+        interleaved_segments(descs, K, threads, c.shape.grid, segs, blk_off);
+        c.partition = 2;
+      } else {
+        build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition, bucketed ? 64 : 1);
+      }
       SX_HIP(hipMalloc((void**)&c.d_segs, sizeof(SxSegment) * std::max<size_t>(segs.size(), 1)));
       SX_HIP(hipMalloc((void**)&c.d_blk_off, sizeof(unsigned) * blk_off.size()));
       if (!segs.empty()) {
@@ -1091,8 +1318,12 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
     const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
     c.shape.debug_mode = g->debug_mode;
-    SX_HIP(sx_launch_fill(c.shape, (sparse && c.d_descs_sparse) ? c.d_descs_sparse : c.d_descs, c.d_segs,
-                          c.d_blk_off, s));
+    if (sparse && c.d_descs_sparse && c.shape.sparse_runs) {
+      SX_HIP(sx_launch_fill_sparse_runs(c.shape, c.d_descs_sparse, c.d_segs, c.d_blk_off, s));
+    } else {
+      SX_HIP(sx_launch_fill(c.shape, (sparse && c.d_descs_sparse) ? c.d_descs_sparse : c.d_descs, c.d_segs,
+                            c.d_blk_off, s));
+    }
     if (rec) {
       SX_HIP(hipEventRecord(g->ev1[g->prof_n], s));
       g->prof_n++;
@@ -1970,7 +2201,7 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
     if (const SampleStore::Bucketed* bk = i < g->member_bucket.size() ? g->member_bucket[i] : nullptr) {
       // bucketed table: the columns that change, for the samples inside the domain of the untouched observables,
       // + one word per granule
-      fr += (double)bk->nkept * 4.0 * (double)bk->fields.size() + 4.0 * (double)bk->ngranules;
+      fr += (double)bk->nkept * 4.0 * (double)bk->fields.size() + (bk->runs > 1 ? 8.0 : 4.0) * (double)bk->ngranules;
     } else {
       fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
     }

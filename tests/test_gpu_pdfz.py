@@ -533,6 +533,53 @@ def test_sparse_counting_matches_dense_lookup():
     assert np.all(np.isnan(lut.get()[:5]))
 
 
+@pytest.mark.parametrize("nobs,nb,systs,params,nfields", [
+    (5, [60, 50, 8, 3, 2], C5_LIKE, [0.02, -0.01, 0.07], 7),                      # C5's shape: 144000 bins
+    (3, [400, 30, 20], [dict(type="scale", obs=0, pars=[0])], [0.02], 4),         # one written observable
+    (3, [5, 300, 40], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=1, pars=[1])], [0.01, -0.02], 4),
+    (2, [3, 20000], [dict(type="shift", obs=1, pars=[0])], [0.0001], 3),          # 3 buckets, > 1024 event bins each
+])
+def test_sparse_counting_over_bucketed_runs(nobs, nb, systs, params, nfields):
+    """Histograms beyond LDS capacity whose table is bucketed: every wave walks its own run of granules, the event
+    bins are grouped by bucket and counted in per-wave LDS tables that are flushed when the wave leaves the bucket
+    (fill_sparse_kernel).  lut and norms must equal the dense evaluation's and the oracle's, bit for bit --
+    including events outside the domain (-1), of another dataset (-2), many events in one bin, buckets with
+    more event bins than a wave's table holds, and a second set of evaluation points."""
+    rng = np.random.default_rng(26)
+    sizes = [150001, 70001, 9, 0, 30011]
+    pts = np.concatenate([table(rng, 6000, nobs, lo=-0.2, hi=1.2), rng.integers(0, 2, size=(6000, 1)).astype(np.float32)],
+                         axis=1)
+    pts[:500, :nobs] = pts[0, :nobs]                      # 500 events share one bin
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nb, systs, params, nfields=nfields, points=pts)
+    group = nll.EvalGroup(evs)
+
+    def check(points):
+        out = {}
+        for sparse, bucket in ((True, True), (False, True), (True, False)):
+            group.SetSparse(sparse)
+            group.SetBucketing(bucket)
+            lut.set(np.full(lut.size, 777.0, np.float32))
+            group.EvalAsync(True)
+            group.EvalFinished()
+            out[(sparse, bucket)] = (lut.get(), norms.get())
+        ne = points.shape[0]
+        for k, v in out.items():
+            assert np.array_equal(v[0].view(np.uint32), out[(True, True)][0].view(np.uint32)), k
+            assert np.array_equal(v[1], out[(True, True)][1]), k
+        for j, t in enumerate(tabs):
+            o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nb, systs, params, points=points, dataset=j % 2)
+            got = out[(True, True)][0][j * 6000: j * 6000 + ne]
+            assert_same_bits(got, o["out"])
+            assert out[(True, True)][1][j] == o["norm"]
+
+    check(pts)
+    group.SetBucketing(True)
+    pts2 = pts[1000:3500].copy()                          # a new data set: the bucket tables are rebuilt
+    for e in evs:
+        e.SetEvalPoints(pts2)
+    check(pts2)
+
+
 def test_shared_table_with_different_prebinned_columns():
     """Two evaluators over one sample table whose systematics leave different observables untouched: each
     group keeps its own pre-binned column, and evaluating one does not disturb the other."""
