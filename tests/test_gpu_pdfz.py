@@ -281,7 +281,7 @@ def test_eval_before_binding_buffers_is_an_error():
 
 
 # ---------------------------------------------------------------- group (batched) evaluation
-def build_group(rng, sizes, nobs, nbins, systs, params, nfields=None, points=None):
+def build_group(rng, sizes, nobs, nbins, systs, params, nfields=None, points=None, lo=-0.5, hi=1.5):
     nfields = nfields or nobs + 1
     evs, tabs = [], []
     S = len(sizes)
@@ -290,7 +290,7 @@ def build_group(rng, sizes, nobs, nbins, systs, params, nfields=None, points=Non
     norms = DeviceArray(np.full(S, 55, np.uint32))
     pbuf = DeviceArray(np.asarray(params, np.float64))
     for j, n in enumerate(sizes):
-        t = table(rng, n, nfields)
+        t = table(rng, n, nfields, lo, hi)
         tabs.append(t)
         ev = pdfz.EvalHist(t, nfields, nobs, [0.0] * nobs, [1.0] * nobs, nbins, dataset=j % 2)
         for s in systs:
@@ -535,8 +535,8 @@ def test_sparse_counting_matches_dense_lookup():
 
 @pytest.mark.parametrize("nobs,nb,systs,params,nfields", [
     (5, [60, 50, 8, 3, 2], C5_LIKE, [0.02, -0.01, 0.07], 7),                      # C5's shape: 144000 bins
-    (3, [400, 30, 20], [dict(type="scale", obs=0, pars=[0])], [0.02], 4),         # one written observable
-    (3, [5, 300, 40], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=1, pars=[1])], [0.01, -0.02], 4),
+    (3, [4000, 4, 3], [dict(type="scale", obs=0, pars=[0])], [0.02], 4),          # one written observable
+    (3, [5, 3000, 4], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=1, pars=[1])], [0.01, -0.02], 4),
     (2, [3, 20000], [dict(type="shift", obs=1, pars=[0])], [0.0001], 3),          # 3 buckets, > 1024 event bins each
 ])
 def test_sparse_counting_over_bucketed_runs(nobs, nb, systs, params, nfields):
@@ -550,8 +550,11 @@ def test_sparse_counting_over_bucketed_runs(nobs, nb, systs, params, nfields):
     pts = np.concatenate([table(rng, 6000, nobs, lo=-0.2, hi=1.2), rng.integers(0, 2, size=(6000, 1)).astype(np.float32)],
                          axis=1)
     pts[:500, :nobs] = pts[0, :nobs]                      # 500 events share one bin
-    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nb, systs, params, nfields=nfields, points=pts)
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nb, systs, params, nfields=nfields, points=pts,
+                                              lo=-0.05, hi=1.05)
     group = nll.EvalGroup(evs)
+    fr = group.AlgorithmicBytes()["fill_read"]
+    assert fr < 4.0 * sum(sizes) * (nobs + 1) * 0.8       # the big members really are bucketed
 
     def check(points):
         out = {}
