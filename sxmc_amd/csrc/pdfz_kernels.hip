@@ -584,6 +584,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restri
 // (pdfz.cpp:388-398 lets such an index alias into the next row of the flat index; the bucket tables assume the
 // canonical decomposition, the global table is keyed by the flat index itself).
 typedef unsigned vuint2g __attribute__((ext_vector_type(2)));
+typedef unsigned vuint4g __attribute__((ext_vector_type(4)));
 
 template <int NOBS, int NSLOT, typename PROG>
 __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* __restrict__ descs,
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* _
 
     unsigned cnt = 0;
     // the bucket this wave is in: its table sits in wkeys[0 .. 1 << cur_log2), counts in wcnt
-    unsigned cur_key = 0xFFFFFFFFu, cur_off = 0u, cur_info = SXMC_SPARSE_EMPTY;
+    unsigned cur_key = 0xFFFFFFFFu, cur_off = 0u, cur_info = SXMC_SPARSE_EMPTY, cur_probes = 1u;
 
     auto flush = [&]() {
       if (cur_info <= SXMC_SPARSE_SMAX_LOG2) {
@@ -684,6 +685,12 @@ __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* _
       }
       const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane((int)kp[0]);
       const unsigned pre = (unsigned)__builtin_amdgcn_readfirstlane((int)kp[1]);
+      // (the bucket state is wave-uniform; say so, or the loop-carried copies live in vector registers and every
+      // test on them becomes exec-mask code)
+      cur_key = (unsigned)uniform_i((int)cur_key);
+      cur_off = (unsigned)uniform_i((int)cur_off);
+      cur_info = (unsigned)uniform_i((int)cur_info);
+      cur_probes = (unsigned)uniform_i((int)cur_probes);
 #pragma unroll
       for (int k = 0; k < NSLOT; k++) {
 #pragma unroll
@@ -706,7 +713,9 @@ __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* _
         const vuint2g e = dir[key];
         cur_key = key;
         cur_off = (unsigned)__builtin_amdgcn_readfirstlane((int)e[0]);
-        cur_info = (unsigned)__builtin_amdgcn_readfirstlane((int)e[1]) & 0xFFu;
+        const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane((int)e[1]);
+        cur_info = info & 0xFFu;            // log2(table size) >= 2, or a flag
+        cur_probes = (info >> 8) & 0xFFu;   // cells a key may have been pushed along
         if (cur_info <= SXMC_SPARSE_SMAX_LOG2) {
           const unsigned S = 1u << cur_info;
           for (unsigned b = lane; b < S; b += kWave) wkeys[b] = tkeys[cur_off + b];
@@ -741,26 +750,27 @@ __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* _
         slow[q] = count_it && (all_slow || alias != 0u);
       }
       if (table_here) {
-        const unsigned hshift = 32u - cur_info, hmask = (1u << cur_info) - 1u;
-        unsigned h[SXMC_VEC], k0[SXMC_VEC];
+        // The table is cut into cells of four keys (one 16-byte LDS read); a key sits in its home cell or, when
+        // that was full, in one of the next cur_probes - 1 cells.  The trip count is the same for every lane and
+        // almost always one: no divergent probing loop (a per-lane while loop here cost more than the stream).
+        const unsigned cshift = 34u - cur_info, cmask = (1u << (cur_info - 2u)) - 1u;   // cells = size / 4
+        unsigned cell[SXMC_VEC];
 #pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) {
-          h[q] = cur_info ? (p2[q] * 0x9E3779B1u) >> hshift : 0u;
-          k0[q] = wkeys[h[q]];
-        }
+        for (int q = 0; q < SXMC_VEC; q++) cell[q] = cur_info > 2u ? (p2[q] * 0x9E3779B1u) >> cshift : 0u;
+        for (unsigned pr = 0; pr < cur_probes; pr++) {
+          vuint4g kk[SXMC_VEC];
 #pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) {
-          bool pend = fast[q];
-          unsigned hh = h[q], kk = k0[q];
-          while (pend) {
-            if (kk == p2[q]) {
-              __hip_atomic_fetch_add(&wcnt[hh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              pend = false;
-            } else if (kk == 0xFFFFFFFFu) {
-              pend = false;
-            } else {
-              hh = (hh + 1u) & hmask;
-              kk = wkeys[hh];
+          for (int q = 0; q < SXMC_VEC; q++) {
+            kk[q] = *reinterpret_cast<const vuint4g*>(&wkeys[4u * ((cell[q] + pr) & cmask)]);
+          }
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            // keys are distinct, so at most one of the four matches: its position by arithmetic, not by branches
+            const unsigned key = fast[q] ? p2[q] : 0xFFFFFFFEu;   // (never a table key)
+            const unsigned m = (kk[q][1] == key ? 1u : 0u) + (kk[q][2] == key ? 2u : 0u) + (kk[q][3] == key ? 3u : 0u);
+            if ((kk[q][0] == key) | (m != 0u)) {
+              __hip_atomic_fetch_add(&wcnt[4u * ((cell[q] + pr) & cmask) + m], 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
         }

@@ -136,7 +136,7 @@ hipError_t sx_launch_fill_sparse_runs(const SxLaunchShape& shape, const SxSignal
 bool sx_fill_static_supports_sparse_runs(int prog);
 #define SXMC_SPARSE_EMPTY 0xFFu   /* directory flag: the bucket holds no event bin */
 #define SXMC_SPARSE_SLOW 0xFEu    /* directory flag: look every sample up in the global table (see the kernel) */
-#define SXMC_SPARSE_SMAX_LOG2 10  /* largest per-wave table: 1024 entries */
+#define SXMC_SPARSE_SMAX_LOG2 9  /* largest per-wave table: 512 entries */
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
 bool sx_fill_static_supports(int prog, int lds_hist, int prebin);

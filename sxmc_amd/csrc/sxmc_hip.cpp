@@ -754,21 +754,40 @@ int build_bucket_tables(sxmc_hist* h, const SampleStore::BucketSort* bs) {
   for (unsigned key = 0; key < nkeys; key++) {
     if (where[key] < 0) continue;
     const auto& list = by_key[(size_t)where[key]];
-    int lg = std::max(1, ceil_log2(4 * list.size()));                 // load <= 25 %: a miss is ~1.2 probes
-    if (lg > SXMC_SPARSE_SMAX_LOG2) lg = std::max(1, ceil_log2(2 * list.size()));
+    // cells of four keys (one 16-byte LDS read per probe); load <= 25 %, or <= 50 % for the largest buckets
+    int lg = std::max(2, ceil_log2(4 * list.size()));
+    if (lg > SXMC_SPARSE_SMAX_LOG2) lg = std::max(2, ceil_log2(2 * list.size()));
     if (lg > SXMC_SPARSE_SMAX_LOG2) {                                  // more event bins than a wave's slice holds
       dir[2 * (size_t)key + 1] = SXMC_SPARSE_SLOW;
       continue;
     }
-    const size_t off = tkeys.size(), S = (size_t)1 << lg;
+    const size_t off = tkeys.size(), S = (size_t)1 << lg, cells = S / 4;
     tkeys.resize(off + S, 0xFFFFFFFFu);
     tslot.resize(off + S, 0u);
+    unsigned probes = 1;
     for (const auto& e : list) {
-      size_t hp = (size_t)((e.first * 0x9E3779B1u) >> (32 - lg));
-      while (tkeys[off + hp] != 0xFFFFFFFFu) hp = (hp + 1) & (S - 1);
-      tkeys[off + hp] = e.first;
-      tslot[off + hp] = e.second;
+      size_t cell = lg > 2 ? (size_t)((e.first * 0x9E3779B1u) >> (34 - lg)) : 0;
+      unsigned dist = 1;
+      for (;; cell = (cell + 1) & (cells - 1), dist++) {
+        size_t at = off + 4 * cell, free_slot = 4;
+        for (size_t m = 0; m < 4; m++)
+          if (tkeys[at + m] == 0xFFFFFFFFu) {
+            free_slot = m;
+            break;
+          }
+        if (free_slot < 4) {
+          tkeys[at + free_slot] = e.first;
+          tslot[at + free_slot] = e.second;
+          break;
+        }
+      }
+      probes = std::max(probes, dist);
     }
+    if (probes > 255) {   // (cannot happen below 100 % load; keeps the field in range)
+      dir[2 * (size_t)key + 1] = SXMC_SPARSE_SLOW;
+      continue;
+    }
+    lg |= (int)(probes << 8);
     dir[2 * (size_t)key] = (unsigned)off;
     dir[2 * (size_t)key + 1] = (unsigned)lg;
   }
@@ -1024,13 +1043,17 @@ int group_rebuild(sxmc_group* g) {
     c.shape.sparse_lds_bytes = 0;
     std::vector<int> K;   // runs mode: workgroups per member
     if (c.runs_mode) {
-      // one full workgroup per CU; every wave owns 2 x 1024 words of LDS (table keys + counts) and walks its own
-      // run of consecutive granules: member j gets K_j workgroups (in proportion to its granules) = K_j x waves runs
-      const int rthreads = g->cfg_threads > 0 ? c.shape.threads : 1024;
+      // every wave owns 2 x 512 words of LDS (table keys + counts) and walks its own run of consecutive granules:
+      // member j gets K_j workgroups (in proportion to its granules) = K_j x waves runs.  Three workgroups of
+      // 512 per CU measured best at BASELINE config 5 (2.14 ms; one of 1024: 2.29 ms; thread counts that are not
+      // powers of two 2.4 ms); the kernel is bound by vector-instruction issue and HBM together, and 24 waves
+      // per CU is what its registers allow.
+      const int rthreads = g->cfg_threads > 0 ? c.shape.threads : 512;
       const size_t need = (size_t)(rthreads / 64) * 2u * ((size_t)4 << SXMC_SPARSE_SMAX_LOG2);
       std::vector<unsigned long long> sizes;
       for (int idx : c.member_idx) sizes.push_back((unsigned long long)plans[(size_t)idx].sort->lsrc.size() * 64ull);
-      const int rbpc = std::min(g->cfg_bpc > 0 ? g->cfg_bpc : 1, std::max(1, (int)((size_t)props.lds_per_cu / need)));
+      const int rbpc = std::min(g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, 1536 / rthreads),
+                                std::max(1, (int)((size_t)props.lds_per_cu / need)));
       if (need > (size_t)props.lds_per_cu || !apportion_workgroups(sizes, props.cus * rbpc, rthreads, K)) {
         c.runs_mode = false;   // (more such members than workgroups: the table stays in sorted order)
       } else {
