@@ -202,6 +202,7 @@ class Leg:
         m.group.SetPartition(args.partition)
         m.group.SetPrebinning(not args.no_prebin)
         m.group.SetBucketing(not args.no_bucket)
+        m.group.SetTailKernel(not args.no_tail)
         m.group.SetSparse(not args.no_sparse)
         self.graph_state = {"steps_per_graph": args.graph_steps if form == "graph" else 0, "fallback": None}
         self.tuned_threads = 0
@@ -279,6 +280,8 @@ class Leg:
         return elapsed
 
     def launches_per_step(self):
+        if self.m.consume and self.m.tail and self.form != "pdfz":
+            return self.m.group.LastStepLaunches()     # what the library actually launched for the last step
         return 3 if (self.form in ("pdfz", "step") or self.m.consume) else 4
 
     def roofline(self, world=1):
@@ -473,6 +476,9 @@ def main():
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
     ap.add_argument("--no-sparse", action="store_true", help="fill HBM-resident histograms densely (global atomics)")
     ap.add_argument("--no-prebin", action="store_true", help="bin every observable in the kernel (no pre-binned column)")
+    ap.add_argument("--no-tail", action="store_true",
+                    help="step end as its own kernels (lookup + event sum, then step end + clearing: 3 launches per step) "
+                         "instead of one workgroup doing all of it in one launch")
     ap.add_argument("--no-bucket", action="store_true",
                     help="stream the table in the caller's row order (no copy grouped by the untouched observables' bins)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")

@@ -98,6 +98,10 @@ SIGNATURES = {
     "sxmc_group_eval_nll_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi],
     "sxmc_group_mcmc_step_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp,
                                    _vp, _vp, _vp, _vp, _i],
+    "sxmc_group_step_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp,
+                              _vp, _vp, _vp, _vp, _i],
+    "sxmc_group_set_tail_kernel": [_vp, _i],
+    "sxmc_group_last_step_launches": [_vp, _pi],
     "sxmc_group_finish_step_async": [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz,
                                      _vp, _vp, _vp, _vp, _vp, _i],
     "sxmc_group_synchronize": [_vp],

@@ -1073,6 +1073,36 @@ __global__ __launch_bounds__(256) void eval_nll_finish_kernel(const SxSignalDesc
                             a.debug_mode != 0);
 }
 
+// The whole end of an MCMC step in ONE workgroup: lookup + event sum over the rows (events, or classes of events
+// with a weight each), finish_nll_jump_pick_combo, and the clearing of histograms and normalisations the next
+// evaluation would start with.  With a few thousand rows (event classes at BASELINE configs 1-3) the end of a step
+// is a chain of memory latencies, not work: as its own kernels (lookup + event sum over ~40 workgroups, then the
+// step end beside the zeroing) it costs two launch ramps, two kernel boundaries and a round trip of the partial
+// sums through memory; here it is one ramp, and the step's other inputs are in flight under the gathers.
+__global__ __launch_bounds__(1024) void tail_step_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                         unsigned long long npoints,
+                                                         const unsigned* __restrict__ weight, SxStepArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double s_total;
+  const double t =
+      eval_nll_block(descs, nsig, npoints, weight, a.v_proposed, a.nexpected, a.n_mc, a.source_id, a.norms, sh);
+  if (threadIdx.x == 0) s_total = isnan(t) ? 0.0 : t;   // (nll_kernels.cpp:113-115: a NaN partial is not stored)
+  __syncthreads();
+  sxdev::finish_step_device(1, &s_total, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                            a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                            a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
+                            a.debug_mode != 0);
+  // (the normalisations were last read before the barriers inside finish_step_device)
+  for (int j = 0; j < nsig; j++) {
+    const SxSignalDesc& d = descs[j];
+    const unsigned n = (unsigned)d.total_nbins, n4 = n >> 2;
+    uint4* b4 = reinterpret_cast<uint4*>(d.bins);
+    for (unsigned i = threadIdx.x; i < n4; i += blockDim.x) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < (n & 3u)) d.bins[(n4 << 2) + threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *d.norm = 0u;
+  }
+}
+
 // finish_nll_jump_pick_combo (workgroup 0) and, beside it in the same launch, what zero_kernel does for
 // the NEXT evaluation (all other workgroups): a walk that does not look at histograms or normalisations
 // between steps saves a launch per step.  Workgroup 0 clears the normalisations itself, after it has read
@@ -1383,6 +1413,13 @@ hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsi
   const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
   hipLaunchKernelGGL(eval_nll_finish_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, weight, sums,
                      ticket, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_tail_step(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
+                               const unsigned* weight, const SxStepArgs& a, hipStream_t s) {
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
+  hipLaunchKernelGGL(tail_step_kernel, dim3(1), dim3(1024), shmem, s, d_descs, nsig, npoints, weight, a);
   return hipGetLastError();
 }
 

@@ -129,6 +129,8 @@ hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_
 hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
                                       const unsigned* weight, double* sums, unsigned* ticket, const SxStepArgs& a,
                                       int grid, int block, hipStream_t s);
+hipError_t sx_launch_tail_step(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
+                               const unsigned* weight, const SxStepArgs& a, hipStream_t s);
 hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,
                           const unsigned* d_blk_off, hipStream_t s);
 hipError_t sx_launch_fill_sparse_runs(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,

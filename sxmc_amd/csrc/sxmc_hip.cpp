@@ -357,6 +357,8 @@ struct sxmc_group {
   int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
   int cfg_prebin = 1, cfg_seen_prebin = -1;        // pre-bin the observables no systematic writes
   int cfg_bucket = 1, cfg_seen_bucket = -1;        // stream a bucketed copy of the table where that pays
+  int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
+  int last_step_launches = 0;                      // kernels the last sxmc_group_step_async launched
   std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
   int debug_mode = 0;
   int max_bins = 0;
@@ -2163,6 +2165,99 @@ int sxmc_group_finish_step_async(sxmc_group_t g, sxmc_stream_t s, size_t npartia
     h->bins_valid = false;
     h->cleared_by = g;
   }
+  return SXMC_OK;
+}
+
+int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means, const double* d_sigmas,
+                          sxmc_rng_state* d_rng, double* d_nll_current, double* d_nll_proposed, double* d_v_current,
+                          double* d_v_proposed, int* d_accepted, int* d_counter, float* d_jump_buffer, int nparameters,
+                          size_t nsources, const float* d_jump_width, const double* d_nexpected, const unsigned* d_n_mc,
+                          const short* d_source_id, const unsigned* d_norms, int debug_mode) {
+  SX_REQUIRE(g && d_means && d_sigmas && d_rng && d_nll_current && d_nll_proposed && d_v_current && d_v_proposed &&
+                 d_accepted && d_counter && d_jump_buffer && d_jump_width && d_nexpected && d_n_mc && d_source_id &&
+                 d_norms,
+             "null argument");
+  SX_REQUIRE(nparameters > 0, "nparameters must be positive");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  rc = group_check_bound(g, true);
+  if (rc) return rc;
+  if (!g->same_points) return fail(SXMC_ERR_STATE, "members do not share one set of evaluation points");
+  SX_REQUIRE(g->members.size() <= 1024, "too many members for the fused step");
+  hipStream_t st = (hipStream_t)s;
+  g->last_stream = st;
+  const bool sparse = g->sparse_ready && g->cfg_sparse;
+  unsigned long long ne = g->members[0]->npoints;
+  const SxSignalDesc* descs = sparse ? g->d_descs_sparse : g->d_descs;
+  const unsigned* weight = nullptr;
+  if (!g->cfg_lut) {
+    rc = ensure_event_classes(g, sparse);  // (may upload tables: before anything is launched)
+    if (rc) return rc;
+    const sxmc_group::EventClasses& ec = g->ec[sparse ? 1 : 0];
+    ne = ec.K;
+    descs = ec.d_descs;
+    weight = ec.d_weight;
+  }
+  const bool zero_launched = g->prezeroed != (sparse ? 2 : 1);   // (group_fill decides the same way, plus bookkeeping)
+  rc = group_fill(g, st, sparse);
+  if (rc) return rc;
+  g->last_step_launches = (int)g->classes.size() + (zero_launched ? 1 : 0);
+  SxStepArgs a;
+  a.nsignals = g->members.size();
+  a.nsources = nsources;
+  a.means = d_means;
+  a.sigmas = d_sigmas;
+  a.rng = d_rng;
+  a.nll_current = d_nll_current;
+  a.nll_proposed = d_nll_proposed;
+  a.v_current = d_v_current;
+  a.v_proposed = d_v_proposed;
+  a.accepted = d_accepted;
+  a.counter = d_counter;
+  a.jump_buffer = d_jump_buffer;
+  a.nparameters = nparameters;
+  a.debug_mode = debug_mode;
+  a.jump_width = d_jump_width;
+  a.nexpected = d_nexpected;
+  a.n_mc = d_n_mc;
+  a.source_id = d_source_id;
+  a.norms = d_norms;
+  // How much the end of the step has to touch decides its shape: a few thousand rows and histograms of a few
+  // hundred kilobytes are latency, and one workgroup does it all in one launch; more is work for many.
+  unsigned long long words = 0;
+  const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
+  for (const SxSignalDesc& d : flavour) words += (unsigned long long)d.total_nbins;
+  const unsigned long long gathers = ne * g->members.size();
+  if (gathers <= 262144ull && words <= (1ull << 20) && g->cfg_tail != 0) {
+    SX_HIP(sx_launch_tail_step(descs, (int)g->members.size(), ne, weight, a, st));
+    g->last_step_launches += 1;
+  } else {
+    g->last_step_launches += 2;
+    const int block = 128;
+    const int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
+    SX_HIP(sx_launch_eval_nll(descs, (int)g->members.size(), ne, weight, d_v_proposed, d_nexpected, d_n_mc, d_source_id,
+                              d_norms, g->d_step_sums, grid, block, st));
+    SX_HIP(sx_launch_finish_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
+                                 sparse ? g->max_bins_sparse : g->max_bins, (size_t)grid, g->d_step_sums, g->d_ticket, a,
+                                 128, st));
+  }
+  g->prezeroed = sparse ? 2 : 1;
+  for (sxmc_hist* h : g->members) {
+    h->bins_valid = false;
+    h->cleared_by = g;
+  }
+  return SXMC_OK;
+}
+
+int sxmc_group_last_step_launches(sxmc_group_t g, int* launches) {
+  SX_REQUIRE(g && launches, "null argument");
+  *launches = g->last_step_launches;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_tail = enable ? 1 : 0;
   return SXMC_OK;
 }
 

@@ -41,7 +41,7 @@ class MCMC {
   bool optimize = true;         //!< EvalHist's `optimize` constructor flag for the batched launch: a few trial
                                 //!< launches at the start of a walk pick the lane count per CU (sxmc_group_optimize)
   bool consume = true;          //!< batched form: the step end also clears histograms and normalisations for the
-                                //!< next step (sxmc_group_finish_step_async: 3 launches per step; nothing reads them
+                                //!< next step (sxmc_group_step_async: 2 launches per step; nothing reads them
                                 //!< between the steps of a walk)
   std::mutex* exclusive = nullptr;  //!< with one chain per host thread: the mutex this walk holds while it
                                     //!< allocates, uploads, rebuilds launch plans, records its graph and frees
@@ -272,6 +272,13 @@ class MCMC {
     };
     auto one_step = [&]() {
       int npartial = (int)nnllthreads;
+      if (batched && reevaluate && consume) {
+        // two launches: fill of all signals; lookup + event sum + step end + clearing for the next step
+        check(sxmc_group_step_async(group, strm, d.means, d.sigmas, d.rng, d.nll_current, d.nll_proposed, d.current,
+                                    d.proposed, d.accepted, d.counter, d.jump_buffer, (int)nparameters, nsources,
+                                    d.jump_width, d.nexpected, d.n_mc, d.source_id, d.norms, debug_mode ? 1 : 0));
+        return;
+      }
       if (batched && reevaluate) {
         // zero, fill of all signals in one kernel, lookup fused with the event partial sums
         check(sxmc_group_eval_nll_async(group, strm, d.proposed, d.nexpected, d.n_mc, d.source_id, d.norms, d.sums,
@@ -283,13 +290,6 @@ class MCMC {
         }
         SXMC_KERNEL_LAUNCH(nll_event_chunks, nnllblocks, nllblocksize, 0, strm, d.lut, d.proposed, nevents, nsignals,
                            d.nexpected, d.n_mc, d.source_id, d.norms, d.sums);
-      }
-      if (batched && reevaluate && consume) {
-        check(sxmc_group_finish_step_async(group, strm, (size_t)npartial, d.sums, d.means, d.sigmas, d.rng,
-                                           d.nll_current, d.nll_proposed, d.current, d.proposed, d.accepted,
-                                           d.counter, d.jump_buffer, (int)nparameters, nsources, d.jump_width,
-                                           d.nexpected, d.n_mc, d.source_id, d.norms, debug_mode ? 1 : 0));
-        return;
       }
       SXMC_KERNEL_LAUNCH(finish_nll_jump_pick_combo, 1, nreducethreads, nreducethreads * sizeof(double), strm,
                          (size_t)npartial, d.sums, nsignals, nsources, d.means, d.sigmas, d.rng, d.nll_current,

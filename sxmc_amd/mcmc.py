@@ -46,6 +46,7 @@ class MCMC:
         self.stream = stream
         self.fused = fused
         self.consume = bool(consume) and fused is True
+        self.tail = True        # consume: one call per step (sxmc_group_step_async) instead of EvalNllAsync + FinishStepAsync
         self.nsources, self.nsignals = w.nsources, w.nsignals
         self.nparameters = w.nparameters
         self.nnllthreads = NLL_BLOCKS * NLL_BLOCK_SIZE
@@ -157,6 +158,13 @@ class MCMC:
                                      self.proposed_vector, self.accept_counter, self.jump_counter,
                                      self.jump_buffer, self.nparameters, self.nsources, self.jump_width,
                                      self.nexpected, self.n_mc, self.source_id, self.normalizations, debug_mode)
+            return
+        if self.consume and self.tail:
+            self.group.StepAsync(self.stream, self.parameter_means, self.parameter_sigma, self.rngs,
+                                 self.current_nll, self.proposed_nll, self.current_vector, self.proposed_vector,
+                                 self.accept_counter, self.jump_counter, self.jump_buffer, self.nparameters,
+                                 self.nsources, self.jump_width, self.nexpected, self.n_mc, self.source_id,
+                                 self.normalizations, debug_mode)
             return
         if self.fused:
             npartial = self.group.EvalNllAsync(self.stream, self.proposed_vector, self.nexpected, self.n_mc,

@@ -125,6 +125,24 @@ class EvalGroup:
                   ptr(counter), ptr(jump_buffer), int(nparameters), int(nsources), ptr(jump_width),
                   ptr(nexpected), ptr(n_mc), ptr(source_id), ptr(norms), int(bool(debug_mode)))
 
+    def StepAsync(self, stream, means, sigmas, rng, nll_current, nll_proposed, v_current, v_proposed,
+                  accepted, counter, jump_buffer, nparameters, nsources, jump_width, nexpected, n_mc,
+                  source_id, norms, debug_mode=False):
+        """One whole MCMC step in two launches: fill, then lookup + event sum + step end + clearing for the next
+        step in one workgroup (sxmc_group_step_async; three launches where that is too much for one workgroup)."""
+        capi.call("sxmc_group_step_async", self._g, ptr(stream), ptr(means), ptr(sigmas), ptr(rng),
+                  ptr(nll_current), ptr(nll_proposed), ptr(v_current), ptr(v_proposed), ptr(accepted),
+                  ptr(counter), ptr(jump_buffer), int(nparameters), int(nsources), ptr(jump_width),
+                  ptr(nexpected), ptr(n_mc), ptr(source_id), ptr(norms), int(bool(debug_mode)))
+
+    def LastStepLaunches(self):
+        n = C.c_int(0)
+        capi.call("sxmc_group_last_step_launches", self._g, C.byref(n))
+        return n.value
+
+    def SetTailKernel(self, enable):
+        capi.call("sxmc_group_set_tail_kernel", self._g, int(bool(enable)))
+
     def FinishStepAsync(self, stream, npartial_sums, sums, means, sigmas, rng, nll_current, nll_proposed, v_current,
                         v_proposed, accepted, counter, jump_buffer, nparameters, nsources, jump_width, nexpected,
                         n_mc, source_id, norms, debug_mode=False):
