@@ -266,26 +266,27 @@ int sxmc_group_finish_step_async(sxmc_group_t g, sxmc_stream_t s, size_t npartia
                                  const double* d_nexpected, const unsigned* d_n_mc, const short* d_source_id,
                                  const unsigned* d_norms, int debug_mode);
 /* One whole MCMC step (mcmc.cpp:264-271 + 314-348) for a walk that reads neither histograms, normalisations nor
- * the lookup table between steps, in TWO launches: the fill of all members, and one kernel that does lookup +
- * nll_event_chunks (nll_kernels.cpp:89-116) + nll_event_reduce + nll_total + finish_nll_jump_pick_combo
- * (:230-271) + the clearing the next evaluation would start with (so that one skips its zero launch).  The end
- * of a step over a few thousand rows (event classes, see sxmc_group_set_lut_output) is a chain of memory
- * latencies; one workgroup walks it once instead of three kernels handing partial sums through memory.  Where
- * the rows or the histograms are too many for one workgroup (more than 262 144 row x member look-ups or 2^20
- * counters) the same work runs as sxmc_group_eval_nll_async + sxmc_group_finish_step_async would (3 launches).
+ * the lookup table between steps: the fill of all members, then lookup + nll_event_chunks (nll_kernels.cpp:89-116)
+ * + nll_event_reduce + nll_total + finish_nll_jump_pick_combo (:230-271) + the clearing the next evaluation
+ * would start with (so that one skips its zero launch).  The step end runs as ONE workgroup in ONE launch
+ * (2 launches per step) where it is small -- at most 256 row x member look-ups and 65 536 counters: BASELINE
+ * config 1 -- and as two launches otherwise (lookup + event sum over many workgroups,
+ * then step end beside the clearing: what sxmc_group_eval_nll_async + sxmc_group_finish_step_async do).  A row
+ * costs one double division per member and a log, so beyond a few hundred of them one CU is slower than the
+ * extra launch (measured: config 3, ~8000 x 12, 59 us against 15.6 us; bench_pdfz, 1000 x 1, 8 against 7;
+ * config 1, 10 x 2, 7.0 against 7.6).
  * The NLL is evaluated at d_v_proposed, which is also the members' parameter buffer in a walk (mcmc.cpp:241).
  * Histograms and normalisations are CLEARED when this returns, as after sxmc_group_finish_step_async; the
- * lookup table is written only when sxmc_group_set_lut_output is on.  Chains are bit-identical to the other
- * step forms whenever the partial sums are (one workgroup adds them in another order: the NLL agrees to
- * ~1e-15 relative and an accept/reject decision could in principle differ on a tie). */
+ * lookup table is written only when sxmc_group_set_lut_output is on.  The one-workgroup form adds the log terms
+ * in another order than the many-workgroup form (NLL equal to ~1e-15 relative). */
 int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means, const double* d_sigmas,
                           sxmc_rng_state* d_rng, double* d_nll_current, double* d_nll_proposed,
                           double* d_v_current, double* d_v_proposed, int* d_accepted, int* d_counter,
                           float* d_jump_buffer, int nparameters, size_t nsources,
                           const float* d_jump_width, const double* d_nexpected, const unsigned* d_n_mc,
                           const short* d_source_id, const unsigned* d_norms, int debug_mode);
-/* Kernels launched by the last sxmc_group_step_async (2 in a walk of BASELINE configs 1-3; +1 when the
- * histograms had to be zeroed first; 3 where the step end is work for more than one workgroup). */
+/* Kernels launched by the last sxmc_group_step_async (2 or 3, see there; +1 when the histograms had to be
+ * zeroed first). */
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches);
 /* 0: sxmc_group_step_async always takes its three-launch route (measurement / tests).  Default 1. */
 int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);

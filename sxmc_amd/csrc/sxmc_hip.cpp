@@ -2222,13 +2222,16 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
   a.n_mc = d_n_mc;
   a.source_id = d_source_id;
   a.norms = d_norms;
-  // How much the end of the step has to touch decides its shape: a few thousand rows and histograms of a few
-  // hundred kilobytes are latency, and one workgroup does it all in one launch; more is work for many.
+  // How much the end of the step has to touch decides its shape.  One workgroup doing all of it in one launch
+  // saves a launch and a boundary, but a row costs S double divisions and a log: measured at BASELINE config 3
+  // (~8000 rows x 12 members) one CU needs 59 us for what ~60 workgroups + the step-end launch do in 15.6 us, and
+  // at config 2 (~2500 x 6) 16 us against 9, at the bench_pdfz shape (1000 x 1) 8 us against 7; config 1 (10 x 2)
+  // gains 0.6 us of 14.7.  Only the smallest problems take it.
   unsigned long long words = 0;
   const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
   for (const SxSignalDesc& d : flavour) words += (unsigned long long)d.total_nbins;
   const unsigned long long gathers = ne * g->members.size();
-  if (gathers <= 262144ull && words <= (1ull << 20) && g->cfg_tail != 0) {
+  if (gathers <= 256ull && words <= (1ull << 16) && g->cfg_tail != 0) {
     SX_HIP(sx_launch_tail_step(descs, (int)g->members.size(), ne, weight, a, st));
     g->last_step_launches += 1;
   } else {
