@@ -177,6 +177,10 @@ class Leg:
             a.events = events
         self.scale = a.scale
         w, tensors = make_workload(a, torch, dev, seed)
+        if args.extra_ctscale and w.name == "C3":
+            w.systematics = list(w.systematics) + [dict(type="ctscale", obs=2, pars=[3])]
+            w.syst_sigmas = list(w.syst_sigmas) + [0.01]
+            w.description += " + ctscale(c)"
         if args.nsyst >= 0:
             w.systematics = w.systematics[:args.nsyst]
             w.description += " [first %d systematics only]" % args.nsyst
@@ -203,6 +207,7 @@ class Leg:
         m.group.SetPrebinning(not args.no_prebin)
         m.group.SetBucketing(not args.no_bucket)
         m.group.SetTailKernel(not args.no_tail)
+        m.group.SetRuntimeKernels(not args.no_rtc)
         m.group.SetSparse(not args.no_sparse)
         self.graph_state = {"steps_per_graph": args.graph_steps if form == "graph" else 0, "fallback": None}
         self.tuned_threads = 0
@@ -331,6 +336,7 @@ class Leg:
             "steps_launched_one_by_one_with_events":
                 self.eager_share(self.steps) if self.graph_state["steps_per_graph"] else self.steps,
             "autotuned_lanes_per_cu": self.tuned_threads, "scale": self.scale,
+            "launch_plan": m.group.LaunchInfo().strip().split("\n"),
         }
 
     def parity(self, time_evals=0):
@@ -479,6 +485,11 @@ def main():
     ap.add_argument("--no-tail", action="store_true",
                     help="step end as its own kernels (lookup + event sum, then step end + clearing: 3 launches per step) "
                          "instead of one workgroup doing all of it in one launch")
+    ap.add_argument("--no-rtc", action="store_true",
+                    help="programs of systematics outside the library's table run the run-time decoded kernel instead "
+                         "of one specialised through hiprtc")
+    ap.add_argument("--extra-ctscale", action="store_true",
+                    help="C3 with a fourth systematic, a cos-theta scale on c: a program that is not in the table")
     ap.add_argument("--no-bucket", action="store_true",
                     help="stream the table in the caller's row order (no copy grouped by the untouched observables' bins)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")

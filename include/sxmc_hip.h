@@ -214,6 +214,19 @@ int sxmc_group_set_prebinning(sxmc_group_t g, int enable);
  * caller's row order (it reads the original table).  Skipped for a table whose granule padding would outweigh
  * the saving (few samples, many buckets).  sxmc_group_algorithmic_bytes counts the bytes actually needed. */
 int sxmc_group_set_bucketing(sxmc_group_t g, int enable);
+/* Run-time kernels (default on).  The fill is fastest as straight-line code with the program of systematics
+ * (apply_systematic, pdfz.cpp:306-331: which systematic writes which column, in which order, with how many
+ * polynomial coefficients) fixed at compile time.  The library carries such kernels for a handful of programs;
+ * for any other program of at most 8 systematics and 16 coefficients in all it compiles the same kernel template
+ * with hiprtc when the group's launch plan is built (about half a second per program and process, cached) and
+ * launches it like a built-in one -- bucketing and sparse counting included.  Off, or when hiprtc fails, such
+ * programs run the kernel that decodes the program at run time (same results; sxmc_group_launch_info says why).
+ * Results are bit-identical either way (same source, same flags: -ffp-contract=off). */
+int sxmc_group_set_runtime_kernels(sxmc_group_t g, int enable);
+/* One text line per fill launch of the group's current plan: members, shape, where the histogram lives, how the
+ * program runs (builtin / runtime / decoded / generic), how the table is streamed (rows / prebinned / bucketed),
+ * launch shape.  For logs and tests. */
+int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n);
 /* 1 (default): sxmc_group_eval_nll_async / sxmc_group_mcmc_step_async write the lookup table
  * (lut[j * E + i], the array eval_pdf produces at pdfz.cpp:411-436) as they consume it.  0: the table is
  * an intermediate nobody reads (the MCMC loop, mcmc.cpp:264-348), so it is not written, and the event
@@ -290,6 +303,13 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches);
 /* 0: sxmc_group_step_async always takes its three-launch route (measurement / tests).  Default 1. */
 int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);
+/* Compiles (does not load or run) the fill kernel the library would specialise at run time for a program of
+ * systematics -- see sxmc_group_set_runtime_kernels.  Needs no GPU: a build check, and the test hook of the
+ * run-time compilation.  ops[i] = type | obs_slot << 4 | extra_slot << 8 | npars << 12 (npars 0 = one coefficient);
+ * pre_width 0 or 3 (bucketed table); sparse_runs != 0: the kernel for histograms beyond LDS over a bucketed
+ * table walked in runs.  *code_bytes (optional): size of the gfx950 code object. */
+int sxmc_rtc_compile_check(int nobs, int nslot, int lds_hist, int pre_width, int sparse_runs, const unsigned* ops,
+                           int nops, size_t* code_bytes);
 int sxmc_group_synchronize(sxmc_group_t g);
 /* Live timing of the dominant kernel (the histogram fill) with HIP events on the stream it is
  * launched on.  enable!=0 starts recording (at most `capacity` launches are kept). */

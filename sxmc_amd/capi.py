@@ -92,6 +92,8 @@ SIGNATURES = {
     "sxmc_group_set_sparse": [_vp, _i],
     "sxmc_group_set_prebinning": [_vp, _i],
     "sxmc_group_set_bucketing": [_vp, _i],
+    "sxmc_group_set_runtime_kernels": [_vp, _i],
+    "sxmc_group_launch_info": [_vp, C.c_char_p, _sz],
     "sxmc_group_set_lut_output": [_vp, _i],
     "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_group_eval_async": [_vp, _i, _vp],
@@ -101,6 +103,7 @@ SIGNATURES = {
     "sxmc_group_step_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp,
                               _vp, _vp, _vp, _vp, _i],
     "sxmc_group_set_tail_kernel": [_vp, _i],
+    "sxmc_rtc_compile_check": [_i, _i, _i, _i, _i, _vp, _i, _psz],
     "sxmc_group_last_step_launches": [_vp, _pi],
     "sxmc_group_finish_step_async": [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz,
                                      _vp, _vp, _vp, _vp, _vp, _i],

@@ -18,32 +18,14 @@
 // multiplication (exact for i <= 1, correctly rounded for i == 2).
 #include "nll_device.h"
 
-#include <type_traits>
-#include <utility>
+#include "fill_kernels.inc.h"
 
 #pragma clang fp contract(off)
 
 namespace {
 
-constexpr int kWave = 64;
+using namespace sxfill;
 
-// Pointers read out of a descriptor are generic (flat) to the compiler; every buffer they name is
-// HBM, so say so: global_* instructions keep vmcnt in order (flat_* would force vmcnt(0)
-// lgkmcnt(0) before every use and defeat the load pipelining below).
-template <typename T>
-using gptr = __attribute__((address_space(1))) T*;
-template <typename T>
-__device__ __forceinline__ gptr<T> to_global(T* p) {
-  return (gptr<T>)p;
-}
-
-__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
-
-__device__ __forceinline__ double uniform_d(double x) {
-  int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
-  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-  return __hiloint2double(hi, lo);
-}
 
 // ------------------------------------------------------------------------------------ zero
 // bins <- 0, norm <- 0 for every member (blockIdx.y = member).
@@ -64,735 +46,6 @@ __global__ __launch_bounds__(256) void zero_kernel(const SxSignalDesc* __restric
   }
 }
 
-// ------------------------------------------------------------------------------------ fill
-// Compile-time slot dispatch: the slot index is wave-uniform (it comes from the descriptor),
-// so this is a scalar branch to code that addresses the slot's registers directly.
-template <int NSLOT, typename Fn>
-__device__ __forceinline__ void with_slot(int slot, Fn&& fn) {
-  switch (slot) {
-    case 0: fn(std::integral_constant<int, 0>{}); break;
-    case 1: if constexpr (NSLOT > 1) fn(std::integral_constant<int, 1>{}); break;
-    case 2: if constexpr (NSLOT > 2) fn(std::integral_constant<int, 2>{}); break;
-    case 3: if constexpr (NSLOT > 3) fn(std::integral_constant<int, 3>{}); break;
-    case 4: if constexpr (NSLOT > 4) fn(std::integral_constant<int, 4>{}); break;
-    case 5: if constexpr (NSLOT > 5) fn(std::integral_constant<int, 5>{}); break;
-    case 6: if constexpr (NSLOT > 6) fn(std::integral_constant<int, 6>{}); break;
-    default: break;
-  }
-}
-
-// apply_systematic (pdfz.cpp:316-330) on SXMC_VEC samples of one slot, p already formed.
-template <int NSLOT>
-__device__ __forceinline__ void apply_transform(double (&f)[NSLOT][SXMC_VEC], int type,
-                                                double (&x)[SXMC_VEC], int extra_slot,
-                                                const double (&p)[SXMC_VEC]) {
-  switch (type) {
-    case SXMC_SYST_SHIFT:
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) x[q] = x[q] + p[q];
-      break;
-    case SXMC_SYST_SCALE:
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) x[q] = x[q] * (1 + p[q]);
-      break;
-    case SXMC_SYST_CTSCALE:
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) x[q] = 1 + (x[q] - 1) * (1 + p[q]);
-      break;
-    case SXMC_SYST_RESOLUTION_SCALE:
-      with_slot<NSLOT>(extra_slot, [&](auto E) {
-#pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) x[q] = x[q] + (p[q] * (x[q] - f[E][q]));
-      });
-      break;
-    default:
-      break;
-  }
-}
-
-__device__ __forceinline__ double readlane_d(double x, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// The systematics of one member as a "program" held in two lane-indexed registers:
-//   lane s of `opword` = type | obs_slot << 4 | extra_slot << 8 | npars << 12 | coef_start << 16
-//   lane c of `coef`   = the c-th polynomial coefficient, already read from the parameter buffer
-__device__ __forceinline__ unsigned pack_opword(const SxSystOp& op) {
-  return (unsigned)op.type | ((unsigned)op.obs_slot << 4) | ((unsigned)op.extra_slot << 8) |
-         ((unsigned)op.npars << 12) | ((unsigned)op.coef_start << 16);
-}
-
-// DYNAMIC program: one systematic (apply_systematic, pdfz.cpp:306-331) on SXMC_VEC samples per
-// lane, decoded at run time.  A wave-uniform loop over the systematics reads `opword` / `coef`
-// back with v_readlane, so any number of systematics of any kind runs through one copy of this
-// code.  It costs scalar-unit time (decode + branches), which the CU's 16 waves share: the
-// STATIC programs below exist because that, not HBM, bounded the kernel.
-template <int NSLOT>
-__device__ __forceinline__ void apply_op(double (&f)[NSLOT][SXMC_VEC], unsigned w, double coef) {
-  const int type = (int)(w & 15u);
-  const int obs_slot = (int)((w >> 4) & 15u);
-  const int extra_slot = (int)((w >> 8) & 15u);
-  const int npars = (int)((w >> 12) & 15u);
-  const int cstart = (int)(w >> 16);
-  with_slot<NSLOT>(obs_slot, [&](auto K) {
-    double p[SXMC_VEC];
-    if (npars == 1) {
-      // p = 0 + c0 * pow(x, 0) = 0 + c0 * 1 for every x (pdfz.cpp:310-314)
-      const double pc = 0.0 + readlane_d(coef, cstart) * 1.0;
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) p[q] = pc;
-    } else {
-      // p = sum_i c_i * x^i at the current x; x^i by repeated multiplication
-      double pw[SXMC_VEC];
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) {
-        p[q] = 0.0;
-        pw[q] = 1.0;
-      }
-      for (int i = 0; i < npars; i++) {
-        const double c = readlane_d(coef, cstart + i);
-#pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) {
-          p[q] = p[q] + c * pw[q];
-          pw[q] = pw[q] * f[K][q];
-        }
-      }
-    }
-    apply_transform<NSLOT>(f, type, f[K], extra_slot, p);
-  });
-}
-
-// STATIC program: the list of one-coefficient systematics is a template argument, so the sample
-// loop is straight-line vector code with the p's in scalar registers -- no decode, no branches.
-// The host picks a static kernel when a launch's program matches one in the table at the end of
-// this file, and the dynamic kernel otherwise.
-constexpr unsigned sx_op(int type, int obs_slot, int extra_slot = 0) {
-  return (unsigned)type | ((unsigned)obs_slot << 4) | ((unsigned)extra_slot << 8);
-}
-template <unsigned... OPS>
-struct StaticProg {
-  static constexpr bool dynamic = false;
-  static constexpr int n = (int)sizeof...(OPS);
-  // bit k set: some systematic writes slot k (its value changes from evaluation to evaluation)
-  static constexpr unsigned touched = (0u | ... | (1u << ((OPS >> 4) & 15u)));
-};
-struct DynamicProg {
-  static constexpr bool dynamic = true;
-  static constexpr int n = 0;
-  static constexpr unsigned touched = ~0u;
-};
-
-template <int NSLOT, unsigned OPC>
-__device__ __forceinline__ void apply_static(double (&f)[NSLOT][SXMC_VEC], double pc) {
-  constexpr int type = (int)(OPC & 15u), K = (int)((OPC >> 4) & 15u), E = (int)((OPC >> 8) & 15u);
-  static_assert(K < NSLOT && E < NSLOT, "slot out of range");
-#pragma unroll
-  for (int q = 0; q < SXMC_VEC; q++) {
-    if constexpr (type == SXMC_SYST_SHIFT) f[K][q] = f[K][q] + pc;
-    if constexpr (type == SXMC_SYST_SCALE) f[K][q] = f[K][q] * (1 + pc);
-    if constexpr (type == SXMC_SYST_CTSCALE) f[K][q] = 1 + (f[K][q] - 1) * (1 + pc);
-    if constexpr (type == SXMC_SYST_RESOLUTION_SCALE) f[K][q] = f[K][q] + (pc * (f[K][q] - f[E][q]));
-  }
-}
-
-template <int NSLOT, unsigned... OPS, size_t... I>
-__device__ __forceinline__ void run_static(double (&f)[NSLOT][SXMC_VEC], const double* pc, StaticProg<OPS...>,
-                                           std::index_sequence<I...>) {
-  (apply_static<NSLOT, OPS>(f, pc[I]), ...);
-}
-
-typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load per lane
-
-// SPARSE COUNTING.  A histogram too large for LDS costs one scattered HBM atomic per sample plus zeroing
-// the whole array, but the likelihood only ever looks it up at the data events' bins.  When an evaluation
-// is for lookup, such a member counts into one counter per distinct event bin instead: flat bin index ->
-// one-hash bit filter (rejects ~98 % of the samples with one cached word) -> open-addressing table ->
-// counter slot.  Same counts at the bins that are read, same norm.
-typedef unsigned vuint2 __attribute__((ext_vector_type(2)));
-
-// table part: the bit filter said "maybe"
-__device__ __forceinline__ void sparse_lookup(const SxSignalDesc& d, gptr<unsigned> counters, unsigned bin) {
-  const unsigned mask = (1u << (32 - d.sparse_table_shift)) - 1u;
-  unsigned hp = (bin * 0x85EBCA6Bu) >> d.sparse_table_shift;
-  for (unsigned probe = 0; probe <= mask; probe++) {
-    const vuint2 e = to_global(reinterpret_cast<const vuint2*>(d.sparse_table))[hp];
-    if (e[0] == bin) {
-      __hip_atomic_fetch_add(&counters[e[1]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    if (e[0] == 0xFFFFFFFFu) return;
-    hp = (hp + 1u) & mask;
-  }
-}
-
-__device__ __forceinline__ void sparse_count(const SxSignalDesc& d, gptr<unsigned> counters, unsigned bin) {
-  const unsigned hb = (bin * 0x9E3779B1u) >> d.sparse_filter_shift;
-  if (!((to_global(d.sparse_filter)[hb >> 5] >> (hb & 31u)) & 1u)) return;
-  sparse_lookup(d, counters, bin);
-}
-
-// PRE-BINNING.  An observable that no systematic writes has the same value, hence the same bin index
-// and the same in/out-of-domain status, at every evaluation.  For static programs the host builds, once,
-// a narrow column holding sum_k idx_k * stride_k over those observables (all ones = outside the domain)
-// with exactly the arithmetic below, and the fill streams that column (PREW = 1, 2 or 4 bytes per
-// sample) instead of the float columns it replaces.  PREW = 0: every observable is read and binned here.
-//
-// BUCKETING (PREW = kPreGranule).  The same fact taken further (layout_kernels.hip): the evaluator keeps a
-// copy of the table sorted by the bin indices of the untouched observables, holding only the columns that
-// change (samples outside the domain in an untouched observable are not in it at all).  The kernel then
-// sees a lower-dimensional problem -- every observable it is given is binned here -- plus ONE word per
-// 256-sample granule: the granule's constant contribution to the flat bin index.  A wave reads exactly one
-// granule per step (units are 4 samples, a wave covers 64 consecutive units), so that word is wave-uniform.
-constexpr int kPreGranule = 3;
-template <int PREW> struct PreVec { typedef unsigned type; };
-template <> struct PreVec<2> { typedef unsigned type __attribute__((ext_vector_type(2))); };
-template <> struct PreVec<4> { typedef unsigned type __attribute__((ext_vector_type(4))); };
-
-template <int NSLOT, int PREW>
-struct Columns {
-  vfloat4 v[NSLOT];
-  typename PreVec<PREW>::type pre;
-};
-
-// slot k is streamed unless it is an observable that the pre-binned column covers
-template <int NOBS, int PREW, typename PROG>
-constexpr bool slot_loaded(int k) {
-  return PREW == 0 || PREW == kPreGranule || k >= NOBS || ((PROG::touched >> k) & 1u);
-}
-
-template <int PREW>
-__device__ __forceinline__ unsigned pre_value(const typename PreVec<PREW>::type& p, int q) {
-  if constexpr (PREW == 1) return (p >> (8 * q)) & 0xFFu;
-  if constexpr (PREW == 2) return (p[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-  if constexpr (PREW == 4) return p[q];
-  if constexpr (PREW == kPreGranule) return p;
-  return 0u;
-}
-template <int PREW>
-constexpr unsigned pre_sentinel() {
-  return PREW == 1 ? 0xFFu : PREW == 2 ? 0xFFFFu : 0xFFFFFFFFu;
-}
-
-template <int NOBS, int NSLOT, int PREW, typename PROG>
-__device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr<const vfloat4> (&col)[NSLOT],
-                                             gptr<const typename PreVec<PREW>::type> pre, unsigned long long v) {
-  // Issue order is pinned (sched_barrier): the wait-counter bookkeeping at the loop header merges
-  // the prologue's and the steady state's load order, and only identical orders give counted
-  // waits (vmcnt(#loads)) instead of a full drain.
-#pragma unroll
-  for (int k = 0; k < NSLOT; k++) {
-    if constexpr (true) {
-      if (slot_loaded<NOBS, PREW, PROG>(k)) {
-        // streamed once per evaluation and far larger than the caches: nontemporal (+3% measured)
-        c.v[k] = __builtin_nontemporal_load(&col[k][v]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  if constexpr (PREW == kPreGranule) {
-    c.pre = pre[v >> 6];   // one word per granule: every lane of the wave asks for the same address
-    __builtin_amdgcn_sched_barrier(0);
-  } else if constexpr (PREW != 0) {
-    c.pre = __builtin_nontemporal_load(&pre[v]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// The histogram fill.  grid = a few workgroups per CU.  The host cuts the 4-sample units of all
-// members into SEGMENTS (member, first unit, end unit, step) and gives each workgroup a short list of
-// them (sxmc_hip.cpp: build_partition): either one strided segment of one member ("interleaved":
-// workgroups that share a member read neighbouring 8 KiB chunks at the same time, like a grid-stride
-// copy) or a contiguous slice that may span members ("sliced", for many tiny members).
-//
-// LDS layout (LDS_HIST): word 0 workgroup in-domain counter, words 4.. the histogram (hist_words
-// = largest member), then 64 "trash" words, one per lane: a sample that is outside the domain
-// adds to its lane's trash word instead of being branched around, so the whole per-sample path
-// is unpredicated vector code (no exec-mask juggling on the scalar unit).
-template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>
-__global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restrict__ descs,
-                                                    const SxSegment* __restrict__ segs,
-                                                    const unsigned* __restrict__ blk_off,
-                                                    unsigned hist_words, unsigned dbg) {
-  extern __shared__ unsigned lds[];
-  const unsigned tid = threadIdx.x;
-  const unsigned nthreads = blockDim.x;
-  const unsigned lane = tid & (kWave - 1);
-
-  unsigned* s_norm = lds;
-  unsigned* hist = lds + 4;
-  const unsigned trash = hist_words + lane;
-
-  bool lds_clean = false;
-  const unsigned* coarse_in_lds = nullptr;
-  const unsigned seg_end = blk_off[blockIdx.x + 1];
-
-  for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
-    const SxSegment& sg = segs[si];
-    const SxSignalDesc& d = descs[sg.sig];
-    const unsigned long long v0 = sg.v0;
-    const unsigned long long v1 = sg.v1;
-    const unsigned long long step = sg.step;
-
-    const bool sparse = !LDS_HIST && d.sparse_table != nullptr;
-    const unsigned B = sparse ? (unsigned)d.sparse_real_nbins : (unsigned)d.total_nbins;
-    gptr<unsigned> gbins = to_global(d.bins);
-
-    // ---- the member's systematics: coefficients (and, for the dynamic program, the op words into
-    // lane-indexed registers).  Requested FIRST: loads return in order, so waiting for a coefficient that
-    // was asked for after the columns below would drain those too.
-    const int nsyst = d.nsyst;
-    unsigned opword = 0u;
-    double coef = 0.0;
-    double craw[PROG::n > 0 ? PROG::n : 1];
-    if constexpr (PROG::dynamic) {
-      if ((int)lane < nsyst) opword = pack_opword(d.syst[lane]);
-      if ((int)lane < d.ncoef) coef = to_global(d.params)[(long)d.coef_par[lane] * d.param_stride];
-    } else {
-      // one coefficient per systematic: its parameter index comes with the descriptor (scalar), the value is
-      // one uniform load each
-#pragma unroll
-      for (int q = 0; q < PROG::n; q++) craw[q] = to_global(d.params)[(long)d.coef_par[q] * d.param_stride];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- the first units' columns are requested before anything else is set up: their addresses need
-    // only the descriptor, and the loads fly while LDS is cleared and the geometry arrives
-    gptr<const vfloat4> col[NSLOT];
-#pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
-      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
-    }
-    gptr<const typename PreVec<PREW>::type> precol =
-        to_global(reinterpret_cast<const typename PreVec<PREW>::type*>(d.pre));
-    const unsigned long long vlast = v1 - 1;
-    const unsigned long long vfirst = v0 + tid;
-    Columns<NSLOT, PREW> bufA;
-    load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, vfirst < v1 ? vfirst : vlast);
-
-    if (!lds_clean) {
-      // whole LDS histogram (sized for the largest member), once per workgroup
-      if (LDS_HIST) {
-        for (unsigned b = tid; b < hist_words; b += nthreads) hist[b] = 0u;
-      }
-      if (tid == 0) *s_norm = 0u;
-      __syncthreads();
-    }
-    // sparse counting: stage the member's coarse bit filter in LDS (it rejects most samples without
-    // touching L2); members that share their tables share it, so it is reloaded only when it changes
-    const int cshift = sparse ? d.sparse_coarse_shift : 0;
-    if (sparse && d.sparse_coarse != coarse_in_lds) {
-      const unsigned cwords = 1u << (32 - cshift - 5);
-      for (unsigned b = tid; b < cwords && b < hist_words; b += nthreads) hist[b] = to_global(d.sparse_coarse)[b];
-      coarse_in_lds = d.sparse_coarse;
-      __syncthreads();
-    }
-
-    // ---- wave-uniform geometry into scalar registers
-    double lo[NOBS], hi[NOBS], sc[NOBS];
-    int st[NOBS];
-#pragma unroll
-    for (int k = 0; k < NOBS; k++) {
-      lo[k] = d.lower[k];
-      hi[k] = d.upper[k];
-      sc[k] = d.scale[k];
-      st[k] = d.bin_stride[k];
-    }
-    // static program: p_s = 0 + c_s * pow(x, 0) = 0 + c_s * 1 (pdfz.cpp:310-314), wave-uniform
-    double pc[PROG::n > 0 ? PROG::n : 1];
-#pragma unroll
-    for (int s = 0; s < PROG::n; s++) pc[s] = 0.0 + craw[s] * 1.0;
-
-    unsigned cnt = 0;
-
-    // ---- the sample loop.  One stage = wait for the unit's raw columns, widen them to double,
-    // immediately re-issue the loads for the next unit into the same registers, then do the arithmetic
-    // under them.  ONE unit in flight per lane, on purpose: HBM delivers most when a CU keeps about 32 KiB
-    // of loads in flight (tools/hbm_probe.hip: 7.1 TB/s there, 5.5-6.5 TB/s at twice that), and 512 lanes
-    // per CU x 3-4 columns x 16 bytes is that much; a second unit in flight (tried: a two-deep register
-    // ring) or more waves per CU only queue up behind the memory system (-8 %).  Loads are unconditional
-    // (index clamped into the slice) so the wait counters stay exact; lanes past the end of the slice
-    // are treated like out-of-domain samples.
-    auto stage = [&](Columns<NSLOT, PREW>& buf, const unsigned long long vc) {
-      double f[NSLOT][SXMC_VEC];
-#pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
-        if (slot_loaded<NOBS, PREW, PROG>(k)) {
-          f[k][0] = (double)buf.v[k].x;
-          f[k][1] = (double)buf.v[k].y;
-          f[k][2] = (double)buf.v[k].z;
-          f[k][3] = (double)buf.v[k].w;
-        } else {
-          f[k][0] = f[k][1] = f[k][2] = f[k][3] = 0.0;
-        }
-      }
-      typename PreVec<PREW>::type prebits = buf.pre;
-      // Pin every widening BEFORE the buffer is re-loaded: if the compiler sinks one of them
-      // below, that column's registers stay live across the reload, the reload lands in fresh
-      // registers and the loop latch copies them back behind a vmcnt(0) that drains the ring.
-#pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
-        if (slot_loaded<NOBS, PREW, PROG>(k)) {
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f[k][q]));
-        }
-      }
-      if constexpr (PREW != 0) asm volatile("" : "+v"(prebits));
-      // dbg is a measurement hook (sxmc_group_set_debug_mode), 0 in production:
-      //   bit 1: every reload hits one cached address -> the kernel without its HBM stream
-      //   bit 0: skip the arithmetic and the histogram -> the HBM stream alone
-      //   bit 2: skip only the histogram update
-      const unsigned long long vl = vc + step;
-      load_columns<NOBS, NSLOT, PREW, PROG>(buf, col, precol, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
-      if (dbg & 1u) {
-#pragma unroll
-        for (int k = 0; k < NSLOT; k++) {
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) cnt += (f[k][q] == 12345.678) ? 1u : 0u;
-        }
-        if constexpr (PREW != 0) cnt += (pre_value<PREW>(prebits, 0) == 12345u) ? 1u : 0u;
-        return;
-      }
-
-      if constexpr (PROG::dynamic) {
-        for (int s = 0; s < nsyst; s++) {
-          apply_op<NSLOT>(f, (unsigned)__builtin_amdgcn_readlane((int)opword, s), coef);
-        }
-      } else {
-        run_static<NSLOT>(f, pc, PROG{}, std::make_index_sequence<(size_t)PROG::n>{});
-      }
-
-      // lanes past the end of the slice hold clamped duplicates: count them as failures
-      const unsigned dead = (vc < v1) ? 0u : 1u;
-      unsigned okbin[SXMC_VEC];   // flat bin index of a sample to be counted, or all ones (non-LDS modes)
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) {
-        // pdfz.cpp:388-398.  `bad` counts failed domain tests (each a vector compare feeding an
-        // add-with-carry, nothing on the scalar unit); the tests are written so that NaN fails.
-        unsigned bad = dead;
-        int bin = 0;
-        if constexpr (PREW != 0) {
-          const unsigned pv = pre_value<PREW>(prebits, q);
-          if constexpr (PREW != kPreGranule) bad += (pv == pre_sentinel<PREW>()) ? 1u : 0u;
-          bin = (int)pv;
-        }
-#pragma unroll
-        for (int k = 0; k < NOBS; k++) {
-          if (!slot_loaded<NOBS, PREW, PROG>(k)) continue;  // covered by the pre-binned column
-          const double x = f[k][q];
-          bad += !(x >= lo[k]) ? 1u : 0u;
-          bad += !(x < hi[k]) ? 1u : 0u;
-          const int idx = (int)((x - lo[k]) * sc[k]);
-          if (LDS_HIST) {
-            // histogram fits LDS => every index and stride is far below 2^23
-            // (the last observable of a full-dimensional problem has stride 1; a bucketed one need not)
-            bin = (k == NOBS - 1 && PREW != kPreGranule) ? bin + idx : __mul24(idx, st[k]) + bin;
-          } else {
-            bin += idx * st[k];
-          }
-        }
-        const unsigned in_domain = (bad == 0u) ? 1u : 0u;
-        cnt += in_domain;
-        // in domain but index out of range (the reference's one-past-the-end case) still counts in the
-        // norm; it and every failure are not histogrammed
-        const bool store = (bad == 0u) && ((unsigned)bin < B) && !(dbg & 4u);
-        if (LDS_HIST) {
-          const unsigned slot = store ? (unsigned)bin : trash;   // failures go to the lane's trash word
-          __hip_atomic_fetch_add(&hist[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-          okbin[q] = store ? (unsigned)bin : 0xFFFFFFFFu;
-        }
-      }
-      if (!LDS_HIST) {
-        if (sparse) {
-          // all four filter words are requested before any is tested: one L2 round trip, not four
-          // level 1: coarse filter in LDS, two bits per bin (passes ~3 % of the non-members at 1e5 event bins)
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) {
-            const unsigned hc = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0xC2B2AE35u) >> cshift : 0u;
-            const unsigned hd = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0x27D4EB2Fu) >> cshift : 0u;
-            if (!((hist[hc >> 5] >> (hc & 31u)) & (hist[hd >> 5] >> (hd & 31u)) & 1u)) okbin[q] = 0xFFFFFFFFu;
-          }
-          // level 2: fine filter through L2; all four words are requested before any is tested
-          unsigned hb[SXMC_VEC], word[SXMC_VEC];
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) {
-            hb[q] = (okbin[q] != 0xFFFFFFFFu) ? (okbin[q] * 0x9E3779B1u) >> d.sparse_filter_shift : 0u;
-            word[q] = to_global(d.sparse_filter)[hb[q] >> 5];
-          }
-          // level 3: the table, for the ~1 % that remain
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) {
-            if (okbin[q] != 0xFFFFFFFFu && ((word[q] >> (hb[q] & 31u)) & 1u)) sparse_lookup(d, gbins, okbin[q]);
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) {
-            if (okbin[q] != 0xFFFFFFFFu) {
-              __hip_atomic_fetch_add(&gbins[okbin[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-        }
-      }
-    };
-
-    // wave-uniform trip count: every lane runs the same number of stages
-    unsigned long long v = vfirst;
-    const unsigned long long niter = (v1 - v0 + step - 1) / step;
-    for (unsigned long long it = 0; it < niter; ++it, v += step) stage(bufA, v);
-
-    // ---- in-domain count: lane registers -> wave -> workgroup -> one global atomic
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
-    if (lane == 0 && cnt != 0u) {
-      __hip_atomic_fetch_add(s_norm, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-
-    // ---- flush: only non-zero bins reach HBM; leave the LDS histogram zeroed for the next member
-    if (LDS_HIST) {
-      for (unsigned b = tid; b < B; b += nthreads) {
-        const unsigned c = hist[b];
-        if (c != 0u) {
-          __hip_atomic_fetch_add(&gbins[b], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hist[b] = 0u;
-        }
-      }
-    }
-    if (tid == 0) {
-      const unsigned c = *s_norm;
-      if (c != 0u) __hip_atomic_fetch_add(to_global(d.norm), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_norm = 0u;
-    }
-    __syncthreads();
-    lds_clean = true;
-  }
-}
-
-// SPARSE COUNTING OVER A BUCKETED TABLE, WALKED IN RUNS.  Histograms beyond LDS capacity, evaluated for lookup
-// (BASELINE config 5).  The table is bucketed (layout_kernels.hip) and laid out so that every WAVE walks its own
-// run of consecutive granules of the sorted order: a wave stays inside one bucket -- one tuple of bin indices of
-// the untouched observables -- for many steps.  The event bins are grouped by the same buckets on the host, each
-// bucket with a small open-addressing table keyed by the index contribution of the WRITTEN observables.  On
-// entering a bucket a wave copies that table into its private slice of LDS; a sample then costs one LDS probe
-// (no L2 filter, no global table, no global atomic), hits are counted in LDS beside the keys, and the counts go to
-// the global event-bin counters once, when the wave leaves the bucket.  Counts are integers: same counters as
-// every other evaluation form, bit for bit.
-// Left to the global table (sparse_lookup): buckets with more event bins than a wave's slice holds, buckets whose
-// key contains an index equal to nbins, and single samples whose written observable's index comes out as nbins
-// (pdfz.cpp:388-398 lets such an index alias into the next row of the flat index; the bucket tables assume the
-// canonical decomposition, the global table is keyed by the flat index itself).
-typedef unsigned vuint2g __attribute__((ext_vector_type(2)));
-typedef unsigned vuint4g __attribute__((ext_vector_type(4)));
-
-template <int NOBS, int NSLOT, typename PROG>
-__global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* __restrict__ descs,
-                                                           const SxSegment* __restrict__ segs,
-                                                           const unsigned* __restrict__ blk_off, unsigned smax,
-                                                           unsigned dbg) {
-  static_assert(!PROG::dynamic, "static programs only");
-  extern __shared__ unsigned lds[];
-  const unsigned tid = threadIdx.x;
-  const unsigned lane = tid & (kWave - 1);
-  const unsigned wave = tid / kWave;
-  unsigned* wkeys = lds + (size_t)wave * 2u * smax;   // this wave's table keys ...
-  unsigned* wcnt = wkeys + smax;                      // ... and the hit counts beside them
-  for (unsigned b = lane; b < smax; b += kWave) wcnt[b] = 0u;
-
-  const unsigned seg_end = blk_off[blockIdx.x + 1];
-  for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
-    const SxSegment& sg = segs[si];
-    const SxSignalDesc& d = descs[sg.sig];
-    const unsigned long long v0 = sg.v0;
-    const unsigned long long v1 = sg.v1;
-    const unsigned long long step = sg.step;
-    const unsigned B = (unsigned)d.sparse_real_nbins;
-    gptr<unsigned> gcnt = to_global(d.bins);
-    gptr<const unsigned> tkeys = to_global(d.sparse_tkeys);
-    gptr<const unsigned> tslot = to_global(d.sparse_tslot);
-    gptr<const vuint2g> dir = to_global(reinterpret_cast<const vuint2g*>(d.sparse_dir));
-
-    double craw[PROG::n > 0 ? PROG::n : 1];
-#pragma unroll
-    for (int q = 0; q < PROG::n; q++) craw[q] = to_global(d.params)[(long)d.coef_par[q] * d.param_stride];
-    __builtin_amdgcn_sched_barrier(0);
-
-    gptr<const vfloat4> col[NSLOT];
-#pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
-      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
-    }
-    gptr<const vuint2g> gkp = to_global(reinterpret_cast<const vuint2g*>(d.pre));  // {bucket key, bin offset} per granule
-    const unsigned long long vlast = v1 - 1;
-    const unsigned long long vfirst = v0 + tid;
-
-    vfloat4 raw[NSLOT];
-    vuint2g kp;
-    auto load = [&](unsigned long long v) {
-#pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
-        raw[k] = __builtin_nontemporal_load(&col[k][v]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      kp = gkp[v >> 6];
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    load(vfirst < v1 ? vfirst : vlast);
-
-    double lo[NOBS], hi[NOBS], sc[NOBS];
-    int st[NOBS];
-    unsigned nb[NOBS];
-#pragma unroll
-    for (int k = 0; k < NOBS; k++) {
-      lo[k] = d.lower[k];
-      hi[k] = d.upper[k];
-      sc[k] = d.scale[k];
-      st[k] = d.bin_stride[k];
-      nb[k] = (unsigned)d.nbins[k];
-    }
-    double pc[PROG::n > 0 ? PROG::n : 1];
-#pragma unroll
-    for (int s = 0; s < PROG::n; s++) pc[s] = 0.0 + craw[s] * 1.0;
-
-    unsigned cnt = 0;
-    // the bucket this wave is in: its table sits in wkeys[0 .. 1 << cur_log2), counts in wcnt
-    unsigned cur_key = 0xFFFFFFFFu, cur_off = 0u, cur_info = SXMC_SPARSE_EMPTY, cur_probes = 1u;
-
-    auto flush = [&]() {
-      if (cur_info <= SXMC_SPARSE_SMAX_LOG2) {
-        const unsigned S = 1u << cur_info;
-        for (unsigned b = lane; b < S; b += kWave) {
-          const unsigned c = wcnt[b];
-          if (c != 0u) {
-            __hip_atomic_fetch_add(&gcnt[tslot[cur_off + b]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            wcnt[b] = 0u;
-          }
-        }
-      }
-    };
-
-    unsigned long long v = vfirst;
-    const unsigned long long niter = (v1 - v0 + step - 1) / step;
-    for (unsigned long long it = 0; it < niter; ++it, v += step) {
-      double f[NSLOT][SXMC_VEC];
-#pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
-        f[k][0] = (double)raw[k].x;
-        f[k][1] = (double)raw[k].y;
-        f[k][2] = (double)raw[k].z;
-        f[k][3] = (double)raw[k].w;
-      }
-      const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane((int)kp[0]);
-      const unsigned pre = (unsigned)__builtin_amdgcn_readfirstlane((int)kp[1]);
-      // (the bucket state is wave-uniform; say so, or the loop-carried copies live in vector registers and every
-      // test on them becomes exec-mask code)
-      cur_key = (unsigned)uniform_i((int)cur_key);
-      cur_off = (unsigned)uniform_i((int)cur_off);
-      cur_info = (unsigned)uniform_i((int)cur_info);
-      cur_probes = (unsigned)uniform_i((int)cur_probes);
-#pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
-#pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f[k][q]));
-      }
-      const unsigned long long vl = v + step;
-      load(vl < v1 ? vl : vlast);
-      if (dbg & 1u) {
-#pragma unroll
-        for (int k = 0; k < NSLOT; k++) {
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) cnt += (f[k][q] == 12345.678) ? 1u : 0u;
-        }
-        continue;
-      }
-
-      // ---- a new bucket: counts of the old one go to the global counters, the new table comes into LDS
-      if (key != cur_key) {
-        flush();
-        const vuint2g e = dir[key];
-        cur_key = key;
-        cur_off = (unsigned)__builtin_amdgcn_readfirstlane((int)e[0]);
-        const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane((int)e[1]);
-        cur_info = info & 0xFFu;            // log2(table size) >= 2, or a flag
-        cur_probes = (info >> 8) & 0xFFu;   // cells a key may have been pushed along
-        if (cur_info <= SXMC_SPARSE_SMAX_LOG2) {
-          const unsigned S = 1u << cur_info;
-          for (unsigned b = lane; b < S; b += kWave) wkeys[b] = tkeys[cur_off + b];
-        }
-      }
-
-      run_static<NSLOT>(f, pc, PROG{}, std::make_index_sequence<(size_t)PROG::n>{});
-
-      const unsigned dead = (v < v1) ? 0u : 1u;
-      unsigned p2[SXMC_VEC];
-      bool fast[SXMC_VEC], slow[SXMC_VEC];
-      const bool table_here = cur_info <= SXMC_SPARSE_SMAX_LOG2;
-      const bool all_slow = cur_info == SXMC_SPARSE_SLOW;
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) {
-        unsigned bad = dead, alias = 0u;
-        int bin = 0;
-#pragma unroll
-        for (int k = 0; k < NOBS; k++) {
-          const double x = f[k][q];
-          bad += !(x >= lo[k]) ? 1u : 0u;
-          bad += !(x < hi[k]) ? 1u : 0u;
-          const int idx = (int)((x - lo[k]) * sc[k]);
-          alias += ((unsigned)idx >= nb[k]) ? 1u : 0u;
-          bin += idx * st[k];
-        }
-        const bool in_domain = bad == 0u;
-        cnt += in_domain ? 1u : 0u;
-        p2[q] = (unsigned)bin;
-        const bool count_it = in_domain && !(dbg & 4u);
-        fast[q] = count_it && table_here && alias == 0u;
-        slow[q] = count_it && (all_slow || alias != 0u);
-      }
-      if (table_here) {
-        // The table is cut into cells of four keys (one 16-byte LDS read); a key sits in its home cell or, when
-        // that was full, in one of the next cur_probes - 1 cells.  The trip count is the same for every lane and
-        // almost always one: no divergent probing loop (a per-lane while loop here cost more than the stream).
-        const unsigned cshift = 34u - cur_info, cmask = (1u << (cur_info - 2u)) - 1u;   // cells = size / 4
-        unsigned cell[SXMC_VEC];
-#pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) cell[q] = cur_info > 2u ? (p2[q] * 0x9E3779B1u) >> cshift : 0u;
-        for (unsigned pr = 0; pr < cur_probes; pr++) {
-          vuint4g kk[SXMC_VEC];
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) {
-            kk[q] = *reinterpret_cast<const vuint4g*>(&wkeys[4u * ((cell[q] + pr) & cmask)]);
-          }
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) {
-            // keys are distinct, so at most one of the four matches: its position by arithmetic, not by branches
-            const unsigned key = fast[q] ? p2[q] : 0xFFFFFFFEu;   // (never a table key)
-            const unsigned m = (kk[q][1] == key ? 1u : 0u) + (kk[q][2] == key ? 2u : 0u) + (kk[q][3] == key ? 3u : 0u);
-            if ((kk[q][0] == key) | (m != 0u)) {
-              __hip_atomic_fetch_add(&wcnt[4u * ((cell[q] + pr) & cmask) + m], 1u, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < SXMC_VEC; q++) {
-        if (slow[q]) {
-          const unsigned flat = pre + p2[q];
-          if (flat < B) sparse_lookup(d, gcnt, flat);
-        }
-      }
-    }
-    flush();
-    cur_info = SXMC_SPARSE_EMPTY;
-
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
-    if (lane == 0 && cnt != 0u) {
-      __hip_atomic_fetch_add(to_global(d.norm), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
 
 // Shape-agnostic fallback (any nobs/nslot up to SXMC_MAX_NFIELDS): one sample per lane per
 // iteration, fields in a dynamically indexed array.  Correctness path for shapes without a
@@ -1253,7 +506,10 @@ struct StaticEntry {
 #define SX_P1(NO, NS, PRE, G, GR, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE, G, GR}
 #define SX_P2(NO, NS, PRE, G, GR, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE, G, GR}
 #define SX_P3(NO, NS, PRE, G, GR, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE, G, GR}
+#define SX_P0(NO) {NO, NO, 0, {0, 0, 0, 0}, launch_fill_k<NO, NO, true, StaticProg<>>, SX_NOPRE, SX_NOG, SX_NOGRAN}
 const StaticEntry kStaticPrograms[] = {
+    // no systematics at all (BASELINE config 2)
+    SX_P0(1), SX_P0(2), SX_P0(3),
     // 1-D (bench_sxmc pdfz: one shift; config/example.json: scale + resolution_scale).  These are also what a
     // bucketed higher-dimensional table with ONE observable written by systematics reduces to.
     SX_P1(1, 1, SX_NOPRE, SX_NOG, SX_GRAN(1, 1, SX_SHIFT(0)), SX_SHIFT(0)),
@@ -1315,6 +571,11 @@ bool sx_fill_static_supports_sparse_runs(int prog) {
 hipError_t sx_launch_fill_sparse_runs(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                                       const unsigned* blk_off, hipStream_t s) {
   if (sh.grid <= 0) return hipSuccess;
+  if (sh.rtc_sparse) {
+    const unsigned smax = (unsigned)(sh.sparse_lds_bytes / 4 / ((unsigned)sh.threads / 64u) / 2);
+    return sx_rtc_launch(sh.rtc_sparse, sh.grid, sh.threads, sh.sparse_lds_bytes, descs, segs, blk_off, smax,
+                         (unsigned)sh.debug_mode, s);
+  }
   if (!sx_fill_static_supports_sparse_runs(sh.static_prog)) return hipErrorInvalidValue;
   return kStaticPrograms[sh.static_prog].fn_sruns(sh, descs, segs, blk_off, s);
 }
@@ -1342,6 +603,11 @@ int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* o
 hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                           const unsigned* blk_off, hipStream_t s) {
   if (sh.grid <= 0) return hipSuccess;
+  if (sh.rtc_fill) {
+    const unsigned hist_words = (unsigned)(sh.lds_bytes / 4 - 4 - (sh.lds_hist ? 64 : 0));
+    return sx_rtc_launch(sh.rtc_fill, sh.grid, sh.threads, sh.lds_bytes, descs, segs, blk_off, hist_words,
+                         (unsigned)sh.debug_mode, s);
+  }
   if (sh.static_prog >= 0 && sh.static_prog < kNumStatic) {
     const StaticEntry& e = kStaticPrograms[sh.static_prog];
     FillLauncher fn = nullptr;

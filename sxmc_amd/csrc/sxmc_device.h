@@ -5,85 +5,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/sxmc_hip.h"
 
-#define SXMC_VEC 4         // samples per lane per iteration (one 16-byte load per column)
-#define SXMC_OP_NOP (-1)
-
-// One systematic, addressed by SLOT (position among the columns a launch loads), not by field.
-// Restates SystematicDescriptor (pdfz.cpp:48-54) with the parameter indices inlined.
-struct SxSystOp {
-  short type;
-  short obs_slot;
-  short extra_slot;
-  short npars;
-  short pars[SXMC_MAX_SYST_PARS];
-  short coef_start;  // first lane of this systematic's coefficients in the coefficient table
-  short pad[3];
-};
-
-// Everything the kernels need to know about one evaluator (one signal's PDF).
-// Lives in device memory as an array, one entry per group member; every field is read with
-// wave-uniform addresses (scalar loads).
-struct SxSignalDesc {
-  // --- samples: column-major, column k at cols + k*col_pitch, padded with NaN to a multiple
-  //     of SXMC_VEC samples (NaN is outside every domain, so padding needs no masking)
-  const float* cols;
-  unsigned long long col_pitch;  // floats, multiple of 64
-  unsigned long long nsamples;
-  unsigned long long nvec;       // ceil(nsamples / SXMC_VEC)
-  unsigned long long vec_start;  // prefix sum of nvec over the launch's members
-  // --- histogram
-  unsigned* bins;
-  unsigned* norm;                // norm_buffer + norm_offset
-  int total_nbins;
-  int nobs;
-  int nslot;                     // columns loaded: nobs observables + referenced extra fields
-  int nsyst;
-  int ncoef;                     // total polynomial coefficients of all systematics (<= 64 for the
-                                 // specialized kernels: one lane each)
-  int param_stride;
-  const double* params;          // param_buffer + param_offset
-  int slot_col[SXMC_MAX_NFIELDS];
-  int bin_stride[SXMC_MAX_NFIELDS];
-  double lower[SXMC_MAX_NFIELDS];
-  double upper[SXMC_MAX_NFIELDS];
-  double scale[SXMC_MAX_NFIELDS];  // nbins / (upper - lower), computed on the host in double
-  SxSystOp syst[SXMC_MAX_SYST];
-  short coef_par[64];            // coefficient lane -> parameter index
-  const void* pre;               // pre-binned column of the observables no systematic writes (or null); for a
-                                 // bucketed table: one bin offset per 256-sample granule
-  // --- sparse counting (histograms too large for LDS, evaluation for lookup only): `bins` then points
-  //     at one counter per DISTINCT EVENT BIN, `read_bins` at the events' counter slots, and the fill maps
-  //     a sample's flat bin index to its slot through a one-hash bit filter and an open-addressing table
-  const unsigned* sparse_filter; // filter_bits / 32 words
-  const unsigned* sparse_table;  // pairs {flat bin index, slot}; empty key = 0xFFFFFFFF
-  int sparse_filter_shift;       // hash >> shift selects a filter bit
-  int sparse_table_shift;        // hash >> shift selects a table entry
-  int sparse_real_nbins;         // the histogram's true bin count (total_nbins is the counter count here)
-  int sparse_coarse_shift;       // hash >> shift selects a bit of the coarse filter (staged in LDS; two hashes per bin)
-  const unsigned* sparse_coarse; // coarse two-hash bit filter, at most 128 KiB
-  // --- sparse counting over a bucketed table walked in runs (fill_sparse_kernel): the event bins are grouped by
-  //     bucket (the bin indices of the untouched observables), each bucket with its own small hash table
-  const unsigned* sparse_dir;    // pairs {first table entry, log2(table size) | flags}, indexed by bucket key
-  const unsigned* sparse_tkeys;  // table entries: the event bin's index contribution of the written observables
-  const unsigned* sparse_tslot;  // ... and its counter slot
-  int nbins[SXMC_MAX_NFIELDS];   // bins per observable (an index that comes out as nbins is the aliasing case)
-  // --- evaluation at the data events
-  const int* read_bins;
-  unsigned long long npoints;
-  float* pdf_out;                // pdf_buffer + pdf_offset
-  int pdf_stride;
-  int pad0;
-  double bin_volume;
-};
-
-// One piece of fill work: units v0 + tid, + step, ... < v1 of member `sig` (a unit = SXMC_VEC samples).
-struct SxSegment {
-  int sig;
-  int pad;
-  unsigned long long v0, v1, step;
-};
+#include "sxmc_device_types.h"
 
 // Arguments of finish_nll_jump_pick_combo (nll_kernels.h:190-207) for the fused step end.
 struct SxStepArgs {
@@ -117,11 +43,24 @@ struct SxLaunchShape {
   size_t lds_bytes;
   int debug_mode;   // measurement hook, see fill_kernel
   int static_prog;  // index into the static program table, or -1: decode the program at run time
+  void* rtc_fill;   // kernel specialised at run time for this launch (hipFunction_t), or null: built-in kernels
+  void* rtc_sparse; // ... and for its sparse flavour over runs
   int sparse_runs;  // 1: the sparse flavour of this launch runs fill_sparse_kernel (bucketed table laid out in runs)
   size_t sparse_lds_bytes;
   int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none, 3 = bucketed table (one
                     // bin offset per 256-sample granule)
 };
+
+// A fill kernel specialised at run time (sxmc_rtc.cpp): the template arguments of fill_body / fill_sparse_body.
+struct SxRtcSpec {
+  int nobs, nslot, lds_hist, pre_width, sparse_runs;
+  int nops;
+  unsigned ops[SXMC_MAX_SYST];   // type | obs_slot << 4 | extra_slot << 8 | npars << 12 (0 = one coefficient)
+};
+bool sx_rtc_compile_only(const SxRtcSpec& k, size_t* code_bytes, std::string* err);
+void* sx_rtc_get(const SxRtcSpec& k, std::string* err);
+hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, const SxSignalDesc* descs,
+                         const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s);
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
 hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,
@@ -136,9 +75,7 @@ hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_desc
 hipError_t sx_launch_fill_sparse_runs(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,
                                       const unsigned* d_blk_off, hipStream_t s);
 bool sx_fill_static_supports_sparse_runs(int prog);
-#define SXMC_SPARSE_EMPTY 0xFFu   /* directory flag: the bucket holds no event bin */
-#define SXMC_SPARSE_SLOW 0xFEu    /* directory flag: look every sample up in the global table (see the kernel) */
-#define SXMC_SPARSE_SMAX_LOG2 9  /* largest per-wave table: 512 entries */
+
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
 bool sx_fill_static_supports(int prog, int lds_hist, int prebin);

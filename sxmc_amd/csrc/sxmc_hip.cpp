@@ -357,6 +357,8 @@ struct sxmc_group {
   int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
   int cfg_prebin = 1, cfg_seen_prebin = -1;        // pre-bin the observables no systematic writes
   int cfg_bucket = 1, cfg_seen_bucket = -1;        // stream a bucketed copy of the table where that pays
+  int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
+  std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
   int last_step_launches = 0;                      // kernels the last sxmc_group_step_async launched
   std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
@@ -880,16 +882,50 @@ int group_rebuild(sxmc_group* g) {
     std::vector<unsigned> prog;
     bool prog_simple = false;
 
+    // A program every systematic of which is a short polynomial can run as straight-line code: from the table of
+    // kernels built into the library, or specialised now through hiprtc (sxmc_rtc.cpp).
+    int prog_ncoef = 0;
+    bool specialisable = d.nsyst <= 8;
+    for (int q = 0; q < d.nsyst; q++) {
+      prog_ncoef += d.syst[q].npars;
+      specialisable = specialisable && d.syst[q].npars >= 1 && d.syst[q].npars <= SXMC_MAX_SYST_PARS;
+    }
+    specialisable = specialisable && prog_ncoef <= 16;
+    auto prog_words = [](const SxSignalDesc& x) {
+      std::vector<unsigned> w;
+      for (int q = 0; q < x.nsyst; q++) {
+        w.push_back((unsigned)x.syst[q].type | ((unsigned)x.syst[q].obs_slot << 4) |
+                    ((unsigned)x.syst[q].extra_slot << 8) | (x.syst[q].npars > 1 ? (unsigned)x.syst[q].npars << 12 : 0u));
+      }
+      return w;
+    };
+    // is there a kernel for this specialisation?  *fn: the run-time one, or null for a built-in one
+    auto have_kernel = [&](int nobs_, int nslot_, int prew, int runs, const std::vector<unsigned>& words, int sp,
+                           void** fn) {
+      *fn = nullptr;
+      if (runs ? sx_fill_static_supports_sparse_runs(sp) : sx_fill_static_supports(sp, lds_hist, prew)) return true;
+      if (!g->cfg_rtc) return false;
+      SxRtcSpec k{};
+      k.nobs = nobs_;
+      k.nslot = nslot_;
+      k.lds_hist = lds_hist;
+      k.pre_width = prew;
+      k.sparse_runs = runs;
+      k.nops = (int)words.size();
+      for (size_t q = 0; q < words.size(); q++) k.ops[q] = words[q];
+      std::string err;
+      *fn = sx_rtc_get(k, &err);
+      if (!*fn) g->rtc_note = err;
+      return *fn != nullptr;
+    };
+    void *rtc_fill = nullptr, *rtc_sparse = nullptr;
+
     // ---- bucketed table: the observables no systematic writes become a per-granule bin offset and the
     // fill sees the lower-dimensional problem of the ones that are written
     bool bucketed = false;
-    if (g->cfg_bucket && d.nsyst > 0 && d.nsyst <= 4 && d.ncoef <= 64) {
+    if (g->cfg_bucket && d.nsyst > 0 && specialisable) {
       unsigned touched = 0;
-      bool one_coef = true;
-      for (int q = 0; q < d.nsyst; q++) {
-        touched |= 1u << d.syst[q].obs_slot;
-        one_coef = one_coef && d.syst[q].npars == 1;
-      }
+      for (int q = 0; q < d.nsyst; q++) touched |= 1u << d.syst[q].obs_slot;
       unsigned mask = 0;
       std::vector<int> keep((size_t)d.nslot, -1), fields;
       int nobs2 = 0;
@@ -902,16 +938,12 @@ int group_rebuild(sxmc_group* g) {
         fields.push_back(d.slot_col[k]);
         if (k < d.nobs) nobs2++;
       }
-      if (mask && nobs2 >= 1 && one_coef && sx_fill_has_specialization(nobs2, (int)fields.size())) {
+      if (mask && nobs2 >= 1 && sx_fill_has_specialization(nobs2, (int)fields.size())) {
         SxSignalDesc cd;
         compact_desc(d, keep, cd);
-        std::vector<unsigned> prog2;
-        for (int q = 0; q < cd.nsyst; q++) {
-          prog2.push_back((unsigned)cd.syst[q].type | ((unsigned)cd.syst[q].obs_slot << 4) |
-                          ((unsigned)cd.syst[q].extra_slot << 8));
-        }
+        const std::vector<unsigned> prog2 = prog_words(cd);
         const int sp = sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
-        if (sx_fill_static_supports(sp, lds_hist, 3)) {
+        if (have_kernel(cd.nobs, cd.nslot, 3, 0, prog2, sp, &rtc_fill)) {
           const SampleStore::BucketSort* bs = nullptr;
           rc = get_bucket_sort(h, g->d_descs + i, mask, &bs);
           if (rc) return rc;
@@ -921,7 +953,8 @@ int group_rebuild(sxmc_group* g) {
             plans[(size_t)i].fields = fields;
             bucketed = true;
             // histograms beyond LDS, evaluated at data events: per-wave runs + event bins grouped by bucket
-            runs_mode = !lds_hist && h->has_points && h->d_table && sx_fill_static_supports_sparse_runs(sp);
+            runs_mode = !lds_hist && h->has_points && h->d_table &&
+                        have_kernel(cd.nobs, cd.nslot, 3, 1, prog2, sp, &rtc_sparse);
             if (runs_mode) {
               rc = build_bucket_tables(h, bs);
               if (rc) return rc;
@@ -930,9 +963,11 @@ int group_rebuild(sxmc_group* g) {
             key_nslot = cd.nslot;
             prog = prog2;
             prog_simple = true;
-            static_prog = sp;
+            static_prog = rtc_fill ? -1 : sp;
             pre_mask = mask;
             pre_width = 3;
+          } else {
+            rtc_fill = nullptr;
           }
         }
       }
@@ -941,19 +976,13 @@ int group_rebuild(sxmc_group* g) {
       const bool spec = sx_fill_has_specialization(d.nobs, d.nslot) && d.ncoef <= 64;
       key_nobs = spec ? d.nobs : 0;
       key_nslot = spec ? d.nslot : 0;
-      // the member's program as static-table words (type | obs_slot << 4 | extra_slot << 8)
-      prog_simple = spec && d.nsyst <= 4;
-      for (int q = 0; q < d.nsyst; q++) {
-        if (d.syst[q].npars != 1) prog_simple = false;
-        prog.push_back((unsigned)d.syst[q].type | ((unsigned)d.syst[q].obs_slot << 4) |
-                       ((unsigned)d.syst[q].extra_slot << 8));
-      }
-      // pre-binning: observables that no systematic writes (static programs only)
-      static_prog = (prog_simple && !prog.empty())
-                        ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
-                        : -1;
-      if (!sx_fill_static_supports(static_prog, lds_hist, 0)) static_prog = -1;
-      if (static_prog < 0) prog_simple = false;
+      prog = prog_words(d);
+      const int sp = (spec && specialisable)
+                         ? sx_fill_find_static_program(key_nobs, key_nslot, (int)prog.size(), prog.data())
+                         : -1;
+      prog_simple = spec && specialisable && have_kernel(key_nobs, key_nslot, 0, 0, prog, sp, &rtc_fill);
+      static_prog = (prog_simple && !rtc_fill) ? sp : -1;
+      // pre-binning: observables that no systematic writes (built-in programs only; bucketing covers the rest)
       if (g->cfg_prebin && sx_fill_static_supports(static_prog, lds_hist, 1)) {
         unsigned touched = 0;
         for (int q = 0; q < d.nsyst; q++) touched |= 1u << d.syst[q].obs_slot;
@@ -975,7 +1004,8 @@ int group_rebuild(sxmc_group* g) {
     for (LaunchClass& c : g->classes) {
       if (c.shape.nobs == key_nobs && c.shape.nslot == key_nslot && c.shape.lds_hist == lds_hist &&
           c.prog_simple == prog_simple && (!prog_simple || c.prog == prog) && c.pre_mask == pre_mask &&
-          c.shape.pre_width == pre_width && c.runs_mode == runs_mode) {
+          c.shape.pre_width == pre_width && c.runs_mode == runs_mode && c.shape.rtc_fill == rtc_fill &&
+          c.shape.rtc_sparse == rtc_sparse) {
         cls = &c;
       }
     }
@@ -993,6 +1023,8 @@ int group_rebuild(sxmc_group* g) {
       cls->shape.pre_width = pre_width;
       cls->pre_mask = pre_mask;
       cls->runs_mode = runs_mode;
+      cls->shape.rtc_fill = rtc_fill;
+      cls->shape.rtc_sparse = rtc_sparse;
     }
     cls->member_idx.push_back(i);
   }
@@ -1115,7 +1147,8 @@ int group_rebuild(sxmc_group* g) {
     // of two or more systematics, the shape-agnostic kernel) or that probe L2 per sample (histograms
     // beyond LDS) need the second set of waves to hide it.
     const double stream_bytes = (double)c.total_vec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot);
-    const bool light = c.shape.lds_hist && c.shape.nobs > 0 && (c.shape.static_prog >= 0 || cls_nsyst <= 1) &&
+    const bool light = c.shape.lds_hist && c.shape.nobs > 0 &&
+                       (c.shape.static_prog >= 0 || c.shape.rtc_fill || cls_nsyst <= 1) &&
                        stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
     c.light = light;
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
@@ -1187,6 +1220,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_partition = g->cfg_partition;
   g->cfg_seen_prebin = g->cfg_prebin;
   g->cfg_seen_bucket = g->cfg_bucket;
+  g->cfg_seen_rtc = g->cfg_rtc;
   g->built = true;
   return SXMC_OK;
 }
@@ -1194,7 +1228,7 @@ int group_rebuild(sxmc_group* g) {
 int group_refresh(sxmc_group* g) {
   bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc ||
                g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_prebin != g->cfg_prebin ||
-               g->cfg_seen_bucket != g->cfg_bucket;
+               g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
   }
@@ -1992,6 +2026,34 @@ int sxmc_group_set_bucketing(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_runtime_kernels(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_rtc = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
+  SX_REQUIRE(g && out && n > 0, "null argument");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  std::string text;
+  for (size_t i = 0; i < g->classes.size(); i++) {
+    const LaunchClass& c = g->classes[i];
+    char line[512];
+    const char* kind = c.shape.rtc_fill ? "runtime" : c.shape.static_prog >= 0 ? "builtin" : c.shape.nobs ? "decoded" : "generic";
+    std::snprintf(line, sizeof line,
+                  "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d\n",
+                  i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
+                  c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
+                  c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
+                  c.shape.grid, c.partition);
+    text += line;
+  }
+  if (!g->rtc_note.empty()) text += "runtime specialisation failed: " + g->rtc_note.substr(0, 300) + "\n";
+  std::snprintf(out, n, "%s", text.c_str());
+  return SXMC_OK;
+}
+
 int sxmc_group_set_lut_output(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_lut = enable ? 1 : 0;
@@ -2261,6 +2323,22 @@ int sxmc_group_last_step_launches(sxmc_group_t g, int* launches) {
 int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_tail = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_rtc_compile_check(int nobs, int nslot, int lds_hist, int pre_width, int sparse_runs, const unsigned* ops,
+                           int nops, size_t* code_bytes) {
+  SX_REQUIRE(nops >= 0 && nops <= SXMC_MAX_SYST && (ops || nops == 0), "bad program");
+  SxRtcSpec k{};
+  k.nobs = nobs;
+  k.nslot = nslot;
+  k.lds_hist = lds_hist;
+  k.pre_width = pre_width;
+  k.sparse_runs = sparse_runs;
+  k.nops = nops;
+  for (int i = 0; i < nops; i++) k.ops[i] = ops[i];
+  std::string err;
+  if (!sx_rtc_compile_only(k, code_bytes, &err)) return fail(SXMC_ERR_HIP, err);
   return SXMC_OK;
 }
 

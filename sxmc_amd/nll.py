@@ -97,6 +97,15 @@ class EvalGroup:
         """Stream a copy of the table grouped by the bins of the observables no systematic writes (default on)."""
         capi.call("sxmc_group_set_bucketing", self._g, int(bool(enable)))
 
+    def SetRuntimeKernels(self, enable):
+        """Specialise the fill kernel through hiprtc for programs of systematics that are not built in (default on)."""
+        capi.call("sxmc_group_set_runtime_kernels", self._g, int(bool(enable)))
+
+    def LaunchInfo(self):
+        buf = C.create_string_buffer(8192)
+        capi.call("sxmc_group_launch_info", self._g, buf, len(buf))
+        return buf.value.decode()
+
     def SetLutOutput(self, enable):
         """False: EvalNllAsync / McmcStepAsync do not write the lookup table and sum over the distinct tuples
         of event bins, weighted by multiplicity (see include/sxmc_hip.h).  Default True."""

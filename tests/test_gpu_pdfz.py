@@ -583,6 +583,76 @@ def test_sparse_counting_over_bucketed_runs(nobs, nb, systs, params, nfields):
     check(pts2)
 
 
+RTC_CASES = [
+    # BASELINE config 3's program + a cos-theta scale on c: every observable is written, no table entry
+    ("c3+ctscale", 3, [20, 20, 20], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+                                     dict(type="resolution_scale", obs=0, true_obs=3, pars=[2]),
+                                     dict(type="ctscale", obs=2, pars=[3])], [0.02, -0.01, 0.07, 0.03], 5, "rows"),
+    # a 4-D shape, one observable left alone: bucketed, program not in the table
+    ("4d", 4, [8, 7, 6, 5], [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+                             dict(type="resolution_scale", obs=0, true_obs=4, pars=[2]),
+                             dict(type="ctscale", obs=3, pars=[3])], [0.02, -0.01, 0.07, 0.03], 6, "bucketed"),
+    # polynomial systematics (3 and 2 coefficients), one observable left alone
+    ("poly", 3, [12, 9, 10], [dict(type="shift", obs=0, pars=[0, 1, 2]), dict(type="scale", obs=1, pars=[3, 0])],
+     [0.02, -0.03, 0.01, 0.05], 4, "bucketed"),
+    # the histogram fills LDS to the last word (40 800 bins = 163 KB of dynamic LDS through the module launch)
+    ("lds-full", 2, [200, 204], [dict(type="ctscale", obs=0, pars=[0]), dict(type="shift", obs=1, pars=[1])],
+     [0.01, 0.02], 3, "rows"),
+]
+
+
+@pytest.mark.parametrize("name,nobs,nbins,systs,params,nfields,table_kind", RTC_CASES, ids=[c[0] for c in RTC_CASES])
+def test_runtime_specialised_kernels_match_the_decoded_program_and_the_oracle(name, nobs, nbins, systs, params, nfields,
+                                                                              table_kind):
+    """Programs of systematics that are not in the library's table are compiled at set-up (hiprtc) from the same
+    kernel template; the result must be that of the run-time decoded program and of the oracle, bit for bit."""
+    rng = np.random.default_rng(31)
+    sizes = [90001, 5, 40013]
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=nfields, lo=-0.1, hi=1.1)
+    group = nll.EvalGroup(evs)
+    info = group.LaunchInfo()
+    assert "program=runtime" in info and "table=" + table_kind in info, info
+    assert "failed" not in info, info
+    results = []
+    for rtc in (True, False):
+        group.SetRuntimeKernels(rtc)
+        group.EvalAsync(False)
+        group.EvalFinished()
+        results.append(([e.GetBins() for e in evs], norms.get()))
+    assert "program=runtime" not in group.LaunchInfo()
+    for j, t in enumerate(tabs):
+        o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, systs, params)
+        for bins, nrm in results:
+            assert np.array_equal(bins[j], o["bins"]) and nrm[j] == o["norm"]
+
+
+def test_runtime_specialised_sparse_runs_kernel():
+    """Histograms beyond LDS + a program that is not built in: the run-time kernels cover the dense fill of the
+    bucketed table and the sparse counting over runs."""
+    rng = np.random.default_rng(32)
+    nobs, nb, nfields = 5, [60, 50, 8, 3, 2], 7
+    systs = C5_LIKE + [dict(type="ctscale", obs=2, pars=[1])]
+    params = [0.02, -0.01, 0.07]
+    pts = np.concatenate([table(rng, 5000, nobs, lo=-0.2, hi=1.2), np.zeros((5000, 1), np.float32)], axis=1)
+    evs, tabs, lut, norms, pbuf = build_group(rng, [150001, 60001], nobs, nb, systs, params, nfields=nfields, points=pts,
+                                              lo=-0.05, hi=1.05)
+    group = nll.EvalGroup(evs)
+    info = group.LaunchInfo()
+    assert "program=runtime" in info and "table=bucketed+runs(runtime)" in info, info
+    out = {}
+    for sparse in (True, False):
+        group.SetSparse(sparse)
+        lut.set(np.full(lut.size, 777.0, np.float32))
+        group.EvalAsync(True)
+        group.EvalFinished()
+        out[sparse] = (lut.get(), norms.get())
+    assert np.array_equal(out[True][0].view(np.uint32), out[False][0].view(np.uint32))
+    for j, t in enumerate(tabs):
+        o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nb, systs, params, points=pts, dataset=j % 2)
+        assert_same_bits(out[True][0].reshape(2, -1)[j], o["out"])
+        assert out[True][1][j] == o["norm"]
+
+
 def test_shared_table_with_different_prebinned_columns():
     """Two evaluators over one sample table whose systematics leave different observables untouched: each
     group keeps its own pre-binned column, and evaluating one does not disturb the other."""

@@ -1,0 +1,38 @@
+"""No GPU needed: the fill-kernel template the library specialises at run time (hiprtc) compiles for gfx950 for
+the shapes and programs the GPU tests use -- built-in programs, polynomial systematics, the empty program, bucketed
+tables and the sparse counting over runs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sxmc_amd import capi
+
+SHIFT, SCALE, RES, CTSCALE = 0, 1, 2, 3
+
+
+def op(type_, obs_slot, extra_slot=0, npars=0):
+    return type_ | (obs_slot << 4) | (extra_slot << 8) | (npars << 12)
+
+
+@pytest.mark.parametrize("nobs,nslot,lds,prew,runs,ops", [
+    (3, 4, 1, 0, 0, [op(SHIFT, 1), op(SCALE, 0), op(RES, 0, 3), op(CTSCALE, 2)]),     # C3 + ctscale(c)
+    (2, 3, 1, 3, 0, [op(SHIFT, 1), op(SCALE, 0), op(RES, 0, 2)]),                      # C3 bucketed
+    (2, 3, 0, 3, 1, [op(SHIFT, 1), op(SCALE, 0), op(RES, 0, 2)]),                      # C5: sparse counting over runs
+    (2, 2, 1, 0, 0, [op(SHIFT, 0, 0, 3), op(SCALE, 1, 0, 2)]),                         # polynomials
+    (5, 7, 0, 0, 0, []),                                                               # no systematics, 5-D
+])
+def test_runtime_specialisation_compiles_without_a_gpu(nobs, nslot, lds, prew, runs, ops):
+    lib = capi.load()
+    arr = np.asarray(ops, dtype=np.uint32)
+    n = C.c_size_t(0)
+    rc = lib.sxmc_rtc_compile_check(nobs, nslot, lds, prew, runs, capi.ptr(arr), len(ops), C.byref(n))
+    assert rc == 0, capi.last_error()
+    assert n.value > 1000            # a gfx950 code object came out
+
+
+def test_runtime_specialisation_reports_a_bad_shape():
+    lib = capi.load()
+    arr = np.asarray([op(RES, 0, 5)], dtype=np.uint32)        # truth field slot 5 of a 2-slot kernel
+    rc = lib.sxmc_rtc_compile_check(1, 2, 1, 0, 0, capi.ptr(arr), 1, None)
+    assert rc != 0 and "slot out of range" in capi.last_error()
