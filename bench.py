@@ -281,12 +281,13 @@ class Leg:
             elapsed = dist.max_over_ranks(elapsed)
         self.fill_ms_total, self.nfill = m.group.ProfileRead()
         m.group.Profile(False, 0)
+        self._launches = m.group.LastStepLaunches() if (m.consume and m.tail and self.form != "pdfz") else None
         self.elapsed, self.steps = elapsed, steps
         return elapsed
 
     def launches_per_step(self):
-        if self.m.consume and self.m.tail and self.form != "pdfz":
-            return self.m.group.LastStepLaunches()     # what the library actually launched for the last step
+        if getattr(self, "_launches", None):
+            return self._launches                      # what the library actually launched for the last timed step
         return 3 if (self.form in ("pdfz", "step") or self.m.consume) else 4
 
     def roofline(self, world=1):
@@ -307,6 +308,8 @@ class Leg:
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else ""))
+            if args.extra_ctscale or args.no_sparse:
+                t = None
             if t and self.scale == 1.0 and args.nsyst < 0:
                 traffic = t["bytes_per_launch"]
         except (OSError, ValueError):

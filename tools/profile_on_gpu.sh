@@ -22,4 +22,4 @@ python3 tools/summarize_rocprof.py pmc $OUT/pmc_summary.csv $OUT/pmc_sq $OUT/pmc
 rm -rf $OUT/trace $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
 cut -c1-400 $OUT/bench.json
 cat $OUT/kernel_stats_summary.csv | head -8
-grep -E "fill_kernel" $OUT/pmc_summary.csv
+grep -E "fill_" $OUT/pmc_summary.csv
