@@ -367,6 +367,27 @@ int sxmc_launch_finish_nll_jump_pick_combo(int grid, int block, sxmc_stream_t s,
                                            const short* d_source_id, const unsigned* d_norms,
                                            int debug_mode);
 
+/* ---------------------------------------------------------------- multi-GPU exchange (RCCL) ----- */
+/* Fake experiments shard over the GPUs of a node one experiment per rank with NO data-path collective
+ * (sxmc.cpp:59-145 is a loop of independent iterations; every rank holds a replica of the MC tables).  The only
+ * exchange is one all-gather, at the end, of the per-experiment intervals (interval.h:22-27: point_estimate,
+ * lower, upper, coverage per parameter) from which rank 0 takes the medians (sxmc.cpp:126-145, utils.h:76-90).
+ * These entry points are that exchange on RCCL (xGMI between the GPUs of a node): plain float buffers. */
+typedef struct sxmc_comm* sxmc_comm_t;
+/* One communicator per device, all in THIS process (one host thread per GPU: sxmc::ensemble_multi_gpu).
+ * out: ndevices handles, out[i] is rank i on devices[i]. */
+int sxmc_comm_init_all(const int* devices, int ndevices, sxmc_comm_t* out);
+/* One process per GPU: rank 0 makes the id (128 bytes), passes it to the others by any means (a file, MPI,
+ * torch.distributed), and every rank joins with the current device. */
+int sxmc_comm_unique_id(char* id, size_t id_bytes);
+int sxmc_comm_init_rank(const char* id, size_t id_bytes, int nranks, int rank, sxmc_comm_t* out);
+int sxmc_comm_rank(sxmc_comm_t c, int* rank, int* nranks);
+/* d_recv[r * count .. (r + 1) * count) = rank r's d_send[0 .. count) on every rank; device buffers; asynchronous
+ * on `s` of the communicator's device. */
+int sxmc_comm_allgather_f32(sxmc_comm_t c, const float* d_send, float* d_recv, size_t count, sxmc_stream_t s);
+int sxmc_comm_destroy(sxmc_comm_t c);
+const char* sxmc_comm_last_error(void);
+
 /* Test hook: raw Philox4x32-10 output of d_state[0], 4 words per draw; advances the state. */
 int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws);
 

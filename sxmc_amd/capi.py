@@ -119,9 +119,15 @@ SIGNATURES = {
     "sxmc_launch_nll_total": [_i, _i, _vp, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sxmc_launch_finish_nll_jump_pick_combo": [_i, _i, _vp, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
                                                _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i],
+    "sxmc_comm_init_all": [_vp, _i, _pvp],
+    "sxmc_comm_unique_id": [C.c_char_p, _sz],
+    "sxmc_comm_init_rank": [C.c_char_p, _sz, _i, _i, _pvp],
+    "sxmc_comm_rank": [_vp, _pi, _pi],
+    "sxmc_comm_allgather_f32": [_vp, _vp, _vp, _sz, _vp],
+    "sxmc_comm_destroy": [_vp],
     "sxmc_debug_philox_dump": [_vp, _vp, _i],
 }
-STRING_GETTERS = ("sxmc_last_error", "sxmc_version")
+STRING_GETTERS = ("sxmc_last_error", "sxmc_version", "sxmc_comm_last_error")
 
 _lib = None
 

@@ -20,6 +20,7 @@
 #include <exception>
 #include <memory>
 #include <mutex>
+#include <limits>
 #include <random>
 #include <string>
 #include <thread>
@@ -218,17 +219,22 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
                                                          std::vector<Systematic>& systematics,
                                                          std::vector<Observable>& observables, unsigned nsteps,
                                                          float burnin_fraction, unsigned nconcurrent, float cl = 0.9f,
-                                                         unsigned sync_interval = 10000, unsigned graph_steps = 0) {
+                                                         unsigned sync_interval = 10000, unsigned graph_steps = 0,
+                                                         int device = -1, std::mutex* process_exclusive = nullptr) {
   const size_t lanes = std::max<size_t>(1, std::min<size_t>(nconcurrent, experiments.size()));
   std::vector<ExperimentResult> out(experiments.size());
   std::vector<std::exception_ptr> errors(lanes);
-  std::mutex exclusive;  // set-up, graph recording and tear-down of the lanes, one at a time
+  // set-up, graph recording and tear-down of the lanes, one at a time (process-wide when several GPUs are driven
+  // from one process: ensemble_multi_gpu passes its mutex)
+  std::mutex own_exclusive;
+  std::mutex& exclusive = process_exclusive ? *process_exclusive : own_exclusive;
   std::vector<std::thread> threads;
   for (size_t t = 0; t < lanes; t++) {
     threads.emplace_back([&, t]() {
       sxmc_stream_t strm = nullptr;
       std::vector<Signal> mine;
       try {
+        if (device >= 0) check(sxmc_set_device(device));   // (the current device is a per-thread setting)
         {
           std::lock_guard<std::mutex> lock(exclusive);
           check(sxmc_stream_create_nonblocking(&strm));
@@ -256,6 +262,129 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
   for (std::thread& th : threads) th.join();
   for (std::exception_ptr& e : errors)
     if (e) std::rethrow_exception(e);
+  return out;
+}
+
+/** utils.h:76-90 `median`. */
+inline float median(std::vector<float> v) {
+  std::sort(v.begin(), v.end());
+  const size_t half = v.size() / 2;
+  return v.size() % 2 == 0 ? (v[half - 1] + v[half]) / 2 : v[half];
+}
+
+struct MultiGpuEnsemble {
+  std::vector<ExperimentResult> results;  //!< one per experiment, in experiment order (computed on its own GPU)
+  std::vector<float> gathered;            //!< [nexperiments][nparameters][4] = point_estimate, lower, upper, coverage:
+                                          //!< what rank 0 received through the RCCL all-gather, in experiment order
+  std::vector<float> median_upper;        //!< per parameter: median over the experiments of the upper limit
+  size_t nparameters = 0;
+};
+
+/** The ensemble of sxmc.cpp:44-145 over the GPUs of one node, driven from one process: a host thread per
+ *  device; every device builds its own replica of the evaluators from the host tables (`tables[j]` = signal j's
+ *  row-major samples, what build_pdfz takes); experiment k runs on device k mod G with `nconcurrent` experiments
+ *  in flight per device (ensemble_concurrent); no data-path collective.  At the end each device contributes its
+ *  experiments' intervals to ONE RCCL all-gather (sxmc_comm_allgather_f32: interval.h:22-27 as 4 floats per
+ *  parameter, padded to equal blocks), and rank 0's copy gives the medians (sxmc.cpp:126-145).
+ *  `signals`: name, dataset, source, nexpected of every signal (histogram ignored). */
+inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsigned nexperiments,
+                                           unsigned long long base_seed, std::vector<Source>& sources,
+                                           const std::vector<Signal>& signals,
+                                           const std::vector<const std::vector<float>*>& tables, int nfields,
+                                           std::vector<Systematic>& systematics, std::vector<Observable>& observables,
+                                           unsigned nsteps, float burnin_fraction, unsigned nconcurrent,
+                                           float cl = 0.9f, unsigned sync_interval = 10000, unsigned graph_steps = 0) {
+  const size_t G = devices.size();
+  if (G == 0 || tables.size() != signals.size()) throw pdfz::Error("ensemble_multi_gpu: bad arguments");
+  size_t P = sources.size();
+  for (const Systematic& s : systematics) P += s.npars;
+  const size_t per = (nexperiments + G - 1) / G, block = per * P * 4;
+  std::vector<sxmc_comm_t> comms(G, nullptr);
+  check(sxmc_comm_init_all(devices.data(), (int)G, comms.data()));
+  MultiGpuEnsemble out;
+  out.nparameters = P;
+  out.results.resize(nexperiments);
+  std::vector<float> rank0((size_t)G * block, std::numeric_limits<float>::quiet_NaN());
+  std::vector<std::exception_ptr> errors(G);
+  std::mutex exclusive;   // graph recording on one device does not tolerate allocation on another thread
+  std::vector<std::thread> threads;
+  for (size_t r = 0; r < G; r++) {
+    threads.emplace_back([&, r]() {
+      std::vector<Signal> mine;
+      float *d_send = nullptr, *d_recv = nullptr;
+      sxmc_stream_t strm = nullptr;
+      try {
+        check(sxmc_set_device(devices[r]));
+        std::vector<Systematic> sys = systematics;
+        std::vector<Observable> obs = observables;
+        std::vector<Source> src = sources;
+        {
+          std::lock_guard<std::mutex> lock(exclusive);
+          for (size_t j = 0; j < signals.size(); j++) {
+            Signal s = signals[j];
+            s.histogram = nullptr;
+            s.par_arrays.clear();
+            build_pdfz(s, *tables[j], nfields, obs, sys);
+            mine.push_back(s);
+          }
+        }
+        std::vector<unsigned> ks;
+        for (unsigned k = (unsigned)r; k < nexperiments; k += (unsigned)G) ks.push_back(k);
+        std::vector<ExperimentResult> res = ensemble_concurrent(ks, base_seed, src, mine, sys, obs, nsteps,
+                                                                burnin_fraction, nconcurrent, cl, sync_interval,
+                                                                graph_steps, devices[r], &exclusive);
+        std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());
+        for (size_t i = 0; i < res.size(); i++) {
+          out.results[ks[i]] = res[i];
+          for (size_t p = 0; p < P && p < res[i].intervals.size(); p++) {
+            const Interval& iv = res[i].intervals[p];
+            float* at = &send[(i * P + p) * 4];
+            at[0] = iv.point_estimate;
+            at[1] = iv.lower;
+            at[2] = iv.upper;
+            at[3] = iv.coverage;
+          }
+        }
+        {
+          std::lock_guard<std::mutex> lock(exclusive);
+          check(sxmc_malloc((void**)&d_send, sizeof(float) * std::max<size_t>(block, 1)));
+          check(sxmc_malloc((void**)&d_recv, sizeof(float) * std::max<size_t>(G * block, 1)));
+          check(sxmc_stream_create_nonblocking(&strm));
+          check(sxmc_memcpy_h2d(d_send, send.data(), sizeof(float) * block));
+        }
+        // the one exchange of the multi-GPU path
+        if (sxmc_comm_allgather_f32(comms[r], d_send, d_recv, block, strm) != SXMC_OK) {
+          throw pdfz::Error(std::string("all-gather of the intervals: ") + sxmc_comm_last_error());
+        }
+        check(sxmc_stream_synchronize(strm));
+        if (r == 0) check(sxmc_memcpy_d2h(rank0.data(), d_recv, sizeof(float) * G * block));
+      } catch (...) {
+        errors[r] = std::current_exception();
+      }
+      std::lock_guard<std::mutex> lock(exclusive);
+      for (Signal& s : mine) delete s.histogram;
+      if (d_send) sxmc_free(d_send);
+      if (d_recv) sxmc_free(d_recv);
+      if (strm) sxmc_stream_destroy(strm);
+    });
+  }
+  for (std::thread& th : threads) th.join();
+  for (sxmc_comm_t c : comms) sxmc_comm_destroy(c);
+  for (std::exception_ptr& e : errors)
+    if (e) std::rethrow_exception(e);
+  // rank r's block holds its experiments r, r + G, ... in that order
+  out.gathered.assign((size_t)nexperiments * P * 4, 0.0f);
+  for (unsigned k = 0; k < nexperiments; k++) {
+    const size_t r = k % G, i = k / G;
+    std::copy(rank0.begin() + (std::ptrdiff_t)(r * block + i * P * 4),
+              rank0.begin() + (std::ptrdiff_t)(r * block + (i + 1) * P * 4),
+              out.gathered.begin() + (std::ptrdiff_t)((size_t)k * P * 4));
+  }
+  for (size_t p = 0; p < P; p++) {
+    std::vector<float> ups;
+    for (unsigned k = 0; k < nexperiments; k++) ups.push_back(out.gathered[((size_t)k * P + p) * 4 + 2]);
+    out.median_upper.push_back(ups.empty() ? 0.0f : median(ups));
+  }
   return out;
 }
 

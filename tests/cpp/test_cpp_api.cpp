@@ -358,6 +358,7 @@ struct SmallFit {
       sig.nexpected = 100 + 50 * j;
       sxmc::build_pdfz(sig, tab, 4, observables, systematics);
       signals.push_back(sig);
+      tables.push_back(tab);
       sources.push_back(sig.source);
       for (int e = 0; e < 150; e++) {
         const size_t i = lcg(s) % n;
@@ -375,6 +376,7 @@ struct SmallFit {
   std::vector<sxmc::Systematic> systematics;
   std::vector<sxmc::Observable> observables;
   std::vector<float> data;
+  std::vector<std::vector<float>> tables;   // host copies of the sample tables (replicas on other GPUs)
 };
 
 TEST_F(SmallFit, EfficiencyIsInDomainFraction) {
@@ -550,6 +552,42 @@ TEST_F(SmallFit, ConcurrentExperimentsMatchSequential) {
       EXPECT_EQ(seq[i].intervals[p].point_estimate, par[i].intervals[p].point_estimate);
     }
   }
+}
+
+TEST_F(SmallFit, MultiGpuRunnerGathersTheIntervalsThroughRccl) {
+  // sxmc::ensemble_multi_gpu on the GPUs of this box (one here): a host thread per device with its own replica
+  // of the evaluators, experiment k on device k mod G, ONE RCCL all-gather of the intervals at the end.  What
+  // comes back through the all-gather must be the intervals of the one-at-a-time loop, bit for bit.
+  int ndev = 0;
+  ASSERT_EQ(SXMC_OK, sxmc_device_count(&ndev));
+  std::vector<int> devices;
+  for (int d = 0; d < ndev && d < 8; d++) devices.push_back(d);
+  const unsigned N = 5;
+  std::vector<unsigned> ks;
+  for (unsigned k = 0; k < N; k++) ks.push_back(k);
+  std::vector<sxmc::ExperimentResult> seq =
+      sxmc::ensemble(ks, 21, sources, signals, systematics, observables, 400, 0.2f, 0.9f, 100);
+  std::vector<const std::vector<float>*> tabs;
+  for (const std::vector<float>& t : tables) tabs.push_back(&t);
+  sxmc::MultiGpuEnsemble mg = sxmc::ensemble_multi_gpu(devices, N, 21, sources, signals, tabs, 4, systematics,
+                                                       observables, 400, 0.2f, 2, 0.9f, 100, 8);
+  EXPECT_EQ((size_t)5, mg.nparameters);
+  EXPECT_EQ((size_t)N * 5 * 4, mg.gathered.size());
+  for (unsigned k = 0; k < N; k++) {
+    EXPECT_EQ(k, mg.results[k].index);
+    EXPECT_EQ(seq[k].accepted, mg.results[k].accepted);
+    for (size_t p = 0; p < 5; p++) {
+      const float* g = &mg.gathered[((size_t)k * 5 + p) * 4];
+      EXPECT_EQ(seq[k].intervals[p].point_estimate, g[0]);
+      EXPECT_EQ(seq[k].intervals[p].lower, g[1]);
+      EXPECT_EQ(seq[k].intervals[p].upper, g[2]);
+      EXPECT_EQ(seq[k].intervals[p].coverage, g[3]);
+    }
+  }
+  std::vector<float> ups;
+  for (unsigned k = 0; k < N; k++) ups.push_back(seq[k].intervals[0].upper);
+  EXPECT_EQ(sxmc::median(ups), mg.median_upper[0]);
+  EXPECT_EQ(2.5f, sxmc::median({1.0f, 4.0f, 2.0f, 3.0f}));   // utils.h:76-90: mean of the two middle ones
 }
 
 int main(int argc, char** argv) {
