@@ -142,7 +142,12 @@ int sxmc_hist_add_systematic(sxmc_hist_t h, int type, int obs, int extra_field,
                              int npars, const short* pars);
 
 /* EvalHist::SetEvalPoints (pdfz.cpp:245-302).  points: host, rows of nobservables+1 floats
- * (last = dataset id).  SXMC_ERR_INVALID if npoints_floats % (nobservables+1) != 0. */
+ * (last = dataset id).  SXMC_ERR_INVALID if npoints_floats % (nobservables+1) != 0.
+ * The evaluator's previous evaluations must have finished (as for the reference: it replaces the arrays they
+ * read).  A new data set that fits the buffers of the previous one -- every fake experiment after the first --
+ * costs one host-to-device copy: no device-wide synchronisation and no allocation, so other chains running on
+ * the same GPU are not stalled, and the groups the evaluator belongs to patch their descriptors instead of
+ * re-planning their launches. */
 int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints_floats);
 
 /* Eval::SetPDFValueBuffer / SetNormalizationBuffer / SetParameterBuffer (pdfz.cpp:106-124).
@@ -165,6 +170,17 @@ int sxmc_hist_get_bins(sxmc_hist_t h, unsigned* h_bins, size_t n);       /* afte
 int sxmc_hist_get_read_bins(sxmc_hist_t h, int* h_read_bins, size_t n);
 /* GetSamples: rows of nobservables+1 floats (observables, dataset id); n = nsamples*(nobs+1). */
 int sxmc_hist_get_samples(sxmc_hist_t h, float* h_out, size_t n);
+/* EvalHist::RandomSample's sampling step (pdfz.cpp:817-922; 1-3 observables, as there) on the device: nobserved
+ * events drawn from the histogram of the evaluator's LAST evaluation (evaluate with do_eval_pdf = 0 first, what
+ * CreateHistogram does) -- a bin with probability proportional to its content, a point uniform inside it (TH1::
+ * GetRandom's rule) -- redrawn while outside [lowers, uppers] when those are given (pdfz.cpp:853-857).  The
+ * histogram stays in HBM (the reference, and round 1 of this library, copied every signal's histogram to the
+ * host per fake experiment); only the events come back: h_events receives nobserved rows of nobservables + 1
+ * floats (last = the evaluator's dataset id), the layout sxmc_hist_set_eval_points takes.  Counter-based
+ * generator (Philox4x32-10 keyed by `seed`): the same seed gives the same events.  The Poisson fluctuation of
+ * the event count (pdfz.cpp:836-841) is the caller's, on the host: it decides array sizes. */
+int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long seed, const float* lowers,
+                            const float* uppers, float* h_events);
 int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s);
 
 /* Replaces EvalHist::Optimize/OptimizeBin/OptimizeEval (pdfz.cpp:622-814): the launch shape

@@ -82,6 +82,7 @@ SIGNATURES = {
     "sxmc_hist_get_bins": [_vp, _vp, _sz],
     "sxmc_hist_get_read_bins": [_vp, _vp, _sz],
     "sxmc_hist_get_samples": [_vp, _vp, _sz],
+    "sxmc_hist_random_sample": [_vp, _sz, _ull, _vp, _vp, _vp],
     "sxmc_hist_get_stream": [_vp, _pvp],
     "sxmc_hist_set_launch_config": [_vp, _i, _i],
     "sxmc_group_create": [_vp, _i, _pvp],

@@ -12,7 +12,7 @@
 //
 // Steps (host side: sxmc_hip.cpp build_bucketed): key per sample -> stable radix sort of (key, row) ->
 // first row of every key -> host lays the granules out -> gather of the streamed columns.
-#include "sxmc_device.h"
+#include "nll_device.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -82,6 +82,50 @@ __global__ __launch_bounds__(256) void bucket_gather_kernel(const float* __restr
   }
 }
 
+// EvalHist::RandomSample (pdfz.cpp:817-922) without leaving the device: a bin is drawn with probability
+// proportional to its content (inverse CDF: `cdf` is the inclusive prefix sum of the histogram), then a point
+// uniform inside the bin (what TH1::GetRandom does); redrawn while it falls outside the cuts, as the reference
+// does (:853-857).  Counter-based generator: event e, attempt t -> Philox4x32-10(counter = (e, t), key = seed).
+struct SampleGeom {
+  int nobs;
+  int has_cuts;
+  int nbins[3];
+  double lower[3], width[3];
+  float cut_lo[3], cut_hi[3];
+};
+
+__global__ __launch_bounds__(256) void random_sample_kernel(const unsigned* __restrict__ cdf, unsigned nbins_total,
+                                                            SampleGeom g, unsigned long long seed,
+                                                            unsigned long long n, float dataset,
+                                                            float* __restrict__ out) {
+  const unsigned total = cdf[nbins_total - 1];
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += step) {
+    float x[3] = {0.0f, 0.0f, 0.0f};
+    for (unsigned attempt = 0; attempt < 1024; attempt++) {
+      const sxdev::Philox4 r = sxdev::philox4x32_10(e, attempt, seed);
+      const unsigned target = (unsigned)(((unsigned long long)r.x * total) >> 32);   // uniform in [0, total)
+      unsigned lo = 0, hi = nbins_total - 1;                                          // first bin with cdf > target
+      while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (cdf[mid] > target) hi = mid; else lo = mid + 1;
+      }
+      unsigned flat = lo;
+      const unsigned u[3] = {r.y, r.z, r.w};
+      bool ok = true;
+      for (int k = g.nobs - 1; k >= 0; k--) {
+        const unsigned idx = flat % (unsigned)g.nbins[k];
+        flat /= (unsigned)g.nbins[k];
+        x[k] = (float)(g.lower[k] + ((double)idx + ((double)u[k] + 0.5) * 2.3283064365386963e-10) * g.width[k]);
+        if (g.has_cuts) ok = ok && !(x[k] > g.cut_hi[k] || x[k] < g.cut_lo[k]);
+      }
+      if (ok) break;
+    }
+    for (int k = 0; k < g.nobs; k++) out[e * (unsigned long long)(g.nobs + 1) + k] = x[k];
+    out[e * (unsigned long long)(g.nobs + 1) + g.nobs] = dataset;
+  }
+}
+
 unsigned grid_for(unsigned long long n, unsigned cap) {
   unsigned long long b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -135,5 +179,38 @@ hipError_t sx_bucket_gather(const float* cols, unsigned long long pitch, int nco
   const unsigned grid = (unsigned)(ngranules > 65536ull * 4 ? 65536ull * 4 : ngranules);
   hipLaunchKernelGGL(bucket_gather_kernel, dim3(grid), dim3(256), 0, s, cols, pitch, gc, sorted_rows, d_src, d_valid,
                      ngranules, out, out_pitch);
+  return hipGetLastError();
+}
+
+// inclusive prefix sum of the histogram (counts fit 32 bits: the reference's norm is a uint32 too)
+hipError_t sx_hist_cdf(const unsigned* d_bins, unsigned* d_cdf, int nbins_total, hipStream_t s) {
+  size_t temp_bytes = 0;
+  hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, d_bins, d_cdf, nbins_total, s);
+  if (e != hipSuccess) return e;
+  void* temp = nullptr;
+  e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
+  if (e != hipSuccess) return e;
+  e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, d_bins, d_cdf, nbins_total, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(temp);
+  return e != hipSuccess ? e : e2;
+}
+
+hipError_t sx_random_sample(const unsigned* d_cdf, int nbins_total, int nobs, const int* nbins, const double* lower,
+                            const double* upper, const float* cut_lo, const float* cut_hi, unsigned long long seed,
+                            unsigned long long n, float dataset, float* d_out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  SampleGeom g{};
+  g.nobs = nobs;
+  g.has_cuts = (cut_lo && cut_hi) ? 1 : 0;
+  for (int k = 0; k < nobs && k < 3; k++) {
+    g.nbins[k] = nbins[k];
+    g.lower[k] = lower[k];
+    g.width[k] = (upper[k] - lower[k]) / nbins[k];
+    g.cut_lo[k] = cut_lo ? cut_lo[k] : 0.0f;
+    g.cut_hi[k] = cut_hi ? cut_hi[k] : 0.0f;
+  }
+  hipLaunchKernelGGL(random_sample_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, s, d_cdf, (unsigned)nbins_total, g, seed,
+                     n, dataset, d_out);
   return hipGetLastError();
 }

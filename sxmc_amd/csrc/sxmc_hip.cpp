@@ -176,6 +176,9 @@ struct sxmc_hist {
   double bin_volume = 0;
   unsigned* d_bins = nullptr;
   int* d_read_bins = nullptr;
+  size_t read_bins_cap = 0;        // (grow-only: a new data set of about the same size re-uses the buffer)
+  std::vector<void*> retired;      // outgrown device buffers, freed with the evaluator
+  unsigned* d_cdf = nullptr;       // prefix sums of the histogram, for sxmc_hist_random_sample
   bool has_points = false;
   size_t npoints = 0;
   float* pdf = nullptr;
@@ -345,6 +348,7 @@ void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threa
 struct sxmc_group {
   std::vector<sxmc_hist*> members;
   std::vector<unsigned long long> seen;
+  std::vector<unsigned long long> seen_points;   // members' points_version at the last (re)plan
   std::vector<SxSignalDesc> h_descs;
   SxSignalDesc* d_descs = nullptr;  // member order: zero / eval kernels
   SxSignalDesc* d_descs_sparse = nullptr;  // member order, sparse flavour where a member supports it
@@ -375,7 +379,7 @@ struct sxmc_group {
     int* d_rb = nullptr;             // [nmembers][K]
     unsigned* d_weight = nullptr;    // [K]
     SxSignalDesc* d_descs = nullptr; // member descriptors reading the class tables, no lookup-table output
-    size_t K = 0;
+    size_t K = 0, cap_rb = 0, cap_weight = 0;
     bool tables_valid = false, descs_valid = false;
     std::vector<unsigned long long> seen_points;
   };
@@ -1214,7 +1218,11 @@ int group_rebuild(sxmc_group* g) {
   }
 
   g->seen.resize((size_t)n);
-  for (int i = 0; i < n; i++) g->seen[i] = g->members[i]->version;
+  g->seen_points.resize((size_t)n);
+  for (int i = 0; i < n; i++) {
+    g->seen[i] = g->members[i]->version;
+    g->seen_points[i] = g->members[i]->points_version;
+  }
   g->cfg_seen_threads = g->cfg_threads;
   g->cfg_seen_bpc = g->cfg_bpc;
   g->cfg_seen_partition = g->cfg_partition;
@@ -1225,17 +1233,46 @@ int group_rebuild(sxmc_group* g) {
   return SXMC_OK;
 }
 
+// New evaluation points of the same size class (same buffers, sxmc_hist_set_eval_points) change two fields of
+// the members' descriptors and nothing else: they are patched and re-uploaded, with no device-wide
+// synchronisation and no re-planning, so a fake experiment's set-up does not stall the other chains on the GPU.
+int group_update_points(sxmc_group* g) {
+  const int n = (int)g->members.size();
+  g->max_points = 0;
+  g->same_points = n > 0;
+  for (int i = 0; i < n; i++) {
+    sxmc_hist* h = g->members[i];
+    const unsigned long long np = h->has_points ? h->npoints : 0;
+    for (std::vector<SxSignalDesc>* set : {&g->h_descs, &g->h_descs_sparse}) {
+      (*set)[(size_t)i].read_bins = h->has_points ? h->d_read_bins : nullptr;
+      (*set)[(size_t)i].npoints = np;
+    }
+    g->max_points = std::max(g->max_points, np);
+    if (!h->has_points || h->npoints != g->members[0]->npoints) g->same_points = false;
+    g->seen_points[(size_t)i] = h->points_version;
+  }
+  if (n) {
+    SX_HIP(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
+    SX_HIP(hipMemcpy(g->d_descs_sparse, g->h_descs_sparse.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
+  }
+  g->ec[0].descs_valid = g->ec[1].descs_valid = false;
+  return SXMC_OK;
+}
+
 int group_refresh(sxmc_group* g) {
   bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc ||
                g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_prebin != g->cfg_prebin ||
                g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc;
+  bool points = false;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
+    if (g->seen_points[i] != g->members[i]->points_version) points = true;
   }
-  if (stale && t_capturing) {
+  if ((stale || points) && t_capturing) {
     return fail(SXMC_ERR_STATE, "the group's launch plan is out of date: evaluate once before recording a graph");
   }
-  return stale ? group_rebuild(g) : SXMC_OK;
+  if (stale) return group_rebuild(g);
+  return points ? group_update_points(g) : SXMC_OK;
 }
 
 int group_check_bound(sxmc_group* g, bool need_pdf) {
@@ -1267,7 +1304,7 @@ int ensure_event_classes(sxmc_group* g, bool sparse) {
   if (t_capturing) {
     return fail(SXMC_ERR_STATE, "the event classes are out of date: evaluate once before recording a graph");
   }
-  SX_HIP(hipDeviceSynchronize());  // kernels in flight may still read the old tables
+  // (the caller is done with the group's previous evaluations; buffers are re-used, so nothing stalls the device)
   const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
   if (!tables_ok) {
     const size_t E = g->members[0]->npoints;
@@ -1323,13 +1360,19 @@ int ensure_event_classes(sxmc_group* g, bool sparse) {
     std::vector<int> tables(std::max<size_t>(S * K, 1));
     for (size_t j = 0; j < S; j++)
       for (size_t k = 0; k < K; k++) tables[j * K + k] = (*arr[j])[first[k]];
-    if (ec.d_rb) SX_HIP(hipFree(ec.d_rb));
-    if (ec.d_weight) SX_HIP(hipFree(ec.d_weight));
-    ec.d_rb = nullptr;
-    ec.d_weight = nullptr;
-    SX_HIP(hipMalloc((void**)&ec.d_rb, sizeof(int) * tables.size()));
+    if (tables.size() > ec.cap_rb) {
+      if (ec.d_rb) SX_HIP(hipFree(ec.d_rb));
+      ec.d_rb = nullptr;
+      ec.cap_rb = tables.size() + tables.size() / 4;
+      SX_HIP(hipMalloc((void**)&ec.d_rb, sizeof(int) * ec.cap_rb));
+    }
+    if (std::max<size_t>(K, 1) > ec.cap_weight) {
+      if (ec.d_weight) SX_HIP(hipFree(ec.d_weight));
+      ec.d_weight = nullptr;
+      ec.cap_weight = K + K / 4 + 16;
+      SX_HIP(hipMalloc((void**)&ec.d_weight, sizeof(unsigned) * ec.cap_weight));
+    }
     SX_HIP(hipMemcpy(ec.d_rb, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
-    SX_HIP(hipMalloc((void**)&ec.d_weight, sizeof(unsigned) * std::max<size_t>(K, 1)));
     if (K) SX_HIP(hipMemcpy(ec.d_weight, weight.data(), sizeof(unsigned) * K, hipMemcpyHostToDevice));
     ec.K = K;
     ec.seen_points.resize(S);
@@ -1712,6 +1755,8 @@ int sxmc_hist_destroy(sxmc_hist_t h) {
   if (h->self) sxmc_group_destroy(h->self);
   if (h->d_bins) (void)hipFree(h->d_bins);
   if (h->d_read_bins) (void)hipFree(h->d_read_bins);
+  for (void* p : h->retired) (void)hipFree(p);
+  if (h->d_cdf) (void)hipFree(h->d_cdf);
   free_sparse(h);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1775,23 +1820,30 @@ int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints
     if (points[row * ip + (size_t)D] != (float)h->dataset) bin_id = -2;  // pdfz.cpp:289-293
     rb[ip] = in_domain ? bin_id : -1;
   }
-  // in-flight evaluations may still read the old table
-  SX_HIP(hipDeviceSynchronize());
-  if (h->d_read_bins) {
-    SX_HIP(hipFree(h->d_read_bins));
+  // The caller has finished with the evaluator's previous evaluations (pdfz.h:354-357), so the table is
+  // replaced in place: no device-wide synchronisation, and no hipFree / hipMalloc (both stall every stream of
+  // the device) unless the new data set outgrows the buffer -- other chains on the GPU keep running.
+  bool moved = !h->has_points;
+  if (n > h->read_bins_cap) {
+    if (h->d_read_bins) h->retired.push_back(h->d_read_bins);
     h->d_read_bins = nullptr;
+    const size_t cap = std::max<size_t>(n + n / 4, 1024);
+    SX_HIP(hipMalloc((void**)&h->d_read_bins, sizeof(int) * cap));
+    h->read_bins_cap = cap;
+    moved = true;
   }
-  SX_HIP(hipMalloc((void**)&h->d_read_bins, sizeof(int) * std::max<size_t>(n, 1)));
   if (n) SX_HIP(hipMemcpy(h->d_read_bins, rb.data(), sizeof(int) * n, hipMemcpyHostToDevice));
   h->npoints = n;
   h->has_points = true;
-  h->version++;
   h->points_version++;
   h->h_read_bins = rb;
   if (h->total_nbins > kLdsMaxBins) {
+    SX_HIP(hipDeviceSynchronize());   // (the sparse structures are rebuilt: in-flight lookups may read the old ones)
     int rc = build_sparse(h, rb);
     if (rc) return rc;
+    moved = true;
   }
+  if (moved) h->version++;   // descriptors hold the pointers: a full re-plan; otherwise only the points changed
   return SXMC_OK;
 }
 
@@ -1890,6 +1942,30 @@ int sxmc_hist_get_samples(sxmc_hist_t h, float* out, size_t n) {
   if (e != hipSuccess) return fail(SXMC_ERR_HIP, std::string("get_samples: ") + hipGetErrorString(e));
   return SXMC_OK;
 }
+int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long seed, const float* lowers,
+                            const float* uppers, float* h_events) {
+  SX_REQUIRE(h && (h_events || nobserved == 0), "null argument");
+  SX_REQUIRE(h->nobs <= 3, "Cannot EvalHist::CreateHistogram for dimensions greater than 3!");   // pdfz.cpp:499-501
+  SX_REQUIRE((lowers == nullptr) == (uppers == nullptr), "give both cut arrays or neither");
+  if (!h->bins_valid) {
+    return fail(SXMC_ERR_STATE, "the histogram is not filled: evaluate with do_eval_pdf = 0 first (CreateHistogram)");
+  }
+  if (nobserved == 0) return SXMC_OK;
+  if (!h->d_cdf) SX_HIP(hipMalloc((void**)&h->d_cdf, sizeof(unsigned) * (size_t)h->total_nbins));
+  SX_HIP(sx_hist_cdf(h->d_bins, h->d_cdf, h->total_nbins, h->stream));
+  unsigned total = 0;
+  SX_HIP(hipMemcpy(&total, h->d_cdf + (h->total_nbins - 1), sizeof(unsigned), hipMemcpyDeviceToHost));
+  SX_REQUIRE(total > 0, "cannot sample an empty histogram");
+  const size_t row = (size_t)h->nobs + 1;
+  DevBuf out;
+  SX_HIP(out.alloc(sizeof(float) * nobserved * row));
+  SX_HIP(sx_random_sample(h->d_cdf, h->total_nbins, h->nobs, h->nbins.data(), h->lower.data(), h->upper.data(), lowers,
+                          uppers, seed, nobserved, (float)h->dataset, out.as<float>(), h->stream));
+  SX_HIP(hipStreamSynchronize(h->stream));
+  SX_HIP(hipMemcpy(h_events, out.p, sizeof(float) * nobserved * row, hipMemcpyDeviceToHost));
+  return SXMC_OK;
+}
+
 int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s) {
   SX_REQUIRE(h && s, "null argument");
   *s = h->stream;

@@ -28,7 +28,7 @@ INTERVAL_FIELDS = ("point_estimate", "lower", "upper", "coverage")
 
 
 # ------------------------------------------------------------------------------------ fake data
-def get_efficiency(ev, nsyst_pars, syst_means, n_mc=None):
+def get_efficiency(ev, nsyst_pars, syst_means, n_mc=None, want_bins=True):
     """Signal::get_efficiency (signal.cpp:172-199): in-domain count with every systematic at its mean,
     divided by the signal's n_mc -- the number of simulated events BEFORE cuts (signal.cpp:198), which is
     what the NLL kernels divide by too.  n_mc=None: the evaluator's row count (no cuts were applied).
@@ -41,7 +41,7 @@ def get_efficiency(ev, nsyst_pars, syst_means, n_mc=None):
     ev.EvalAsync(False)
     ev.EvalFinished()
     n = int(norm.get()[0])
-    return n / float(ev.nsamples if n_mc is None else n_mc), ev.GetBins(), n
+    return n / float(ev.nsamples if n_mc is None else n_mc), (ev.GetBins() if want_bins else None), n
 
 
 def random_sample(rng, bins, lower, upper, nbins, nobserved):
@@ -70,11 +70,16 @@ def make_fake_dataset(rng, workload, evaluators, poisson=True):
     syst_means = w.parameter_means()[w.nsources:]
     rows, observed = [], []
     for sig, ev in zip(w.signals, evaluators):
-        eff, bins, _ = get_efficiency(ev, w.nsyst_pars, syst_means, sig.n_mc)
+        if w.nobs > 3:
+            raise ValueError("Cannot sample histograms of more than 3 dimensions")   # pdfz.cpp:499-501
+        eff, _, indomain = get_efficiency(ev, w.nsyst_pars, syst_means, sig.n_mc, want_bins=False)
         nevents = sig.nexpected * eff
         n = int(rng.poisson(nevents)) if poisson else int(math.floor(nevents + 0.5))
-        pts = random_sample(rng, bins, w.lower, w.upper, w.nbins, n)
-        rows.append(np.concatenate([pts, np.full((n, 1), sig.dataset, np.float32)], axis=1))
+        if indomain == 0:
+            n = 0                                        # an empty histogram yields no events
+        # drawn on the device from the histogram get_efficiency just filled: it never leaves HBM
+        rows.append(ev.RandomSample(n, int(rng.integers(0, 2 ** 63 - 1))) if n else
+                    np.zeros((0, w.nobs + 1), np.float32))
         observed.append(n)
     return np.concatenate(rows, axis=0).astype(np.float32), observed
 

@@ -140,8 +140,10 @@ inline std::vector<float> make_fake_dataset(std::mt19937_64& rng, std::vector<Si
     } else {
       observed = (size_t)std::floor(nevents + 0.5);
     }
-    std::vector<unsigned> bins = dynamic_cast<pdfz::EvalHist*>(s.histogram)->GetBins();
-    random_sample(rng, bins, observables, observed, s.dataset, events);
+    if (observables.size() > 3) throw pdfz::Error("Cannot EvalHist::CreateHistogram for dimensions greater than 3!");
+    if (eff <= 0) observed = 0;   // an empty histogram yields no events
+    // drawn on the device from the histogram get_efficiency just filled: it never leaves HBM
+    if (observed) dynamic_cast<pdfz::EvalHist*>(s.histogram)->SampleEvents(events, observed, rng());
     if (observed_out) observed_out->push_back((unsigned)observed);
   }
   return events;

@@ -227,6 +227,19 @@ class EvalHist : public Eval {
     return out;
   }
 
+  /** The sampling step of RandomSample (pdfz.cpp:843-918) on the device: appends `observed` events (rows of
+   *  nobservables + 1 floats, last = dataset id) drawn from the histogram of the last evaluation
+   *  (EvalAsync(false) first, as CreateHistogram does), redrawn while outside [lowers, uppers] when given. */
+  void SampleEvents(std::vector<float>& events, size_t observed, unsigned long long seed,
+                    const std::vector<float>& uppers = std::vector<float>(),
+                    const std::vector<float>& lowers = std::vector<float>()) {
+    const size_t row = (size_t)nobservables + 1, old = events.size();
+    events.resize(old + observed * row);
+    const bool cuts = !uppers.empty() && !lowers.empty();
+    throw_on(sxmc_hist_random_sample(handle, observed, seed, cuts ? lowers.data() : nullptr,
+                                     cuts ? uppers.data() : nullptr, events.data() + old));
+  }
+
   sxmc_hist_t Handle() const { return handle; }
 
  protected:

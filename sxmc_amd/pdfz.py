@@ -174,6 +174,16 @@ class EvalHist:
         _raise(capi.load().sxmc_hist_get_bins(self._h, capi.ptr(out), out.size))
         return out
 
+    def RandomSample(self, nobserved, seed, lowers=None, uppers=None):
+        """EvalHist::RandomSample's sampling step on the device (pdfz.cpp:817-922): nobserved events drawn from
+        the histogram of the last evaluation (EvalAsync(False) first), rows of nobservables + 1 floats."""
+        out = np.empty((int(nobserved), self.nobservables + 1), dtype=np.float32)
+        lo = None if lowers is None else np.ascontiguousarray(lowers, dtype=np.float32)
+        hi = None if uppers is None else np.ascontiguousarray(uppers, dtype=np.float32)
+        _raise(capi.load().sxmc_hist_random_sample(self._h, int(nobserved), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                   capi.ptr(lo), capi.ptr(hi), capi.ptr(out)))
+        return out
+
     def GetReadBins(self):
         out = np.empty(self.npoints, dtype=np.int32)
         _raise(capi.load().sxmc_hist_get_read_bins(self._h, capi.ptr(out), out.size))

@@ -38,6 +38,49 @@ def test_efficiency_and_fake_dataset_follow_the_histograms():
     assert start == data.shape[0]
 
 
+def test_device_random_sample_is_reproducible_and_respects_cuts():
+    """sxmc_hist_random_sample: events drawn on the device from the histogram of the last evaluation (it never
+    leaves HBM): same seed -> same events, another seed -> other events, cuts are honoured (pdfz.cpp:853-857),
+    empty bins are never drawn, and new evaluation points of the same size re-use the evaluator's buffers."""
+    w = workloads.config3(0.003, nevents=100)
+    m = MCMC(w, seed=1)
+    ev = m.pdfs[2]
+    eff, bins, n_in = ensemble.get_efficiency(ev, w.nsyst_pars, w.parameter_means()[w.nsources:], w.signals[2].n_mc)
+    assert 0 < eff <= 1 and n_in == bins.sum()
+    a = ev.RandomSample(5000, 77)
+    b = ev.RandomSample(5000, 77)
+    c = ev.RandomSample(5000, 78)
+    assert a.shape == (5000, 4) and np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.all(a[:, 3] == w.signals[2].dataset)
+    geom = oracle.HistGeometry(w.lower, w.upper, w.nbins)
+    rb = oracle.set_eval_points(geom, a, w.signals[2].dataset)
+    assert np.all(rb >= 0) and np.all(bins[rb] > 0)
+    cut = ev.RandomSample(3000, 5, lowers=[1.0, 2.0, -0.5], uppers=[4.0, 5.0, 0.5])
+    assert np.all((cut[:, 0] >= 1.0) & (cut[:, 0] <= 4.0) & (cut[:, 1] >= 2.0) & (cut[:, 1] <= 5.0) &
+                  (np.abs(cut[:, 2]) <= 0.5))
+    # a second and third data set on the same evaluators: descriptors are patched, results are those of a fresh chain
+    for seed in (3, 4):
+        data, _ = ensemble.make_fake_dataset(np.random.default_rng(seed), w, m.pdfs, poisson=True)
+        m.setup(data=data, sync_interval=8)
+        v = m.proposed_vector.get()
+        m.step(debug_mode=True)
+        rows, _ = m.flush()
+        w2 = workloads.Workload.__new__(workloads.Workload)
+        w2.__dict__.update(w.__dict__)
+        w2.events = data
+        lut = np.zeros((w.nsignals, data.shape[0]), np.float32)
+        norms = np.zeros(w.nsignals, np.uint32)
+        for j, s_ in enumerate(w.signals):
+            rbj = oracle.set_eval_points(geom, data, s_.dataset)
+            bj, nj = oracle.bin_samples(geom, s_.samples, s_.nfields, w.systematics, v[w.nsources:])
+            oracle.eval_pdf(rbj, bj, nj, geom.bin_volume, out=lut[j])
+            norms[j] = nj
+        want, _ = oracle.full_nll(lut, v, data.shape[0], w.nsignals, w.nsources, w.parameter_means(),
+                                  w.parameter_sigmas(), [s_.nexpected for s_ in w.signals],
+                                  [s_.n_mc for s_ in w.signals], [s_.source_id for s_ in w.signals], norms)
+        assert abs(rows[0, -1] - np.float32(want)) <= 1e-6 * abs(want)
+
+
 def test_efficiency_divides_by_the_count_before_cuts():
     """signal.cpp:198: efficiency = in-domain count / n_mc, the number of simulated events BEFORE cuts -- the
     same n_mc the NLL kernels divide the norms by -- not the number of rows that survived the cuts."""
