@@ -404,6 +404,10 @@ int sxmc_comm_allgather_f32(sxmc_comm_t c, const float* d_send, float* d_recv, s
 int sxmc_comm_destroy(sxmc_comm_t c);
 const char* sxmc_comm_last_error(void);
 
+/* Test hook: d_out[k] = d_x[k]^i as the polynomial systematics form it (p = sum_i c_i * pow(x, i),
+ * pdfz.cpp:310-314): the power rounded ONCE, like libm's pow for small integer exponents -- not the i - 1
+ * roundings of repeated multiplication.  Exact for i <= 1, the plain product for i = 2. */
+int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out);
 /* Test hook: raw Philox4x32-10 output of d_state[0], 4 words per draw; advances the state. */
 int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws);
 

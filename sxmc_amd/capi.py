@@ -126,6 +126,7 @@ SIGNATURES = {
     "sxmc_comm_rank": [_vp, _pi, _pi],
     "sxmc_comm_allgather_f32": [_vp, _vp, _vp, _sz, _vp],
     "sxmc_comm_destroy": [_vp],
+    "sxmc_debug_pow_int": [_vp, _i, _i, _vp],
     "sxmc_debug_philox_dump": [_vp, _vp, _i],
 }
 STRING_GETTERS = ("sxmc_last_error", "sxmc_version", "sxmc_comm_last_error")

@@ -46,6 +46,20 @@ __device__ __forceinline__ double uniform_d(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// x^i for the polynomial systematics (p = sum_i c_i * pow(x, i), pdfz.cpp:310-314).  The reference calls libm's
+// pow, whose result for these small integer exponents is the correctly rounded power (up to the rare cases libm
+// itself misrounds).  Repeated multiplication rounds i - 1 times and differs from that in the last bit for
+// i >= 3 (~20 % of the values), so the running power is kept as an unevaluated sum h + l (error-free product
+// by FMA, renormalised): h is x^i rounded ONCE -- exact for i <= 1, the plain product for i = 2, the correctly
+// rounded power beyond unless x^i lies within 2^-100 of a rounding boundary.
+__device__ __forceinline__ void pow_step(double& h, double& l, double x) {
+  const double ph = h * x;
+  const double pl = __builtin_fma(h, x, -ph) + l * x;
+  const double s = ph + pl;
+  l = pl - (s - ph);
+  h = s;
+}
+
 // ------------------------------------------------------------------------------------ fill
 // Compile-time slot dispatch: the slot index is wave-uniform (it comes from the descriptor),
 // so this is a scalar branch to code that addresses the slot's registers directly.
@@ -127,18 +141,19 @@ __device__ __forceinline__ void apply_op(double (&f)[NSLOT][SXMC_VEC], unsigned 
       for (int q = 0; q < SXMC_VEC; q++) p[q] = pc;
     } else {
       // p = sum_i c_i * x^i at the current x; x^i by repeated multiplication
-      double pw[SXMC_VEC];
+      double pw[SXMC_VEC], pl[SXMC_VEC];
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
         p[q] = 0.0;
         pw[q] = 1.0;
+        pl[q] = 0.0;
       }
       for (int i = 0; i < npars; i++) {
         const double c = readlane_d(coef, cstart + i);
 #pragma unroll
         for (int q = 0; q < SXMC_VEC; q++) {
           p[q] = p[q] + c * pw[q];
-          pw[q] = pw[q] * f[K][q];
+          pow_step(pw[q], pl[q], f[K][q]);
         }
       }
     }
@@ -196,11 +211,11 @@ __device__ __forceinline__ void apply_static(double (&f)[NSLOT][SXMC_VEC], const
     // repeated multiplication otherwise, as in the run-time decoded program
     double pc = 0.0 + c[0] * 1.0;
     if constexpr (NP > 1) {
-      double pw = 1.0 * f[K][q];
+      double pw = 1.0 * f[K][q], pl = 0.0;
 #pragma unroll
       for (int i = 1; i < NP; i++) {
         pc = pc + c[i] * pw;
-        pw = pw * f[K][q];
+        pow_step(pw, pl, f[K][q]);
       }
     }
     if constexpr (type == SXMC_SYST_SHIFT) f[K][q] = f[K][q] + pc;

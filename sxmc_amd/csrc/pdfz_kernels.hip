@@ -14,8 +14,8 @@
 //
 // Exactness: double arithmetic is IEEE add/sub/mul with NO contraction (compile flag
 // -ffp-contract=off plus the pragma below), in the reference's operation order, so bin
-// indices are bit-identical to the reference CPU loop.  x^i is formed by repeated
-// multiplication (exact for i <= 1, correctly rounded for i == 2).
+// indices are bit-identical to the reference CPU loop.  x^i of the polynomial systematics is
+// rounded once (pow_step in fill_kernels.inc.h), like libm's pow for these exponents.
 #include "nll_device.h"
 
 #include "fill_kernels.inc.h"
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(1024) void fill_kernel_generic(const SxSignalDesc* 
       for (int s = 0; s < nsyst; s++) {
         const SxSystOp& op = d.syst[s];
         double x = f[op.obs_slot];
-        double p = 0.0, pw = 1.0;
+        double p = 0.0, pw = 1.0, pl = 0.0;
         for (int t = 0; t < op.npars; t++) {
           p = p + params[(long)op.pars[t] * pstride] * pw;
-          pw = pw * x;
+          pow_step(pw, pl, x);
         }
         switch (op.type) {
           case SXMC_SYST_SHIFT: x = x + p; break;
@@ -414,6 +414,15 @@ __global__ __launch_bounds__(256) void prebin_kernel(const SxSignalDesc* __restr
   }
 }
 
+// test hook: out[k] = x[k]^i as the polynomial systematics form it
+__global__ void pow_int_kernel(const double* __restrict__ x, int n, int i, double* __restrict__ out) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    double h = 1.0, l = 0.0;
+    for (int t = 0; t < i; t++) pow_step(h, l, x[k]);
+    out[k] = h;
+  }
+}
+
 // ------------------------------------------------------------------------------------ layout
 // Row-major [n][F] -> column-major with pitch; pads [n, nvec*4) with NaN in every column.
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ aos, float* __restrict__ cols,
@@ -696,6 +705,12 @@ hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(finish_zero_kernel, dim3(1 + (unsigned)zb * (unsigned)nsig), dim3(block), 0, s, d_descs, nsig,
                      (unsigned)zb, npartial, sums, ticket, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_pow_int(const double* x, int n, int i, double* out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pow_int_kernel, dim3((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), dim3(256), 0, s, x, n, i, out);
   return hipGetLastError();
 }
 

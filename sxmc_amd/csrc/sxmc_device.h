@@ -100,6 +100,7 @@ hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned lo
                               const unsigned* weight, const double* pars, const double* nexpected, const unsigned* n_mc,
                               const short* source_id, const unsigned* norms, double* sums,
                               int grid, int block, hipStream_t s);
+hipError_t sx_launch_pow_int(const double* x, int n, int i, double* out, hipStream_t s);
 hipError_t sx_launch_transpose(const float* aos, float* cols, unsigned long long nsamples,
                                int nfields, unsigned long long col_pitch, hipStream_t s);
 hipError_t sx_launch_untranspose_obs(const float* cols, float* out, unsigned long long nsamples,

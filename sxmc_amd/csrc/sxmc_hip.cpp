@@ -2572,6 +2572,14 @@ int sxmc_launch_finish_nll_jump_pick_combo(int grid, int block, sxmc_stream_t s,
   return SXMC_OK;
 }
 
+// test hook: d_out[k] = d_x[k]^i, formed as the polynomial systematics form it
+int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out) {
+  SX_REQUIRE(d_x && d_out && n >= 0 && i >= 0 && i < 64, "bad arguments");
+  SX_HIP(sx_launch_pow_int(d_x, n, i, d_out, nullptr));
+  SX_HIP(hipDeviceSynchronize());
+  return SXMC_OK;
+}
+
 // test hook: raw Philox output of state[0] (advances it by ndraws)
 int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws) {
   SX_HIP(sx_nll_philox_dump(nullptr, d_state, d_out, ndraws));

@@ -653,6 +653,42 @@ def test_runtime_specialised_sparse_runs_kernel():
         assert out[True][1][j] == o["norm"]
 
 
+def test_polynomial_powers_are_rounded_once_like_libm_pow():
+    """p = sum_i c_i * pow(x, i) (pdfz.cpp:310-314): the reference's x^i is libm's pow -- the correctly rounded
+    power for these small integer exponents, except where libm itself misrounds.  The kernels keep the running
+    power as an unevaluated sum (error-free FMA product) and round once: every x^i must equal the exactly
+    rounded rational power; repeated multiplication would be off in the last bit for ~1 in 5 values at i >= 3."""
+    import ctypes as C
+    from fractions import Fraction
+    rng = np.random.default_rng(41)
+    x = np.concatenate([rng.uniform(-3, 12, 6000).astype(np.float32).astype(np.float64),     # widened sample fields
+                        rng.uniform(-3, 12, 6000) * (1 + rng.normal(0, 1e-3, 6000))])        # ... and transformed ones
+    dx, dout = DeviceArray(x), DeviceArray.zeros(x.size, np.float64)
+    naive_off = libm_off = 0
+    for i in range(0, 8):
+        capi.call("sxmc_debug_pow_int", capi.ptr(dx), x.size, i, capi.ptr(dout))
+        got = dout.get()
+        exact = np.array([float(Fraction(v) ** i) for v in x])          # Fraction -> float rounds correctly
+        assert np.array_equal(got, exact), "x^%d is not the correctly rounded power" % i
+        naive = np.ones_like(x)
+        for _ in range(i):
+            naive = naive * x
+        naive_off += int(np.count_nonzero(naive != exact))
+        libm_off += int(np.count_nonzero(np.array([math.pow(v, i) for v in x]) != exact))
+    assert naive_off > 1000                  # what the kernels did before: thousands of last-bit differences
+    assert libm_off < naive_off // 20        # libm's pow is (almost always) the correctly rounded power
+
+
+def test_polynomial_systematics_at_a_million_samples():
+    """Three- and four-coefficient systematics on 1.2e6 samples: bins and norm equal the oracle's (libm pow)."""
+    rng = np.random.default_rng(42)
+    systs = [dict(type="shift", obs=0, pars=[0, 1, 2, 3]), dict(type="scale", obs=1, pars=[4, 5, 6])]
+    params = [0.01, -0.02, 0.015, -0.004, 0.01, 0.03, -0.02]
+    t = table(rng, 1200000, 3, lo=-0.1, hi=1.1)
+    kw = dict(samples=t, nfields=3, lower=[0.0, 0.0], upper=[1.0, 1.0], nbins=[60, 50], systs=systs, params=params)
+    compare(kw)
+
+
 def test_shared_table_with_different_prebinned_columns():
     """Two evaluators over one sample table whose systematics leave different observables untouched: each
     group keeps its own pre-binned column, and evaluating one does not disturb the other."""
