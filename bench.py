@@ -443,6 +443,28 @@ def also_record(args, torch, dev, name, form, lut_output, steps, warmup, exp_see
     return rec
 
 
+def cpp_host_record(args, nsteps=4000):
+    """BASELINE config 3 at full size walked entirely by the C++ host layer (tests/cpp/bench_cpp: sxmc::build_pdfz +
+    sxmc::MCMC over the C ABI, graph-replayed steps, no Python in that process): the north star's "host code stays
+    C++".  The walk includes its set-up, both burn-in re-tunings and the jump-buffer flushes."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "bench_cpp")
+    if not os.path.exists(exe):
+        return {"skipped": "tests/cpp/bench_cpp is not built (__graft_entry__.build() builds it)"}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([exe, "1.0", str(nsteps), str(args.graph_steps)], capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return {"skipped": "tests/cpp/bench_cpp did not finish within 300 s"}
+    if r.returncode != 0:
+        return {"skipped": "tests/cpp/bench_cpp failed: " + r.stderr[-300:]}
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
+    rec["leg_seconds"] = time.perf_counter() - t0
+    rec["note"] = "whole walk of %d steps including set-up, re-tuning and flushes; host = C++ only" % nsteps
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -479,8 +501,8 @@ def main():
     ap.add_argument("--exp-concurrent", type=int, default=3,
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
-                    help="sub-records measured after the headline: comma list of c3_lut_materialized, c2, c5; "
-                         "auto = all three when the headline is the full-size C3 on one GPU; none = skip")
+                    help="sub-records measured after the headline: comma list of c3_lut_materialized, c2, c5, cpp_host; "
+                         "auto = all of them when the headline is the full-size C3 on one GPU; none = skip")
     ap.add_argument("--also-steps", type=int, default=200, help="timed steps of each sub-record (C5: a quarter)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
     ap.add_argument("--no-sparse", action="store_true", help="fill HBM-resident histograms densely (global atomics)")
@@ -641,7 +663,7 @@ def main():
     also = args.also
     if also == "auto":
         full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and world == 1 and not args.debug_mode
-        also = "c3_lut_materialized,c2,c5" if full_c3 and want_cpu and args.form == "graph" else "none"
+        also = "c3_lut_materialized,c2,c5,cpp_host" if full_c3 and want_cpu and args.form == "graph" else "none"
     if also != "none" and rank == 0:
         leg.close()
         recs = {}
@@ -653,6 +675,8 @@ def main():
             elif name == "c5":
                 recs[name] = also_record(args, torch, dev, "c5", "graph", False, max(10, args.also_steps // 4), 10,
                                          exp_seed, "ends")
+            elif name == "cpp_host":
+                recs[name] = cpp_host_record(args)
             else:
                 raise SystemExit("unknown --also entry %r" % name)
         result["also"] = recs

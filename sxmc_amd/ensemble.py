@@ -98,20 +98,32 @@ def chisquare_quantile_1dof(cl):
     return 0.5 * (lo + hi)
 
 
+def as_printed(v):
+    """What `ostream << float` writes (6 significant digits, %g), read back.  The reference builds its selections
+    as TEXT -- "likelihood+" << -lmin << "<" << delta (likelihood.cpp:93-94, contour.cpp:45-46) -- so the offset
+    and threshold it actually applies are the printed, rounded ones: with |lmin| of a few 1e5 (BASELINE config 3)
+    the offset is off by up to 0.5, which moves the contour.  Reproduced because the intervals are results."""
+    return float("%g" % float(np.float32(v)))
+
+
 def contour_intervals(chain, cl=0.9):
-    """Contour::get_interval for every parameter.  chain: [n, P + 1] (last column = NLL).
-    Returns float32 [P, 4]: point_estimate, lower, upper, coverage (-999 as in the reference)."""
-    nll = chain[:, -1]
-    lmin = nll.min()
-    delta = 0.5 * chisquare_quantile_1dof(cl)
-    contour = chain[nll - lmin < delta]                      # likelihood.cpp:90-102
-    assert contour.shape[0] > 0
-    cn = contour[:, -1]
-    clmin = cn.min()
-    dnll = 0.13
-    while True:                                              # contour.cpp:41-53
-        near = contour[cn - clmin < dnll]
-        dnll *= 5
+    """Contour::get_interval for every parameter (contour.cpp:17-69, likelihood.cpp:90-102).  chain: [n, P + 1]
+    float32 (last column = NLL).  Returns float32 [P, 4]: point_estimate, lower, upper, coverage (-999 as in
+    the reference)."""
+    chain = np.asarray(chain, np.float32)
+    nll = chain[:, -1].astype(np.float64)
+    lmin = np.float32(chain[:, -1].min())
+    delta = np.float32(0.5 * chisquare_quantile_1dof(cl))                     # contour.cpp:19: a float
+    inside = nll + as_printed(-lmin) < as_printed(delta)                      # likelihood.cpp:90-102
+    if not inside.any():       # (the reference asserts here: the printed offset lost the minimum; use the exact one)
+        inside = chain[:, -1] - lmin < delta
+    contour = chain[inside]
+    cn = contour[:, -1].astype(np.float64)
+    coff = as_printed(-np.float32(contour[:, -1].min()))
+    dnll = np.float32(0.13)
+    while True:                                              # contour.cpp:39-53: 0.13, 0.65, 3.25, ...
+        near = contour[cn + coff < as_printed(dnll)]
+        dnll = np.float32(dnll * np.float32(5))
         if near.shape[0] >= 1:
             break
     P = chain.shape[1] - 1

@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -58,22 +60,43 @@ inline double chisquare_quantile_1dof(double cl) {
   return 0.5 * (lo + hi);
 }
 
-/** Contour::get_interval for every parameter of a chain (contour.cpp:30-69, likelihood.cpp:90-102). */
+/** What `ostream << float` writes (6 significant digits, %g) read back: the reference builds its selections as
+ *  TEXT -- "likelihood+" << -lmin << "<" << delta (likelihood.cpp:93-94, contour.cpp:45-46) -- so the offset and
+ *  the threshold it actually applies are the printed, rounded ones.  With |lmin| of a few 1e5 (BASELINE config 3)
+ *  the offset is off by up to 0.5, which moves the contour; reproduced here because the intervals are results. */
+inline double as_printed(float v) {
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%g", (double)v);
+  return std::strtod(buf, nullptr);
+}
+
+/** Contour::get_interval for every parameter of a chain (contour.cpp:17-69, likelihood.cpp:90-102). */
 inline std::vector<Interval> contour_intervals(const Chain& chain, float cl = 0.9f) {
   const size_t ncol = chain.names.size(), P = ncol - 1, n = chain.nrows();
   float lmin = chain.at(0, P);
   for (size_t r = 1; r < n; r++) lmin = std::min(lmin, chain.at(r, P));
-  const float delta = 0.5 * chisquare_quantile_1dof(cl);
+  const float delta = 0.5 * chisquare_quantile_1dof(cl);   // contour.cpp:19 (a float there too)
+  // likelihood.cpp:90-102: rows with likelihood + (-lmin as printed) < (delta as printed)
   std::vector<size_t> contour;
+  const double off = as_printed(-lmin), dprinted = as_printed(delta);
   for (size_t r = 0; r < n; r++)
-    if (chain.at(r, P) - lmin < delta) contour.push_back(r);
-  // points near the maximum-likelihood point: widen until at least one is found
+    if ((double)chain.at(r, P) + off < dprinted) contour.push_back(r);
+  if (contour.empty()) {   // (the reference asserts here: the printed offset lost the minimum; use the exact one)
+    for (size_t r = 0; r < n; r++)
+      if (chain.at(r, P) - lmin < delta) contour.push_back(r);
+  }
+  // contour.cpp:39-53: points near the maximum-likelihood point, widened 0.13, 0.65, 3.25, ... until one is found;
+  // the offset is the minimum over the contour points, printed the same way
+  float cmin = chain.at(contour[0], P);
+  for (size_t r : contour) cmin = std::min(cmin, chain.at(r, P));
+  const double coff = as_printed(-cmin);
   std::vector<size_t> near;
   float dnll = 0.13f;
   do {
     near.clear();
+    const double dn = as_printed(dnll);
     for (size_t r : contour)
-      if (chain.at(r, P) - lmin < dnll) near.push_back(r);
+      if ((double)chain.at(r, P) + coff < dn) near.push_back(r);
     dnll *= 5;
   } while (near.empty());
   std::vector<Interval> out(P);
@@ -265,13 +288,6 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
   for (std::exception_ptr& e : errors)
     if (e) std::rethrow_exception(e);
   return out;
-}
-
-/** utils.h:76-90 `median`. */
-inline float median(std::vector<float> v) {
-  std::sort(v.begin(), v.end());
-  const size_t half = v.size() / 2;
-  return v.size() % 2 == 0 ? (v[half - 1] + v[half]) / 2 : v[half];
 }
 
 struct MultiGpuEnsemble {

@@ -501,6 +501,42 @@ TEST(Ensemble, ContourIntervalOnAParabola) {
   EXPECT_EQ(-999.0f, iv[0].coverage);
 }
 
+static sxmc::Chain chain_of(std::initializer_list<std::pair<float, float>> rows) {
+  sxmc::Chain c;
+  c.names = {"x", "likelihood"};
+  for (const auto& r : rows) {
+    c.rows.push_back(r.first);
+    c.rows.push_back(r.second);
+  }
+  return c;
+}
+
+TEST(Ensemble, ContourKnownAnswers) {
+  // (the same three cases as tests/test_ensemble_cpu.py, against contour.cpp:17-69 / likelihood.cpp:90-102)
+  // 1. the threshold is delta = 0.5 * chi2_1(0.9) = 1.35277 and strict
+  std::vector<sxmc::Interval> iv =
+      sxmc::contour_intervals(chain_of({{1.0f, 10.0f}, {2.0f, 10.0f + 1.35277f - 1e-3f},
+                                        {3.0f, 10.0f + 1.35277f + 1e-3f}, {0.5f, 10.05f}}), 0.9f);
+  EXPECT_EQ(0.5f, iv[0].lower);
+  EXPECT_EQ(2.0f, iv[0].upper);
+  EXPECT_EQ(0.75f, iv[0].point_estimate);
+  EXPECT_EQ(-999.0f, iv[0].coverage);
+  // 2. -lmin goes into the selection as text with 6 significant digits: 348086.3125 -> "348086"
+  EXPECT_EQ(348086.0, sxmc::as_printed(348086.3125f));
+  const float l2 = -348086.3125f;
+  iv = sxmc::contour_intervals(chain_of({{0.0f, l2}, {5.0f, l2 + 1.5625f}, {7.0f, l2 + 1.6875f}}), 0.9f);
+  EXPECT_EQ(0.0f, iv[0].lower);
+  EXPECT_EQ(5.0f, iv[0].upper);
+  EXPECT_EQ(0.0f, iv[0].point_estimate);
+  // 3. the 0.13 * 5^k widening: with lmin = -348085.6875 the first pass finds nothing
+  const float l3 = -348085.6875f;
+  iv = sxmc::contour_intervals(chain_of({{0.0f, l3}, {4.0f, l3 + 0.25f}, {9.0f, l3 + 0.9375f}, {20.0f, l3 + 1.0625f}}),
+                               0.9f);
+  EXPECT_EQ(2.0f, iv[0].point_estimate);
+  EXPECT_EQ(0.0f, iv[0].lower);
+  EXPECT_EQ(9.0f, iv[0].upper);
+}
+
 TEST_F(SmallFit, FakeDatasetAndWholeExperiments) {
   std::mt19937_64 rng(5);
   std::vector<unsigned> observed;
@@ -587,7 +623,7 @@ TEST_F(SmallFit, MultiGpuRunnerGathersTheIntervalsThroughRccl) {
   std::vector<float> ups;
   for (unsigned k = 0; k < N; k++) ups.push_back(seq[k].intervals[0].upper);
   EXPECT_EQ(sxmc::median(ups), mg.median_upper[0]);
-  EXPECT_EQ(2.5f, sxmc::median({1.0f, 4.0f, 2.0f, 3.0f}));   // utils.h:76-90: mean of the two middle ones
+  EXPECT_EQ(2.5f, sxmc::median(std::vector<float>{1.0f, 4.0f, 2.0f, 3.0f}));   // utils.h:76-90: mean of the two middle ones
 }
 
 int main(int argc, char** argv) {

@@ -35,6 +35,42 @@ def test_contour_widens_until_it_finds_a_point():
     assert iv[0, 0] == 1.0 and iv[0, 1] == 1.0 and iv[0, 2] == 1.0
 
 
+DELTA90 = float(np.float32(0.5 * 2.705543454))            # contour.cpp:19: 1.3527717 as a float, printed "1.35277"
+
+
+def test_contour_known_answers_threshold_is_strict_and_exact():
+    # NLL values straddling lmin + delta by 1e-3: strictly-less-than selects the first two (likelihood.cpp:93-96)
+    chain = np.array([[1.0, 10.0], [2.0, 10.0 + 1.35277 - 1e-3], [3.0, 10.0 + 1.35277 + 1e-3], [0.5, 10.05]],
+                     np.float32)
+    iv = ensemble.contour_intervals(chain, cl=0.9)
+    assert iv[0, 1] == 0.5 and iv[0, 2] == 2.0             # min / max of the parameter inside the contour
+    assert iv[0, 0] == 0.75                                # mid-range of the points with dNLL < 0.13: x = 1 and 0.5
+    assert iv[0, 3] == -999
+
+
+def test_contour_known_answers_the_printed_offset_moves_the_contour():
+    # lmin = -348086.3125 is written into the selection as "348086" (6 significant digits): a point 1.55 above the
+    # minimum satisfies likelihood + 348086 < 1.35277 although 1.55 > delta -- the reference's contour, reproduced
+    lmin = np.float32(-348086.3125)
+    chain = np.array([[0.0, lmin], [5.0, lmin + np.float32(1.5625)], [7.0, lmin + np.float32(1.6875)]], np.float32)
+    assert ensemble.as_printed(-lmin) == 348086.0
+    iv = ensemble.contour_intervals(chain, cl=0.9)
+    assert iv[0, 1] == 0.0 and iv[0, 2] == 5.0             # -0.3125 + 1.5625 = 1.25 < 1.35277; 1.375 is not
+    assert iv[0, 0] == 0.0
+
+
+def test_contour_known_answers_widening_by_fives():
+    # lmin = -348085.6875 prints as "348086": even the minimum is 0.3125 above the printed offset, so the first
+    # pass (0.13) finds nothing and the second (0.65) takes the points up to 0.65 - 0.3125 above the minimum
+    lmin = np.float32(-348085.6875)
+    chain = np.array([[0.0, lmin], [4.0, lmin + np.float32(0.25)], [9.0, lmin + np.float32(0.9375)],
+                      [20.0, lmin + np.float32(1.0625)]], np.float32)
+    assert ensemble.as_printed(-lmin) == 348086.0
+    iv = ensemble.contour_intervals(chain, cl=0.9)
+    assert iv[0, 0] == 2.0                                 # (0 + 4) / 2: 0.3125 and 0.5625 < 0.65, 1.25 is not
+    assert iv[0, 1] == 0.0 and iv[0, 2] == 9.0             # 0.3125 + 0.9375 = 1.25 < 1.35277 <= 0.3125 + 1.0625
+
+
 def test_projection_interval_central_and_one_sided():
     rng = np.random.default_rng(0)
     v = rng.normal(5.0, 1.0, 200000)
