@@ -2051,7 +2051,7 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
     g->cfg_bpc = 1;
     if ((failure = group_refresh(g)) != SXMC_OK) break;
     float ms = 1e30f;
-    for (int rep = 0; rep < 4 && failure == SXMC_OK; rep++) {  // first repetition warms up
+    for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {  // first repetition warms up; the minimum of seven counts
       hipError_t e = hipEventRecord(e0, st);
       if (e == hipSuccess) failure = group_fill(g, st, false);
       if (failure == SXMC_OK && e == hipSuccess) e = hipEventRecord(e1, st);
