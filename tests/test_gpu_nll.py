@@ -258,6 +258,45 @@ def test_free_chain_runs_and_accepts_some():
     assert np.all(np.isfinite(chain))
 
 
+@pytest.mark.parametrize("make,scale", [(workloads.config2, 1.0), (workloads.config3, 0.25)])
+def test_baseline_configs_at_size_against_the_oracle(make, scale):
+    """BASELINE config 2 at its full size (10^7 samples) and config 3 at a quarter (2.5 10^7; its full size is
+    asserted by every bench.py run, see the `parity` object of the bench line): one whole MCMC step in the walk's
+    default form (bucketed table, event classes, graph-recorded launches) against the oracle -- every bin, the
+    norms, the lookup table bits and the NLL."""
+    w = make(scale, nevents=100000)
+    m = MCMC(w, seed=31, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
+    m.setup(sync_interval=8)
+    proposal = m.proposed_vector.get()
+    m.step(debug_mode=True)
+    m.steps(4, graph_steps=2, debug_mode=True)
+    rows, nacc = m.flush()
+    assert nacc == 5
+    ncores = 16
+    geom = oracle.HistGeometry(w.lower, w.upper, w.nbins)
+    ne = w.events.shape[0]
+    lut = np.zeros((w.nsignals, ne), np.float32)
+    norms = np.zeros(w.nsignals, np.uint32)
+    m.proposed_vector.set(proposal)
+    m.group.EvalAsync(True, m.stream)            # the same vector again, histograms and lookup table readable
+    m.group.EvalFinished()
+    for j, s in enumerate(w.signals):
+        rb = oracle.set_eval_points(geom, w.events, s.dataset)
+        bins, norm = oracle.bin_samples(geom, s.samples, s.nfields, w.systematics, proposal[w.nsources:], nthreads=ncores)
+        oracle.eval_pdf(rb, bins, norm, geom.bin_volume, out=lut[j])
+        norms[j] = norm
+        assert np.array_equal(m.pdfs[j].GetBins(), bins), "signal %d" % j
+    assert np.array_equal(m.normalizations.get(), norms)
+    assert np.array_equal(m.lut.get().view(np.uint32), lut.ravel().view(np.uint32))
+    want, _ = oracle.full_nll(lut, proposal, ne, w.nsignals, w.nsources, w.parameter_means(), w.parameter_sigmas(),
+                              [s.nexpected for s in w.signals], [s.n_mc for s in w.signals],
+                              [s.source_id for s in w.signals], norms)
+    assert abs(rows[0, -1] - np.float32(want)) <= 1e-6 * abs(want)     # the walk's own step, float32 in the chain
+    m.nll(m.proposed_vector, m.proposed_nll)
+    capi.synchronize()
+    assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
+
+
 def test_step_forms_walk_the_same_chain():
     """Same seed => same proposals and uniforms: the three step forms must accept the same steps and
     store the same chain (NLL equal to summation-order precision, compared as stored floats)."""
