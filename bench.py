@@ -496,9 +496,12 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--experiments", type=int, default=-1,
                     help="fake experiments for the ensemble leg (fake data + MCMC + intervals), sharded k mod N; "
-                         "-1 = three per rank, 0 = skip")
+                         "-1 = four per rank, 0 = skip")
     ap.add_argument("--exp-steps", type=int, default=2000, help="MCMC steps per fake experiment in the ensemble leg")
-    ap.add_argument("--exp-concurrent", type=int, default=3,
+    ap.add_argument("--exp-lockstep", type=int, default=2,
+                    help="ensemble leg, second pass: chains per lockstep set (one fill pass per step for the set); 0 = skip")
+    ap.add_argument("--exp-sets", type=int, default=2, help="lockstep sets in flight per GPU (one stream each)")
+    ap.add_argument("--exp-concurrent", type=int, default=4,
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
                     help="sub-records measured after the headline: comma list of c3_lut_materialized, c2, c5, cpp_host; "
@@ -565,7 +568,7 @@ def main():
     # tables stay resident; one RCCL all_gather of the per-experiment intervals at the end.  Outside the
     # timed region of the headline metric; reported beside it.
     experiments = None
-    nexp = 3 * world if args.experiments < 0 else args.experiments
+    nexp = 4 * world if args.experiments < 0 else args.experiments
     # (fake data sets are drawn from 1-3 D histograms only, as in the reference: pdfz.cpp:499-501)
     if nexp > 0 and not args.debug_mode and args.form != "pdfz" and w.nobs <= 3:
         from sxmc_amd import ensemble
@@ -595,10 +598,66 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         exp_elapsed = dist.max_over_ranks(time.perf_counter() - t1)
+        separate = {"concurrent_per_gpu": nconc, "seconds": exp_elapsed, "experiments_per_sec": nexp / exp_elapsed,
+                    "steps_per_sec_inside": nexp * args.exp_steps / exp_elapsed,
+                    "note": "one fill per chain per step, chains on their own streams (round 1's form)"}
+        # ---- the same experiments with the chains in LOCKSTEP sets: one fill pass per step for the chains of a set
+        lockstep = None
+        L = args.exp_lockstep
+        if L >= 2 and form is True and len(mine) >= L:
+            from sxmc_amd.mcmc import LockstepChains
+            nsets = max(1, args.exp_sets)
+            sets = []
+            for _ in range(nsets):
+                st = capi.new_stream()
+                cs = [MCMC(w, seed=1, fused=True, stream=st, share_with=m, lut_output=False, consume=True)
+                      for _ in range(L)]
+                for c in cs:
+                    c.group.SetLaunchConfig(*((tuned_threads, 1) if tuned_threads not in (0, 512) else (threads, bpc)))
+                sets.append(LockstepChains(cs))
+            per_round = nsets * L
+            local2 = np.zeros_like(local)
+            try:
+                dist.barrier()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                done = 0
+                for lo in range(0, len(mine) - len(mine) % per_round, per_round):
+                    batch = mine[lo:lo + per_round]
+                    res = ensemble.run_experiments_in_lockstep(
+                        w, [dist.experiment_seed(args.seed, k) for k in batch], args.exp_steps, sets,
+                        burnin_fraction=0.1, sync_interval=args.exp_steps, graph_steps=exp_graph)
+                    for i, r in enumerate(res):
+                        local2[lo + i] = r[0]
+                    done += len(batch)
+                torch.cuda.synchronize()
+                dist.barrier()
+                ls_elapsed = dist.max_over_ranks(time.perf_counter() - t2)
+                ndone = int(dist.sum_over_ranks(done))
+                same = bool(np.array_equal(local2[:done], local[:done]))
+                lockstep = {"chains_per_fill": L, "sets_per_gpu": nsets, "count": ndone, "seconds": ls_elapsed,
+                            "experiments_per_sec": ndone / ls_elapsed,
+                            "steps_per_sec_inside": ndone * args.exp_steps / ls_elapsed,
+                            "intervals_identical_to_separate_fills": same,
+                            "note": "sxmc_multigroup_step_async: the chains of a set share ONE pass over the tables per "
+                                    "step; sets on their own streams"}
+            except capi.SxmcError as exc:
+                lockstep = {"skipped": str(exc)}
+            for st in sets:
+                capi.synchronize()
+                st.close()
+                for c in st.chains:
+                    for p in c.pdfs:
+                        p.close()
+                    c.group.close()
+        best = lockstep if lockstep and "experiments_per_sec" in lockstep and \
+            lockstep["experiments_per_sec"] > separate["experiments_per_sec"] else separate
         allint = dist.gather_intervals(local, nexp, w.nparameters)
         experiments = {
             "count": nexp, "steps_each": args.exp_steps, "seconds": exp_elapsed, "concurrent_per_gpu": nconc,
-            "steps_per_graph": exp_graph,
+            "steps_per_graph": exp_graph, "separate_fills": separate, "lockstep": lockstep,
+            "best_steps_per_sec_inside": best["steps_per_sec_inside"],
+            "best_experiments_per_sec": best["experiments_per_sec"],
             "experiments_per_sec": nexp / exp_elapsed,
             "steps_per_sec_inside": nexp * args.exp_steps / exp_elapsed,
             "median_upper_limit_source0": dist.median(allint[:, 0, 2]),

@@ -314,6 +314,42 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
                           float* d_jump_buffer, int nparameters, size_t nsources,
                           const float* d_jump_width, const double* d_nexpected, const unsigned* d_n_mc,
                           const short* d_source_id, const unsigned* d_norms, int debug_mode);
+/* LOCKSTEP CHAINS.  Several chains over the SAME sample tables -- the fake experiments in flight on one GPU,
+ * BASELINE config 4's per-GPU shape: evaluators made with sxmc_hist_create_shared, same systematics, each chain
+ * with its own group, parameters, data and state -- evaluate different parameter vectors on identical samples.
+ * Stepped one by one each evaluation streams the tables again while the vector units idle under the stream
+ * (config 3: 175 us of stream against 122 us of arithmetic).  A multigroup steps 2-4 such chains TOGETHER: one
+ * fill pass streams the tables once and bins every sample under each chain's parameters into that chain's LDS
+ * histogram (bytes per evaluation divided by the number of chains; per chain exactly the operations of its own
+ * fill, so its counts are bit-identical), then every chain's own step end runs as in sxmc_group_step_async.
+ * Chains advanced this way walk exactly the chains they walk alone (tests).  The kernel is compiled through
+ * hiprtc for the chains' program.  SXMC_ERR_STATE (with the reason) when the chains cannot share a pass --
+ * different tables, systematics or launch configuration, histograms beyond LDS or not fitting LDS together, a
+ * run-time decoded program: step them separately then.  args: one sxmc_step_args per chain, in group order. */
+typedef struct {
+  const double* d_means;
+  const double* d_sigmas;
+  sxmc_rng_state* d_rng;
+  double* d_nll_current;
+  double* d_nll_proposed;
+  double* d_v_current;
+  double* d_v_proposed;
+  int* d_accepted;
+  int* d_counter;
+  float* d_jump_buffer;
+  int nparameters;
+  size_t nsources;
+  const float* d_jump_width;
+  const double* d_nexpected;
+  const unsigned* d_n_mc;
+  const short* d_source_id;
+  const unsigned* d_norms;
+  int debug_mode;
+} sxmc_step_args; /* the arguments of finish_nll_jump_pick_combo (nll_kernels.h:190-207) */
+typedef struct sxmc_multigroup* sxmc_multigroup_t;
+int sxmc_multigroup_create(const sxmc_group_t* groups, int ngroups, sxmc_multigroup_t* out);
+int sxmc_multigroup_destroy(sxmc_multigroup_t mg);
+int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args);
 /* Kernels launched by the last sxmc_group_step_async (2 or 3, see there; +1 when the histograms had to be
  * zeroed first). */
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches);

@@ -27,6 +27,16 @@ class SxmcError(RuntimeError):
         self.msg = msg
 
 
+class StepArgs(C.Structure):
+    """sxmc_step_args (include/sxmc_hip.h): the arguments of finish_nll_jump_pick_combo for one chain."""
+    _fields_ = [("d_means", C.c_void_p), ("d_sigmas", C.c_void_p), ("d_rng", C.c_void_p),
+                ("d_nll_current", C.c_void_p), ("d_nll_proposed", C.c_void_p), ("d_v_current", C.c_void_p),
+                ("d_v_proposed", C.c_void_p), ("d_accepted", C.c_void_p), ("d_counter", C.c_void_p),
+                ("d_jump_buffer", C.c_void_p), ("nparameters", C.c_int), ("nsources", C.c_size_t),
+                ("d_jump_width", C.c_void_p), ("d_nexpected", C.c_void_p), ("d_n_mc", C.c_void_p),
+                ("d_source_id", C.c_void_p), ("d_norms", C.c_void_p), ("debug_mode", C.c_int)]
+
+
 class RngState(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("subsequence", C.c_uint64), ("offset", C.c_uint64),
                 ("reserved", C.c_uint64)]
@@ -106,6 +116,9 @@ SIGNATURES = {
     "sxmc_group_set_tail_kernel": [_vp, _i],
     "sxmc_rtc_compile_check": [_i, _i, _i, _i, _i, _vp, _i, _psz],
     "sxmc_group_last_step_launches": [_vp, _pi],
+    "sxmc_multigroup_create": [_vp, _i, _pvp],
+    "sxmc_multigroup_destroy": [_vp],
+    "sxmc_multigroup_step_async": [_vp, _vp, _vp],
     "sxmc_group_finish_step_async": [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz,
                                      _vp, _vp, _vp, _vp, _vp, _i],
     "sxmc_group_synchronize": [_vp],

@@ -811,6 +811,167 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
   }
 }
 
+// LOCKSTEP CHAINS.  Several MCMC chains over the SAME sample tables (the fake experiments in flight on one GPU:
+// BASELINE config 4's per-GPU shape) evaluate different parameter vectors on identical samples.  Stepped one by
+// one, each streams the tables again and the vector units idle under the stream (config 3: 175 us of stream
+// against 122 us of arithmetic per evaluation).  Here ONE pass streams the tables and bins every sample under
+// each chain's parameters into that chain's LDS histogram: the bytes per evaluation divide by the number of
+// chains, the arithmetic does not change -- per chain exactly the operations of fill_body, so every chain's
+// counts are those of its own evaluation, bit for bit.  Static programs, histograms in LDS (NCHAIN of them),
+// PREW 0 (rows) or kPreGranule (bucketed).  descs.d[c]: the launch's members as chain c's evaluators describe
+// them (same tables and geometry; their own parameters, histogram, normalisation slot).
+struct SxChainDescs {
+  const SxSignalDesc* d[4];
+};
+
+template <int NOBS, int NSLOT, typename PROG, int PREW, int NCHAIN>
+__device__ __forceinline__ void fill_multi_body(SxChainDescs chains, const SxSegment* __restrict__ segs,
+                                                const unsigned* __restrict__ blk_off, unsigned hist_words) {
+  static_assert(!PROG::dynamic && (PREW == 0 || PREW == kPreGranule) && NCHAIN >= 2 && NCHAIN <= 4, "unsupported");
+  extern __shared__ unsigned lds[];
+  const unsigned tid = threadIdx.x;
+  const unsigned nthreads = blockDim.x;
+  const unsigned lane = tid & (kWave - 1);
+  // LDS: words 0..3 the chains' in-domain counters, then NCHAIN histograms of hist_words, then 64 trash words
+  unsigned* s_norm = lds;
+  unsigned* hist = lds + 4;
+  const unsigned trash = NCHAIN * hist_words + lane;
+
+  bool lds_clean = false;
+  const unsigned seg_end = blk_off[blockIdx.x + 1];
+  for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
+    const SxSegment& sg = segs[si];
+    const SxSignalDesc& d = chains.d[0][sg.sig];     // tables and geometry: the same for every chain
+    const unsigned long long v0 = sg.v0;
+    const unsigned long long v1 = sg.v1;
+    const unsigned long long step = sg.step;
+    const unsigned B = (unsigned)d.total_nbins;
+
+    double craw[NCHAIN][PROG::ncoef > 0 ? PROG::ncoef : 1];
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) {
+      const SxSignalDesc& dc = chains.d[c][sg.sig];
+#pragma unroll
+      for (int q = 0; q < PROG::ncoef; q++) craw[c][q] = to_global(dc.params)[(long)dc.coef_par[q] * dc.param_stride];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    gptr<const vfloat4> col[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
+    }
+    gptr<const typename PreVec<PREW>::type> precol =
+        to_global(reinterpret_cast<const typename PreVec<PREW>::type*>(d.pre));
+    const unsigned long long vlast = v1 - 1;
+    const unsigned long long vfirst = v0 + tid;
+    Columns<NSLOT, PREW> buf;
+    load_columns<NOBS, NSLOT, PREW, PROG>(buf, col, precol, vfirst < v1 ? vfirst : vlast);
+
+    if (!lds_clean) {
+      for (unsigned b = tid; b < NCHAIN * hist_words; b += nthreads) hist[b] = 0u;
+      if (tid < 4) s_norm[tid] = 0u;
+      __syncthreads();
+    }
+
+    double lo[NOBS], hi[NOBS], sc[NOBS];
+    int st[NOBS];
+#pragma unroll
+    for (int k = 0; k < NOBS; k++) {
+      lo[k] = d.lower[k];
+      hi[k] = d.upper[k];
+      sc[k] = d.scale[k];
+      st[k] = d.bin_stride[k];
+    }
+    unsigned cnt[NCHAIN];
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) cnt[c] = 0u;
+
+    unsigned long long v = vfirst;
+    const unsigned long long niter = (v1 - v0 + step - 1) / step;
+    for (unsigned long long it = 0; it < niter; ++it, v += step) {
+      double f0[NSLOT][SXMC_VEC];
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+        f0[k][0] = (double)buf.v[k].x;
+        f0[k][1] = (double)buf.v[k].y;
+        f0[k][2] = (double)buf.v[k].z;
+        f0[k][3] = (double)buf.v[k].w;
+      }
+      typename PreVec<PREW>::type prebits = buf.pre;
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f0[k][q]));
+      }
+      if constexpr (PREW != 0) asm volatile("" : "+v"(prebits));
+      const unsigned long long vl = v + step;
+      load_columns<NOBS, NSLOT, PREW, PROG>(buf, col, precol, vl < v1 ? vl : vlast);
+
+      const unsigned dead = (v < v1) ? 0u : 1u;
+#pragma unroll
+      for (int c = 0; c < NCHAIN; c++) {
+        double f[NSLOT][SXMC_VEC];
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) f[k][q] = f0[k][q];
+        }
+        run_static<NSLOT>(f, craw[c], PROG{}, typename MakeISeq<PROG::n>::type{});
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          unsigned bad = dead;
+          int bin = 0;
+          if constexpr (PREW != 0) bin = (int)pre_value<PREW>(prebits, q);
+#pragma unroll
+          for (int k = 0; k < NOBS; k++) {
+            const double x = f[k][q];
+            bad += !(x >= lo[k]) ? 1u : 0u;
+            bad += !(x < hi[k]) ? 1u : 0u;
+            const int idx = (int)((x - lo[k]) * sc[k]);
+            bin = (k == NOBS - 1 && PREW != kPreGranule) ? bin + idx : __mul24(idx, st[k]) + bin;
+          }
+          const unsigned in_domain = (bad == 0u) ? 1u : 0u;
+          cnt[c] += in_domain;
+          const bool store = (bad == 0u) && ((unsigned)bin < B);
+          const unsigned slot = store ? (unsigned)c * hist_words + (unsigned)bin : trash;
+          __hip_atomic_fetch_add(&hist[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) {
+      unsigned t = cnt[c];
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off, kWave);
+      if (lane == 0 && t != 0u) {
+        __hip_atomic_fetch_add(&s_norm[c], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) {
+      const SxSignalDesc& dc = chains.d[c][sg.sig];
+      gptr<unsigned> gbins = to_global(dc.bins);
+      for (unsigned b = tid; b < B; b += nthreads) {
+        const unsigned n = hist[(unsigned)c * hist_words + b];
+        if (n != 0u) {
+          __hip_atomic_fetch_add(&gbins[b], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hist[(unsigned)c * hist_words + b] = 0u;
+        }
+      }
+      if (tid == 0) {
+        const unsigned n = s_norm[c];
+        if (n != 0u) __hip_atomic_fetch_add(to_global(dc.norm), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_norm[c] = 0u;
+      }
+    }
+    __syncthreads();
+    lds_clean = true;
+  }
+}
+
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>
 __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restrict__ descs,
                                                     const SxSegment* __restrict__ segs,

@@ -54,11 +54,17 @@ struct SxLaunchShape {
 // A fill kernel specialised at run time (sxmc_rtc.cpp): the template arguments of fill_body / fill_sparse_body.
 struct SxRtcSpec {
   int nobs, nslot, lds_hist, pre_width, sparse_runs;
+  int nchain;                    // > 1: the lockstep-chains kernel (fill_multi_body), histograms in LDS
   int nops;
   unsigned ops[SXMC_MAX_SYST];   // type | obs_slot << 4 | extra_slot << 8 | npars << 12 (0 = one coefficient)
 };
 bool sx_rtc_compile_only(const SxRtcSpec& k, size_t* code_bytes, std::string* err);
 void* sx_rtc_get(const SxRtcSpec& k, std::string* err);
+struct SxChainDescsHost {
+  const SxSignalDesc* d[4];
+};
+hipError_t sx_rtc_launch_multi(void* fn, int grid, int threads, size_t lds_bytes, const SxChainDescsHost& chains,
+                               const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, hipStream_t s);
 hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, const SxSignalDesc* descs,
                          const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s);
 

@@ -365,6 +365,7 @@ struct sxmc_group {
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
   int last_step_launches = 0;                      // kernels the last sxmc_group_step_async launched
+  unsigned long long plan_generation = 0;          // counts launch plans built (a multigroup re-validates on change)
   std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
   int debug_mode = 0;
   int max_bins = 0;
@@ -1229,6 +1230,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_prebin = g->cfg_prebin;
   g->cfg_seen_bucket = g->cfg_bucket;
   g->cfg_seen_rtc = g->cfg_rtc;
+  g->plan_generation++;
   g->built = true;
   return SXMC_OK;
 }
@@ -1392,8 +1394,9 @@ int ensure_event_classes(sxmc_group* g, bool sparse) {
   return SXMC_OK;
 }
 
-int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
-  sparse = sparse && g->sparse_ready && g->cfg_sparse;
+// What precedes a group's fill launches: the zeroing (unless the last step end already cleared for this
+// evaluation) and the bookkeeping of who cleared what.
+int group_prepare_fill(sxmc_group* g, hipStream_t s, bool sparse) {
   // Recorded launches do not run now, so what a recording "pre-zeroed" is not zero yet: the first
   // evaluation of every recording zeroes explicitly, and sxmc_graph_end_capture drops the flag.
   bool first_in_recording = false;
@@ -1416,6 +1419,13 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
   for (size_t i = 0; i < g->members.size(); i++) {
     g->members[i]->bins_valid = g->members[i]->total_nbins > kLdsMaxBins ? !sparse : true;
   }
+  return SXMC_OK;
+}
+
+int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
+  sparse = sparse && g->sparse_ready && g->cfg_sparse;
+  int rc = group_prepare_fill(g, s, sparse);
+  if (rc) return rc;
   for (LaunchClass& c : g->classes) {
     const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
@@ -2306,6 +2316,46 @@ int sxmc_group_finish_step_async(sxmc_group_t g, sxmc_stream_t s, size_t npartia
   return SXMC_OK;
 }
 
+}  // extern "C" (helpers below are internal)
+
+namespace {
+// The end of a step after the fill: lookup + event sum + finish_nll_jump_pick_combo + the clearing for the next
+// evaluation -- one workgroup in one launch where that is small, two launches otherwise (see sxmc_group_step_async).
+int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDesc* descs, unsigned long long ne,
+                    const unsigned* weight, const SxStepArgs& a) {
+  // How much the end of the step has to touch decides its shape.  One workgroup doing all of it in one launch
+  // saves a launch and a boundary, but a row costs S double divisions and a log: measured at BASELINE config 3
+  // (~8000 rows x 12 members) one CU needs 59 us for what ~60 workgroups + the step-end launch do in 15.6 us, and
+  // at config 2 (~2500 x 6) 16 us against 9, at the bench_pdfz shape (1000 x 1) 8 us against 7; config 1 (10 x 2)
+  // gains 0.6 us of 14.7.  Only the smallest problems take it.
+  unsigned long long words = 0;
+  const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
+  for (const SxSignalDesc& d : flavour) words += (unsigned long long)d.total_nbins;
+  const unsigned long long gathers = ne * g->members.size();
+  if (gathers <= 256ull && words <= (1ull << 16) && g->cfg_tail != 0) {
+    SX_HIP(sx_launch_tail_step(descs, (int)g->members.size(), ne, weight, a, st));
+    g->last_step_launches += 1;
+  } else {
+    g->last_step_launches += 2;
+    const int block = 128;
+    const int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
+    SX_HIP(sx_launch_eval_nll(descs, (int)g->members.size(), ne, weight, a.v_proposed, a.nexpected, a.n_mc, a.source_id,
+                              a.norms, g->d_step_sums, grid, block, st));
+    SX_HIP(sx_launch_finish_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
+                                 sparse ? g->max_bins_sparse : g->max_bins, (size_t)grid, g->d_step_sums, g->d_ticket, a,
+                                 128, st));
+  }
+  g->prezeroed = sparse ? 2 : 1;
+  for (sxmc_hist* h : g->members) {
+    h->bins_valid = false;
+    h->cleared_by = g;
+  }
+  return SXMC_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means, const double* d_sigmas,
                           sxmc_rng_state* d_rng, double* d_nll_current, double* d_nll_proposed, double* d_v_current,
                           double* d_v_proposed, int* d_accepted, int* d_counter, float* d_jump_buffer, int nparameters,
@@ -2360,32 +2410,195 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
   a.n_mc = d_n_mc;
   a.source_id = d_source_id;
   a.norms = d_norms;
-  // How much the end of the step has to touch decides its shape.  One workgroup doing all of it in one launch
-  // saves a launch and a boundary, but a row costs S double divisions and a log: measured at BASELINE config 3
-  // (~8000 rows x 12 members) one CU needs 59 us for what ~60 workgroups + the step-end launch do in 15.6 us, and
-  // at config 2 (~2500 x 6) 16 us against 9, at the bench_pdfz shape (1000 x 1) 8 us against 7; config 1 (10 x 2)
-  // gains 0.6 us of 14.7.  Only the smallest problems take it.
-  unsigned long long words = 0;
-  const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
-  for (const SxSignalDesc& d : flavour) words += (unsigned long long)d.total_nbins;
-  const unsigned long long gathers = ne * g->members.size();
-  if (gathers <= 256ull && words <= (1ull << 16) && g->cfg_tail != 0) {
-    SX_HIP(sx_launch_tail_step(descs, (int)g->members.size(), ne, weight, a, st));
-    g->last_step_launches += 1;
-  } else {
-    g->last_step_launches += 2;
-    const int block = 128;
-    const int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
-    SX_HIP(sx_launch_eval_nll(descs, (int)g->members.size(), ne, weight, d_v_proposed, d_nexpected, d_n_mc, d_source_id,
-                              d_norms, g->d_step_sums, grid, block, st));
-    SX_HIP(sx_launch_finish_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
-                                 sparse ? g->max_bins_sparse : g->max_bins, (size_t)grid, g->d_step_sums, g->d_ticket, a,
-                                 128, st));
+  return group_step_tail(g, st, sparse, descs, ne, weight, a);
+}
+
+}  // extern "C"
+
+struct sxmc_multigroup {
+  std::vector<sxmc_group*> groups;
+  std::vector<void*> fill_fn;        // per launch of the plan: the lockstep kernel (hipFunction_t)
+  std::vector<size_t> lds_bytes;
+  std::vector<unsigned long long> seen;  // the groups' plan generations the kernels were chosen for
+  std::string why_not;               // set when the chains cannot be stepped together
+};
+
+namespace {
+// Chains can share a fill pass when their launch plans are the same plan over the same tables.
+bool multigroup_prepare(sxmc_multigroup* mg) {
+  const size_t C = mg->groups.size();
+  sxmc_group* g0 = mg->groups[0];
+  mg->why_not.clear();
+  for (size_t c = 1; c < C; c++) {
+    sxmc_group* g = mg->groups[c];
+    if (g->members.size() != g0->members.size() || g->classes.size() != g0->classes.size()) {
+      mg->why_not = "the chains' groups differ in members or launches";
+      return false;
+    }
+    for (size_t j = 0; j < g->members.size(); j++) {
+      if (g->members[j]->store != g0->members[j]->store || g->members[j]->nbins != g0->members[j]->nbins ||
+          g->members[j]->lower != g0->members[j]->lower || g->members[j]->upper != g0->members[j]->upper) {
+        mg->why_not = "the chains' evaluators do not share their sample tables (sxmc_hist_create_shared) or geometry";
+        return false;
+      }
+    }
   }
-  g->prezeroed = sparse ? 2 : 1;
-  for (sxmc_hist* h : g->members) {
-    h->bins_valid = false;
-    h->cleared_by = g;
+  DeviceProps props;
+  if (get_props(props)) return false;
+  mg->fill_fn.assign(g0->classes.size(), nullptr);
+  mg->lds_bytes.assign(g0->classes.size(), 0);
+  for (size_t i = 0; i < g0->classes.size(); i++) {
+    const LaunchClass& c0 = g0->classes[i];
+    if (!c0.shape.lds_hist || !c0.prog_simple || !(c0.shape.pre_width == 0 || c0.shape.pre_width == 3) ||
+        c0.shape.nobs == 0) {
+      mg->why_not = "a launch of the plan has its histogram beyond LDS, a run-time decoded program or a pre-binned column";
+      return false;
+    }
+    for (size_t c = 1; c < C; c++) {
+      const LaunchClass& cc = mg->groups[c]->classes[i];
+      if (cc.shape.nobs != c0.shape.nobs || cc.shape.nslot != c0.shape.nslot || cc.shape.lds_hist != c0.shape.lds_hist ||
+          cc.shape.pre_width != c0.shape.pre_width || cc.prog != c0.prog || cc.prog_simple != c0.prog_simple ||
+          cc.shape.grid != c0.shape.grid || cc.shape.threads != c0.shape.threads || cc.member_idx != c0.member_idx ||
+          cc.partition != c0.partition) {
+        mg->why_not = "the chains' launch plans differ (systematics, launch configuration)";
+        return false;
+      }
+    }
+    const size_t hist_words = c0.shape.lds_bytes / 4 - 4 - 64;
+    const size_t lds = (4 + C * hist_words + 64) * 4;
+    if (lds > (size_t)props.lds_per_cu) {
+      mg->why_not = "the chains' histograms do not fit LDS together";
+      return false;
+    }
+    SxRtcSpec k{};
+    k.nobs = c0.shape.nobs;
+    k.nslot = c0.shape.nslot;
+    k.lds_hist = 1;
+    k.pre_width = c0.shape.pre_width;
+    k.nchain = (int)C;
+    k.nops = (int)c0.prog.size();
+    for (size_t q = 0; q < c0.prog.size(); q++) k.ops[q] = c0.prog[q];
+    std::string err;
+    mg->fill_fn[i] = sx_rtc_get(k, &err);
+    if (!mg->fill_fn[i]) {
+      mg->why_not = "the lockstep kernel could not be compiled: " + err.substr(0, 300);
+      return false;
+    }
+    mg->lds_bytes[i] = lds;
+  }
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+int sxmc_multigroup_create(const sxmc_group_t* groups, int ngroups, sxmc_multigroup_t* out) {
+  SX_REQUIRE(groups && out && ngroups >= 2 && ngroups <= 4, "a multigroup steps 2 to 4 chains together");
+  for (int i = 0; i < ngroups; i++) SX_REQUIRE(groups[i], "null group");
+  sxmc_multigroup* mg = new sxmc_multigroup;
+  mg->groups.assign(groups, groups + ngroups);
+  *out = mg;
+  return SXMC_OK;
+}
+
+int sxmc_multigroup_destroy(sxmc_multigroup_t mg) {
+  delete mg;
+  return SXMC_OK;
+}
+
+int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args) {
+  SX_REQUIRE(mg && args, "null argument");
+  hipStream_t st = (hipStream_t)s;
+  const size_t C = mg->groups.size();
+  // every chain's own plan first (may upload: before anything is launched)
+  bool replan = mg->seen.size() != C;
+  for (size_t c = 0; c < C; c++) {
+    sxmc_group* g = mg->groups[c];
+    const sxmc_step_args& a = args[c];
+    SX_REQUIRE(a.d_means && a.d_sigmas && a.d_rng && a.d_nll_current && a.d_nll_proposed && a.d_v_current &&
+                   a.d_v_proposed && a.d_accepted && a.d_counter && a.d_jump_buffer && a.d_jump_width &&
+                   a.d_nexpected && a.d_n_mc && a.d_source_id && a.d_norms && a.nparameters > 0,
+               "null argument");
+    int rc = group_refresh(g);
+    if (rc) return rc;
+    if (!replan && mg->seen[c] != g->plan_generation) replan = true;
+    rc = group_check_bound(g, true);
+    if (rc) return rc;
+    if (!g->same_points) return fail(SXMC_ERR_STATE, "members do not share one set of evaluation points");
+    if (!g->cfg_lut) {
+      rc = ensure_event_classes(g, false);
+      if (rc) return rc;
+    }
+    g->last_stream = st;
+  }
+  if (replan) {
+    if (t_capturing) return fail(SXMC_ERR_STATE, "the chains' plans are out of date: step once before recording a graph");
+    mg->seen.resize(C);
+    for (size_t c = 0; c < C; c++) mg->seen[c] = mg->groups[c]->plan_generation;
+    if (!multigroup_prepare(mg)) {
+      mg->seen.clear();
+      return fail(SXMC_ERR_STATE, "these chains cannot share a fill pass: " + mg->why_not);
+    }
+  }
+  for (size_t c = 0; c < C; c++) {
+    sxmc_group* g = mg->groups[c];
+    const bool zero_launched = g->prezeroed != 1;
+    int rc = group_prepare_fill(g, st, false);
+    if (rc) return rc;
+    g->last_step_launches = zero_launched ? 1 : 0;
+  }
+  // ONE pass over the tables for all chains
+  sxmc_group* g0 = mg->groups[0];
+  for (size_t i = 0; i < g0->classes.size(); i++) {
+    const LaunchClass& c0 = g0->classes[i];
+    if (c0.shape.grid <= 0) continue;
+    SxChainDescsHost ch{};
+    for (size_t c = 0; c < C; c++) ch.d[c] = mg->groups[c]->classes[i].d_descs;
+    const bool rec = g0->prof && !t_capturing && g0->prof_n < (int)g0->ev0.size();
+    if (rec) SX_HIP(hipEventRecord(g0->ev0[g0->prof_n], st));
+    SX_HIP(sx_rtc_launch_multi(mg->fill_fn[i], c0.shape.grid, c0.shape.threads, mg->lds_bytes[i], ch, c0.d_segs,
+                               c0.d_blk_off, (unsigned)(c0.shape.lds_bytes / 4 - 4 - 64), st));
+    if (rec) {
+      SX_HIP(hipEventRecord(g0->ev1[g0->prof_n], st));
+      g0->prof_n++;
+    }
+  }
+  // every chain's own step end
+  for (size_t c = 0; c < C; c++) {
+    sxmc_group* g = mg->groups[c];
+    const sxmc_step_args& p = args[c];
+    g->last_step_launches += (int)g0->classes.size();
+    unsigned long long ne = g->members[0]->npoints;
+    const SxSignalDesc* descs = g->d_descs;
+    const unsigned* weight = nullptr;
+    if (!g->cfg_lut) {
+      const sxmc_group::EventClasses& ec = g->ec[0];
+      ne = ec.K;
+      descs = ec.d_descs;
+      weight = ec.d_weight;
+    }
+    SxStepArgs a;
+    a.nsignals = g->members.size();
+    a.nsources = p.nsources;
+    a.means = p.d_means;
+    a.sigmas = p.d_sigmas;
+    a.rng = p.d_rng;
+    a.nll_current = p.d_nll_current;
+    a.nll_proposed = p.d_nll_proposed;
+    a.v_current = p.d_v_current;
+    a.v_proposed = p.d_v_proposed;
+    a.accepted = p.d_accepted;
+    a.counter = p.d_counter;
+    a.jump_buffer = p.d_jump_buffer;
+    a.nparameters = p.nparameters;
+    a.debug_mode = p.debug_mode;
+    a.jump_width = p.d_jump_width;
+    a.nexpected = p.d_nexpected;
+    a.n_mc = p.d_n_mc;
+    a.source_id = p.d_source_id;
+    a.norms = p.d_norms;
+    int rc = group_step_tail(g, st, false, descs, ne, weight, a);
+    if (rc) return rc;
   }
   return SXMC_OK;
 }

@@ -34,6 +34,13 @@ std::string kernel_source(const SxRtcSpec& k) {
   for (int i = 0; i < k.nops; i++) prog += (i ? ", " : "") + std::to_string(k.ops[i]) + "u";
   prog += ">";
   std::string s = "#include \"fill_kernels.inc.h\"\nusing namespace sxfill;\n";
+  if (k.nchain > 1) {
+    s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(SxChainDescs chains, "
+         "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w) {\n";
+    s += "  fill_multi_body<" + std::to_string(k.nobs) + ", " + std::to_string(k.nslot) + ", " + prog + ", " +
+         std::to_string(k.pre_width) + ", " + std::to_string(k.nchain) + ">(chains, segs, blk_off, w);\n}\n";
+    return s;
+  }
   s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(const SxSignalDesc* __restrict__ descs, "
        "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";
   if (k.sparse_runs) {
@@ -50,7 +57,7 @@ std::string kernel_source(const SxRtcSpec& k) {
 
 std::string spec_key(const SxRtcSpec& k) {
   std::string s = std::to_string(k.nobs) + "/" + std::to_string(k.nslot) + "/" + std::to_string(k.lds_hist) + "/" +
-                  std::to_string(k.pre_width) + "/" + std::to_string(k.sparse_runs) + ":";
+                  std::to_string(k.pre_width) + "/" + std::to_string(k.sparse_runs) + "/" + std::to_string(k.nchain) + ":";
   for (int i = 0; i < k.nops; i++) s += std::to_string(k.ops[i]) + ",";
   return s;
 }
@@ -144,6 +151,14 @@ void* sx_rtc_get(const SxRtcSpec& k, std::string* err) {
 hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, const SxSignalDesc* descs,
                          const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s) {
   void* args[] = {(void*)&descs, (void*)&segs, (void*)&blk_off, (void*)&w, (void*)&dbg};
+  return hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds_bytes, s,
+                               args, nullptr);
+}
+
+hipError_t sx_rtc_launch_multi(void* fn, int grid, int threads, size_t lds_bytes, const SxChainDescsHost& chains,
+                               const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, hipStream_t s) {
+  SxChainDescsHost c = chains;
+  void* args[] = {(void*)&c, (void*)&segs, (void*)&blk_off, (void*)&hist_words};
   return hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds_bytes, s,
                                args, nullptr);
 }

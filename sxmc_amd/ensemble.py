@@ -195,6 +195,41 @@ def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_int
     return contour_intervals(chain, cl), chain, accepted
 
 
+def run_experiments_in_lockstep(workload, seeds, nsteps, sets, burnin_fraction=0.1, cl=0.9, sync_interval=10000,
+                                graph_steps=0):
+    """len(seeds) fake experiments at once on one GPU, the chains grouped into lockstep sets (mcmc.LockstepChains:
+    the chains of a set share a stream and ONE fill pass per step; different sets run on different streams, so one
+    set's step ends overlap another's fill).  Same schedule of re-tunings and flushes as a single walk; every
+    chain walks what it walks alone.  Returns a list of (intervals, chain, accepted) in the order of `seeds`."""
+    chains = [m for st in sets for m in st.chains]
+    assert len(seeds) == len(chains)
+    for st in sets:
+        st.drop_graph()                              # new data: recorded steps hold the old evaluation-point tables
+    for m, seed in zip(chains, seeds):
+        rng = np.random.default_rng(seed)
+        m.reseed(seed & 0xFFFFFFFF)
+        data, _ = make_fake_dataset(rng, workload, m.pdfs, poisson=True)
+        m.walk_begin(data, nsteps, burnin_fraction, sync_interval=sync_interval)
+    i = 0
+    for f in chains[0].flush_schedule():            # the same schedule for every chain
+        for m in chains:
+            m._retune_if_due(i)
+        n = f - i + 1
+        while n > 0:
+            k = graph_steps if graph_steps > 0 and n >= graph_steps else n
+            for st in sets:
+                st.steps(k, graph_steps)
+            n -= k
+        for m in chains:
+            m._flush_if_due(f)
+        i = f + 1
+    out = []
+    for m in chains:
+        chain, accepted = m.walk_end()
+        out.append((contour_intervals(chain, cl), chain, accepted))
+    return out
+
+
 def run_experiments_concurrently(workload, seeds, nsteps, chains, burnin_fraction=0.1, cl=0.9, sync_interval=10000,
                                  graph_steps=0):
     """len(chains) fake experiments at once on one GPU (BASELINE config 4: one experiment per stream):

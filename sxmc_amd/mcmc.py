@@ -308,3 +308,43 @@ class MCMC:
                 chunks.append(rows)
                 accepted += nacc
         return np.concatenate(chunks, axis=0), accepted
+
+
+class LockstepChains:
+    """2-4 chains over the same sample tables (MCMC(..., share_with=base), all on ONE stream) advanced together:
+    every step is one fill pass over the tables for all of them (nll.MultiGroup / sxmc_multigroup_step_async)
+    followed by each chain's own step end.  The chains walk exactly what they walk when stepped alone."""
+
+    def __init__(self, chains):
+        self.chains = list(chains)
+        self.stream = self.chains[0].stream
+        assert all(c.stream == self.stream for c in self.chains), "lockstep chains share one stream"
+        assert all(c.consume for c in self.chains), "lockstep chains clear for the next step (consume=True)"
+        self.mg = nll.MultiGroup(self.chains)
+        self._graph, self._graph_steps = None, 0
+
+    def step(self, debug_mode=False):
+        self.mg.StepAsync(self.stream, debug_mode)
+
+    def drop_graph(self):
+        if self._graph is not None:
+            self._graph.close()
+        self._graph = None
+
+    def steps(self, n, graph_steps=0, debug_mode=False):
+        """n lockstep steps: graph replays of graph_steps recorded steps, the remainder launched one by one."""
+        if graph_steps > 0 and n >= graph_steps:
+            if self._graph is None or self._graph_steps != graph_steps:
+                self.drop_graph()
+                with capi.Graph.capture(self.stream) as g:
+                    for _ in range(graph_steps):
+                        self.step(debug_mode)
+                self._graph, self._graph_steps = g, graph_steps
+            self._graph.launch(n // graph_steps)
+            n %= graph_steps
+        for _ in range(n):
+            self.step(debug_mode)
+
+    def close(self):
+        self.drop_graph()
+        self.mg.close()

@@ -188,3 +188,39 @@ class EvalGroup:
             self.close()
         except Exception:
             pass
+
+
+class MultiGroup:
+    """2-4 chains over the same sample tables stepped TOGETHER: one fill pass streams the tables once for all of
+    them (sxmc_multigroup_*, include/sxmc_hip.h).  chains: objects with the MCMC attributes (sxmc_amd.mcmc.MCMC)."""
+
+    def __init__(self, chains):
+        self.chains = list(chains)
+        arr = (C.c_void_p * len(self.chains))(*[c.group._g for c in self.chains])
+        mg = C.c_void_p(0)
+        capi.call("sxmc_multigroup_create", arr, len(self.chains), C.byref(mg))
+        self._mg = mg
+        self._args = (capi.StepArgs * len(self.chains))()
+
+    def StepAsync(self, stream, debug_mode=False):
+        for a, m in zip(self._args, self.chains):
+            a.d_means, a.d_sigmas, a.d_rng = ptr(m.parameter_means).value, ptr(m.parameter_sigma).value, ptr(m.rngs).value
+            a.d_nll_current, a.d_nll_proposed = ptr(m.current_nll).value, ptr(m.proposed_nll).value
+            a.d_v_current, a.d_v_proposed = ptr(m.current_vector).value, ptr(m.proposed_vector).value
+            a.d_accepted, a.d_counter = ptr(m.accept_counter).value, ptr(m.jump_counter).value
+            a.d_jump_buffer, a.nparameters, a.nsources = ptr(m.jump_buffer).value, m.nparameters, m.nsources
+            a.d_jump_width, a.d_nexpected, a.d_n_mc = ptr(m.jump_width).value, ptr(m.nexpected).value, ptr(m.n_mc).value
+            a.d_source_id, a.d_norms = ptr(m.source_id).value, ptr(m.normalizations).value
+            a.debug_mode = int(bool(debug_mode))
+        capi.call("sxmc_multigroup_step_async", self._mg, ptr(stream), C.cast(self._args, C.c_void_p))
+
+    def close(self):
+        if getattr(self, "_mg", None):
+            capi.load().sxmc_multigroup_destroy(self._mg)
+            self._mg = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -267,6 +267,7 @@ def test_baseline_configs_at_size_against_the_oracle(make, scale):
     w = make(scale, nevents=100000)
     m = MCMC(w, seed=31, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
     m.setup(sync_interval=8)
+    capi.synchronize()                           # (the first proposal is drawn on the chain's non-blocking stream)
     proposal = m.proposed_vector.get()
     m.step(debug_mode=True)
     m.steps(4, graph_steps=2, debug_mode=True)
@@ -295,6 +296,52 @@ def test_baseline_configs_at_size_against_the_oracle(make, scale):
     m.nll(m.proposed_vector, m.proposed_nll)
     capi.synchronize()
     assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
+
+
+@pytest.mark.parametrize("nchains,graph_steps", [(2, 0), (2, 6), (3, 4), (4, 0)])
+def test_lockstep_chains_walk_what_they_walk_alone(nchains, graph_steps):
+    """sxmc_multigroup_step_async: chains over the same sample tables (different seeds, different data) advanced
+    together -- ONE fill pass per step bins every sample under each chain's parameters -- must walk, bit for
+    bit, the chains they walk when stepped alone (same kernels for everything but the fill; counts are integers)."""
+    from sxmc_amd.mcmc import LockstepChains
+    w = workloads.config3(0.004, nevents=3000)
+    rng = np.random.default_rng(5)
+    datas = [w.events[rng.permutation(w.events.shape[0])[: 2000 + 100 * c]] for c in range(nchains)]
+    nsteps = 41
+    base = MCMC(w, seed=100, lut_output=False, consume=True, stream=capi.new_stream())
+    alone = []
+    for c in range(nchains):
+        m = MCMC(w, seed=200 + c, lut_output=False, consume=True, stream=capi.new_stream(), share_with=base)
+        m.setup(data=datas[c], sync_interval=64)
+        alone.append(m.run(nsteps))
+    stream = capi.new_stream()
+    chains = [MCMC(w, seed=200 + c, lut_output=False, consume=True, stream=stream, share_with=base)
+              for c in range(nchains)]
+    for c, m in enumerate(chains):
+        m.setup(data=datas[c], sync_interval=64)
+    ls = LockstepChains(chains)
+    ls.step()                                     # (the first step is launched; recording needs the plans in place)
+    ls.steps(nsteps - 1, graph_steps)
+    for c, m in enumerate(chains):
+        rows, nacc = m.flush()
+        assert nacc == alone[c][1] and 0 < nacc < nsteps
+        assert np.array_equal(rows, alone[c][0]), "chain %d" % c
+        assert m.group.LastStepLaunches() == 3    # its share: the fill pass + lookup/event sum + step end
+    ls.close()
+
+
+def test_lockstep_refuses_chains_that_cannot_share_a_pass():
+    from sxmc_amd.mcmc import LockstepChains
+    w = workloads.config3(0.002, nevents=500)
+    stream = capi.new_stream()
+    a = MCMC(w, seed=1, lut_output=False, consume=True, stream=stream)
+    b = MCMC(w, seed=2, lut_output=False, consume=True, stream=stream)      # its own copy of the tables
+    for m in (a, b):
+        m.setup(sync_interval=8)
+    ls = LockstepChains([a, b])
+    with pytest.raises(capi.SxmcError, match="share"):
+        ls.step()
+    ls.close()
 
 
 def test_step_forms_walk_the_same_chain():
