@@ -195,7 +195,8 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
                                        std::vector<Signal>& signals, std::vector<Systematic>& systematics,
                                        std::vector<Observable>& observables, unsigned nsteps, float burnin_fraction,
                                        float cl, unsigned sync_interval, unsigned graph_steps = 0,
-                                       sxmc_stream_t stream = nullptr, std::mutex* exclusive = nullptr) {
+                                       sxmc_stream_t stream = nullptr, std::mutex* exclusive = nullptr,
+                                       LockstepSet* lockstep = nullptr, size_t lockstep_index = 0) {
   const unsigned long long x = experiment_seed(base_seed, k);
   std::mt19937_64 rng(x);
   // `exclusive` (one chain per host thread): held over everything that allocates, copies through the
@@ -206,6 +207,8 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   std::unique_ptr<MCMC> mcmc(new MCMC(sources, signals, systematics, observables, x, stream));
   mcmc->graph_steps = graph_steps;
   mcmc->exclusive = exclusive;
+  mcmc->lockstep = lockstep;
+  mcmc->lockstep_index = lockstep_index;
   if (exclusive) lock.unlock();   // the walk takes it itself
   Chain chain = (*mcmc)(data, nsteps, burnin_fraction, false, sync_interval);
   if (exclusive) lock.lock();
@@ -290,6 +293,83 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
   return out;
 }
 
+/** The same loop with the experiments in flight advanced in LOCKSTEP sets (BASELINE config 4's per-GPU shape, taken
+ *  further): `nsets` sets of `chains_per_set` chains; the chains of a set walk on one stream and share ONE pass
+ *  over the sample tables per step (LockstepSet / sxmc_multigroup_step_async: the bytes streamed per evaluation
+ *  divide by the chains per set; config 3: 9 500 steps/s with 2 sets of 4 against 5 500 with a fill per chain),
+ *  different sets run on different streams so that one set's step ends overlap another's fill.  Every lane is a
+ *  host thread, as in ensemble_concurrent; experiments that do not fill a whole round of nsets x chains_per_set
+ *  lanes run through ensemble_concurrent at the end.  Results are those of `ensemble`, in the order of
+ *  `experiments`. */
+inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigned>& experiments,
+                                                       unsigned long long base_seed, std::vector<Source>& sources,
+                                                       std::vector<Signal>& signals, std::vector<Systematic>& systematics,
+                                                       std::vector<Observable>& observables, unsigned nsteps,
+                                                       float burnin_fraction, unsigned chains_per_set, unsigned nsets,
+                                                       float cl = 0.9f, unsigned sync_interval = 10000, int device = -1,
+                                                       std::mutex* process_exclusive = nullptr) {
+  const size_t L = std::max(2u, std::min(4u, chains_per_set)), S = std::max(1u, nsets), lanes = L * S;
+  const size_t usable = experiments.size() / lanes * lanes;
+  std::vector<ExperimentResult> out(experiments.size());
+  std::mutex own_exclusive;
+  std::mutex& exclusive = process_exclusive ? *process_exclusive : own_exclusive;
+  if (usable) {
+    std::vector<std::unique_ptr<LockstepSet>> sets;
+    std::vector<sxmc_stream_t> streams(S, nullptr);
+    if (device >= 0) check(sxmc_set_device(device));
+    for (size_t k = 0; k < S; k++) {
+      check(sxmc_stream_create_nonblocking(&streams[k]));
+      sets.emplace_back(new LockstepSet(L, streams[k]));
+    }
+    std::vector<std::exception_ptr> errors(lanes);
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < lanes; t++) {
+      threads.emplace_back([&, t]() {
+        LockstepSet& set = *sets[t / L];
+        std::vector<Signal> mine;
+        try {
+          if (device >= 0) check(sxmc_set_device(device));
+          {
+            std::lock_guard<std::mutex> lock(exclusive);
+            transfer_stream() = set.stream;
+            for (const Signal& s : signals) mine.push_back(share_pdfz(s));
+          }
+          std::vector<Source> src = sources;
+          std::vector<Systematic> sys = systematics;
+          std::vector<Observable> obs = observables;
+          for (size_t i = t; i < usable; i += lanes) {
+            out[i] = run_experiment(experiments[i], base_seed, src, mine, sys, obs, nsteps, burnin_fraction, cl,
+                                    sync_interval, 0, set.stream, &exclusive, &set, t % L);
+          }
+        } catch (const pdfz::Error& e) {
+          errors[t] = std::current_exception();
+          set.abandon(e.msg);
+        } catch (...) {
+          errors[t] = std::current_exception();
+          set.abandon("a chain of the set failed");
+        }
+        std::lock_guard<std::mutex> lock(exclusive);
+        for (Signal& s : mine) delete s.histogram;
+        transfer_stream() = nullptr;
+      });
+    }
+    for (std::thread& th : threads) th.join();
+    sets.clear();
+    for (sxmc_stream_t st : streams)
+      if (st) sxmc_stream_destroy(st);
+    for (std::exception_ptr& e : errors)
+      if (e) std::rethrow_exception(e);
+  }
+  if (usable < experiments.size()) {
+    std::vector<unsigned> rest(experiments.begin() + (std::ptrdiff_t)usable, experiments.end());
+    std::vector<ExperimentResult> r = ensemble_concurrent(rest, base_seed, sources, signals, systematics, observables,
+                                                          nsteps, burnin_fraction, (unsigned)lanes, cl, sync_interval, 0,
+                                                          device, &exclusive);
+    for (size_t i = 0; i < r.size(); i++) out[usable + i] = r[i];
+  }
+  return out;
+}
+
 struct MultiGpuEnsemble {
   std::vector<ExperimentResult> results;  //!< one per experiment, in experiment order (computed on its own GPU)
   std::vector<float> gathered;            //!< [nexperiments][nparameters][4] = point_estimate, lower, upper, coverage:
@@ -311,7 +391,8 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
                                            const std::vector<const std::vector<float>*>& tables, int nfields,
                                            std::vector<Systematic>& systematics, std::vector<Observable>& observables,
                                            unsigned nsteps, float burnin_fraction, unsigned nconcurrent,
-                                           float cl = 0.9f, unsigned sync_interval = 10000, unsigned graph_steps = 0) {
+                                           float cl = 0.9f, unsigned sync_interval = 10000, unsigned graph_steps = 0,
+                                           unsigned lockstep_chains = 0, unsigned lockstep_sets = 2) {
   const size_t G = devices.size();
   if (G == 0 || tables.size() != signals.size()) throw pdfz::Error("ensemble_multi_gpu: bad arguments");
   size_t P = sources.size();
@@ -348,9 +429,14 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
         }
         std::vector<unsigned> ks;
         for (unsigned k = (unsigned)r; k < nexperiments; k += (unsigned)G) ks.push_back(k);
-        std::vector<ExperimentResult> res = ensemble_concurrent(ks, base_seed, src, mine, sys, obs, nsteps,
-                                                                burnin_fraction, nconcurrent, cl, sync_interval,
-                                                                graph_steps, devices[r], &exclusive);
+        // per device: experiments in flight either as lockstep sets (one pass over the tables per step and set)
+        // or each with its own fill
+        std::vector<ExperimentResult> res =
+            lockstep_chains >= 2
+                ? ensemble_lockstep(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, lockstep_chains,
+                                    lockstep_sets, cl, sync_interval, devices[r], &exclusive)
+                : ensemble_concurrent(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, nconcurrent, cl,
+                                      sync_interval, graph_steps, devices[r], &exclusive);
         std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());
         for (size_t i = 0; i < res.size(); i++) {
           out.results[ks[i]] = res[i];

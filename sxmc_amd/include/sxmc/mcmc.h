@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -33,8 +34,79 @@ struct Chain {
   float at(size_t row, size_t col) const { return rows[row * names.size() + col]; }
 };
 
+/** Chains advanced TOGETHER (sxmc_multigroup_step_async): one fill pass over the shared sample tables per step for
+ *  all of them, then every chain's own step end.  Shared by the MCMC objects of one lockstep set, each walking on
+ *  its own host thread and on the set's ONE stream: a chain that is ready to step leaves its arguments here; the
+ *  last one to arrive launches the step of all.  Every chain of the set must take the same number of steps. */
+class LockstepSet {
+ public:
+  LockstepSet(size_t nchains, sxmc_stream_t stream_) : stream(stream_), groups(nchains, nullptr), args(nchains) {}
+  ~LockstepSet() {
+    if (mg) sxmc_multigroup_destroy(mg);
+  }
+  LockstepSet(const LockstepSet&) = delete;
+  LockstepSet& operator=(const LockstepSet&) = delete;
+
+  void step(size_t index, sxmc_group_t group, const sxmc_step_args& a) {
+    std::unique_lock<std::mutex> lock(m);
+    if (broken) throw pdfz::Error("lockstep set: " + why);
+    if (groups[index] != group) dirty = true;
+    groups[index] = group;
+    args[index] = a;
+    const unsigned long long gen = generation;
+    if (++arrived == groups.size()) {
+      if (dirty && mg) {
+        sxmc_multigroup_destroy(mg);
+        mg = nullptr;
+      }
+      int rc = mg ? SXMC_OK : sxmc_multigroup_create(groups.data(), (int)groups.size(), &mg);
+      dirty = false;
+      if (rc == SXMC_OK) rc = sxmc_multigroup_step_async(mg, stream, args.data());
+      arrived = 0;
+      generation++;
+      if (rc != SXMC_OK) {
+        broken = true;
+        why = sxmc_last_error();
+      }
+      cv.notify_all();
+      if (broken) throw pdfz::Error("lockstep set: " + why);
+    } else {
+      cv.wait(lock, [&] { return generation != gen || broken; });
+      if (broken) throw pdfz::Error("lockstep set: " + why);
+    }
+  }
+  /** The chain's group is about to be destroyed: the multigroup is rebuilt at the next step. */
+  void leave(size_t index) {
+    std::lock_guard<std::mutex> lock(m);
+    groups[index] = nullptr;
+    dirty = true;
+  }
+  /** A chain of the set failed: its partners must not wait for it. */
+  void abandon(const std::string& reason) {
+    std::lock_guard<std::mutex> lock(m);
+    broken = true;
+    why = reason;
+    cv.notify_all();
+  }
+  sxmc_stream_t stream;
+
+ private:
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<sxmc_group_t> groups;
+  std::vector<sxmc_step_args> args;
+  sxmc_multigroup_t mg = nullptr;
+  size_t arrived = 0;
+  unsigned long long generation = 0;
+  bool dirty = true, broken = false;
+  std::string why;
+};
+
 class MCMC {
  public:
+  LockstepSet* lockstep = nullptr;  //!< set: this chain steps together with the other chains of the set (same
+  size_t lockstep_index = 0;        //!< sample tables, same systematics, the set's stream); steps are launched one
+                                    //!< by one (no graph), each by whichever chain of the set arrives last
   bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
   bool verbose = false;
   unsigned graph_steps = 0;     //!< > 0: replay the batched step from a HIP graph of this many recorded steps
@@ -231,7 +303,7 @@ class MCMC {
 
     // Recorded steps need a created stream (blocking: it still orders with the copies of the array
     // accessors, which go through the legacy default stream) and the batched form.
-    const unsigned gsteps = (batched && reevaluate) ? graph_steps : 0;
+    const unsigned gsteps = (batched && reevaluate && !lockstep) ? graph_steps : 0;
     sxmc_stream_t strm = stream;
     sxmc_graph_t graph = nullptr;
     const bool own_stream = gsteps > 0 && !strm;
@@ -272,6 +344,29 @@ class MCMC {
     };
     auto one_step = [&]() {
       int npartial = (int)nnllthreads;
+      if (lockstep && batched && reevaluate && consume) {
+        sxmc_step_args a;
+        a.d_means = d.means;
+        a.d_sigmas = d.sigmas;
+        a.d_rng = reinterpret_cast<sxmc_rng_state*>(d.rng);
+        a.d_nll_current = d.nll_current;
+        a.d_nll_proposed = d.nll_proposed;
+        a.d_v_current = d.current;
+        a.d_v_proposed = d.proposed;
+        a.d_accepted = d.accepted;
+        a.d_counter = d.counter;
+        a.d_jump_buffer = d.jump_buffer;
+        a.nparameters = (int)nparameters;
+        a.nsources = nsources;
+        a.d_jump_width = d.jump_width;
+        a.d_nexpected = d.nexpected;
+        a.d_n_mc = d.n_mc;
+        a.d_source_id = d.source_id;
+        a.d_norms = d.norms;
+        a.debug_mode = debug_mode ? 1 : 0;
+        lockstep->step(lockstep_index, group, a);
+        return;
+      }
       if (batched && reevaluate && consume) {
         // two launches: fill of all signals; lookup + event sum + step end + clearing for the next step
         check(sxmc_group_step_async(group, strm, d.means, d.sigmas, d.rng, d.nll_current, d.nll_proposed, d.current,
@@ -334,8 +429,9 @@ class MCMC {
         check(sxmc_graph_launch(graph, strm, (int)(n / gsteps)));
         n %= gsteps;
       }
-      // set-up is over once the first run of steps after step 0 has its graph (or needs none)
-      if (i > 0 && excl.owns_lock()) excl.unlock();
+      // set-up is over once the first run of steps after step 0 has its graph (or needs none); a lockstep chain
+      // must not hold the lock while it waits for its partners, who need it for their own set-up
+      if ((i > 0 || lockstep) && excl.owns_lock()) excl.unlock();
       for (unsigned k = 0; k < n; k++) one_step();
 
       // Flush the jump buffer (mcmc.cpp:351-377); the host reads go through blocking copies
@@ -352,6 +448,7 @@ class MCMC {
       i = f + 1;
     }
     if (strm) check(sxmc_stream_synchronize(strm));
+    if (lockstep) lockstep->leave(lockstep_index);
     if (exclusive && !excl.owns_lock()) excl.lock();  // tear-down frees device memory
     if (graph) check(sxmc_graph_destroy(graph));
     if (own_stream) check(sxmc_stream_destroy(strm));

@@ -590,6 +590,27 @@ TEST_F(SmallFit, ConcurrentExperimentsMatchSequential) {
   }
 }
 
+TEST_F(SmallFit, LockstepExperimentsMatchSequential) {
+  // nine experiments: two rounds of 2 sets x 2 chains advanced together (one pass over the sample tables per step
+  // and set, sxmc_multigroup_step_async) + one left over: the intervals of the one-at-a-time loop, exactly
+  const std::vector<unsigned> ks = {0u, 1u, 2u, 3u, 4u, 5u, 6u, 7u, 8u};
+  std::vector<sxmc::ExperimentResult> seq =
+      sxmc::ensemble(ks, 31, sources, signals, systematics, observables, 300, 0.2f, 0.9f, 100);
+  std::vector<sxmc::ExperimentResult> par =
+      sxmc::ensemble_lockstep(ks, 31, sources, signals, systematics, observables, 300, 0.2f, 2, 2, 0.9f, 100);
+  EXPECT_EQ(seq.size(), par.size());
+  for (size_t i = 0; i < seq.size(); i++) {
+    EXPECT_EQ(seq[i].index, par[i].index);
+    EXPECT_EQ(seq[i].accepted, par[i].accepted);
+    EXPECT_EQ(seq[i].nevents, par[i].nevents);
+    for (size_t p = 0; p < seq[i].intervals.size(); p++) {
+      EXPECT_EQ(seq[i].intervals[p].lower, par[i].intervals[p].lower);
+      EXPECT_EQ(seq[i].intervals[p].upper, par[i].intervals[p].upper);
+      EXPECT_EQ(seq[i].intervals[p].point_estimate, par[i].intervals[p].point_estimate);
+    }
+  }
+}
+
 TEST_F(SmallFit, MultiGpuRunnerGathersTheIntervalsThroughRccl) {
   // sxmc::ensemble_multi_gpu on the GPUs of this box (one here): a host thread per device with its own replica
   // of the evaluators, experiment k on device k mod G, ONE RCCL all-gather of the intervals at the end.  What
