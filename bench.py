@@ -453,12 +453,16 @@ def cpp_host_record(args, nsteps=4000):
         return {"skipped": "tests/cpp/bench_cpp is not built (__graft_entry__.build() builds it)"}
     t0 = time.perf_counter()
     try:
-        r = subprocess.run([exe, "1.0", str(nsteps), str(args.graph_steps)], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, "1.0", str(nsteps), str(args.graph_steps), "8", "2000", "4", "2"], capture_output=True,
+                           text=True, timeout=300)
     except subprocess.TimeoutExpired:
         return {"skipped": "tests/cpp/bench_cpp did not finish within 300 s"}
     if r.returncode != 0:
         return {"skipped": "tests/cpp/bench_cpp failed: " + r.stderr[-300:]}
-    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [json.loads(x) for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    rec = lines[0]
+    if len(lines) > 1:
+        rec["ensemble_lockstep"] = lines[1]     # 8 whole fake experiments as 2 lockstep sets of 4 chains
     rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
     rec["leg_seconds"] = time.perf_counter() - t0
     rec["note"] = "whole walk of %d steps including set-up, re-tuning and flushes; host = C++ only" % nsteps
@@ -496,9 +500,9 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--experiments", type=int, default=-1,
                     help="fake experiments for the ensemble leg (fake data + MCMC + intervals), sharded k mod N; "
-                         "-1 = four per rank, 0 = skip")
+                         "-1 = eight per rank, 0 = skip")
     ap.add_argument("--exp-steps", type=int, default=2000, help="MCMC steps per fake experiment in the ensemble leg")
-    ap.add_argument("--exp-lockstep", type=int, default=2,
+    ap.add_argument("--exp-lockstep", type=int, default=4,
                     help="ensemble leg, second pass: chains per lockstep set (one fill pass per step for the set); 0 = skip")
     ap.add_argument("--exp-sets", type=int, default=2, help="lockstep sets in flight per GPU (one stream each)")
     ap.add_argument("--exp-concurrent", type=int, default=4,
@@ -568,7 +572,7 @@ def main():
     # tables stay resident; one RCCL all_gather of the per-experiment intervals at the end.  Outside the
     # timed region of the headline metric; reported beside it.
     experiments = None
-    nexp = 4 * world if args.experiments < 0 else args.experiments
+    nexp = 8 * world if args.experiments < 0 else args.experiments
     # (fake data sets are drawn from 1-3 D histograms only, as in the reference: pdfz.cpp:499-501)
     if nexp > 0 and not args.debug_mode and args.form != "pdfz" and w.nobs <= 3:
         from sxmc_amd import ensemble
