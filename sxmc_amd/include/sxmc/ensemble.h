@@ -306,7 +306,8 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
                                                        std::vector<Signal>& signals, std::vector<Systematic>& systematics,
                                                        std::vector<Observable>& observables, unsigned nsteps,
                                                        float burnin_fraction, unsigned chains_per_set, unsigned nsets,
-                                                       float cl = 0.9f, unsigned sync_interval = 10000, int device = -1,
+                                                       float cl = 0.9f, unsigned sync_interval = 10000,
+                                                       unsigned graph_steps = 10, int device = -1,
                                                        std::mutex* process_exclusive = nullptr) {
   const size_t L = std::max(2u, std::min(4u, chains_per_set)), S = std::max(1u, nsets), lanes = L * S;
   const size_t usable = experiments.size() / lanes * lanes;
@@ -319,7 +320,7 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
     if (device >= 0) check(sxmc_set_device(device));
     for (size_t k = 0; k < S; k++) {
       check(sxmc_stream_create_nonblocking(&streams[k]));
-      sets.emplace_back(new LockstepSet(L, streams[k]));
+      sets.emplace_back(new LockstepSet(L, streams[k], &exclusive));
     }
     std::vector<std::exception_ptr> errors(lanes);
     std::vector<std::thread> threads;
@@ -339,7 +340,7 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
           std::vector<Observable> obs = observables;
           for (size_t i = t; i < usable; i += lanes) {
             out[i] = run_experiment(experiments[i], base_seed, src, mine, sys, obs, nsteps, burnin_fraction, cl,
-                                    sync_interval, 0, set.stream, &exclusive, &set, t % L);
+                                    sync_interval, graph_steps, set.stream, &exclusive, &set, t % L);
           }
         } catch (const pdfz::Error& e) {
           errors[t] = std::current_exception();
@@ -363,8 +364,8 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
   if (usable < experiments.size()) {
     std::vector<unsigned> rest(experiments.begin() + (std::ptrdiff_t)usable, experiments.end());
     std::vector<ExperimentResult> r = ensemble_concurrent(rest, base_seed, sources, signals, systematics, observables,
-                                                          nsteps, burnin_fraction, (unsigned)lanes, cl, sync_interval, 0,
-                                                          device, &exclusive);
+                                                          nsteps, burnin_fraction, (unsigned)lanes, cl, sync_interval,
+                                                          graph_steps, device, &exclusive);
     for (size_t i = 0; i < r.size(); i++) out[usable + i] = r[i];
   }
   return out;
@@ -434,7 +435,8 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
         std::vector<ExperimentResult> res =
             lockstep_chains >= 2
                 ? ensemble_lockstep(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, lockstep_chains,
-                                    lockstep_sets, cl, sync_interval, devices[r], &exclusive)
+                                    lockstep_sets, cl, sync_interval, graph_steps ? graph_steps : 10, devices[r],
+                                    &exclusive)
                 : ensemble_concurrent(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, nconcurrent, cl,
                                       sync_interval, graph_steps, devices[r], &exclusive);
         std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());

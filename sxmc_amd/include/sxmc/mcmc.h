@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -36,32 +37,32 @@ struct Chain {
 
 /** Chains advanced TOGETHER (sxmc_multigroup_step_async): one fill pass over the shared sample tables per step for
  *  all of them, then every chain's own step end.  Shared by the MCMC objects of one lockstep set, each walking on
- *  its own host thread and on the set's ONE stream: a chain that is ready to step leaves its arguments here; the
- *  last one to arrive launches the step of all.  Every chain of the set must take the same number of steps. */
+ *  its own host thread and on the set's ONE stream: a chain that is ready for its next run of steps leaves its
+ *  arguments here; the last one to arrive launches the run for all -- replays of a HIP graph of `graph_steps`
+ *  recorded lockstep steps, the remainder step by step -- so the host threads meet once per run (a handful of
+ *  times per walk), not once per step.  Every chain of the set must ask for the same runs. */
 class LockstepSet {
  public:
-  LockstepSet(size_t nchains, sxmc_stream_t stream_) : stream(stream_), groups(nchains, nullptr), args(nchains) {}
+  /** exclusive: the mutex that serialises set-up, graph recording and tear-down in this process (may be null). */
+  LockstepSet(size_t nchains, sxmc_stream_t stream_, std::mutex* exclusive_ = nullptr)
+      : stream(stream_), exclusive(exclusive_), groups(nchains, nullptr), args(nchains) {}
   ~LockstepSet() {
+    if (graph) sxmc_graph_destroy(graph);
     if (mg) sxmc_multigroup_destroy(mg);
   }
   LockstepSet(const LockstepSet&) = delete;
   LockstepSet& operator=(const LockstepSet&) = delete;
 
-  void step(size_t index, sxmc_group_t group, const sxmc_step_args& a) {
+  /** Chain `index` is ready to take `nsteps` steps with `a`: returns when those steps of ALL chains are launched. */
+  void advance(size_t index, sxmc_group_t group, const sxmc_step_args& a, unsigned nsteps, unsigned graph_steps) {
     std::unique_lock<std::mutex> lock(m);
     if (broken) throw pdfz::Error("lockstep set: " + why);
-    if (groups[index] != group) dirty = true;
+    if (groups[index] != group || std::memcmp(&args[index], &a, sizeof a) != 0) dirty = true;
     groups[index] = group;
     args[index] = a;
     const unsigned long long gen = generation;
     if (++arrived == groups.size()) {
-      if (dirty && mg) {
-        sxmc_multigroup_destroy(mg);
-        mg = nullptr;
-      }
-      int rc = mg ? SXMC_OK : sxmc_multigroup_create(groups.data(), (int)groups.size(), &mg);
-      dirty = false;
-      if (rc == SXMC_OK) rc = sxmc_multigroup_step_async(mg, stream, args.data());
+      int rc = launch(nsteps, graph_steps);
       arrived = 0;
       generation++;
       if (rc != SXMC_OK) {
@@ -75,7 +76,7 @@ class LockstepSet {
       if (broken) throw pdfz::Error("lockstep set: " + why);
     }
   }
-  /** The chain's group is about to be destroyed: the multigroup is rebuilt at the next step. */
+  /** The chain's group is about to be destroyed: multigroup and graph are rebuilt at the next run. */
   void leave(size_t index) {
     std::lock_guard<std::mutex> lock(m);
     groups[index] = nullptr;
@@ -91,22 +92,69 @@ class LockstepSet {
   sxmc_stream_t stream;
 
  private:
+  int launch(unsigned nsteps, unsigned graph_steps) {
+    if (dirty) {
+      if (graph) sxmc_graph_destroy(graph);
+      graph = nullptr;
+      if (mg) sxmc_multigroup_destroy(mg);
+      mg = nullptr;
+      int rc = sxmc_multigroup_create(groups.data(), (int)groups.size(), &mg);
+      if (rc) return rc;
+      dirty = false;
+      stepped = false;
+    }
+    if (graph_steps > 0 && stepped && nsteps >= graph_steps) {
+      if (!graph || recorded != graph_steps) {
+        // recording does not tolerate another thread's allocations: under the process's set-up mutex
+        std::unique_lock<std::mutex> excl;
+        if (exclusive) excl = std::unique_lock<std::mutex>(*exclusive);
+        if (graph) sxmc_graph_destroy(graph);
+        graph = nullptr;
+        int rc = sxmc_graph_begin_capture(stream);
+        if (rc) return rc;
+        for (unsigned k = 0; k < graph_steps && rc == SXMC_OK; k++) rc = sxmc_multigroup_step_async(mg, stream, args.data());
+        const std::string err = rc ? sxmc_last_error() : "";
+        int rc2 = sxmc_graph_end_capture(stream, &graph);
+        if (rc) {
+          if (graph) sxmc_graph_destroy(graph);
+          graph = nullptr;
+          (void)err;
+          return rc;
+        }
+        if (rc2) return rc2;
+        recorded = graph_steps;
+      }
+      int rc = sxmc_graph_launch(graph, stream, (int)(nsteps / graph_steps));
+      if (rc) return rc;
+      nsteps %= graph_steps;
+    }
+    for (unsigned k = 0; k < nsteps; k++) {
+      int rc = sxmc_multigroup_step_async(mg, stream, args.data());
+      if (rc) return rc;
+      stepped = true;   // (the launch plans are in place once a step has been launched: recording may follow)
+    }
+    return SXMC_OK;
+  }
+
   std::mutex m;
   std::condition_variable cv;
+  std::mutex* exclusive;
   std::vector<sxmc_group_t> groups;
   std::vector<sxmc_step_args> args;
   sxmc_multigroup_t mg = nullptr;
+  sxmc_graph_t graph = nullptr;
+  unsigned recorded = 0;
   size_t arrived = 0;
   unsigned long long generation = 0;
-  bool dirty = true, broken = false;
+  bool dirty = true, broken = false, stepped = false;
   std::string why;
 };
 
 class MCMC {
  public:
   LockstepSet* lockstep = nullptr;  //!< set: this chain steps together with the other chains of the set (same
-  size_t lockstep_index = 0;        //!< sample tables, same systematics, the set's stream); steps are launched one
-                                    //!< by one (no graph), each by whichever chain of the set arrives last
+  size_t lockstep_index = 0;        //!< sample tables, same systematics, the set's stream); every run of steps is
+                                    //!< launched (graph replays of graph_steps steps) by the chain that arrives last
   bool reference_form = false;  //!< launch the reference's own kernel sequence instead of the batched one
   bool verbose = false;
   unsigned graph_steps = 0;     //!< > 0: replay the batched step from a HIP graph of this many recorded steps
@@ -303,7 +351,8 @@ class MCMC {
 
     // Recorded steps need a created stream (blocking: it still orders with the copies of the array
     // accessors, which go through the legacy default stream) and the batched form.
-    const unsigned gsteps = (batched && reevaluate && !lockstep) ? graph_steps : 0;
+    const bool in_lockstep = lockstep && batched && reevaluate && consume;
+    const unsigned gsteps = (batched && reevaluate && !in_lockstep) ? graph_steps : 0;
     sxmc_stream_t strm = stream;
     sxmc_graph_t graph = nullptr;
     const bool own_stream = gsteps > 0 && !strm;
@@ -344,29 +393,6 @@ class MCMC {
     };
     auto one_step = [&]() {
       int npartial = (int)nnllthreads;
-      if (lockstep && batched && reevaluate && consume) {
-        sxmc_step_args a;
-        a.d_means = d.means;
-        a.d_sigmas = d.sigmas;
-        a.d_rng = reinterpret_cast<sxmc_rng_state*>(d.rng);
-        a.d_nll_current = d.nll_current;
-        a.d_nll_proposed = d.nll_proposed;
-        a.d_v_current = d.current;
-        a.d_v_proposed = d.proposed;
-        a.d_accepted = d.accepted;
-        a.d_counter = d.counter;
-        a.d_jump_buffer = d.jump_buffer;
-        a.nparameters = (int)nparameters;
-        a.nsources = nsources;
-        a.d_jump_width = d.jump_width;
-        a.d_nexpected = d.nexpected;
-        a.d_n_mc = d.n_mc;
-        a.d_source_id = d.source_id;
-        a.d_norms = d.norms;
-        a.debug_mode = debug_mode ? 1 : 0;
-        lockstep->step(lockstep_index, group, a);
-        return;
-      }
       if (batched && reevaluate && consume) {
         // two launches: fill of all signals; lookup + event sum + step end + clearing for the next step
         check(sxmc_group_step_async(group, strm, d.means, d.sigmas, d.rng, d.nll_current, d.nll_proposed, d.current,
@@ -431,7 +457,32 @@ class MCMC {
       }
       // set-up is over once the first run of steps after step 0 has its graph (or needs none); a lockstep chain
       // must not hold the lock while it waits for its partners, who need it for their own set-up
-      if ((i > 0 || lockstep) && excl.owns_lock()) excl.unlock();
+      if ((i > 0 || in_lockstep) && excl.owns_lock()) excl.unlock();
+      if (in_lockstep) {
+        // this run of steps together with the other chains of the set (recorded and replayed there)
+        sxmc_step_args a;
+        std::memset(&a, 0, sizeof a);   // (padding too: the set compares argument blocks bytewise)
+        a.d_means = d.means;
+        a.d_sigmas = d.sigmas;
+        a.d_rng = reinterpret_cast<sxmc_rng_state*>(d.rng);
+        a.d_nll_current = d.nll_current;
+        a.d_nll_proposed = d.nll_proposed;
+        a.d_v_current = d.current;
+        a.d_v_proposed = d.proposed;
+        a.d_accepted = d.accepted;
+        a.d_counter = d.counter;
+        a.d_jump_buffer = d.jump_buffer;
+        a.nparameters = (int)nparameters;
+        a.nsources = nsources;
+        a.d_jump_width = d.jump_width;
+        a.d_nexpected = d.nexpected;
+        a.d_n_mc = d.n_mc;
+        a.d_source_id = d.source_id;
+        a.d_norms = d.norms;
+        a.debug_mode = debug_mode ? 1 : 0;
+        lockstep->advance(lockstep_index, group, a, n, graph_steps);
+        n = 0;
+      }
       for (unsigned k = 0; k < n; k++) one_step();
 
       // Flush the jump buffer (mcmc.cpp:351-377); the host reads go through blocking copies

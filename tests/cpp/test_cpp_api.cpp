@@ -597,7 +597,7 @@ TEST_F(SmallFit, LockstepExperimentsMatchSequential) {
   std::vector<sxmc::ExperimentResult> seq =
       sxmc::ensemble(ks, 31, sources, signals, systematics, observables, 300, 0.2f, 0.9f, 100);
   std::vector<sxmc::ExperimentResult> par =
-      sxmc::ensemble_lockstep(ks, 31, sources, signals, systematics, observables, 300, 0.2f, 2, 2, 0.9f, 100);
+      sxmc::ensemble_lockstep(ks, 31, sources, signals, systematics, observables, 300, 0.2f, 2, 2, 0.9f, 100, 8);
   EXPECT_EQ(seq.size(), par.size());
   for (size_t i = 0; i < seq.size(); i++) {
     EXPECT_EQ(seq[i].index, par[i].index);
