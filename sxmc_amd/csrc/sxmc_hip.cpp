@@ -50,7 +50,8 @@ int fail(int code, const std::string& msg) {
   do {                                                                                      \
     hipError_t _e = (expr);                                                                 \
     if (_e != hipSuccess) {                                                                 \
-      return fail(SXMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+      return fail(SXMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (sxmc_hip.cpp:" +    \
+                                    std::to_string(__LINE__) + ")");                          \
     }                                                                                       \
   } while (0)
 

@@ -209,6 +209,7 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   mcmc->exclusive = exclusive;
   mcmc->lockstep = lockstep;
   mcmc->lockstep_index = lockstep_index;
+  if (lockstep) mcmc->optimize = false;   // chains that share a fill pass share ONE launch shape: the default one
   if (exclusive) lock.unlock();   // the walk takes it itself
   Chain chain = (*mcmc)(data, nsteps, burnin_fraction, false, sync_interval);
   if (exclusive) lock.lock();
@@ -345,6 +346,9 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
         } catch (const pdfz::Error& e) {
           errors[t] = std::current_exception();
           set.abandon(e.msg);
+        } catch (const std::exception& e) {
+          errors[t] = std::current_exception();
+          set.abandon(e.what());
         } catch (...) {
           errors[t] = std::current_exception();
           set.abandon("a chain of the set failed");

@@ -112,7 +112,9 @@ inline double get_efficiency(Signal& sig, const std::vector<Systematic>& systema
   sig.histogram->SetParameterBuffer(&param_buffer);
   sig.histogram->EvalAsync(false);
   sig.histogram->EvalFinished();
-  return 1.0 * norms_buffer.readOnlyHostPtr()[0] / (double)sig.n_mc;
+  const double in_domain = norms_buffer.readOnlyHostPtr()[0];
+  sig.histogram->ForgetBuffers();   // the two arrays above die with this call
+  return 1.0 * in_domain / (double)sig.n_mc;
 }
 
 }  // namespace sxmc

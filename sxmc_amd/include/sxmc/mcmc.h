@@ -18,6 +18,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -56,7 +57,7 @@ class LockstepSet {
   /** Chain `index` is ready to take `nsteps` steps with `a`: returns when those steps of ALL chains are launched. */
   void advance(size_t index, sxmc_group_t group, const sxmc_step_args& a, unsigned nsteps, unsigned graph_steps) {
     std::unique_lock<std::mutex> lock(m);
-    if (broken) throw pdfz::Error("lockstep set: " + why);
+    if (broken) throw std::runtime_error("lockstep set: " + why);
     if (groups[index] != group || std::memcmp(&args[index], &a, sizeof a) != 0) dirty = true;
     groups[index] = group;
     args[index] = a;
@@ -70,10 +71,10 @@ class LockstepSet {
         why = sxmc_last_error();
       }
       cv.notify_all();
-      if (broken) throw pdfz::Error("lockstep set: " + why);
+      if (broken) throw std::runtime_error("lockstep set: " + why);
     } else {
       cv.wait(lock, [&] { return generation != gen || broken; });
-      if (broken) throw pdfz::Error("lockstep set: " + why);
+      if (broken) throw std::runtime_error("lockstep set: " + why);
     }
   }
   /** The chain's group is about to be destroyed: multigroup and graph are rebuilt at the next run. */
@@ -129,6 +130,10 @@ class LockstepSet {
       nsteps %= graph_steps;
     }
     for (unsigned k = 0; k < nsteps; k++) {
+      // the first step of a new set of chains builds launch plans (allocations, a device-wide synchronisation),
+      // which another set's recording does not tolerate: under the process's set-up mutex, like the recording
+      std::unique_lock<std::mutex> excl;
+      if (!stepped && exclusive) excl = std::unique_lock<std::mutex>(*exclusive);
       int rc = sxmc_multigroup_step_async(mg, stream, args.data());
       if (rc) return rc;
       stepped = true;   // (the launch plans are in place once a step has been launched: recording may follow)
@@ -500,6 +505,9 @@ class MCMC {
     }
     if (strm) check(sxmc_stream_synchronize(strm));
     if (lockstep) lockstep->leave(lockstep_index);
+    // the evaluators borrowed this walk's arrays (lookup table, normalisations, parameter vectors): un-bind them
+    // before they die, or the next evaluation of an evaluator would touch destroyed arrays
+    for (pdfz::Eval* p : pdfs) p->ForgetBuffers();
     if (exclusive && !excl.owns_lock()) excl.lock();  // tear-down frees device memory
     if (graph) check(sxmc_graph_destroy(graph));
     if (own_stream) check(sxmc_stream_destroy(strm));

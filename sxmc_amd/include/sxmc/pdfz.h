@@ -106,6 +106,14 @@ class Eval {
   virtual void AddSystematic(const Systematic& syst) = 0;
   virtual void EvalAsync(bool do_eval_pdf = true) = 0;
   virtual void EvalFinished() = 0;
+  /** The three buffers are BORROWED (pdfz.cpp:106-124 stores raw pointers, like this class): a caller whose
+   *  buffers are about to die un-binds them, so that the next evaluation binds afresh or fails loudly instead of
+   *  touching destroyed arrays.  (The reference leaves the dangling pointers in place.) */
+  virtual void ForgetBuffers() {
+    pdf_buffer = nullptr;
+    norm_buffer = nullptr;
+    param_buffer = nullptr;
+  }
 
  protected:
   int nfields;
@@ -184,6 +192,13 @@ class EvalHist : public Eval {
 
   /** The accessor calls of pdfz.cpp:457-470, 484-487: outputs become device-valid (host copies are
    *  stale until read back), parameters are uploaded if the host side is newer. */
+  void ForgetBuffers() override {
+    Eval::ForgetBuffers();
+    throw_on(sxmc_hist_set_pdf_value_buffer(handle, nullptr, 0, 1));
+    throw_on(sxmc_hist_set_normalization_buffer(handle, nullptr, 0));
+    throw_on(sxmc_hist_set_parameter_buffer(handle, nullptr, 0, 1));
+  }
+
   void Bind() {
     if (pdf_buffer) throw_on(sxmc_hist_set_pdf_value_buffer(handle, pdf_buffer->writeOnlyPtr(), pdf_offset, pdf_stride));
     if (norm_buffer) throw_on(sxmc_hist_set_normalization_buffer(handle, norm_buffer->writeOnlyPtr(), norm_offset));
