@@ -347,6 +347,7 @@ typedef struct {
   int debug_mode;
 } sxmc_step_args; /* the arguments of finish_nll_jump_pick_combo (nll_kernels.h:190-207) */
 typedef struct sxmc_multigroup* sxmc_multigroup_t;
+/* groups: borrowed; they must outlive the multigroup (destroy it first). */
 int sxmc_multigroup_create(const sxmc_group_t* groups, int ngroups, sxmc_multigroup_t* out);
 int sxmc_multigroup_destroy(sxmc_multigroup_t mg);
 int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args);
