@@ -363,6 +363,9 @@ int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);
  * table walked in runs.  *code_bytes (optional): size of the gfx950 code object. */
 int sxmc_rtc_compile_check(int nobs, int nslot, int lds_hist, int pre_width, int sparse_runs, const unsigned* ops,
                            int nops, size_t* code_bytes);
+/* The same for the lockstep-chains kernel (sxmc_multigroup_step_async), which exists only as a run-time kernel. */
+int sxmc_rtc_compile_check_lockstep(int nobs, int nslot, int pre_width, int nchains, const unsigned* ops, int nops,
+                                    size_t* code_bytes);
 int sxmc_group_synchronize(sxmc_group_t g);
 /* Live timing of the dominant kernel (the histogram fill) with HIP events on the stream it is
  * launched on.  enable!=0 starts recording (at most `capacity` launches are kept). */

@@ -115,6 +115,7 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _i],
     "sxmc_group_set_tail_kernel": [_vp, _i],
     "sxmc_rtc_compile_check": [_i, _i, _i, _i, _i, _vp, _i, _psz],
+    "sxmc_rtc_compile_check_lockstep": [_i, _i, _i, _i, _vp, _i, _psz],
     "sxmc_group_last_step_launches": [_vp, _pi],
     "sxmc_multigroup_create": [_vp, _i, _pvp],
     "sxmc_multigroup_destroy": [_vp],

@@ -2632,6 +2632,22 @@ int sxmc_rtc_compile_check(int nobs, int nslot, int lds_hist, int pre_width, int
   return SXMC_OK;
 }
 
+int sxmc_rtc_compile_check_lockstep(int nobs, int nslot, int pre_width, int nchains, const unsigned* ops, int nops,
+                                    size_t* code_bytes) {
+  SX_REQUIRE(nops >= 0 && nops <= SXMC_MAX_SYST && (ops || nops == 0) && nchains >= 2 && nchains <= 4, "bad program");
+  SxRtcSpec k{};
+  k.nobs = nobs;
+  k.nslot = nslot;
+  k.lds_hist = 1;
+  k.pre_width = pre_width;
+  k.nchain = nchains;
+  k.nops = nops;
+  for (int i = 0; i < nops; i++) k.ops[i] = ops[i];
+  std::string err;
+  if (!sx_rtc_compile_only(k, code_bytes, &err)) return fail(SXMC_ERR_HIP, err);
+  return SXMC_OK;
+}
+
 int sxmc_group_synchronize(sxmc_group_t g) {
   SX_REQUIRE(g, "null group");
   SX_HIP(hipStreamSynchronize(g->last_stream));

@@ -619,7 +619,7 @@ TEST_F(SmallFit, MultiGpuRunnerGathersTheIntervalsThroughRccl) {
   ASSERT_EQ(SXMC_OK, sxmc_device_count(&ndev));
   std::vector<int> devices;
   for (int d = 0; d < ndev && d < 8; d++) devices.push_back(d);
-  const unsigned N = 5;
+  const unsigned N = 9;   // per device: one round of 2 lockstep sets x 4 chains + one experiment left over
   std::vector<unsigned> ks;
   for (unsigned k = 0; k < N; k++) ks.push_back(k);
   std::vector<sxmc::ExperimentResult> seq =

@@ -44,3 +44,29 @@ def test_graph_recording_beside_an_rccl_communicator():
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl-graph-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_c_abi_rccl_allgather_single_rank():
+    """sxmc_comm_* (the multi-GPU exchange behind the C ABI, librccl): the one-process-per-GPU form -- unique id,
+    init_rank, all-gather -- with a world of one on this box's GPU."""
+    import ctypes as C
+
+    import numpy as np
+
+    from sxmc_amd import capi
+    from sxmc_amd.capi import DeviceArray
+    uid = C.create_string_buffer(128)
+    capi.call("sxmc_comm_unique_id", uid, 128)
+    comm = C.c_void_p(0)
+    capi.call("sxmc_comm_init_rank", uid, 128, 1, 0, C.byref(comm))
+    rank, n = C.c_int(-1), C.c_int(-1)
+    capi.call("sxmc_comm_rank", comm, C.byref(rank), C.byref(n))
+    assert (rank.value, n.value) == (0, 1)
+    send = DeviceArray(np.arange(60, dtype=np.float32))
+    recv = DeviceArray.zeros(60, np.float32)
+    stream = capi.new_stream()
+    capi.call("sxmc_comm_allgather_f32", comm, capi.ptr(send), capi.ptr(recv), 60, capi.ptr(stream))
+    capi.call("sxmc_stream_synchronize", capi.ptr(stream))
+    assert np.array_equal(recv.get(), np.arange(60, dtype=np.float32))
+    capi.call("sxmc_comm_destroy", comm)

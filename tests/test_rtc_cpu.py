@@ -36,3 +36,17 @@ def test_runtime_specialisation_reports_a_bad_shape():
     arr = np.asarray([op(RES, 0, 5)], dtype=np.uint32)        # truth field slot 5 of a 2-slot kernel
     rc = lib.sxmc_rtc_compile_check(1, 2, 1, 0, 0, capi.ptr(arr), 1, None)
     assert rc != 0 and "slot out of range" in capi.last_error()
+
+
+@pytest.mark.parametrize("nobs,nslot,prew,nchains,ops", [
+    (2, 3, 3, 4, [op(SHIFT, 1), op(SCALE, 0), op(RES, 0, 2)]),        # config 3, bucketed, four chains per pass
+    (2, 3, 0, 2, [op(SHIFT, 1), op(RES, 0, 2)]),                      # rows, two chains
+    (1, 1, 3, 3, [op(SHIFT, 0, 0, 3)]),                               # a polynomial, three chains
+])
+def test_lockstep_kernel_compiles_without_a_gpu(nobs, nslot, prew, nchains, ops):
+    lib = capi.load()
+    arr = np.asarray(ops, dtype=np.uint32)
+    n = C.c_size_t(0)
+    rc = lib.sxmc_rtc_compile_check_lockstep(nobs, nslot, prew, nchains, capi.ptr(arr), len(ops), C.byref(n))
+    assert rc == 0, capi.last_error()
+    assert n.value > 1000
