@@ -135,9 +135,58 @@ def contour_intervals(chain, cl=0.9):
     return out
 
 
+def gaus_fit(centers, counts, iterations=200):
+    """What `TH1::Fit("gaus")` minimises (projection.cpp:22-23): chi2 = sum over the non-empty bins of
+    ((n_i - A exp(-(x_i - mu)^2 / (2 sigma^2))) / sqrt(n_i))^2, the function taken at the bin centre, started
+    from the histogram's maximum, mean and RMS as TH1's InitGaus does.  Minimised by Levenberg-Marquardt (ROOT:
+    Minuit MIGRAD; the minimum is the same, the path is not).  Returns (A, mu, sigma) or None when it does not
+    converge to a positive width."""
+    x = np.asarray(centers, np.float64)
+    y = np.asarray(counts, np.float64)
+    keep = y > 0
+    x, y = x[keep], y[keep]
+    if x.size < 3:
+        return None
+    e = np.sqrt(y)
+    mean = float(np.sum(x * y) / np.sum(y))
+    rms = float(np.sqrt(max(np.sum(y * (x - mean) ** 2) / np.sum(y), 0.0)))
+    if rms <= 0:
+        return None
+    p = np.array([float(y.max()), mean, rms])
+
+    def residuals(q):
+        return (y - q[0] * np.exp(-0.5 * ((x - q[1]) / q[2]) ** 2)) / e
+
+    lam, chi2 = 1e-3, float(np.sum(residuals(p) ** 2))
+    for _ in range(iterations):
+        g = np.exp(-0.5 * ((x - p[1]) / p[2]) ** 2)
+        jac = np.stack([g, p[0] * g * (x - p[1]) / p[2] ** 2, p[0] * g * (x - p[1]) ** 2 / p[2] ** 3], axis=1) / e[:, None]
+        r = residuals(p)
+        a, b = jac.T @ jac, jac.T @ r
+        try:
+            step = np.linalg.solve(a + lam * np.diag(np.diag(a) + 1e-300), b)
+        except np.linalg.LinAlgError:
+            return None
+        trial = p + step
+        c2 = float(np.sum(residuals(trial) ** 2)) if trial[2] > 0 else np.inf
+        if c2 <= chi2:
+            converged = chi2 - c2 <= 1e-12 * max(chi2, 1e-300) and np.all(np.abs(step) <= 1e-10 * (np.abs(p) + 1e-300))
+            p, chi2, lam = trial, c2, max(lam * 0.3, 1e-12)
+            if converged:
+                break
+        else:
+            lam *= 10.0
+            if lam > 1e12:
+                break
+    return (float(p[0]), float(p[1]), float(p[2])) if p[2] > 0 and np.all(np.isfinite(p)) else None
+
+
 def projection_interval(values, cl=0.9, nbins=100):
-    """Projection::get_interval on one parameter's samples (see the module note on the mode estimate).
-    Returns (point_estimate, lower, upper, coverage, one_sided)."""
+    """Projection::get_interval on one parameter's samples (projection.cpp:14-77): the parameter's samples are
+    histogrammed (ROOT's TTree::Draw picks the range and 100 bins by its own "nice limits" rule, which is not
+    reproduced: [min, max] here), a Gaussian is fitted (gaus_fit) and its mean is the point estimate; the limits
+    walk outwards from the mean's bin until cl / 2 of the samples lie on either side (or one-sided from the low
+    edge when less than cl / 2 lies below the mean).  Returns (point_estimate, lower, upper, coverage, one_sided)."""
     values = np.asarray(values, np.float64)
     lo, hi = values.min(), values.max()
     if hi <= lo:
@@ -145,12 +194,8 @@ def projection_interval(values, cl=0.9, nbins=100):
     counts, edges = np.histogram(values, bins=nbins, range=(lo, hi))
     total = counts.sum()
     centers = 0.5 * (edges[:-1] + edges[1:])
-    peak = counts >= 0.5 * counts.max()
-    mu = float(centers[np.argmax(counts)])
-    if peak.sum() >= 3:
-        c2, c1, _ = np.polyfit(centers[peak], np.log(counts[peak]), 2, w=np.sqrt(counts[peak]))
-        if c2 < 0:
-            mu = float(-c1 / (2 * c2))
+    fit = gaus_fit(centers, counts)
+    mu = fit[1] if fit is not None else float(centers[np.argmax(counts)])     # (no fit: the mode's bin)
     imax = int(np.searchsorted(edges, mu, side="right"))                        # 1-based bin of the mode
     if imax < 1:                                                               # projection.cpp:28-31
         imax, mu = 1, float(edges[0])

@@ -122,6 +122,170 @@ inline std::vector<Interval> contour_intervals(const Chain& chain, float cl = 0.
   return out;
 }
 
+/** What `TH1::Fit("gaus")` minimises (projection.cpp:22-23): chi2 over the non-empty bins of
+ *  ((n_i - A exp(-(x_i - mu)^2 / (2 sigma^2))) / sqrt(n_i))^2, the function taken at the bin centre, started from
+ *  the histogram's maximum, mean and RMS (TH1's InitGaus).  Levenberg-Marquardt here, Minuit MIGRAD in ROOT: the
+ *  same minimum.  false when it does not converge to a positive width. */
+inline bool gaus_fit(const std::vector<double>& centers, const std::vector<double>& counts, double& A, double& mu,
+                     double& sigma) {
+  std::vector<double> x, y;
+  for (size_t i = 0; i < centers.size(); i++)
+    if (counts[i] > 0) {
+      x.push_back(centers[i]);
+      y.push_back(counts[i]);
+    }
+  const size_t n = x.size();
+  if (n < 3) return false;
+  double sy = 0, sxy = 0, ymax = 0;
+  for (size_t i = 0; i < n; i++) {
+    sy += y[i];
+    sxy += x[i] * y[i];
+    ymax = std::max(ymax, y[i]);
+  }
+  const double mean = sxy / sy;
+  double var = 0;
+  for (size_t i = 0; i < n; i++) var += y[i] * (x[i] - mean) * (x[i] - mean);
+  const double rms = std::sqrt(std::max(var / sy, 0.0));
+  if (!(rms > 0)) return false;
+  double p[3] = {ymax, mean, rms};
+  auto chi2_of = [&](const double* q) {
+    if (!(q[2] > 0)) return std::numeric_limits<double>::infinity();
+    double c = 0;
+    for (size_t i = 0; i < n; i++) {
+      const double z = (x[i] - q[1]) / q[2], r = (y[i] - q[0] * std::exp(-0.5 * z * z)) / std::sqrt(y[i]);
+      c += r * r;
+    }
+    return c;
+  };
+  double lam = 1e-3, chi2 = chi2_of(p);
+  for (int it = 0; it < 200; it++) {
+    double a[3][3] = {{0}}, b[3] = {0};
+    for (size_t i = 0; i < n; i++) {
+      const double e = std::sqrt(y[i]), d = x[i] - p[1], g = std::exp(-0.5 * d * d / (p[2] * p[2]));
+      const double j[3] = {g / e, p[0] * g * d / (p[2] * p[2]) / e, p[0] * g * d * d / (p[2] * p[2] * p[2]) / e};
+      const double r = (y[i] - p[0] * g) / e;
+      for (int u = 0; u < 3; u++) {
+        b[u] += j[u] * r;
+        for (int v = 0; v < 3; v++) a[u][v] += j[u] * j[v];
+      }
+    }
+    double m[3][4];
+    for (int u = 0; u < 3; u++) {
+      for (int v = 0; v < 3; v++) m[u][v] = a[u][v] + (u == v ? lam * (a[u][u] + 1e-300) : 0.0);
+      m[u][3] = b[u];
+    }
+    bool singular = false;
+    for (int c = 0; c < 3 && !singular; c++) {   // Gauss-Jordan with partial pivoting
+      int piv = c;
+      for (int r = c + 1; r < 3; r++)
+        if (std::fabs(m[r][c]) > std::fabs(m[piv][c])) piv = r;
+      if (m[piv][c] == 0.0) singular = true;
+      for (int k = 0; k < 4 && !singular; k++) std::swap(m[c][k], m[piv][k]);
+      for (int r = 0; r < 3 && !singular; r++) {
+        if (r == c) continue;
+        const double f = m[r][c] / m[c][c];
+        for (int k = c; k < 4; k++) m[r][k] -= f * m[c][k];
+      }
+    }
+    if (singular) return false;
+    const double step[3] = {m[0][3] / m[0][0], m[1][3] / m[1][1], m[2][3] / m[2][2]};
+    const double trial[3] = {p[0] + step[0], p[1] + step[1], p[2] + step[2]};
+    const double c2 = chi2_of(trial);
+    if (c2 <= chi2) {
+      bool small = chi2 - c2 <= 1e-12 * std::max(chi2, 1e-300);
+      for (int u = 0; u < 3; u++) small = small && std::fabs(step[u]) <= 1e-10 * (std::fabs(p[u]) + 1e-300);
+      for (int u = 0; u < 3; u++) p[u] = trial[u];
+      chi2 = c2;
+      lam = std::max(lam * 0.3, 1e-12);
+      if (small) break;
+    } else {
+      lam *= 10.0;
+      if (lam > 1e12) break;
+    }
+  }
+  if (!(p[2] > 0) || !std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) return false;
+  A = p[0];
+  mu = p[1];
+  sigma = p[2];
+  return true;
+}
+
+/** Projection::get_interval on one parameter's samples (projection.cpp:14-77): histogram (ROOT's TTree::Draw
+ *  picks range and binning by its own "nice limits" rule, not reproduced: `nbins` bins over [min, max] here),
+ *  Gaussian fit for the point estimate, limits walked outwards from the mean's bin until cl / 2 of the samples
+ *  lie on either side (one-sided from the low edge when less than cl / 2 lies below the mean). */
+inline Interval projection_interval(const std::vector<float>& values, float cl = 0.9f, int nbins = 100) {
+  Interval iv;
+  iv.cl = cl;
+  double lo = values.at(0), hi = lo;
+  for (float v : values) {
+    lo = std::min<double>(lo, v);
+    hi = std::max<double>(hi, v);
+  }
+  if (!(hi > lo)) {
+    iv.point_estimate = iv.lower = (float)lo;
+    iv.upper = (float)hi;
+    iv.coverage = 1;
+    return iv;
+  }
+  const double width = (hi - lo) / nbins;
+  std::vector<double> counts((size_t)nbins, 0.0), centers((size_t)nbins), csum((size_t)nbins + 1, 0.0);
+  for (float v : values) counts[(size_t)std::min<long>(nbins - 1, (long)((v - lo) / width))] += 1;
+  for (int i = 0; i < nbins; i++) centers[(size_t)i] = lo + (i + 0.5) * width;
+  double total = 0;
+  for (int i = 0; i < nbins; i++) csum[(size_t)i + 1] = (total += counts[(size_t)i]);   // csum[i] = bins 1..i
+  double a = 0, mu = 0, sigma = 0;
+  if (!gaus_fit(centers, counts, a, mu, sigma)) {
+    mu = centers[(size_t)(std::max_element(counts.begin(), counts.end()) - counts.begin())];
+  }
+  long imax = (long)std::floor((mu - lo) / width) + 1;   // 1-based bin of the mean (TH1::FindBin)
+  if (mu >= hi) imax = nbins + 1;
+  if (imax < 1) {                                         // projection.cpp:28-31
+    imax = 1;
+    mu = lo;
+  }
+  imax = std::min<long>(imax, nbins);
+  long ilo = 1, ihi = 0;
+  if (csum[(size_t)imax] / total < cl / 2) {              // projection.cpp:36-45
+    iv.one_sided = true;
+    for (long i = 0; i <= nbins; i++)
+      if (csum[(size_t)i] / total >= cl) {
+        ihi = i;
+        break;
+      }
+  } else {
+    iv.one_sided = false;
+    for (long i = imax; i > 0; i--)
+      if ((csum[(size_t)imax] - csum[(size_t)i - 1]) / total >= cl / 2) {
+        ilo = i;
+        break;
+      }
+    for (long i = imax + 1; i <= nbins; i++)
+      if ((csum[(size_t)i] - csum[(size_t)imax]) / total >= cl / 2) {
+        ihi = i;
+        break;
+      }
+  }
+  ihi = ihi ? std::max(ihi, ilo) : nbins;
+  iv.point_estimate = (float)mu;
+  iv.coverage = (float)((csum[(size_t)ihi] - csum[(size_t)ilo - 1]) / total);
+  iv.lower = (float)(lo + (ilo - 1) * width);
+  iv.upper = (float)(lo + ihi * width);
+  return iv;
+}
+
+/** Projection::get_interval for every parameter of a chain. */
+inline std::vector<Interval> projection_intervals(const Chain& chain, float cl = 0.9f) {
+  const size_t P = chain.names.size() - 1;
+  std::vector<Interval> out;
+  for (size_t p = 0; p < P; p++) {
+    std::vector<float> col;
+    for (size_t r = 0; r < chain.nrows(); r++) col.push_back(chain.at(r, p));
+    out.push_back(projection_interval(col, cl));
+  }
+  return out;
+}
+
 /** RandomSample on a flat row-major histogram (1-3 D). */
 inline void random_sample(std::mt19937_64& rng, const std::vector<unsigned>& bins, const std::vector<Observable>& obs,
                           size_t nobserved, unsigned dataset, std::vector<float>& events) {

@@ -537,6 +537,29 @@ TEST(Ensemble, ContourKnownAnswers) {
   EXPECT_EQ(9.0f, iv[0].upper);
 }
 
+TEST(Ensemble, GausFitAndProjectionKnownAnswers) {
+  // bin contents that ARE a Gaussian at the bin centres: chi2 = 0 at (A, mu, sigma), which the fit must find
+  std::vector<double> x, y;
+  for (int i = 0; i < 120; i++) x.push_back(-2.95 + 0.1 * i);
+  for (double v : x) y.push_back(1000.0 * std::exp(-0.5 * ((v - 3.2) / 0.9) * ((v - 3.2) / 0.9)));
+  double a = 0, mu = 0, sigma = 0;
+  EXPECT_TRUE(sxmc::gaus_fit(x, y, a, mu, sigma));
+  EXPECT_TRUE(std::fabs(a - 1000.0) < 1e-3 && std::fabs(mu - 3.2) < 1e-8 && std::fabs(sigma - 0.9) < 1e-8);
+  EXPECT_TRUE(!sxmc::gaus_fit({0.0, 1.0}, {5.0, 5.0}, a, mu, sigma));
+  // samples of N(5, 1): central interval around the fitted mean (projection.cpp:47-66)
+  std::mt19937_64 rng(1);
+  std::normal_distribution<float> gauss(5.0f, 1.0f);
+  std::vector<float> v;
+  for (int i = 0; i < 200000; i++) v.push_back(gauss(rng));
+  sxmc::Interval iv = sxmc::projection_interval(v, 0.9f);
+  EXPECT_TRUE(!iv.one_sided && std::fabs(iv.point_estimate - 5.0f) < 0.02f);
+  EXPECT_TRUE(std::fabs(iv.lower - (5.0f - 1.645f)) < 0.2f && iv.upper > 5.0f + 1.5f && iv.upper < 5.0f + 2.1f);
+  EXPECT_TRUE(iv.coverage >= 0.9f && iv.coverage < 0.96f);
+  for (float& t : v) t = std::fabs(t - 5.0f);   // piled up at its lower boundary: one-sided (projection.cpp:36-45)
+  iv = sxmc::projection_interval(v, 0.9f);
+  EXPECT_TRUE(iv.one_sided && iv.lower <= 1e-3f && iv.coverage >= 0.9f && std::fabs(iv.upper - 1.645f) < 0.1f);
+}
+
 TEST_F(SmallFit, FakeDatasetAndWholeExperiments) {
   std::mt19937_64 rng(5);
   std::vector<unsigned> observed;

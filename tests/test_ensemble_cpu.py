@@ -71,6 +71,18 @@ def test_contour_known_answers_widening_by_fives():
     assert iv[0, 1] == 0.0 and iv[0, 2] == 9.0             # 0.3125 + 0.9375 = 1.25 < 1.35277 <= 0.3125 + 1.0625
 
 
+def test_gaus_fit_known_answers():
+    # bin contents that ARE a Gaussian at the bin centres: chi2 = 0 exactly at (A, mu, sigma), which the fit must find
+    x = np.linspace(-2.95, 8.95, 120)
+    for a, mu, sigma in ((1000.0, 3.2, 0.9), (50.0, -0.5, 2.5), (1e6, 7.0, 0.3)):
+        y = a * np.exp(-0.5 * ((x - mu) / sigma) ** 2)
+        fit = ensemble.gaus_fit(x, y)
+        assert fit is not None
+        assert abs(fit[0] - a) <= 1e-6 * a and abs(fit[1] - mu) <= 1e-8 and abs(fit[2] - sigma) <= 1e-8
+    assert ensemble.gaus_fit(x, np.zeros_like(x)) is None                      # nothing to fit
+    assert ensemble.gaus_fit([0.0, 1.0], [5.0, 5.0]) is None                   # fewer than three non-empty bins
+
+
 def test_projection_interval_central_and_one_sided():
     rng = np.random.default_rng(0)
     v = rng.normal(5.0, 1.0, 200000)
