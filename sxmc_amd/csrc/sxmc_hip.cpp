@@ -959,7 +959,9 @@ int group_rebuild(sxmc_group* g) {
             plans[(size_t)i].fields = fields;
             bucketed = true;
             // histograms beyond LDS, evaluated at data events: per-wave runs + event bins grouped by bucket
-            runs_mode = !lds_hist && h->has_points && h->d_table &&
+            bool narrow = true;   // (the runs kernel forms idx * stride from 24-bit products)
+            for (int k = 0; k < h->nobs; k++) narrow = narrow && h->nbins[(size_t)k] < (1 << 23);
+            runs_mode = !lds_hist && narrow && h->has_points && h->d_table &&
                         have_kernel(cd.nobs, cd.nslot, 3, 1, prog2, sp, &rtc_sparse);
             if (runs_mode) {
               rc = build_bucket_tables(h, bs);
