@@ -689,6 +689,54 @@ def test_polynomial_systematics_at_a_million_samples():
     compare(kw)
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_random_programs_every_path_matches_the_oracle(seed):
+    """Random shapes (1-5 observables, 0-2 extra fields), random programs (1-4 systematics of any kind on any
+    observable, truth field an extra field or another observable, 1-3 polynomial coefficients), with and without
+    points: whatever kernel the plan picks -- built in, compiled at run time, decoded; rows, pre-binned, bucketed --
+    bins, norm and lookup values must be the oracle's, and the same with bucketing / run-time kernels switched off."""
+    rng = np.random.default_rng(1000 + seed)
+    nobs = int(rng.integers(1, 6))
+    nextra = int(rng.integers(0, 3))
+    nfields = nobs + nextra + 1                                   # + the dataset column
+    nbins = [int(rng.integers(2, 9)) for _ in range(nobs)]
+    if seed % 5 == 4:
+        nbins[int(rng.integers(0, nobs))] = 50000                 # beyond LDS: global histogram / sparse counting
+    kinds = ["shift", "scale", "ctscale", "resolution_scale"]
+    systs, npar = [], 0
+    for _ in range(int(rng.integers(1, 5))):
+        kind = kinds[int(rng.integers(0, 4))]
+        ncoef = int(rng.choice([1, 1, 1, 2, 3]))
+        d = dict(type=kind, obs=int(rng.integers(0, nobs)), pars=list(range(npar, npar + ncoef)))
+        npar += ncoef
+        if kind == "resolution_scale":
+            choices = [f for f in range(nobs + nextra) if f != d["obs"]] or [d["obs"]]
+            d["true_obs"] = int(rng.choice(choices))
+        systs.append(d)
+    params = list(rng.normal(0, 0.03, npar))
+    pts = np.concatenate([table(rng, 300, nobs, lo=-0.1, hi=1.1), np.zeros((300, 1), np.float32)], axis=1)
+    evs, tabs, lut, norms, pbuf = build_group(rng, [20011, 4001], nobs, nbins, systs, params, nfields=nfields,
+                                              points=pts, lo=-0.1, hi=1.1)
+    group = nll.EvalGroup(evs)
+    want = [oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, systs, params, points=pts, dataset=j % 2)
+            for j, t in enumerate(tabs)]
+    for bucket, rtc in ((True, True), (False, True), (True, False), (False, False)):
+        group.SetBucketing(bucket)
+        group.SetRuntimeKernels(rtc)
+        info = group.LaunchInfo()
+        assert "failed" not in info, info
+        lut.set(np.full(lut.size, 777.0, np.float32))
+        group.EvalAsync(True)
+        group.EvalFinished()
+        got_lut, got_norms = lut.get().reshape(2, -1), norms.get()
+        group.EvalAsync(False)
+        group.EvalFinished()
+        for j in range(2):
+            assert got_norms[j] == want[j]["norm"], (info, systs)
+            assert_same_bits(got_lut[j], want[j]["out"])
+            assert np.array_equal(evs[j].GetBins(), want[j]["bins"]), (info, systs)
+
+
 def test_shared_table_with_different_prebinned_columns():
     """Two evaluators over one sample table whose systematics leave different observables untouched: each
     group keeps its own pre-binned column, and evaluating one does not disturb the other."""
