@@ -817,24 +817,23 @@ int build_bucket_tables(sxmc_hist* h, const SampleStore::BucketSort* bs) {
 
 // The member's problem as the fill sees it once its table is bucketed: only the observables some systematic
 // writes (+ the extra fields), slots renumbered, columns = the bucketed copy.  `keep`: full slot -> new slot or -1.
-void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, SxSignalDesc& cd) {
+void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, int nobs2, SxSignalDesc& cd) {
   cd = full;
-  int nobs = 0, nslot = 0;
+  int nslot = 0;
   for (int k = 0; k < full.nslot; k++) {
     if (keep[(size_t)k] < 0) continue;
     const int q = keep[(size_t)k];
     cd.slot_col[q] = q;  // the copy holds exactly the streamed fields, in slot order
-    if (k < full.nobs) {
+    if (q < nobs2) {     // an observable the fill still bins (the others it keeps are read-only inputs)
       cd.bin_stride[q] = full.bin_stride[k];
       cd.nbins[q] = full.nbins[k];
       cd.lower[q] = full.lower[k];
       cd.upper[q] = full.upper[k];
       cd.scale[q] = full.scale[k];
-      nobs++;
     }
     nslot++;
   }
-  cd.nobs = nobs;
+  cd.nobs = nobs2;
   cd.nslot = nslot;
   for (int q = 0; q < full.nsyst; q++) {
     cd.syst[q].obs_slot = (short)keep[(size_t)full.syst[q].obs_slot];
@@ -930,23 +929,36 @@ int group_rebuild(sxmc_group* g) {
     // fill sees the lower-dimensional problem of the ones that are written
     bool bucketed = false;
     if (g->cfg_bucket && d.nsyst > 0 && specialisable) {
-      unsigned touched = 0;
-      for (int q = 0; q < d.nsyst; q++) touched |= 1u << d.syst[q].obs_slot;
+      unsigned touched = 0, read = 0;
+      for (int q = 0; q < d.nsyst; q++) {
+        touched |= 1u << d.syst[q].obs_slot;
+        if (d.syst[q].type == SXMC_SYST_RESOLUTION_SCALE) read |= 1u << d.syst[q].extra_slot;
+      }
+      // compacted slots: the observables that are written (still binned by the fill), then everything that is only
+      // read -- the extra fields, and an untouched observable that serves as some systematic's truth field (its own
+      // bin index is the bucket's; its VALUE is still an input)
       unsigned mask = 0;
       std::vector<int> keep((size_t)d.nslot, -1), fields;
       int nobs2 = 0;
-      for (int k = 0; k < d.nslot; k++) {
-        if (k < d.nobs && !((touched >> k) & 1u)) {
+      for (int k = 0; k < d.nobs; k++) {
+        if ((touched >> k) & 1u) {
+          keep[(size_t)k] = (int)fields.size();
+          fields.push_back(d.slot_col[k]);
+          nobs2++;
+        } else {
           mask |= 1u << k;
-          continue;
         }
-        keep[(size_t)k] = (int)fields.size();
-        fields.push_back(d.slot_col[k]);
-        if (k < d.nobs) nobs2++;
+      }
+      for (int k = 0; k < d.nslot; k++) {
+        if (keep[(size_t)k] >= 0) continue;
+        if (k >= d.nobs || ((read >> k) & 1u)) {
+          keep[(size_t)k] = (int)fields.size();
+          fields.push_back(d.slot_col[k]);
+        }
       }
       if (mask && nobs2 >= 1 && sx_fill_has_specialization(nobs2, (int)fields.size())) {
         SxSignalDesc cd;
-        compact_desc(d, keep, cd);
+        compact_desc(d, keep, nobs2, cd);
         const std::vector<unsigned> prog2 = prog_words(cd);
         const int sp = sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
         if (have_kernel(cd.nobs, cd.nslot, 3, 0, prog2, sp, &rtc_fill)) {

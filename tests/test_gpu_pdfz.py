@@ -689,7 +689,7 @@ def test_polynomial_systematics_at_a_million_samples():
     compare(kw)
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_programs_every_path_matches_the_oracle(seed):
     """Random shapes (1-5 observables, 0-2 extra fields), random programs (1-4 systematics of any kind on any
     observable, truth field an extra field or another observable, 1-3 polynomial coefficients), with and without
