@@ -206,6 +206,7 @@ class Leg:
         m.group.SetPartition(args.partition)
         m.group.SetPrebinning(not args.no_prebin)
         m.group.SetBucketing(not args.no_bucket)
+        m.group.SetOrdering(not args.no_order)
         m.group.SetTailKernel(not args.no_tail)
         m.group.SetRuntimeKernels(not args.no_rtc)
         m.group.SetSparse(not args.no_sparse)
@@ -307,7 +308,8 @@ class Leg:
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else ""))
+                t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else "") +
+                                       ("_no_order" if args.no_order and not args.no_bucket else ""))
             if args.extra_ctscale or args.no_sparse:
                 t = None
             if t and self.scale == 1.0 and args.nsyst < 0:
@@ -522,6 +524,8 @@ def main():
                          "of one specialised through hiprtc")
     ap.add_argument("--extra-ctscale", action="store_true",
                     help="C3 with a fourth systematic, a cos-theta scale on c: a program that is not in the table")
+    ap.add_argument("--no-order", action="store_true",
+                    help="bucketed tables without the ordered observable (every written observable is streamed)")
     ap.add_argument("--no-bucket", action="store_true",
                     help="stream the table in the caller's row order (no copy grouped by the untouched observables' bins)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
@@ -683,7 +687,8 @@ def main():
     cfg = leg.config()
     cfg.update({
         "prewarm_steps": args.prewarm, "debug_mode": args.debug_mode, "partition": args.partition,
-        "prebinning": not args.no_prebin, "bucketing": not args.no_bucket, "launch": args.launch,
+        "prebinning": not args.no_prebin, "bucketing": not args.no_bucket, "ordering": not (args.no_order or args.no_bucket),
+        "launch": args.launch,
         "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
         "samples_per_sec": value * w.nsamples_total,
         "experiments_per_sec_at_1e5_steps": value / 1e5,

@@ -230,6 +230,20 @@ int sxmc_group_set_prebinning(sxmc_group_t g, int enable);
  * caller's row order (it reads the original table).  Skipped for a table whose granule padding would outweigh
  * the saving (few samples, many buckets).  sxmc_group_algorithmic_bytes counts the bytes actually needed. */
 int sxmc_group_set_bucketing(sxmc_group_t g, int enable);
+/* Ordering (default on; needs bucketing and a histogram that fits LDS): bucketing taken to ONE observable that is
+ * written -- but only by one-coefficient shift / scale / cos-theta-scale systematics (pdfz.cpp:316-325) and read
+ * by nothing else.  For the evaluation's parameters each of those is a monotone map of the sample's value (IEEE
+ * addition of / multiplication by a constant rounds monotonically), and so is the binning after it
+ * (pdfz.cpp:388-398).  The bucketed copy keeps the rows of every bucket sorted by the raw value; a 256-sample
+ * granule whose first and last sample land in the same bin (or both below / both above the domain) therefore has
+ * ALL its samples there.  The fill works that out per evaluation from two floats per granule, with the per-sample
+ * arithmetic, and does not read the observable's column at all; only the granules that straddle a bin edge (at
+ * most nbins + 1 per bucket) take the per-sample path over the column, granules outside the domain are skipped.
+ * Any NaN (sample value or coefficient) sends a granule down the per-sample path.  BASELINE config 3 streams
+ * 8 bytes per sample instead of 12; a 1-D histogram with one shift (bench_sxmc pdfz) streams 12 bytes per 256
+ * samples.  Histograms, norms and NLL stay bit-identical (parity tests: on/off, the CPU restatement, samples
+ * placed within ulps of the bin edges).  Of several eligible observables the one with the fewest bins is taken. */
+int sxmc_group_set_ordering(sxmc_group_t g, int enable);
 /* Run-time kernels (default on).  The fill is fastest as straight-line code with the program of systematics
  * (apply_systematic, pdfz.cpp:306-331: which systematic writes which column, in which order, with how many
  * polynomial coefficients) fixed at compile time.  The library carries such kernels for a handful of programs;

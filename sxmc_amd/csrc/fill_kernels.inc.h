@@ -40,6 +40,9 @@ __device__ __forceinline__ gptr<T> to_global(T* p) {
 
 __device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// LDS word of histogram bin b in the swizzled layout of fill_ordered_body (an involution inside each 64-word block)
+__device__ __forceinline__ unsigned lds_slot(unsigned b) { return b ^ ((b >> 6) & 63u); }
+
 __device__ __forceinline__ double uniform_d(double x) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
@@ -975,6 +978,315 @@ __device__ __forceinline__ void fill_multi_body(SxChainDescs chains, const SxSeg
   }
 }
 
+// ORDERED OBSERVABLE (PREW = kPreOrdered).  Bucketing taken one step further, to an observable that IS written --
+// but only by one-coefficient shift / scale / cos-theta-scale systematics and read by nothing else.  Each of those
+// is a monotone map of the sample's value for the evaluation's parameters (IEEE addition and multiplication by a
+// constant round monotonically), and so is the binning that follows: along rows sorted by the raw value the
+// observable's "extended bin" (-1 below the domain, the index inside, a large value at or above the upper edge)
+// is a step function.  The bucketed copy keeps the rows of each bucket in that order; a 256-row granule whose
+// first and last row land in the same extended bin has every row there, so the observable's contribution to the
+// flat index is one constant for the granule -- computed per evaluation from the two end values, with exactly the
+// per-sample arithmetic -- and its column is not read at all.  Only granules that straddle a bin edge ("mixed":
+// at most nbins + 1 per bucket) take the per-sample path over the column; granules entirely outside the domain
+// are skipped.  NaN anywhere (a NaN end value or coefficient) makes a granule mixed: the per-sample path decides,
+// as it always has.  Counts are integers and every sample is binned by the same arithmetic or by an argument
+// about that arithmetic, so the histograms stay bit-identical (tests: every ordered case against the unordered
+// evaluation and the CPU restatement, samples placed within ulps of the edges).
+//
+// Slots: 0 .. NOBS-1 the observables binned per sample, NOBS .. NSLOT-2 fields that are only read, NSLOT-1 the
+// ordered observable's column (geometry at index NOBS of the descriptor's arrays).  Granule word `pre`:
+// bits 0-23 the bucket's bin offset, bits 24-31 rows in the granule - 1.  Lane l of a wave works out the codes of
+// the wave's next 64 granules in one go (one 8-byte read per granule), each step then takes its own with
+// v_readlane: scalar from there on.  NCHAIN > 1: lockstep chains (see fill_multi_body), each with its own codes.
+constexpr int kPreOrdered = 5;
+constexpr unsigned kOrdMixed = 0xFFFFFFFEu, kOrdSkip = 0xFFFFFFFFu;
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
+
+template <unsigned OPC>
+__device__ __forceinline__ void apply_ordered_scalar(double& x, const double* c) {
+  constexpr int type = (int)(OPC & 15u);
+  static_assert(sx_op_npars(OPC) == 1 && (type == SXMC_SYST_SHIFT || type == SXMC_SYST_SCALE || type == SXMC_SYST_CTSCALE),
+                "not a monotone systematic");
+  const double pc = 0.0 + c[0] * 1.0;   // (as apply_static)
+  if constexpr (type == SXMC_SYST_SHIFT) x = x + pc;
+  if constexpr (type == SXMC_SYST_SCALE) x = x * (1 + pc);
+  if constexpr (type == SXMC_SYST_CTSCALE) x = 1 + (x - 1) * (1 + pc);
+}
+// the systematics of the program that write slot ORD, on one value
+template <int ORD, unsigned... OPS, unsigned long... I>
+__device__ __forceinline__ void run_ordered_scalar(double& x, const double* c, StaticProg<OPS...>, ISeq<I...>) {
+  ([&] {
+    if constexpr ((int)((OPS >> 4) & 15u) == ORD) apply_ordered_scalar<OPS>(x, c + sx_prog_cstart<OPS...>((int)I));
+  }(), ...);
+}
+// the systematics that write slot ORD (WANT) or the others (!WANT), on the lane's samples
+template <int NSLOT, int ORD, bool WANT, unsigned... OPS, unsigned long... I>
+__device__ __forceinline__ void run_static_part(double (&f)[NSLOT][SXMC_VEC], const double* c, StaticProg<OPS...>,
+                                                ISeq<I...>) {
+  ([&] {
+    if constexpr (((int)((OPS >> 4) & 15u) == ORD) == WANT) apply_static<NSLOT, OPS>(f, c + sx_prog_cstart<OPS...>((int)I));
+  }(), ...);
+}
+template <int NOBS, int NSLOT, typename PROG, int NCHAIN>
+__device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxSegment* __restrict__ segs,
+                                                  const unsigned* __restrict__ blk_off, unsigned layout,
+                                                  unsigned dbg) {
+  static_assert(!PROG::dynamic && NSLOT >= 1 && NOBS >= 0 && NOBS < NSLOT && NCHAIN >= 1 && NCHAIN <= 4, "unsupported");
+  constexpr int ORD = NSLOT - 1;       // the ordered observable's column
+  constexpr int NSTREAM = NSLOT - 1;   // columns every granule streams
+  constexpr int NG = NOBS > 0 ? NOBS : 1, NS = NSTREAM > 0 ? NSTREAM : 1, NC = PROG::ncoef > 0 ? PROG::ncoef : 1;
+  typedef typename MakeISeq<PROG::n>::type Seq;
+  extern __shared__ unsigned lds[];
+  const unsigned tid = threadIdx.x;
+  const unsigned nthreads = blockDim.x;
+  const unsigned lane = tid & (kWave - 1);
+  // LDS: words 0..3 the chains' in-domain counters, then per chain R replicas of the histogram, rstride words
+  // apart, then 64 trash words.  `layout` = rstride | log2(R) << 24.  Inside a granule only the observables
+  // binned per sample vary, so a wave's 64 updates go to a handful of bins, strided by the other observables'
+  // strides: few banks, many lanes per word.  Two remedies: the word of bin b is b with its low six bits XORed
+  // by the next six (bins a multiple of 64 apart land in different banks), and lane l updates replica l mod R
+  // (rstride = 16 mod 64: the replicas of one bin sit in different banks too).  The flush adds the replicas up.
+  unsigned* s_norm = lds;
+  unsigned* hist = lds + 4;
+  const unsigned rstride = layout & 0xFFFFFFu, rlog = layout >> 24, R = 1u << rlog;
+  const unsigned cstride = rstride << rlog;            // one chain's replicas
+  const unsigned trash = NCHAIN * cstride + lane;
+  const unsigned myrep = (lane & (R - 1u)) * rstride;
+
+  bool lds_clean = false;
+  const unsigned seg_end = blk_off[blockIdx.x + 1];
+  for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
+    const SxSegment& sg = segs[si];
+    const SxSignalDesc& d = chains.d[0][sg.sig];     // tables and geometry: the same for every chain
+    const unsigned long long v0 = sg.v0;
+    const unsigned long long v1 = sg.v1;
+    const unsigned long long step = sg.step;
+    const unsigned B = (unsigned)d.total_nbins;
+
+    double craw[NCHAIN][NC];
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) {
+      const SxSignalDesc& dc = chains.d[c][sg.sig];
+#pragma unroll
+      for (int q = 0; q < PROG::ncoef; q++) craw[c][q] = to_global(dc.params)[(long)dc.coef_par[q] * dc.param_stride];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    gptr<const vfloat4> col[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
+    }
+    gptr<const unsigned> precol = to_global(reinterpret_cast<const unsigned*>(d.pre));
+    gptr<const vfloat2> edges = to_global(reinterpret_cast<const vfloat2*>(d.edges));
+    const unsigned long long vlast = v1 - 1;
+    const unsigned long long vfirst = v0 + tid;
+    const unsigned long long vwave = v0 + (tid - lane);   // the wave's first unit: a granule boundary
+
+    vfloat4 raw[NS];
+    unsigned rawpre;
+    auto load = [&](unsigned long long v) {
+#pragma unroll
+      for (int k = 0; k < NSTREAM; k++) {
+        raw[k] = __builtin_nontemporal_load(&col[k][v]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      rawpre = precol[v >> 6];
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    load(vfirst < v1 ? vfirst : vlast);
+
+    if (!lds_clean) {
+      for (unsigned b = tid; b < NCHAIN * cstride; b += nthreads) hist[b] = 0u;
+      if (tid < 4) s_norm[tid] = 0u;
+      __syncthreads();
+    }
+
+    double lo[NG], hi[NG], sc[NG];
+    int st[NG];
+#pragma unroll
+    for (int k = 0; k < NOBS; k++) {
+      lo[k] = d.lower[k];
+      hi[k] = d.upper[k];
+      sc[k] = d.scale[k];
+      st[k] = d.bin_stride[k];
+    }
+    const double olo = d.lower[NOBS], ohi = d.upper[NOBS], osc = d.scale[NOBS];
+    const int ost = d.bin_stride[NOBS];
+    // a coefficient that is not finite: no claim about monotone maps, every granule takes the per-sample path
+    bool wild[NCHAIN];
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) {
+      wild[c] = false;
+#pragma unroll
+      for (int q = 0; q < PROG::ncoef; q++) wild[c] = wild[c] || !(__builtin_fabs(craw[c][q]) < __builtin_inf());
+    }
+
+    unsigned cnt[NCHAIN], codes[NCHAIN];
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) cnt[c] = codes[c] = 0u;
+
+    unsigned long long v = vfirst;
+    const unsigned long long niter = (v1 - v0 + step - 1) / step;
+    for (unsigned long long it = 0; it < niter; ++it, v += step) {
+      const int j = (int)(it & 63ull);
+      if (j == 0) {
+        // ---- codes of this wave's next 64 granules, one per lane
+        const unsigned long long vg = vwave + (it + lane) * step;
+        const bool live = vg < v1;
+        const vfloat2 e = edges[(live ? vg : vlast) >> 6];
+#pragma unroll
+        for (int c = 0; c < NCHAIN; c++) {
+          double x0 = (double)e.x, x1 = (double)e.y;
+          run_ordered_scalar<ORD>(x0, craw[c], PROG{}, Seq{});
+          run_ordered_scalar<ORD>(x1, craw[c], PROG{}, Seq{});
+          const bool nan = wild[c] || !(x0 == x0) || !(x1 == x1);
+          const int i0 = (int)((x0 - olo) * osc), i1 = (int)((x1 - olo) * osc);
+          const int e0 = !(x0 >= olo) ? -1 : (!(x0 < ohi) ? 0x7FFFFFFF : i0);
+          const int e1 = !(x1 >= olo) ? -1 : (!(x1 < ohi) ? 0x7FFFFFFF : i1);
+          unsigned code = (nan || e0 != e1) ? kOrdMixed
+                                            : ((e0 < 0 || e0 == 0x7FFFFFFF) ? kOrdSkip : (unsigned)__mul24(e0, ost));
+          codes[c] = live ? code : kOrdSkip;
+        }
+      }
+      unsigned code[NCHAIN];
+      bool anymixed = false;
+#pragma unroll
+      for (int c = 0; c < NCHAIN; c++) {
+        code[c] = (unsigned)__builtin_amdgcn_readlane((int)codes[c], j);
+        anymixed = anymixed || code[c] == kOrdMixed;
+      }
+
+      double f0[NS][SXMC_VEC];
+#pragma unroll
+      for (int k = 0; k < NSTREAM; k++) {
+        f0[k][0] = (double)raw[k].x;
+        f0[k][1] = (double)raw[k].y;
+        f0[k][2] = (double)raw[k].z;
+        f0[k][3] = (double)raw[k].w;
+      }
+      const unsigned prebits = (unsigned)uniform_i((int)rawpre);
+#pragma unroll
+      for (int k = 0; k < NSTREAM; k++) {
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f0[k][q]));
+      }
+      // a mixed granule: this once the ordered observable's column is needed too
+      vfloat4 rawo = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (anymixed) {
+        rawo = __builtin_nontemporal_load(&col[ORD][v < v1 ? v : vlast]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const unsigned long long vl = v + step;
+      load((vl < v1 && !(dbg & 2u)) ? vl : vlast);
+      if (dbg & 1u) {
+#pragma unroll
+        for (int k = 0; k < NSTREAM; k++) {
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) cnt[0] += (f0[k][q] == 12345.678) ? 1u : 0u;
+        }
+        cnt[0] += (prebits == 12345u) ? 1u : 0u;
+        continue;
+      }
+      const unsigned off = prebits & 0xFFFFFFu, nvalid = (prebits >> 24) + 1u;
+
+#pragma unroll
+      for (int c = 0; c < NCHAIN; c++) {
+        if (code[c] == kOrdSkip) continue;          // (wave-uniform) outside the ordered observable's domain
+        const bool mixed = code[c] == kOrdMixed;
+        if constexpr (NOBS == 0) {
+          if (!mixed) {
+            // nothing varies inside the granule: all its rows go to one bin
+            const unsigned bin = off + code[c];
+            if (lane == 0) {
+              cnt[c] += nvalid;
+              if (bin < B && !(dbg & 4u)) {
+                __hip_atomic_fetch_add(&hist[(unsigned)c * cstride + lds_slot(bin)], nvalid, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+            continue;
+          }
+        }
+        double f[NSLOT][SXMC_VEC];
+#pragma unroll
+        for (int k = 0; k < NSTREAM; k++) {
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) f[k][q] = f0[k][q];
+        }
+        f[ORD][0] = f[ORD][1] = f[ORD][2] = f[ORD][3] = 0.0;
+        run_static_part<NSLOT, ORD, false>(f, craw[c], PROG{}, Seq{});
+        if (mixed) {   // (the wait for the extra column sits in here, off the common path)
+          f[ORD][0] = (double)rawo.x;
+          f[ORD][1] = (double)rawo.y;
+          f[ORD][2] = (double)rawo.z;
+          f[ORD][3] = (double)rawo.w;
+          run_static_part<NSLOT, ORD, true>(f, craw[c], PROG{}, Seq{});
+        }
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          unsigned bad = 0u;
+          int bin = (int)(off + (mixed ? 0u : code[c]));
+#pragma unroll
+          for (int k = 0; k < NOBS; k++) {
+            const double x = f[k][q];
+            bad += !(x >= lo[k]) ? 1u : 0u;
+            bad += !(x < hi[k]) ? 1u : 0u;
+            const int idx = (int)((x - lo[k]) * sc[k]);
+            bin = __mul24(idx, st[k]) + bin;
+          }
+          if (mixed) {
+            const double x = f[ORD][q];
+            bad += !(x >= olo) ? 1u : 0u;
+            bad += !(x < ohi) ? 1u : 0u;
+            const int idx = (int)((x - olo) * osc);
+            bin = __mul24(idx, ost) + bin;
+          }
+          const unsigned in_domain = (bad == 0u) ? 1u : 0u;
+          cnt[c] += in_domain;
+          const bool store = (bad == 0u) && ((unsigned)bin < B) && !(dbg & 4u);
+          const unsigned slot = store ? (unsigned)c * cstride + myrep + lds_slot((unsigned)bin) : trash;
+          __hip_atomic_fetch_add(&hist[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) {
+      unsigned t = cnt[c];
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off, kWave);
+      if (lane == 0 && t != 0u) {
+        __hip_atomic_fetch_add(&s_norm[c], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) {
+      const SxSignalDesc& dc = chains.d[c][sg.sig];
+      gptr<unsigned> gbins = to_global(dc.bins);
+      for (unsigned w = tid; w < ((B + 63u) & ~63u); w += nthreads) {
+        unsigned n = 0u;
+        for (unsigned r = 0; r < R; r++) {
+          const unsigned at = (unsigned)c * cstride + r * rstride + w;
+          const unsigned m = hist[at];
+          if (m != 0u) hist[at] = 0u;
+          n += m;
+        }
+        // (a word of the last block whose bin would be >= B was never written)
+        if (n != 0u) __hip_atomic_fetch_add(&gbins[lds_slot(w)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) {
+        const unsigned n = s_norm[c];
+        if (n != 0u) __hip_atomic_fetch_add(to_global(dc.norm), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_norm[c] = 0u;
+      }
+    }
+    __syncthreads();
+    lds_clean = true;
+  }
+}
+
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>
 __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restrict__ descs,
                                                     const SxSegment* __restrict__ segs,
@@ -989,6 +1301,16 @@ __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* _
                                                            const unsigned* __restrict__ blk_off, unsigned smax,
                                                            unsigned dbg) {
   fill_sparse_body<NOBS, NSLOT, PROG>(descs, segs, blk_off, smax, dbg);
+}
+
+template <int NOBS, int NSLOT, typename PROG>
+__global__ __launch_bounds__(1024) void fill_ordered_kernel(const SxSignalDesc* __restrict__ descs,
+                                                            const SxSegment* __restrict__ segs,
+                                                            const unsigned* __restrict__ blk_off, unsigned layout,
+                                                            unsigned dbg) {
+  SxChainDescs one;
+  one.d[0] = one.d[1] = one.d[2] = one.d[3] = descs;
+  fill_ordered_body<NOBS, NSLOT, PROG, 1>(one, segs, blk_off, layout, dbg);
 }
 
 }  // namespace sxfill

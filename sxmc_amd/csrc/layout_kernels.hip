@@ -29,22 +29,50 @@ struct KeyPlan {
   unsigned radix[SXMC_MAX_NFIELDS];
 };
 
+// rows_in: the rows in an order to keep among equal keys (the sort that follows is stable), or null: 0, 1, 2, ...
 __global__ __launch_bounds__(256) void bucket_key_kernel(const SxSignalDesc* __restrict__ dp, KeyPlan plan,
+                                                         const unsigned* __restrict__ rows_in,
                                                          unsigned* __restrict__ keys, unsigned* __restrict__ rows) {
   const SxSignalDesc& d = *dp;
   const unsigned long long n = d.nsamples;
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const unsigned long long row = rows_in ? rows_in[i] : i;
     bool ok = true;
     unsigned key = 0;
     for (int k = 0; k < d.nobs; k++) {
       if (!((plan.mask >> k) & 1u)) continue;
-      const double x = (double)d.cols[(unsigned long long)k * d.col_pitch + i];
+      const double x = (double)d.cols[(unsigned long long)k * d.col_pitch + row];
       ok = ok && (x >= d.lower[k]) && (x < d.upper[k]);
       key += (unsigned)(int)((x - d.lower[k]) * d.scale[k]) * plan.radix[k];
     }
     keys[i] = ok ? key : plan.outside;
+    rows[i] = (unsigned)row;
+  }
+}
+
+// ORDERED observable (fill_ordered_kernel): key = the float's bits mapped so that unsigned order is numeric order
+// (-inf ... -0 +0 ... +inf, every NaN last).
+__global__ __launch_bounds__(256) void order_key_kernel(const float* __restrict__ col, unsigned long long n,
+                                                        unsigned* __restrict__ keys, unsigned* __restrict__ rows) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const float x = col[i];
+    const unsigned u = __float_as_uint(x);
+    keys[i] = (x != x) ? 0xFFFFFFFFu : ((u >> 31) ? ~u : (u | 0x80000000u));
     rows[i] = (unsigned)i;
+  }
+}
+
+// per granule: the ordered observable's value in its first and in its last row (granules are never empty here)
+__global__ __launch_bounds__(256) void bucket_edges_kernel(const float* __restrict__ col,
+                                                           const unsigned* __restrict__ valid,
+                                                           unsigned long long ngranules, float* __restrict__ edges) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < ngranules; p += step) {
+    const unsigned nv = valid[p] ? valid[p] : 1u;
+    edges[2 * p] = col[p * 256ull];
+    edges[2 * p + 1] = col[p * 256ull + nv - 1u];
   }
 }
 
@@ -135,13 +163,30 @@ unsigned grid_for(unsigned long long n, unsigned cap) {
 }  // namespace
 
 hipError_t sx_bucket_keys(const SxSignalDesc* d_desc, unsigned long long nsamples, unsigned mask, const unsigned* radix,
-                          unsigned outside, unsigned* d_keys, unsigned* d_rows, hipStream_t s) {
+                          unsigned outside, const unsigned* d_rows_in, unsigned* d_keys, unsigned* d_rows,
+                          hipStream_t s) {
   if (nsamples == 0) return hipSuccess;
   KeyPlan plan;
   plan.mask = mask;
   plan.outside = outside;
   for (int k = 0; k < SXMC_MAX_NFIELDS; k++) plan.radix[k] = radix[k];
-  hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_for(nsamples, 16384)), dim3(256), 0, s, d_desc, plan, d_keys, d_rows);
+  hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_for(nsamples, 16384)), dim3(256), 0, s, d_desc, plan, d_rows_in, d_keys,
+                     d_rows);
+  return hipGetLastError();
+}
+
+hipError_t sx_order_keys(const float* d_col, unsigned long long nsamples, unsigned* d_keys, unsigned* d_rows,
+                         hipStream_t s) {
+  if (nsamples == 0) return hipSuccess;
+  hipLaunchKernelGGL(order_key_kernel, dim3(grid_for(nsamples, 16384)), dim3(256), 0, s, d_col, nsamples, d_keys, d_rows);
+  return hipGetLastError();
+}
+
+hipError_t sx_bucket_edges(const float* d_col, const unsigned* d_valid, unsigned long long ngranules, float* d_edges,
+                           hipStream_t s) {
+  if (ngranules == 0) return hipSuccess;
+  hipLaunchKernelGGL(bucket_edges_kernel, dim3(grid_for(ngranules, 4096)), dim3(256), 0, s, d_col, d_valid, ngranules,
+                     d_edges);
   return hipGetLastError();
 }
 

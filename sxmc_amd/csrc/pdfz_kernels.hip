@@ -550,6 +550,37 @@ const StaticEntry kStaticPrograms[] = {
 };
 constexpr int kNumStatic = (int)(sizeof(kStaticPrograms) / sizeof(kStaticPrograms[0]));
 
+// Ordered programs built in (bucketed table with an ordered observable, fill_ordered_kernel): slots are the
+// observables binned per sample, the fields only read, then the ordered observable.  Anything else: hiprtc.
+template <int NOBS, int NSLOT, typename PROG>
+hipError_t launch_fill_ordered_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
+                                 const unsigned* blk_off, hipStream_t s) {
+  auto k = fill_ordered_kernel<NOBS, NSLOT, PROG>;
+  if (sh.lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, sh.lds_layout,
+                     (unsigned)sh.debug_mode);
+  return hipGetLastError();
+}
+struct OrderedEntry {
+  int nobs, nslot, nops;
+  unsigned ops[4];
+  FillLauncher fn;
+};
+#define SX_O1(NO, NS, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_ordered_k<NO, NS, StaticProg<A>>}
+#define SX_O3(NO, NS, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_ordered_k<NO, NS, StaticProg<A, B, C>>}
+const OrderedEntry kOrderedPrograms[] = {
+    // one observable, one shift / scale (bench_sxmc pdfz): nothing is streamed but the granule words
+    SX_O1(0, 1, SX_SHIFT(0)),
+    SX_O1(0, 1, SX_SCALE(0)),
+    // BASELINE configs 3 and 5 bucketed: e (scale + resolution_scale against e_true) binned per sample, r (shift) ordered
+    SX_O3(1, 3, SX_SHIFT(2), SX_SCALE(0), SX_RES(0, 1)),
+};
+constexpr int kNumOrdered = (int)(sizeof(kOrderedPrograms) / sizeof(kOrderedPrograms[0]));
+
 template <int NOBS, int NSLOT>
 hipError_t launch_fill_dyn(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                            const unsigned* blk_off, hipStream_t s) {
@@ -609,11 +640,27 @@ int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* o
   return -1;
 }
 
+int sx_fill_find_ordered_program(int nobs, int nslot, int nops, const unsigned* ops) {
+  for (int i = 0; i < kNumOrdered; i++) {
+    const OrderedEntry& e = kOrderedPrograms[i];
+    if (e.nobs != nobs || e.nslot != nslot || e.nops != nops) continue;
+    bool same = true;
+    for (int k = 0; k < nops; k++) same = same && e.ops[k] == ops[k];
+    if (same) return i;
+  }
+  return -1;
+}
+
 hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                           const unsigned* blk_off, hipStream_t s) {
   if (sh.grid <= 0) return hipSuccess;
+  if (sh.pre_width == kPreOrdered && !sh.rtc_fill) {
+    if (sh.static_prog < 0 || sh.static_prog >= kNumOrdered) return hipErrorInvalidValue;
+    return kOrderedPrograms[sh.static_prog].fn(sh, descs, segs, blk_off, s);
+  }
   if (sh.rtc_fill) {
-    const unsigned hist_words = (unsigned)(sh.lds_bytes / 4 - 4 - (sh.lds_hist ? 64 : 0));
+    const unsigned hist_words = sh.pre_width == kPreOrdered ? sh.lds_layout
+                                                            : (unsigned)(sh.lds_bytes / 4 - 4 - (sh.lds_hist ? 64 : 0));
     return sx_rtc_launch(sh.rtc_fill, sh.grid, sh.threads, sh.lds_bytes, descs, segs, blk_off, hist_words,
                          (unsigned)sh.debug_mode, s);
   }

@@ -47,8 +47,10 @@ struct SxLaunchShape {
   void* rtc_sparse; // ... and for its sparse flavour over runs
   int sparse_runs;  // 1: the sparse flavour of this launch runs fill_sparse_kernel (bucketed table laid out in runs)
   size_t sparse_lds_bytes;
+  unsigned lds_layout;  // pre_width 5: words between the LDS histogram's replicas | log2(replicas) << 24
   int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none, 3 = bucketed table (one
-                    // bin offset per 256-sample granule)
+                    // bin offset per 256-sample granule), 5 = bucketed table with an ordered observable
+                    // (fill_ordered_kernel; static_prog then indexes the ordered programs built in)
 };
 
 // A fill kernel specialised at run time (sxmc_rtc.cpp): the template arguments of fill_body / fill_sparse_body.
@@ -84,12 +86,18 @@ bool sx_fill_static_supports_sparse_runs(int prog);
 
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
+int sx_fill_find_ordered_program(int nobs, int nslot, int nops, const unsigned* ops);
 bool sx_fill_static_supports(int prog, int lds_hist, int prebin);
 hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,
                             hipStream_t s);
 // bucketed copy of a sample table (layout_kernels.hip)
 hipError_t sx_bucket_keys(const SxSignalDesc* d_desc, unsigned long long nsamples, unsigned mask, const unsigned* radix,
-                          unsigned outside, unsigned* d_keys, unsigned* d_rows, hipStream_t s);
+                          unsigned outside, const unsigned* d_rows_in, unsigned* d_keys, unsigned* d_rows,
+                          hipStream_t s);
+hipError_t sx_order_keys(const float* d_col, unsigned long long nsamples, unsigned* d_keys, unsigned* d_rows,
+                         hipStream_t s);
+hipError_t sx_bucket_edges(const float* d_col, const unsigned* d_valid, unsigned long long ngranules, float* d_edges,
+                           hipStream_t s);
 hipError_t sx_bucket_sort(const unsigned* keys_in, unsigned* keys_out, const unsigned* rows_in, unsigned* rows_out,
                           unsigned long long n, int bits, hipStream_t s);
 hipError_t sx_bucket_first(const unsigned* sorted_keys, unsigned long long n, unsigned* d_first, hipStream_t s);

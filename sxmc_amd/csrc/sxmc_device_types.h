@@ -63,6 +63,10 @@ struct SxSignalDesc {
   short coef_par[64];            // coefficient lane -> parameter index
   const void* pre;               // pre-binned column of the observables no systematic writes (or null); for a
                                  // bucketed table: one bin offset per 256-sample granule
+  const float* edges;            // bucketed table with an ORDERED observable (fill_ordered_kernel): per granule the
+                                 // observable's value in the granule's first and last row; its geometry sits at
+                                 // index `nobs` of lower / upper / scale / bin_stride / nbins, its column in slot
+                                 // nslot - 1
   // --- sparse counting (histograms too large for LDS, evaluation for lookup only): `bins` then points
   //     at one counter per DISTINCT EVENT BIN, `read_bins` at the events' counter slots, and the fill maps
   //     a sample's flat bin index to its slot through a one-hash bit filter and an open-addressing table

@@ -117,6 +117,7 @@ struct SampleStore {
   // would have outweighed the columns saved (tiny tables with many buckets).
   struct BucketSort {
     unsigned mask = 0;
+    int ordered = -1;               // observable whose raw value orders the rows inside every bucket, or -1
     bool rejected = true;
     unsigned* d_rows = nullptr;     // [nsamples] row numbers in sorted order (rows outside the domain last)
     size_t nkept = 0;               // rows inside the domain of every untouched observable
@@ -138,19 +139,20 @@ struct SampleStore {
     size_t pitch = 0;
     unsigned* d_gpre = nullptr;     // [ngranules] bin offset of the granule
     unsigned* d_gkp = nullptr;      // [ngranules] pairs {bucket key, bin offset}
+    float* d_gedge = nullptr;       // [ngranules] pairs {first, last} value of the sort's ordered observable
     size_t ngranules = 0;           // physical granules (with the runs' padding)
     size_t nkept = 0;               // samples in the copy
   };
   std::vector<std::unique_ptr<BucketSort>> sorts;
   std::vector<std::unique_ptr<Bucketed>> bucketed;
-  BucketSort* find_sort(unsigned mask) const {
+  BucketSort* find_sort(unsigned mask, int ordered) const {
     for (const auto& b : sorts)
-      if (b->mask == mask) return b.get();
+      if (b->mask == mask && b->ordered == ordered) return b.get();
     return nullptr;
   }
-  Bucketed* find_bucketed(unsigned mask, const std::vector<int>& fields, int runs) const {
+  Bucketed* find_bucketed(const BucketSort* sort, const std::vector<int>& fields, int runs) const {
     for (const auto& b : bucketed)
-      if (b->mask == mask && b->fields == fields && b->runs == runs) return b.get();
+      if (b->sort == sort && b->fields == fields && b->runs == runs) return b.get();
     return nullptr;
   }
   ~SampleStore() {
@@ -160,6 +162,7 @@ struct SampleStore {
       if (b->d_cols) (void)hipFree(b->d_cols);
       if (b->d_gpre) (void)hipFree(b->d_gpre);
       if (b->d_gkp) (void)hipFree(b->d_gkp);
+      if (b->d_gedge) (void)hipFree(b->d_gedge);
     }
     for (auto& b : sorts)
       if (b->d_rows) (void)hipFree(b->d_rows);
@@ -362,6 +365,7 @@ struct sxmc_group {
   int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
   int cfg_prebin = 1, cfg_seen_prebin = -1;        // pre-bin the observables no systematic writes
   int cfg_bucket = 1, cfg_seen_bucket = -1;        // stream a bucketed copy of the table where that pays
+  int cfg_order = 1, cfg_seen_order = -1;          // ... with the rows of a bucket ordered by a monotonically written observable
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
@@ -586,17 +590,20 @@ struct DevBuf {  // device temporary, freed on scope exit
 // The rows of member `h`'s table sorted by their bin indices in the observables of `mask` (those no systematic
 // writes) and cut into 256-row granules, bucket by bucket.  Fetched from the table's cache or built; *out =
 // nullptr when bucketing does not pay for this table.  d_full_desc: the member's descriptor on the device.
-int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask, const SampleStore::BucketSort** out) {
+// `ordered` >= 0: inside every bucket the rows are in ascending order of that observable's raw value (NaN last).
+int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask, int ordered,
+                    const SampleStore::BucketSort** out) {
   *out = nullptr;
   SampleStore& st = *h->store;
   std::lock_guard<std::mutex> lock(st.pre_mutex);
-  if (SampleStore::BucketSort* have = st.find_sort(mask)) {
+  if (SampleStore::BucketSort* have = st.find_sort(mask, ordered)) {
     *out = have->rejected ? nullptr : have;
     return SXMC_OK;
   }
   st.sorts.push_back(std::make_unique<SampleStore::BucketSort>());
   SampleStore::BucketSort* b = st.sorts.back().get();
   b->mask = mask;
+  b->ordered = ordered;
   const size_t n = h->nsamples;
   if (n == 0 || n > 0x7FFFFF00ull) return SXMC_OK;
 
@@ -619,7 +626,19 @@ int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask
   SX_HIP(hipMalloc((void**)&b->d_rows, n * 4));
   SX_HIP(dfirst.alloc((nkeys + 1) * 4));
   SX_HIP(hipMemset(dfirst.p, 0xFF, (nkeys + 1) * 4));
-  SX_HIP(sx_bucket_keys(d_full_desc, n, mask, b->radix, outside, keys0.as<unsigned>(), rows0.as<unsigned>(), nullptr));
+  const unsigned* order_rows = nullptr;
+  DevBuf rows1;
+  if (ordered >= 0) {
+    // rows by the ordered observable's value first; the stable sort by bucket below keeps that order inside a bucket
+    SX_HIP(rows1.alloc(n * 4));
+    SX_HIP(sx_order_keys(st.d_cols + (size_t)ordered * h->pitch, n, keys0.as<unsigned>(),
+                         rows0.as<unsigned>(), nullptr));
+    SX_HIP(sx_bucket_sort(keys0.as<unsigned>(), keys1.as<unsigned>(), rows0.as<unsigned>(), rows1.as<unsigned>(), n, 32,
+                          nullptr));
+    order_rows = rows1.as<unsigned>();
+  }
+  SX_HIP(sx_bucket_keys(d_full_desc, n, mask, b->radix, outside, order_rows, keys0.as<unsigned>(), rows0.as<unsigned>(),
+                        nullptr));
   SX_HIP(sx_bucket_sort(keys0.as<unsigned>(), keys1.as<unsigned>(), rows0.as<unsigned>(), b->d_rows, n, bits, nullptr));
   SX_HIP(sx_bucket_first(keys1.as<unsigned>(), n, dfirst.as<unsigned>(), nullptr));
   std::vector<unsigned> first((size_t)nkeys + 1);
@@ -673,12 +692,12 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
   *out = nullptr;
   SampleStore& st = *h->store;
   std::lock_guard<std::mutex> lock(st.pre_mutex);
-  if (SampleStore::Bucketed* have = st.find_bucketed(bs->mask, fields, runs)) {
+  if (SampleStore::Bucketed* have = st.find_bucketed(bs, fields, runs)) {
     if (!have->complete) return fail(SXMC_ERR_HIP, "an earlier attempt to lay this table out failed");
     *out = have;
     return SXMC_OK;
   }
-  SX_REQUIRE(!fields.empty() && runs >= 1, "bad bucketed layout request");
+  SX_REQUIRE(!fields.empty() && runs >= 1 && (bs->ordered < 0 || runs == 1), "bad bucketed layout request");
   st.bucketed.push_back(std::make_unique<SampleStore::Bucketed>());
   SampleStore::Bucketed* b = st.bucketed.back().get();
   b->mask = bs->mask;
@@ -695,6 +714,8 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
       psrc[p] = bs->lsrc[l];
       pvalid[p] = bs->lvalid[l];
       ppre[p] = bs->key_pre[bs->lwhich[l]];
+      // (ordered tables: histograms in LDS, so the offset is below 2^24 and the row count rides in the top byte)
+      if (bs->ordered >= 0) ppre[p] |= (bs->lvalid[l] - 1u) << 24;
       pkp[2 * p] = bs->keys[bs->lwhich[l]];
     } else {  // padding granule at the end of the last runs: no samples, stays in the last bucket
       pkp[2 * p] = L ? bs->keys[bs->lwhich[L - 1]] : outside;
@@ -716,6 +737,12 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
   SX_HIP(hipMemcpy(dvalid.p, pvalid.data(), A * 4, hipMemcpyHostToDevice));
   SX_HIP(sx_bucket_gather(st.d_cols, h->pitch, (int)fields.size(), fields.data(), bs->d_rows, dsrc.as<unsigned>(),
                           dvalid.as<unsigned>(), P, b->d_cols, b->pitch, nullptr));
+  if (bs->ordered >= 0) {
+    // the ordered observable's column is the last of `fields` (group_rebuild)
+    SX_HIP(hipMalloc((void**)&b->d_gedge, sizeof(float) * 2 * A));
+    SX_HIP(hipMemset(b->d_gedge, 0, sizeof(float) * 2 * A));
+    SX_HIP(sx_bucket_edges(b->d_cols + (fields.size() - 1) * b->pitch, dvalid.as<unsigned>(), P, b->d_gedge, nullptr));
+  }
   SX_HIP(hipDeviceSynchronize());
   b->complete = true;
   *out = b;
@@ -815,10 +842,25 @@ int build_bucket_tables(sxmc_hist* h, const SampleStore::BucketSort* bs) {
   return SXMC_OK;
 }
 
+// LDS of fill_ordered_body: per chain 2^rlog replicas of the histogram, each padded to whole 64-word blocks (the
+// swizzle permutes inside a block) + 16 words (replicas of a bin in different banks), + header and trash words.
+unsigned ordered_rstride(int max_bins) { return (((unsigned)max_bins + 63u) & ~63u) + 16u; }
+size_t ordered_lds_bytes(int max_bins, int nchain, unsigned rlog) {
+  return (4 + ((size_t)nchain * ordered_rstride(max_bins) << rlog) + 64) * 4;
+}
+
 // The member's problem as the fill sees it once its table is bucketed: only the observables some systematic
 // writes (+ the extra fields), slots renumbered, columns = the bucketed copy.  `keep`: full slot -> new slot or -1.
-void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, int nobs2, SxSignalDesc& cd) {
+// `ordered` >= 0: that observable rides in the last slot and its geometry at index nobs2 (fill_ordered_kernel).
+void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, int nobs2, SxSignalDesc& cd, int ordered = -1) {
   cd = full;
+  if (ordered >= 0) {
+    cd.bin_stride[nobs2] = full.bin_stride[ordered];
+    cd.nbins[nobs2] = full.nbins[ordered];
+    cd.lower[nobs2] = full.lower[ordered];
+    cd.upper[nobs2] = full.upper[ordered];
+    cd.scale[nobs2] = full.scale[ordered];
+  }
   int nslot = 0;
   for (int k = 0; k < full.nslot; k++) {
     if (keep[(size_t)k] < 0) continue;
@@ -908,7 +950,11 @@ int group_rebuild(sxmc_group* g) {
     auto have_kernel = [&](int nobs_, int nslot_, int prew, int runs, const std::vector<unsigned>& words, int sp,
                            void** fn) {
       *fn = nullptr;
-      if (runs ? sx_fill_static_supports_sparse_runs(sp) : sx_fill_static_supports(sp, lds_hist, prew)) return true;
+      if (prew == 5) {   // (sp: index into the ordered programs built in)
+        if (sp >= 0) return true;
+      } else if (runs ? sx_fill_static_supports_sparse_runs(sp) : sx_fill_static_supports(sp, lds_hist, prew)) {
+        return true;
+      }
       if (!g->cfg_rtc) return false;
       SxRtcSpec k{};
       k.nobs = nobs_;
@@ -926,9 +972,11 @@ int group_rebuild(sxmc_group* g) {
     void *rtc_fill = nullptr, *rtc_sparse = nullptr;
 
     // ---- bucketed table: the observables no systematic writes become a per-granule bin offset and the
-    // fill sees the lower-dimensional problem of the ones that are written
+    // fill sees the lower-dimensional problem of the ones that are written.  With an ORDERED observable (written
+    // only by monotone one-coefficient systematics, read by nothing): that one too is a per-granule constant,
+    // worked out per evaluation from the granule's end values, except in the granules that straddle a bin edge.
     bool bucketed = false;
-    if (g->cfg_bucket && d.nsyst > 0 && specialisable) {
+    auto try_bucket = [&](int ordered) -> int {
       unsigned touched = 0, read = 0;
       for (int q = 0; q < d.nsyst; q++) {
         touched |= 1u << d.syst[q].obs_slot;
@@ -936,11 +984,12 @@ int group_rebuild(sxmc_group* g) {
       }
       // compacted slots: the observables that are written (still binned by the fill), then everything that is only
       // read -- the extra fields, and an untouched observable that serves as some systematic's truth field (its own
-      // bin index is the bucket's; its VALUE is still an input)
+      // bin index is the bucket's; its VALUE is still an input) --, then the ordered observable
       unsigned mask = 0;
       std::vector<int> keep((size_t)d.nslot, -1), fields;
       int nobs2 = 0;
       for (int k = 0; k < d.nobs; k++) {
+        if (k == ordered) continue;
         if ((touched >> k) & 1u) {
           keep[(size_t)k] = (int)fields.size();
           fields.push_back(d.slot_col[k]);
@@ -950,46 +999,81 @@ int group_rebuild(sxmc_group* g) {
         }
       }
       for (int k = 0; k < d.nslot; k++) {
-        if (keep[(size_t)k] >= 0) continue;
+        if (keep[(size_t)k] >= 0 || k == ordered) continue;
         if (k >= d.nobs || ((read >> k) & 1u)) {
           keep[(size_t)k] = (int)fields.size();
           fields.push_back(d.slot_col[k]);
         }
       }
-      if (mask && nobs2 >= 1 && sx_fill_has_specialization(nobs2, (int)fields.size())) {
-        SxSignalDesc cd;
-        compact_desc(d, keep, nobs2, cd);
-        const std::vector<unsigned> prog2 = prog_words(cd);
-        const int sp = sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
-        if (have_kernel(cd.nobs, cd.nslot, 3, 0, prog2, sp, &rtc_fill)) {
-          const SampleStore::BucketSort* bs = nullptr;
-          rc = get_bucket_sort(h, g->d_descs + i, mask, &bs);
-          if (rc) return rc;
-          if (bs) {
-            fill_descs[(size_t)i] = cd;     // (columns, unit count and granule table: once the layout is chosen)
-            plans[(size_t)i].sort = bs;
-            plans[(size_t)i].fields = fields;
-            bucketed = true;
-            // histograms beyond LDS, evaluated at data events: per-wave runs + event bins grouped by bucket
-            bool narrow = true;   // (the runs kernel forms idx * stride from 24-bit products)
-            for (int k = 0; k < h->nobs; k++) narrow = narrow && h->nbins[(size_t)k] < (1 << 23);
-            runs_mode = !lds_hist && narrow && h->has_points && h->d_table &&
-                        have_kernel(cd.nobs, cd.nslot, 3, 1, prog2, sp, &rtc_sparse);
-            if (runs_mode) {
-              rc = build_bucket_tables(h, bs);
-              if (rc) return rc;
+      if (ordered >= 0) {
+        keep[(size_t)ordered] = (int)fields.size();
+        fields.push_back(d.slot_col[ordered]);
+      }
+      const bool shape_ok = ordered >= 0 ? (nobs2 <= 5 && fields.size() <= 7)
+                                         : (mask && nobs2 >= 1 && sx_fill_has_specialization(nobs2, (int)fields.size()));
+      if (!shape_ok) return SXMC_OK;
+      SxSignalDesc cd;
+      compact_desc(d, keep, nobs2, cd, ordered);
+      const std::vector<unsigned> prog2 = prog_words(cd);
+      const int prew = ordered >= 0 ? 5 : 3;
+      const int sp = ordered >= 0 ? sx_fill_find_ordered_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data())
+                                  : sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
+      if (!have_kernel(cd.nobs, cd.nslot, prew, 0, prog2, sp, &rtc_fill)) return SXMC_OK;
+      const SampleStore::BucketSort* bs = nullptr;
+      int rc2 = get_bucket_sort(h, g->d_descs + i, mask, ordered, &bs);
+      if (rc2) return rc2;
+      if (!bs) {
+        rtc_fill = nullptr;
+        return SXMC_OK;
+      }
+      fill_descs[(size_t)i] = cd;     // (columns, unit count and granule table: once the layout is chosen)
+      plans[(size_t)i].sort = bs;
+      plans[(size_t)i].fields = fields;
+      bucketed = true;
+      // histograms beyond LDS, evaluated at data events: per-wave runs + event bins grouped by bucket
+      bool narrow = true;   // (the runs kernel forms idx * stride from 24-bit products)
+      for (int k = 0; k < h->nobs; k++) narrow = narrow && h->nbins[(size_t)k] < (1 << 23);
+      runs_mode = ordered < 0 && !lds_hist && narrow && h->has_points && h->d_table &&
+                  have_kernel(cd.nobs, cd.nslot, 3, 1, prog2, sp, &rtc_sparse);
+      if (runs_mode) {
+        rc2 = build_bucket_tables(h, bs);
+        if (rc2) return rc2;
+      }
+      key_nobs = cd.nobs;
+      key_nslot = cd.nslot;
+      prog = prog2;
+      prog_simple = true;
+      static_prog = rtc_fill ? -1 : sp;
+      pre_mask = mask | (ordered >= 0 ? 1u << (16 + ordered) : 0u);
+      pre_width = prew;
+      return SXMC_OK;
+    };
+    if (g->cfg_bucket && d.nsyst > 0 && specialisable) {
+      // the ordered observable: written by one-coefficient shift / scale / cos-theta scale only and read by
+      // nothing; of several, the one with the fewest bins (fewest granules that straddle an edge)
+      int ordered = -1;
+      if (g->cfg_order && lds_hist && h->total_nbins < (1 << 24)) {
+        for (int k = 0; k < d.nobs; k++) {
+          bool written = false, ok = true;
+          for (int q = 0; q < d.nsyst; q++) {
+            const SxSystOp& op = d.syst[q];
+            if (op.obs_slot == k) {
+              written = true;
+              ok = ok && op.npars == 1 &&
+                   (op.type == SXMC_SYST_SHIFT || op.type == SXMC_SYST_SCALE || op.type == SXMC_SYST_CTSCALE);
             }
-            key_nobs = cd.nobs;
-            key_nslot = cd.nslot;
-            prog = prog2;
-            prog_simple = true;
-            static_prog = rtc_fill ? -1 : sp;
-            pre_mask = mask;
-            pre_width = 3;
-          } else {
-            rtc_fill = nullptr;
+            if (op.type == SXMC_SYST_RESOLUTION_SCALE && op.extra_slot == k) ok = false;
           }
+          if (written && ok && (ordered < 0 || h->nbins[(size_t)k] < h->nbins[(size_t)ordered])) ordered = k;
         }
+      }
+      if (ordered >= 0) {
+        rc = try_bucket(ordered);
+        if (rc) return rc;
+      }
+      if (!bucketed) {
+        rc = try_bucket(-1);
+        if (rc) return rc;
       }
     }
     if (!bucketed) {
@@ -1085,7 +1169,8 @@ int group_rebuild(sxmc_group* g) {
   if (n) SX_HIP(hipMemcpy(g->d_descs_sparse, sparse_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
 
   for (LaunchClass& c : g->classes) {
-    const bool bucketed = c.shape.pre_width == 3;
+    const bool bucketed = c.shape.pre_width == 3 || c.shape.pre_width == 5;
+    const bool ordered = c.shape.pre_width == 5;
     // ---- threads per workgroup, LDS
     int cls_max_bins = 0, cls_nsyst = 0;
     for (int idx : c.member_idx) {
@@ -1093,6 +1178,7 @@ int group_rebuild(sxmc_group* g) {
       cls_nsyst = std::max(cls_nsyst, g->h_descs[(size_t)idx].nsyst);
     }
     c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4 + 64) * 4 : 64;
+    if (ordered) c.shape.lds_bytes = ordered_lds_bytes(cls_max_bins, 1, 0);   // (replicas: once the shape is known)
     c.shape.sparse_runs = 0;
     c.shape.sparse_lds_bytes = 0;
     std::vector<int> K;   // runs mode: workgroups per member
@@ -1154,6 +1240,7 @@ int group_rebuild(sxmc_group* g) {
         d.nsamples = bk->ngranules * 256;
         d.nvec = bk->ngranules * 64;
         d.pre = bk->d_gpre;
+        d.edges = bk->d_gedge;
         g->member_bucket[(size_t)idx] = bk;
       }
       d.vec_start = prefix;
@@ -1166,8 +1253,8 @@ int group_rebuild(sxmc_group* g) {
     // -8 % at BASELINE config 3).  Members whose per-sample arithmetic is long (a run-time decoded program
     // of two or more systematics, the shape-agnostic kernel) or that probe L2 per sample (histograms
     // beyond LDS) need the second set of waves to hide it.
-    const double stream_bytes = (double)c.total_vec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot);
-    const bool light = c.shape.lds_hist && c.shape.nobs > 0 &&
+    const double stream_bytes = (double)c.total_vec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot - (ordered ? 1 : 0));
+    const bool light = c.shape.lds_hist && (c.shape.nobs > 0 || ordered) &&
                        (c.shape.static_prog >= 0 || c.shape.rtc_fill || cls_nsyst <= 1) &&
                        stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
     c.light = light;
@@ -1175,6 +1262,14 @@ int group_rebuild(sxmc_group* g) {
     const size_t lds_need = std::max(c.shape.lds_bytes, c.shape.sparse_lds_bytes);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(lds_need, 1)));
     bpc = std::min(bpc, lds_limit);
+    if (ordered) {
+      // replicas of the LDS histogram (fill_ordered_body): as many as the workgroup's share of LDS holds, up to 4
+      unsigned rlog = 0;
+      const size_t share = (size_t)props.lds_per_cu / (size_t)std::max(1, bpc);
+      while (rlog < 2 && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) <= share) rlog++;
+      c.shape.lds_layout = ordered_rstride(cls_max_bins) | (rlog << 24);
+      c.shape.lds_bytes = ordered_lds_bytes(cls_max_bins, 1, rlog);
+    }
     unsigned long long grid = (unsigned long long)props.cus * bpc;
     const unsigned long long want = (c.total_vec + threads - 1) / threads;  // >= 1 unit per lane
     grid = std::max<unsigned long long>(1, std::min(grid, want));
@@ -1244,6 +1339,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_partition = g->cfg_partition;
   g->cfg_seen_prebin = g->cfg_prebin;
   g->cfg_seen_bucket = g->cfg_bucket;
+  g->cfg_seen_order = g->cfg_order;
   g->cfg_seen_rtc = g->cfg_rtc;
   g->plan_generation++;
   g->built = true;
@@ -1279,7 +1375,8 @@ int group_update_points(sxmc_group* g) {
 int group_refresh(sxmc_group* g) {
   bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc ||
                g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_prebin != g->cfg_prebin ||
-               g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc;
+               g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc ||
+               g->cfg_seen_order != g->cfg_order;
   bool points = false;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
@@ -2127,6 +2224,12 @@ int sxmc_group_set_bucketing(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_ordering(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_order = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
 int sxmc_group_set_runtime_kernels(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_rtc = enable ? 1 : 0;
@@ -2145,7 +2248,7 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
     std::snprintf(line, sizeof line,
                   "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d\n",
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
-                  c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
+                  c.shape.pre_width == 5 ? "ordered" : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
                   c.shape.grid, c.partition);
     text += line;
@@ -2434,6 +2537,7 @@ struct sxmc_multigroup {
   std::vector<sxmc_group*> groups;
   std::vector<void*> fill_fn;        // per launch of the plan: the lockstep kernel (hipFunction_t)
   std::vector<size_t> lds_bytes;
+  std::vector<unsigned> fill_w;          // the kernels' layout argument: words per histogram, or the ordered fill's replica layout
   std::vector<unsigned long long> seen;  // the groups' plan generations the kernels were chosen for
   std::string why_not;               // set when the chains cannot be stepped together
 };
@@ -2462,10 +2566,12 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
   if (get_props(props)) return false;
   mg->fill_fn.assign(g0->classes.size(), nullptr);
   mg->lds_bytes.assign(g0->classes.size(), 0);
+  mg->fill_w.assign(g0->classes.size(), 0u);
   for (size_t i = 0; i < g0->classes.size(); i++) {
     const LaunchClass& c0 = g0->classes[i];
-    if (!c0.shape.lds_hist || !c0.prog_simple || !(c0.shape.pre_width == 0 || c0.shape.pre_width == 3) ||
-        c0.shape.nobs == 0) {
+    if (!c0.shape.lds_hist || !c0.prog_simple ||
+        !(c0.shape.pre_width == 0 || c0.shape.pre_width == 3 || c0.shape.pre_width == 5) ||
+        (c0.shape.nobs == 0 && c0.shape.pre_width != 5)) {
       mg->why_not = "a launch of the plan has its histogram beyond LDS, a run-time decoded program or a pre-binned column";
       return false;
     }
@@ -2479,8 +2585,16 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
         return false;
       }
     }
-    const size_t hist_words = c0.shape.lds_bytes / 4 - 4 - 64;
-    const size_t lds = (4 + C * hist_words + 64) * 4;
+    size_t hist_words = c0.shape.lds_bytes / 4 - 4 - 64;
+    size_t lds = (4 + C * hist_words + 64) * 4;
+    if (c0.shape.pre_width == 5) {
+      // ordered fill: the kernel argument is the replica layout; as many replicas as fit beside the other chains'
+      const size_t rstride = c0.shape.lds_layout & 0xFFFFFFu;
+      unsigned rlog = 0;
+      while (rlog < 2 && (4 + (C * rstride << (rlog + 1)) + 64) * 4 <= (size_t)props.lds_per_cu) rlog++;
+      lds = (4 + (C * rstride << rlog) + 64) * 4;
+      hist_words = rstride | ((size_t)rlog << 24);
+    }
     if (lds > (size_t)props.lds_per_cu) {
       mg->why_not = "the chains' histograms do not fit LDS together";
       return false;
@@ -2500,6 +2614,7 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
       return false;
     }
     mg->lds_bytes[i] = lds;
+    mg->fill_w[i] = (unsigned)hist_words;
   }
   return true;
 }
@@ -2572,7 +2687,7 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
     const bool rec = g0->prof && !t_capturing && g0->prof_n < (int)g0->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g0->ev0[g0->prof_n], st));
     SX_HIP(sx_rtc_launch_multi(mg->fill_fn[i], c0.shape.grid, c0.shape.threads, mg->lds_bytes[i], ch, c0.d_segs,
-                               c0.d_blk_off, (unsigned)(c0.shape.lds_bytes / 4 - 4 - 64), st));
+                               c0.d_blk_off, mg->fill_w[i], st));
     if (rec) {
       SX_HIP(hipEventRecord(g0->ev1[g0->prof_n], st));
       g0->prof_n++;
@@ -2720,7 +2835,11 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
     if (const SampleStore::Bucketed* bk = i < g->member_bucket.size() ? g->member_bucket[i] : nullptr) {
       // bucketed table: the columns that change, for the samples inside the domain of the untouched observables,
       // + one word per granule
-      fr += (double)bk->nkept * 4.0 * (double)bk->fields.size() + (bk->runs > 1 ? 8.0 : 4.0) * (double)bk->ngranules;
+      // (ordered: that observable's column is needed only in the granules that straddle a bin edge -- which ones
+      // depends on the parameters; not counted -- and each granule has two end values besides its word)
+      const bool ord = bk->sort && bk->sort->ordered >= 0;
+      fr += (double)bk->nkept * 4.0 * (double)(bk->fields.size() - (ord ? 1 : 0)) +
+            (ord ? 12.0 : bk->runs > 1 ? 8.0 : 4.0) * (double)bk->ngranules;
     } else {
       fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
     }

@@ -430,6 +430,7 @@ def test_bucketed_table_gives_identical_histograms(nobs, nbins, systs, params, n
     sizes = [70001, 3, 123457, 0, 255, 257]
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=nfields)
     group = nll.EvalGroup(evs)
+    group.SetOrdering(False)           # plain bucketing here; tests/test_gpu_ordered.py covers the ordered form
     results = []
     for bucket, prebin in ((True, True), (False, True), (False, False)):
         group.SetBucketing(bucket)
@@ -472,6 +473,7 @@ def test_bucketed_table_edge_values():
         ev.SetParameterBuffer(pbuf)
         group = nll.EvalGroup([ev])
         group.SetBucketing(bucket)
+        group.SetOrdering(False)
         group.EvalAsync(False)
         group.EvalFinished()
         bins, nrm = oracle.bin_samples(geom, tab, 4, systs, np.array([0.013]))
@@ -610,12 +612,14 @@ def test_runtime_specialised_kernels_match_the_decoded_program_and_the_oracle(na
     sizes = [90001, 5, 40013]
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, params, nfields=nfields, lo=-0.1, hi=1.1)
     group = nll.EvalGroup(evs)
+    group.SetOrdering(False)           # (tests/test_gpu_ordered.py covers the ordered form; once below as well)
     info = group.LaunchInfo()
     assert "program=runtime" in info and "table=" + table_kind in info, info
     assert "failed" not in info, info
     results = []
-    for rtc in (True, False):
+    for rtc, order in ((True, False), (True, True), (False, False)):
         group.SetRuntimeKernels(rtc)
+        group.SetOrdering(order)
         group.EvalAsync(False)
         group.EvalFinished()
         results.append(([e.GetBins() for e in evs], norms.get()))
@@ -720,9 +724,11 @@ def test_random_programs_every_path_matches_the_oracle(seed):
     group = nll.EvalGroup(evs)
     want = [oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, systs, params, points=pts, dataset=j % 2)
             for j, t in enumerate(tabs)]
-    for bucket, rtc in ((True, True), (False, True), (True, False), (False, False)):
+    for bucket, rtc, order in ((True, True, True), (True, True, False), (False, True, False), (True, False, True),
+                               (False, False, False)):
         group.SetBucketing(bucket)
         group.SetRuntimeKernels(rtc)
+        group.SetOrdering(order)
         info = group.LaunchInfo()
         assert "failed" not in info, info
         lut.set(np.full(lut.size, 777.0, np.float32))
@@ -837,8 +843,8 @@ def test_optimize_keeps_results_and_only_acts_on_pure_streams():
     systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
              dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]
     params = [0.02, -0.01, 0.07]
-    sizes = [3000003] * 12                # 36e6 samples, half of them inside the untouched observable's domain,
-    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], systs, params, nfields=5)   # x 12 B: long
+    sizes = [4600003] * 12                # 55e6 samples, half of them inside the untouched observable's domain,
+    evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], systs, params, nfields=5)   # x 8 B: long
     group = nll.EvalGroup(evs)
     chosen = group.Optimize()
     assert chosen in (448, 512, 576, 640, 768)

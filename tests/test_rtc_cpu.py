@@ -21,6 +21,9 @@ def op(type_, obs_slot, extra_slot=0, npars=0):
     (2, 3, 0, 3, 1, [op(SHIFT, 1), op(SCALE, 0), op(RES, 0, 2)]),                      # C5: sparse counting over runs
     (2, 2, 1, 0, 0, [op(SHIFT, 0, 0, 3), op(SCALE, 1, 0, 2)]),                         # polynomials
     (5, 7, 0, 0, 0, []),                                                               # no systematics, 5-D
+    (1, 3, 1, 5, 0, [op(SHIFT, 2), op(SCALE, 0), op(RES, 0, 1)]),                      # C3 bucketed, r ordered
+    (0, 1, 1, 5, 0, [op(SHIFT, 0)]),                                                   # bench_pdfz ordered: nothing streamed
+    (2, 4, 1, 5, 0, [op(CTSCALE, 3), op(SCALE, 3), op(SCALE, 0), op(RES, 1, 2)]),      # two ops on the ordered observable
 ])
 def test_runtime_specialisation_compiles_without_a_gpu(nobs, nslot, lds, prew, runs, ops):
     lib = capi.load()
@@ -29,6 +32,13 @@ def test_runtime_specialisation_compiles_without_a_gpu(nobs, nslot, lds, prew, r
     rc = lib.sxmc_rtc_compile_check(nobs, nslot, lds, prew, runs, capi.ptr(arr), len(ops), C.byref(n))
     assert rc == 0, capi.last_error()
     assert n.value > 1000            # a gfx950 code object came out
+
+
+def test_ordered_kernel_refuses_a_systematic_that_is_not_monotone():
+    lib = capi.load()
+    arr = np.asarray([op(SHIFT, 1, 0, 2)], dtype=np.uint32)   # a 2-coefficient (polynomial) shift on the ordered slot
+    rc = lib.sxmc_rtc_compile_check(1, 2, 1, 5, 0, capi.ptr(arr), 1, None)
+    assert rc != 0 and "not a monotone systematic" in capi.last_error()
 
 
 def test_runtime_specialisation_reports_a_bad_shape():
@@ -42,6 +52,8 @@ def test_runtime_specialisation_reports_a_bad_shape():
     (2, 3, 3, 4, [op(SHIFT, 1), op(SCALE, 0), op(RES, 0, 2)]),        # config 3, bucketed, four chains per pass
     (2, 3, 0, 2, [op(SHIFT, 1), op(RES, 0, 2)]),                      # rows, two chains
     (1, 1, 3, 3, [op(SHIFT, 0, 0, 3)]),                               # a polynomial, three chains
+    (1, 3, 5, 4, [op(SHIFT, 2), op(SCALE, 0), op(RES, 0, 1)]),        # config 3 with r ordered, four chains
+    (0, 1, 5, 2, [op(SCALE, 0)]),                                     # one ordered observable alone, two chains
 ])
 def test_lockstep_kernel_compiles_without_a_gpu(nobs, nslot, prew, nchains, ops):
     lib = capi.load()
