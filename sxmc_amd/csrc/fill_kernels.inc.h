@@ -40,6 +40,13 @@ __device__ __forceinline__ gptr<T> to_global(T* p) {
 
 __device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// a * b + c on 24-bit operands in ONE instruction (the compiler splits __mul24(a, b) + c into a multiply and an add)
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // LDS word of histogram bin b in the swizzled layout of fill_ordered_body (an involution inside each 64-word block)
 __device__ __forceinline__ unsigned lds_slot(unsigned b) { return b ^ ((b >> 6) & 63u); }
 
@@ -1041,7 +1048,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   const unsigned nthreads = blockDim.x;
   const unsigned lane = tid & (kWave - 1);
   // LDS: words 0..3 the chains' in-domain counters, then per chain R replicas of the histogram, rstride words
-  // apart, then 64 trash words.  `layout` = rstride | log2(R) << 24.  Inside a granule only the observables
+  // apart (then 64 spare words).  `layout` = rstride | log2(R) << 24.  Inside a granule only the observables
   // binned per sample vary, so a wave's 64 updates go to a handful of bins, strided by the other observables'
   // strides: few banks, many lanes per word.  Two remedies: the word of bin b is b with its low six bits XORed
   // by the next six (bins a multiple of 64 apart land in different banks), and lane l updates replica l mod R
@@ -1050,7 +1057,6 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   unsigned* hist = lds + 4;
   const unsigned rstride = layout & 0xFFFFFFu, rlog = layout >> 24, R = 1u << rlog;
   const unsigned cstride = rstride << rlog;            // one chain's replicas
-  const unsigned trash = NCHAIN * cstride + lane;
   const unsigned myrep = (lane & (R - 1u)) * rstride;
 
   bool lds_clean = false;
@@ -1122,9 +1128,18 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       for (int q = 0; q < PROG::ncoef; q++) wild[c] = wild[c] || !(__builtin_fabs(craw[c][q]) < __builtin_inf());
     }
 
-    unsigned cnt[NCHAIN], codes[NCHAIN];
+    unsigned ncnt[NCHAIN], vcnt[NCHAIN], codes[NCHAIN];   // (ncnt: wave-uniform part of the in-domain count)
 #pragma unroll
-    for (int c = 0; c < NCHAIN; c++) cnt[c] = codes[c] = 0u;
+    for (int c = 0; c < NCHAIN; c++) ncnt[c] = vcnt[c] = codes[c] = 0u;
+    unsigned sink = 0u;                     // keeps the loads alive in the stream-only debug mode
+    // the strides in vector registers (an integer multiply-add takes one scalar operand, and the base is one)
+    int stv[NG], ostv = ost;
+#pragma unroll
+    for (int k = 0; k < NOBS; k++) {
+      stv[k] = st[k];
+      asm volatile("" : "+v"(stv[k]));
+    }
+    asm volatile("" : "+v"(ostv));
 
     unsigned long long v = vfirst;
     const unsigned long long niter = (v1 - v0 + step - 1) / step;
@@ -1183,9 +1198,9 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
 #pragma unroll
         for (int k = 0; k < NSTREAM; k++) {
 #pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) cnt[0] += (f0[k][q] == 12345.678) ? 1u : 0u;
+          for (int q = 0; q < SXMC_VEC; q++) sink += (f0[k][q] == 12345.678) ? 1u : 0u;
         }
-        cnt[0] += (prebits == 12345u) ? 1u : 0u;
+        sink += (prebits == 12345u) ? 1u : 0u;
         continue;
       }
       const unsigned off = prebits & 0xFFFFFFu, nvalid = (prebits >> 24) + 1u;
@@ -1198,8 +1213,8 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
           if (!mixed) {
             // nothing varies inside the granule: all its rows go to one bin
             const unsigned bin = off + code[c];
+            ncnt[c] += nvalid;
             if (lane == 0) {
-              cnt[c] += nvalid;
               if (bin < B && !(dbg & 4u)) {
                 __hip_atomic_fetch_add(&hist[(unsigned)c * cstride + lds_slot(bin)], nvalid, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1216,46 +1231,59 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
         }
         f[ORD][0] = f[ORD][1] = f[ORD][2] = f[ORD][3] = 0.0;
         run_static_part<NSLOT, ORD, false>(f, craw[c], PROG{}, Seq{});
+        // The per-sample part, written for the vector unit's instruction count (what bounds several chains in
+        // one pass): the domain tests are compares into scalar mask registers, combined and counted (popcount)
+        // on the scalar unit; the histogram update runs under that mask.  pdfz.cpp:388-398.
+        auto samples = [&](auto MIXED) {
+          constexpr bool kMixed = decltype(MIXED)::value != 0;
+          int base = (int)(off + (kMixed ? 0u : code[c]));
+          asm volatile("" : "+v"(base));   // (in a vector register: idx * stride + base is then one multiply-add)
+          const unsigned cbase = (unsigned)c * cstride + myrep;
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            bool ind = true;
+            int bin = base;
+#pragma unroll
+            for (int k = 0; k < NOBS; k++) {
+              const double x = f[k][q];
+              ind = ind & (x >= lo[k]) & (x < hi[k]);      // (NaN fails)
+              const int idx = (int)((x - lo[k]) * sc[k]);
+              bin = mad24(idx, stv[k], bin);
+            }
+            if constexpr (kMixed) {
+              const double x = f[ORD][q];
+              ind = ind & (x >= olo) & (x < ohi);
+              const int idx = (int)((x - olo) * osc);
+              bin = mad24(idx, ostv, bin);
+            }
+            vcnt[c] += ind ? 1u : 0u;                      // (an add-with-carry straight from the compare mask)
+            // in domain but index out of range (the reference's one-past-the-end case) still counts in the norm
+            if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
+              __hip_atomic_fetch_add(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        };
         if (mixed) {   // (the wait for the extra column sits in here, off the common path)
           f[ORD][0] = (double)rawo.x;
           f[ORD][1] = (double)rawo.y;
           f[ORD][2] = (double)rawo.z;
           f[ORD][3] = (double)rawo.w;
           run_static_part<NSLOT, ORD, true>(f, craw[c], PROG{}, Seq{});
-        }
-#pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) {
-          unsigned bad = 0u;
-          int bin = (int)(off + (mixed ? 0u : code[c]));
-#pragma unroll
-          for (int k = 0; k < NOBS; k++) {
-            const double x = f[k][q];
-            bad += !(x >= lo[k]) ? 1u : 0u;
-            bad += !(x < hi[k]) ? 1u : 0u;
-            const int idx = (int)((x - lo[k]) * sc[k]);
-            bin = __mul24(idx, st[k]) + bin;
-          }
-          if (mixed) {
-            const double x = f[ORD][q];
-            bad += !(x >= olo) ? 1u : 0u;
-            bad += !(x < ohi) ? 1u : 0u;
-            const int idx = (int)((x - olo) * osc);
-            bin = __mul24(idx, ost) + bin;
-          }
-          const unsigned in_domain = (bad == 0u) ? 1u : 0u;
-          cnt[c] += in_domain;
-          const bool store = (bad == 0u) && ((unsigned)bin < B) && !(dbg & 4u);
-          const unsigned slot = store ? (unsigned)c * cstride + myrep + lds_slot((unsigned)bin) : trash;
-          __hip_atomic_fetch_add(&hist[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          samples(IntC<1>{});
+        } else {
+          samples(IntC<0>{});
         }
       }
     }
 
+    // in-domain counts: lane registers -> wave -> workgroup
 #pragma unroll
     for (int c = 0; c < NCHAIN; c++) {
-      unsigned t = cnt[c];
+      unsigned t = vcnt[c] + ((dbg & 1u) ? sink : 0u);
 #pragma unroll
       for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off, kWave);
+      t += ncnt[c];
       if (lane == 0 && t != 0u) {
         __hip_atomic_fetch_add(&s_norm[c], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
