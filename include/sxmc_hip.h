@@ -242,7 +242,11 @@ int sxmc_group_set_bucketing(sxmc_group_t g, int enable);
  * Any NaN (sample value or coefficient) sends a granule down the per-sample path.  BASELINE config 3 streams
  * 8 bytes per sample instead of 12; a 1-D histogram with one shift (bench_sxmc pdfz) streams 12 bytes per 256
  * samples.  Histograms, norms and NLL stay bit-identical (parity tests: on/off, the CPU restatement, samples
- * placed within ulps of the bin edges).  Of several eligible observables the one with the fewest bins is taken. */
+ * placed within ulps of the bin edges).  Of several eligible observables the one with the fewest bins is taken.
+ * enable = 1 (default): where it pays -- the table must have at least twice as many granules as can straddle an edge
+ * (buckets x (nbins + 1)); BASELINE config 5 with its 200 bins of r and 61 granules per bucket does not qualify and
+ * keeps the unordered bucketed table.  enable = 2: wherever it applies (tests).  Histograms beyond LDS capacity: the
+ * sparse counting over runs and the dense evaluation have ordered forms too (run-time compiled). */
 int sxmc_group_set_ordering(sxmc_group_t g, int enable);
 /* Run-time kernels (default on).  The fill is fastest as straight-line code with the program of systematics
  * (apply_systematic, pdfz.cpp:306-331: which systematic writes which column, in which order, with how many

@@ -601,6 +601,56 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
   }
 }
 
+// ORDERED OBSERVABLE (PREW = kPreOrdered).  Bucketing taken one step further, to an observable that IS written --
+// but only by one-coefficient shift / scale / cos-theta-scale systematics and read by nothing else.  Each of those
+// is a monotone map of the sample's value for the evaluation's parameters (IEEE addition and multiplication by a
+// constant round monotonically), and so is the binning that follows: along rows sorted by the raw value the
+// observable's "extended bin" (-1 below the domain, the index inside, a large value at or above the upper edge)
+// is a step function.  The bucketed copy keeps the rows of each bucket in that order; a 256-row granule whose
+// first and last row land in the same extended bin has every row there, so the observable's contribution to the
+// flat index is one constant for the granule -- computed per evaluation from the two end values, with exactly the
+// per-sample arithmetic -- and its column is not read at all.  Only granules that straddle a bin edge ("mixed":
+// at most nbins + 1 per bucket) take the per-sample path over the column; granules entirely outside the domain
+// are skipped.  NaN anywhere (a NaN end value or coefficient) makes a granule mixed: the per-sample path decides,
+// as it always has.  Counts are integers and every sample is binned by the same arithmetic or by an argument
+// about that arithmetic, so the histograms stay bit-identical (tests: every ordered case against the unordered
+// evaluation and the CPU restatement, samples placed within ulps of the edges).
+//
+// Slots: 0 .. NOBS-1 the observables binned per sample, NOBS .. NSLOT-2 fields that are only read, NSLOT-1 the
+// ordered observable's column (geometry at index NOBS of the descriptor's arrays).  Granule word `pre`:
+// bits 0-23 the bucket's bin offset, bits 24-31 rows in the granule - 1.  Lane l of a wave works out the codes of
+// the wave's next 64 granules in one go (one 8-byte read per granule), each step then takes its own with
+// v_readlane: scalar from there on.  NCHAIN > 1: lockstep chains (see fill_multi_body), each with its own codes.
+// The kernel itself (fill_ordered_body) follows fill_multi_body below; fill_sparse_body has an ORDERED variant.
+constexpr int kPreOrdered = 5;
+constexpr unsigned kOrdMixed = 0xFFFFFFFEu, kOrdSkip = 0xFFFFFFFFu;
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
+
+template <unsigned OPC>
+__device__ __forceinline__ void apply_ordered_scalar(double& x, const double* c) {
+  constexpr int type = (int)(OPC & 15u);
+  static_assert(sx_op_npars(OPC) == 1 && (type == SXMC_SYST_SHIFT || type == SXMC_SYST_SCALE || type == SXMC_SYST_CTSCALE),
+                "not a monotone systematic");
+  const double pc = 0.0 + c[0] * 1.0;   // (as apply_static)
+  if constexpr (type == SXMC_SYST_SHIFT) x = x + pc;
+  if constexpr (type == SXMC_SYST_SCALE) x = x * (1 + pc);
+  if constexpr (type == SXMC_SYST_CTSCALE) x = 1 + (x - 1) * (1 + pc);
+}
+// the systematics of the program that write slot ORD, on one value
+template <int ORD, unsigned... OPS, unsigned long... I>
+__device__ __forceinline__ void run_ordered_scalar(double& x, const double* c, StaticProg<OPS...>, ISeq<I...>) {
+  ([&] {
+    if constexpr ((int)((OPS >> 4) & 15u) == ORD) apply_ordered_scalar<OPS>(x, c + sx_prog_cstart<OPS...>((int)I));
+  }(), ...);
+}
+// the systematics that write slot ORD (WANT) or the others (!WANT), on the lane's samples
+template <int NSLOT, int ORD, bool WANT, unsigned... OPS, unsigned long... I>
+__device__ __forceinline__ void run_static_part(double (&f)[NSLOT][SXMC_VEC], const double* c, StaticProg<OPS...>,
+                                                ISeq<I...>) {
+  ([&] {
+    if constexpr (((int)((OPS >> 4) & 15u) == ORD) == WANT) apply_static<NSLOT, OPS>(f, c + sx_prog_cstart<OPS...>((int)I));
+  }(), ...);
+}
 // SPARSE COUNTING OVER A BUCKETED TABLE, WALKED IN RUNS.  Histograms beyond LDS capacity, evaluated for lookup
 // (BASELINE config 5).  The table is bucketed (layout_kernels.hip) and laid out so that every WAVE walks its own
 // run of consecutive granules of the sorted order: a wave stays inside one bucket -- one tuple of bin indices of
@@ -617,11 +667,17 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
 typedef unsigned vuint2g __attribute__((ext_vector_type(2)));
 typedef unsigned vuint4g __attribute__((ext_vector_type(4)));
 
-template <int NOBS, int NSLOT, typename PROG>
+template <int NOBS, int NSLOT, typename PROG, bool ORDERED = false>
 __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict__ descs,
                                                  const SxSegment* __restrict__ segs,
                                                  const unsigned* __restrict__ blk_off, unsigned smax, unsigned dbg) {
   static_assert(!PROG::dynamic, "static programs only");
+  // ORDERED: the table's last slot is an ordered observable (see fill_ordered_body further down): its index
+  // contribution is one constant per granule, worked out from the granule's end values, except in the granules
+  // that straddle one of its bin edges; geometry at index NOBS of the descriptor's arrays
+  static_assert(!ORDERED || (NOBS >= 1 && NOBS < NSLOT), "unsupported");
+  constexpr int ORD = NSLOT - 1, NSTREAM = ORDERED ? NSLOT - 1 : NSLOT;
+  typedef typename MakeISeq<PROG::n>::type Seq;
   extern __shared__ unsigned lds[];
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & (kWave - 1);
@@ -661,7 +717,7 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
     vuint2g kp;
     auto load = [&](unsigned long long v) {
 #pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
+      for (int k = 0; k < NSTREAM; k++) {
         raw[k] = __builtin_nontemporal_load(&col[k][v]);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -683,6 +739,17 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
       nb[k] = (unsigned)d.nbins[k];
     }
 
+    // ordered observable: geometry, and the codes of the wave's next 64 granules (one per lane)
+    const double olo = d.lower[ORDERED ? NOBS : 0], ohi = d.upper[ORDERED ? NOBS : 0], osc = d.scale[ORDERED ? NOBS : 0];
+    const int osth = d.bin_stride[ORDERED ? NOBS : 0] >> 12, ostl = d.bin_stride[ORDERED ? NOBS : 0] & 4095;
+    const unsigned onb = (unsigned)d.nbins[ORDERED ? NOBS : 0];
+    gptr<const vfloat2> edges = to_global(reinterpret_cast<const vfloat2*>(d.edges));
+    const unsigned long long vwave = v0 + (tid - lane);
+    bool wild = false;
+#pragma unroll
+    for (int q = 0; q < PROG::ncoef; q++) wild = wild || !(__builtin_fabs(craw[q]) < __builtin_inf());
+    unsigned codes = 0u;
+
     unsigned cnt = 0;
     // the bucket this wave is in: its table sits in wkeys[0 .. 1 << cur_log2), counts in wcnt
     unsigned cur_key = 0xFFFFFFFFu, cur_off = 0u, cur_info = SXMC_SPARSE_EMPTY, cur_probes = 1u;
@@ -703,9 +770,32 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
     unsigned long long v = vfirst;
     const unsigned long long niter = (v1 - v0 + step - 1) / step;
     for (unsigned long long it = 0; it < niter; ++it, v += step) {
+      unsigned code = 0u;
+      if constexpr (ORDERED) {
+        const int j = (int)(it & 63ull);
+        if (j == 0) {
+          const unsigned long long vg = vwave + (it + lane) * step;
+          const bool live = vg < v1;
+          const vfloat2 e = edges[(live ? vg : vlast) >> 6];
+          double x0 = (double)e.x, x1 = (double)e.y;
+          run_ordered_scalar<ORD>(x0, craw, PROG{}, Seq{});
+          run_ordered_scalar<ORD>(x1, craw, PROG{}, Seq{});
+          const bool nan = wild || !(x0 == x0) || !(x1 == x1);
+          const int i0 = (int)((x0 - olo) * osc), i1 = (int)((x1 - olo) * osc);
+          const int e0 = !(x0 >= olo) ? -1 : (!(x0 < ohi) ? 0x7FFFFFFF : i0);
+          const int e1 = !(x1 >= olo) ? -1 : (!(x1 < ohi) ? 0x7FFFFFFF : i1);
+          const bool outside = e0 < 0 || e0 == 0x7FFFFFFF;
+          // (an index equal to nbins -- one ulp below the upper edge -- aliases into the next row of the flat
+          // index: such granules take the per-sample path, which knows how to deal with it)
+          const bool mixedg = nan || e0 != e1 || (!outside && (unsigned)e0 >= onb);
+          const unsigned cst = (unsigned)((__mul24(e0, osth) << 12) + __mul24(e0, ostl));
+          codes = !live ? kOrdSkip : mixedg ? kOrdMixed : outside ? kOrdSkip : cst;
+        }
+        code = (unsigned)__builtin_amdgcn_readlane((int)codes, j);
+      }
       double f[NSLOT][SXMC_VEC];
 #pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
+      for (int k = 0; k < NSTREAM; k++) {
         f[k][0] = (double)raw[k].x;
         f[k][1] = (double)raw[k].y;
         f[k][2] = (double)raw[k].z;
@@ -720,20 +810,27 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
       cur_info = (unsigned)uniform_i((int)cur_info);
       cur_probes = (unsigned)uniform_i((int)cur_probes);
 #pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
+      for (int k = 0; k < NSTREAM; k++) {
 #pragma unroll
         for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f[k][q]));
+      }
+      const bool mixed = ORDERED && code == kOrdMixed;
+      vfloat4 rawo = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (mixed) {   // a granule that straddles a bin edge of the ordered observable: its column too, this once
+        rawo = __builtin_nontemporal_load(&col[ORD][v < v1 ? v : vlast]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       const unsigned long long vl = v + step;
       load(vl < v1 ? vl : vlast);
       if (dbg & 1u) {
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) {
+        for (int k = 0; k < NSTREAM; k++) {
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) cnt += (f[k][q] == 12345.678) ? 1u : 0u;
         }
         continue;
       }
+      if (ORDERED && code == kOrdSkip) continue;   // (wave-uniform) the whole granule is outside the domain
 
       // ---- a new bucket: counts of the old one go to the global counters, the new table comes into LDS
       if (key != cur_key) {
@@ -750,7 +847,19 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
         }
       }
 
-      run_static<NSLOT>(f, craw, PROG{}, typename MakeISeq<PROG::n>::type{});
+      if constexpr (ORDERED) {
+        f[ORD][0] = f[ORD][1] = f[ORD][2] = f[ORD][3] = 0.0;
+        run_static_part<NSLOT, ORD, false>(f, craw, PROG{}, Seq{});
+        if (mixed) {
+          f[ORD][0] = (double)rawo.x;
+          f[ORD][1] = (double)rawo.y;
+          f[ORD][2] = (double)rawo.z;
+          f[ORD][3] = (double)rawo.w;
+          run_static_part<NSLOT, ORD, true>(f, craw, PROG{}, Seq{});
+        }
+      } else {
+        run_static<NSLOT>(f, craw, PROG{}, Seq{});
+      }
 
       const unsigned dead = (v < v1) ? 0u : 1u;
       unsigned p2[SXMC_VEC];
@@ -760,7 +869,15 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
         unsigned bad = dead, alias = 0u;
-        int bin = 0;
+        int bin = (ORDERED && !mixed) ? (int)code : 0;
+        if (mixed) {
+          const double x = f[ORD][q];
+          bad += !(x >= olo) ? 1u : 0u;
+          bad += !(x < ohi) ? 1u : 0u;
+          const int idx = (int)((x - olo) * osc);
+          alias += ((unsigned)idx >= onb) ? 1u : 0u;
+          bin += (__mul24(idx, osth) << 12) + __mul24(idx, ostl);
+        }
 #pragma unroll
         for (int k = 0; k < NOBS; k++) {
           const double x = f[k][q];
@@ -985,60 +1102,15 @@ __device__ __forceinline__ void fill_multi_body(SxChainDescs chains, const SxSeg
   }
 }
 
-// ORDERED OBSERVABLE (PREW = kPreOrdered).  Bucketing taken one step further, to an observable that IS written --
-// but only by one-coefficient shift / scale / cos-theta-scale systematics and read by nothing else.  Each of those
-// is a monotone map of the sample's value for the evaluation's parameters (IEEE addition and multiplication by a
-// constant round monotonically), and so is the binning that follows: along rows sorted by the raw value the
-// observable's "extended bin" (-1 below the domain, the index inside, a large value at or above the upper edge)
-// is a step function.  The bucketed copy keeps the rows of each bucket in that order; a 256-row granule whose
-// first and last row land in the same extended bin has every row there, so the observable's contribution to the
-// flat index is one constant for the granule -- computed per evaluation from the two end values, with exactly the
-// per-sample arithmetic -- and its column is not read at all.  Only granules that straddle a bin edge ("mixed":
-// at most nbins + 1 per bucket) take the per-sample path over the column; granules entirely outside the domain
-// are skipped.  NaN anywhere (a NaN end value or coefficient) makes a granule mixed: the per-sample path decides,
-// as it always has.  Counts are integers and every sample is binned by the same arithmetic or by an argument
-// about that arithmetic, so the histograms stay bit-identical (tests: every ordered case against the unordered
-// evaluation and the CPU restatement, samples placed within ulps of the edges).
-//
-// Slots: 0 .. NOBS-1 the observables binned per sample, NOBS .. NSLOT-2 fields that are only read, NSLOT-1 the
-// ordered observable's column (geometry at index NOBS of the descriptor's arrays).  Granule word `pre`:
-// bits 0-23 the bucket's bin offset, bits 24-31 rows in the granule - 1.  Lane l of a wave works out the codes of
-// the wave's next 64 granules in one go (one 8-byte read per granule), each step then takes its own with
-// v_readlane: scalar from there on.  NCHAIN > 1: lockstep chains (see fill_multi_body), each with its own codes.
-constexpr int kPreOrdered = 5;
-constexpr unsigned kOrdMixed = 0xFFFFFFFEu, kOrdSkip = 0xFFFFFFFFu;
-typedef float vfloat2 __attribute__((ext_vector_type(2)));
-
-template <unsigned OPC>
-__device__ __forceinline__ void apply_ordered_scalar(double& x, const double* c) {
-  constexpr int type = (int)(OPC & 15u);
-  static_assert(sx_op_npars(OPC) == 1 && (type == SXMC_SYST_SHIFT || type == SXMC_SYST_SCALE || type == SXMC_SYST_CTSCALE),
-                "not a monotone systematic");
-  const double pc = 0.0 + c[0] * 1.0;   // (as apply_static)
-  if constexpr (type == SXMC_SYST_SHIFT) x = x + pc;
-  if constexpr (type == SXMC_SYST_SCALE) x = x * (1 + pc);
-  if constexpr (type == SXMC_SYST_CTSCALE) x = 1 + (x - 1) * (1 + pc);
-}
-// the systematics of the program that write slot ORD, on one value
-template <int ORD, unsigned... OPS, unsigned long... I>
-__device__ __forceinline__ void run_ordered_scalar(double& x, const double* c, StaticProg<OPS...>, ISeq<I...>) {
-  ([&] {
-    if constexpr ((int)((OPS >> 4) & 15u) == ORD) apply_ordered_scalar<OPS>(x, c + sx_prog_cstart<OPS...>((int)I));
-  }(), ...);
-}
-// the systematics that write slot ORD (WANT) or the others (!WANT), on the lane's samples
-template <int NSLOT, int ORD, bool WANT, unsigned... OPS, unsigned long... I>
-__device__ __forceinline__ void run_static_part(double (&f)[NSLOT][SXMC_VEC], const double* c, StaticProg<OPS...>,
-                                                ISeq<I...>) {
-  ([&] {
-    if constexpr (((int)((OPS >> 4) & 15u) == ORD) == WANT) apply_static<NSLOT, OPS>(f, c + sx_prog_cstart<OPS...>((int)I));
-  }(), ...);
-}
-template <int NOBS, int NSLOT, typename PROG, int NCHAIN>
+template <int NOBS, int NSLOT, typename PROG, int NCHAIN, bool LDS_HIST = true>
 __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxSegment* __restrict__ segs,
                                                   const unsigned* __restrict__ blk_off, unsigned layout,
                                                   unsigned dbg) {
   static_assert(!PROG::dynamic && NSLOT >= 1 && NOBS >= 0 && NOBS < NSLOT && NCHAIN >= 1 && NCHAIN <= 4, "unsupported");
+  // LDS_HIST false: a histogram beyond LDS capacity, one global atomic per counted sample (the dense evaluation of
+  // such a table: CreateHistogram; evaluations for lookup run fill_sparse_body); the granule word is then the
+  // bucket's whole 32-bit bin offset, so a granule's row count is not available: NOBS >= 1
+  static_assert(LDS_HIST || (NCHAIN == 1 && NOBS >= 1), "unsupported");
   constexpr int ORD = NSLOT - 1;       // the ordered observable's column
   constexpr int NSTREAM = NSLOT - 1;   // columns every granule streams
   constexpr int NG = NOBS > 0 ? NOBS : 1, NS = NSTREAM > 0 ? NSTREAM : 1, NC = PROG::ncoef > 0 ? PROG::ncoef : 1;
@@ -1068,6 +1140,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     const unsigned long long v1 = sg.v1;
     const unsigned long long step = sg.step;
     const unsigned B = (unsigned)d.total_nbins;
+    gptr<unsigned> gbins0 = to_global(d.bins);
 
     double craw[NCHAIN][NC];
 #pragma unroll
@@ -1103,7 +1176,9 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     load(vfirst < v1 ? vfirst : vlast);
 
     if (!lds_clean) {
-      for (unsigned b = tid; b < NCHAIN * cstride; b += nthreads) hist[b] = 0u;
+      if (LDS_HIST) {
+        for (unsigned b = tid; b < NCHAIN * cstride; b += nthreads) hist[b] = 0u;
+      }
       if (tid < 4) s_norm[tid] = 0u;
       __syncthreads();
     }
@@ -1160,7 +1235,8 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
           const int e0 = !(x0 >= olo) ? -1 : (!(x0 < ohi) ? 0x7FFFFFFF : i0);
           const int e1 = !(x1 >= olo) ? -1 : (!(x1 < ohi) ? 0x7FFFFFFF : i1);
           unsigned code = (nan || e0 != e1) ? kOrdMixed
-                                            : ((e0 < 0 || e0 == 0x7FFFFFFF) ? kOrdSkip : (unsigned)__mul24(e0, ost));
+                          : ((e0 < 0 || e0 == 0x7FFFFFFF) ? kOrdSkip
+                                                         : (unsigned)(LDS_HIST ? __mul24(e0, ost) : e0 * ost));
           codes[c] = live ? code : kOrdSkip;
         }
       }
@@ -1203,7 +1279,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
         sink += (prebits == 12345u) ? 1u : 0u;
         continue;
       }
-      const unsigned off = prebits & 0xFFFFFFu, nvalid = (prebits >> 24) + 1u;
+      const unsigned off = LDS_HIST ? prebits & 0xFFFFFFu : prebits, nvalid = (prebits >> 24) + 1u;
 
 #pragma unroll
       for (int c = 0; c < NCHAIN; c++) {
@@ -1248,19 +1324,23 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
               const double x = f[k][q];
               ind = ind & (x >= lo[k]) & (x < hi[k]);      // (NaN fails)
               const int idx = (int)((x - lo[k]) * sc[k]);
-              bin = mad24(idx, stv[k], bin);
+              bin = LDS_HIST ? mad24(idx, stv[k], bin) : idx * stv[k] + bin;
             }
             if constexpr (kMixed) {
               const double x = f[ORD][q];
               ind = ind & (x >= olo) & (x < ohi);
               const int idx = (int)((x - olo) * osc);
-              bin = mad24(idx, ostv, bin);
+              bin = LDS_HIST ? mad24(idx, ostv, bin) : idx * ostv + bin;
             }
             vcnt[c] += ind ? 1u : 0u;                      // (an add-with-carry straight from the compare mask)
             // in domain but index out of range (the reference's one-past-the-end case) still counts in the norm
             if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
-              __hip_atomic_fetch_add(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+              if constexpr (LDS_HIST) {
+                __hip_atomic_fetch_add(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+              } else {
+                __hip_atomic_fetch_add(&gbins0[(unsigned)bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
             }
           }
         };
@@ -1293,7 +1373,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     for (int c = 0; c < NCHAIN; c++) {
       const SxSignalDesc& dc = chains.d[c][sg.sig];
       gptr<unsigned> gbins = to_global(dc.bins);
-      for (unsigned w = tid; w < ((B + 63u) & ~63u); w += nthreads) {
+      for (unsigned w = tid; LDS_HIST && w < ((B + 63u) & ~63u); w += nthreads) {
         unsigned n = 0u;
         for (unsigned r = 0; r < R; r++) {
           const unsigned at = (unsigned)c * cstride + r * rstride + w;
@@ -1331,14 +1411,14 @@ __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* _
   fill_sparse_body<NOBS, NSLOT, PROG>(descs, segs, blk_off, smax, dbg);
 }
 
-template <int NOBS, int NSLOT, typename PROG>
+template <int NOBS, int NSLOT, typename PROG, bool LDS_HIST = true>
 __global__ __launch_bounds__(1024) void fill_ordered_kernel(const SxSignalDesc* __restrict__ descs,
                                                             const SxSegment* __restrict__ segs,
                                                             const unsigned* __restrict__ blk_off, unsigned layout,
                                                             unsigned dbg) {
   SxChainDescs one;
   one.d[0] = one.d[1] = one.d[2] = one.d[3] = descs;
-  fill_ordered_body<NOBS, NSLOT, PROG, 1>(one, segs, blk_off, layout, dbg);
+  fill_ordered_body<NOBS, NSLOT, PROG, 1, LDS_HIST>(one, segs, blk_off, layout, dbg);
 }
 
 }  // namespace sxfill

@@ -365,6 +365,7 @@ struct sxmc_group {
   int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
   int cfg_prebin = 1, cfg_seen_prebin = -1;        // pre-bin the observables no systematic writes
   int cfg_bucket = 1, cfg_seen_bucket = -1;        // stream a bucketed copy of the table where that pays
+  bool order_blocked = false;                      // a plan with ordered tables beyond LDS could not be laid out in runs
   int cfg_order = 1, cfg_seen_order = -1;          // ... with the rows of a bucket ordered by a monotonically written observable
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
@@ -697,7 +698,8 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
     *out = have;
     return SXMC_OK;
   }
-  SX_REQUIRE(!fields.empty() && runs >= 1 && (bs->ordered < 0 || runs == 1), "bad bucketed layout request");
+  SX_REQUIRE(!fields.empty() && runs >= 1, "bad bucketed layout request");
+  const bool pack_rows = bs->ordered >= 0 && h->total_nbins <= kLdsMaxBins;   // (fill_ordered_body, histogram in LDS)
   st.bucketed.push_back(std::make_unique<SampleStore::Bucketed>());
   SampleStore::Bucketed* b = st.bucketed.back().get();
   b->mask = bs->mask;
@@ -715,7 +717,7 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
       pvalid[p] = bs->lvalid[l];
       ppre[p] = bs->key_pre[bs->lwhich[l]];
       // (ordered tables: histograms in LDS, so the offset is below 2^24 and the row count rides in the top byte)
-      if (bs->ordered >= 0) ppre[p] |= (bs->lvalid[l] - 1u) << 24;
+      if (pack_rows) ppre[p] |= (bs->lvalid[l] - 1u) << 24;
       pkp[2 * p] = bs->keys[bs->lwhich[l]];
     } else {  // padding granule at the end of the last runs: no samples, stays in the last bucket
       pkp[2 * p] = L ? bs->keys[bs->lwhich[L - 1]] : outside;
@@ -950,8 +952,8 @@ int group_rebuild(sxmc_group* g) {
     auto have_kernel = [&](int nobs_, int nslot_, int prew, int runs, const std::vector<unsigned>& words, int sp,
                            void** fn) {
       *fn = nullptr;
-      if (prew == 5) {   // (sp: index into the ordered programs built in)
-        if (sp >= 0) return true;
+      if (prew == 5) {   // (sp: index into the ordered programs built in: histograms in LDS, no runs)
+        if (sp >= 0 && lds_hist && !runs) return true;
       } else if (runs ? sx_fill_static_supports_sparse_runs(sp) : sx_fill_static_supports(sp, lds_hist, prew)) {
         return true;
       }
@@ -1009,7 +1011,8 @@ int group_rebuild(sxmc_group* g) {
         keep[(size_t)ordered] = (int)fields.size();
         fields.push_back(d.slot_col[ordered]);
       }
-      const bool shape_ok = ordered >= 0 ? (nobs2 <= 5 && fields.size() <= 7)
+      // (beyond LDS the granule word has no room for the row count: something must be binned per sample)
+      const bool shape_ok = ordered >= 0 ? (nobs2 <= 5 && fields.size() <= 7 && (lds_hist || nobs2 >= 1))
                                          : (mask && nobs2 >= 1 && sx_fill_has_specialization(nobs2, (int)fields.size()));
       if (!shape_ok) return SXMC_OK;
       SxSignalDesc cd;
@@ -1033,8 +1036,8 @@ int group_rebuild(sxmc_group* g) {
       // histograms beyond LDS, evaluated at data events: per-wave runs + event bins grouped by bucket
       bool narrow = true;   // (the runs kernel forms idx * stride from 24-bit products)
       for (int k = 0; k < h->nobs; k++) narrow = narrow && h->nbins[(size_t)k] < (1 << 23);
-      runs_mode = ordered < 0 && !lds_hist && narrow && h->has_points && h->d_table &&
-                  have_kernel(cd.nobs, cd.nslot, 3, 1, prog2, sp, &rtc_sparse);
+      runs_mode = !lds_hist && narrow && h->has_points && h->d_table &&
+                  have_kernel(cd.nobs, cd.nslot, prew, 1, prog2, sp, &rtc_sparse);
       if (runs_mode) {
         rc2 = build_bucket_tables(h, bs);
         if (rc2) return rc2;
@@ -1052,7 +1055,12 @@ int group_rebuild(sxmc_group* g) {
       // the ordered observable: written by one-coefficient shift / scale / cos-theta scale only and read by
       // nothing; of several, the one with the fewest bins (fewest granules that straddle an edge)
       int ordered = -1;
-      if (g->cfg_order && lds_hist && h->total_nbins < (1 << 24)) {
+      // (a histogram beyond LDS: only with the event-bin counters over runs; the round-1 filter path of a table
+      // left in sorted order has no ordered form)
+      bool narrow_o = true;
+      for (int k = 0; k < h->nobs; k++) narrow_o = narrow_o && h->nbins[(size_t)k] < (1 << 23);
+      const bool beyond_ok = !lds_hist && !g->order_blocked && narrow_o && h->has_points && h->d_table && n <= props.cus;
+      if (g->cfg_order && ((lds_hist && h->total_nbins < (1 << 24)) || beyond_ok)) {
         for (int k = 0; k < d.nobs; k++) {
           bool written = false, ok = true;
           for (int q = 0; q < d.nsyst; q++) {
@@ -1066,10 +1074,29 @@ int group_rebuild(sxmc_group* g) {
           }
           if (written && ok && (ordered < 0 || h->nbins[(size_t)k] < h->nbins[(size_t)ordered])) ordered = k;
         }
+        // Does it pay?  Up to nbins + 1 granules per bucket straddle an edge and stream everything; with fewer
+        // than twice that many granules in all, most do (BASELINE config 5: 61 granules per bucket against 200
+        // bins of r) and the ordered form only adds work.  cfg_order == 2 (tests): wherever it applies.
+        if (ordered >= 0 && g->cfg_order == 1) {
+          double buckets = 1.0;
+          for (int k = 0; k < d.nobs; k++) {
+            bool written = false;
+            for (int q = 0; q < d.nsyst; q++) written = written || d.syst[q].obs_slot == k;
+            if (!written) buckets *= (double)h->nbins[(size_t)k];
+          }
+          const double straddling = buckets * ((double)h->nbins[(size_t)ordered] + 1.0);
+          if ((double)h->nsamples / 256.0 < 2.0 * straddling) ordered = -1;
+        }
       }
       if (ordered >= 0) {
         rc = try_bucket(ordered);
         if (rc) return rc;
+        if (bucketed && !lds_hist && !runs_mode) {   // (no kernel for the runs: the unordered layout has the filter path)
+          bucketed = false;
+          rtc_fill = rtc_sparse = nullptr;
+          fill_descs[(size_t)i] = d;
+          plans[(size_t)i] = BucketPlan{};
+        }
       }
       if (!bucketed) {
         rc = try_bucket(-1);
@@ -1178,7 +1205,7 @@ int group_rebuild(sxmc_group* g) {
       cls_nsyst = std::max(cls_nsyst, g->h_descs[(size_t)idx].nsyst);
     }
     c.shape.lds_bytes = c.shape.lds_hist ? ((size_t)cls_max_bins + 4 + 64) * 4 : 64;
-    if (ordered) c.shape.lds_bytes = ordered_lds_bytes(cls_max_bins, 1, 0);   // (replicas: once the shape is known)
+    if (ordered && c.shape.lds_hist) c.shape.lds_bytes = ordered_lds_bytes(cls_max_bins, 1, 0);   // (replicas: below)
     c.shape.sparse_runs = 0;
     c.shape.sparse_lds_bytes = 0;
     std::vector<int> K;   // runs mode: workgroups per member
@@ -1195,6 +1222,10 @@ int group_rebuild(sxmc_group* g) {
       const int rbpc = std::min(g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, 1536 / rthreads),
                                 std::max(1, (int)((size_t)props.lds_per_cu / need)));
       if (need > (size_t)props.lds_per_cu || !apportion_workgroups(sizes, props.cus * rbpc, rthreads, K)) {
+        if (ordered && !g->order_blocked) {   // the ordered layout needs the runs: plan again without it
+          g->order_blocked = true;
+          return group_rebuild(g);
+        }
         c.runs_mode = false;   // (more such members than workgroups: the table stays in sorted order)
       } else {
         c.shape.threads = rthreads;
@@ -1262,7 +1293,8 @@ int group_rebuild(sxmc_group* g) {
     const size_t lds_need = std::max(c.shape.lds_bytes, c.shape.sparse_lds_bytes);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(lds_need, 1)));
     bpc = std::min(bpc, lds_limit);
-    if (ordered) {
+    c.shape.lds_layout = 0;
+    if (ordered && c.shape.lds_hist) {
       // replicas of the LDS histogram (fill_ordered_body): as many as the workgroup's share of LDS holds, up to 4
       unsigned rlog = 0;
       const size_t share = (size_t)props.lds_per_cu / (size_t)std::max(1, bpc);
@@ -2226,7 +2258,7 @@ int sxmc_group_set_bucketing(sxmc_group_t g, int enable) {
 
 int sxmc_group_set_ordering(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
-  g->cfg_order = enable ? 1 : 0;
+  g->cfg_order = enable == 2 ? 2 : enable ? 1 : 0;
   return SXMC_OK;
 }
 
@@ -2839,7 +2871,7 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
       // depends on the parameters; not counted -- and each granule has two end values besides its word)
       const bool ord = bk->sort && bk->sort->ordered >= 0;
       fr += (double)bk->nkept * 4.0 * (double)(bk->fields.size() - (ord ? 1 : 0)) +
-            (ord ? 12.0 : bk->runs > 1 ? 8.0 : 4.0) * (double)bk->ngranules;
+            ((ord ? 8.0 : 0.0) + (bk->runs > 1 ? 8.0 : 4.0)) * (double)bk->ngranules;
     } else {
       fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
     }

@@ -34,6 +34,21 @@ std::string kernel_source(const SxRtcSpec& k) {
   for (int i = 0; i < k.nops; i++) prog += (i ? ", " : "") + std::to_string(k.ops[i]) + "u";
   prog += ">";
   std::string s = "#include \"fill_kernels.inc.h\"\nusing namespace sxfill;\n";
+  if (k.pre_width == 5 && k.sparse_runs) {   // ... its sparse counting over runs
+    s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(const SxSignalDesc* __restrict__ descs, "
+         "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";
+    s += "  fill_sparse_body<" + std::to_string(k.nobs) + ", " + std::to_string(k.nslot) + ", " + prog +
+         ", true>(descs, segs, blk_off, w, dbg);\n}\n";
+    return s;
+  }
+  if (k.pre_width == 5 && !k.lds_hist) {     // ... its dense evaluation with a histogram beyond LDS
+    s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(const SxSignalDesc* __restrict__ descs, "
+         "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";
+    s += "  SxChainDescs one;\n  one.d[0] = one.d[1] = one.d[2] = one.d[3] = descs;\n";
+    s += "  fill_ordered_body<" + std::to_string(k.nobs) + ", " + std::to_string(k.nslot) + ", " + prog +
+         ", 1, false>(one, segs, blk_off, w, dbg);\n}\n";
+    return s;
+  }
   if (k.pre_width == 5) {   // bucketed table with an ordered observable (fill_ordered_body), 1 to 4 chains
     const std::string targs = std::to_string(k.nobs) + ", " + std::to_string(k.nslot) + ", " + prog + ", " +
                               std::to_string(k.nchain > 1 ? k.nchain : 1);

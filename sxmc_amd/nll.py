@@ -97,10 +97,11 @@ class EvalGroup:
         """Stream a copy of the table grouped by the bins of the observables no systematic writes (default on)."""
         capi.call("sxmc_group_set_bucketing", self._g, int(bool(enable)))
 
-    def SetOrdering(self, enable):
+    def SetOrdering(self, enable, force=False):
         """Keep each bucket's rows sorted by a monotonically written observable: its bin is then one constant per
-        256-sample granule, worked out per evaluation from the granule's end values (default on)."""
-        capi.call("sxmc_group_set_ordering", self._g, int(bool(enable)))
+        256-sample granule, worked out per evaluation from the granule's end values (default: on where the table
+        has enough granules per bin edge to pay; force: wherever it applies)."""
+        capi.call("sxmc_group_set_ordering", self._g, 2 if (enable and force) else int(bool(enable)))
 
     def SetRuntimeKernels(self, enable):
         """Specialise the fill kernel through hiprtc for programs of systematics that are not built in (default on)."""

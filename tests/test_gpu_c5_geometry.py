@@ -75,12 +75,15 @@ def close_chain(m):
     m.group.close()
 
 
-@pytest.mark.parametrize("sparse", [True, False])
-def test_c5_real_geometry_whole_step_against_the_oracle(c5, sparse):
+@pytest.mark.parametrize("sparse,order", [(True, True), (False, True), (True, False), (False, False)])
+def test_c5_real_geometry_whole_step_against_the_oracle(c5, sparse, order):
     w, geom = c5
     m = MCMC(w, seed=21, fused=True)
     m.group.SetSparse(sparse)
+    m.group.SetOrdering(order, force=True)          # forced on: r, which is only shifted, is the ordered observable
+    # (off by default at this geometry: 61 granules per bucket against 200 bins of r)
     m.setup(sync_interval=8)
+    assert ("ordered" in m.group.LaunchInfo()) == order
     rb0 = m.pdfs[0].GetReadBins()
     assert np.array_equal(rb0, oracle.set_eval_points(geom, w.events, 0))
     assert (rb0 == -1).sum() > 1000 and (rb0 == -2).sum() > 1000

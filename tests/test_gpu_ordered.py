@@ -50,13 +50,13 @@ def test_ordered_observable_gives_identical_histograms(name, nobs, nbins, systs,
     sizes = [70001, 3, 123457, 0, 255, 257, 256]
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, param_sets[0], nfields=nfields)
     group = nll.EvalGroup(evs)
-    group.SetOrdering(True)
+    group.SetOrdering(True, force=True)
     assert "ordered" in group.LaunchInfo()
     for params in param_sets:
         pbuf.set(np.asarray(params, np.float64))
         results = []
         for order, bucket in ((True, True), (False, True), (False, False)):
-            group.SetOrdering(order)
+            group.SetOrdering(order, force=True)
             group.SetBucketing(bucket)
             for partition in ((0, 1, 2) if order else (0,)):
                 group.SetPartition(partition)
@@ -111,7 +111,7 @@ def test_ordered_observable_samples_on_the_bin_edges(kind):
         ev.SetNormalizationBuffer(norm)
         ev.SetParameterBuffer(pbuf)
         group = nll.EvalGroup([ev])
-        group.SetOrdering(order)
+        group.SetOrdering(order, force=True)
         assert ("ordered" in group.LaunchInfo()) == order
         for pv in (p, np.nextafter(p, 1.0), np.nextafter(p, -1.0), 0.0, -p):
             pbuf.set(np.array([pv]))
@@ -123,6 +123,23 @@ def test_ordered_observable_samples_on_the_bin_edges(kind):
         ev.close()
 
 
+def test_ordering_by_default_only_where_it_pays():
+    """Default mode: a table needs at least twice as many granules as can straddle a bin edge of the ordered
+    observable (buckets x (nbins + 1)); smaller tables keep the unordered bucketed layout."""
+    rng = np.random.default_rng(47)
+    systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+             dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]
+    for n, nbins, want in ((400001, [6, 5, 4], True), (400001, [6, 50, 40], False)):
+        evs, tabs, lut, norms, pbuf = build_group(rng, [n], 3, nbins, systs, [0.02, -0.01, 0.07], nfields=5)
+        group = nll.EvalGroup(evs)
+        assert ("ordered" in group.LaunchInfo()) == want, group.LaunchInfo()
+        group.EvalAsync(False)
+        group.EvalFinished()
+        o = oracle_eval(tabs[0], 5, [0.0] * 3, [1.0] * 3, nbins, systs, [0.02, -0.01, 0.07])
+        assert np.array_equal(evs[0].GetBins(), o["bins"]) and norms.get()[0] == o["norm"]
+        group.close()
+
+
 def test_ordered_observable_with_wild_parameters():
     """NaN and infinite coefficients: no monotone-map argument is made, every granule takes the per-sample path,
     and the result is whatever the unordered evaluation gives (nothing in the domain for NaN / +-inf shifts)."""
@@ -131,13 +148,14 @@ def test_ordered_observable_with_wild_parameters():
     systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=1, pars=[1])]
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 2, [11, 13], systs, [0.0, 0.0], nfields=3)
     group = nll.EvalGroup(evs)
+    group.SetOrdering(True, force=True)
     assert "ordered" in group.LaunchInfo()
     for params in ([np.nan, 0.0], [0.0, np.nan], [np.inf, 0.0], [0.1, -np.inf], [0.0, np.inf], [0.01, -1.0],
                    [1e300, 1e300], [0.02, 0.03]):
         pbuf.set(np.asarray(params, np.float64))
         out = []
         for order in (True, False):
-            group.SetOrdering(order)
+            group.SetOrdering(order, force=True)
             group.EvalAsync(False)
             group.EvalFinished()
             out.append(([e.GetBins() for e in evs], norms.get()))
@@ -158,6 +176,7 @@ def test_ordered_observable_lookup_and_reuse_across_groups():
     params = [0.02, -0.01, 0.07]
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], C3, params, nfields=5, points=pts)
     group = nll.EvalGroup(evs)
+    group.SetOrdering(True, force=True)     # (tables this small have too few granules per bin edge for the default)
     assert "ordered" in group.LaunchInfo()
     group.EvalAsync(True)
     group.EvalFinished()
@@ -172,6 +191,7 @@ def test_ordered_observable_lookup_and_reuse_across_groups():
         s.SetNormalizationBuffer(norms2, j)
         s.SetParameterBuffer(pbuf2, 0, 1)
     g2 = nll.EvalGroup(shared)
+    g2.SetOrdering(True, force=True)
     assert "ordered" in g2.LaunchInfo()
     g2.EvalAsync(False)
     g2.EvalFinished()

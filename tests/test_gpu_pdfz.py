@@ -560,13 +560,17 @@ def test_sparse_counting_over_bucketed_runs(nobs, nb, systs, params, nfields):
 
     def check(points):
         out = {}
-        for sparse, bucket in ((True, True), (False, True), (True, False)):
+        for sparse, bucket, order in ((True, True, True), (True, True, False), (False, True, True), (False, True, False),
+                                      (True, False, False)):
             group.SetSparse(sparse)
             group.SetBucketing(bucket)
+            group.SetOrdering(order, force=True)       # (on: the written observable that is only shifted / scaled is ordered)
+            info = group.LaunchInfo()
+            assert "failed" not in info, info
             lut.set(np.full(lut.size, 777.0, np.float32))
             group.EvalAsync(True)
             group.EvalFinished()
-            out[(sparse, bucket)] = (lut.get(), norms.get())
+            out[(sparse, bucket) if not order else (sparse, bucket, order)] = (lut.get(), norms.get())
         ne = points.shape[0]
         for k, v in out.items():
             assert np.array_equal(v[0].view(np.uint32), out[(True, True)][0].view(np.uint32)), k
@@ -579,6 +583,7 @@ def test_sparse_counting_over_bucketed_runs(nobs, nb, systs, params, nfields):
 
     check(pts)
     group.SetBucketing(True)
+    group.SetOrdering(True, force=True)
     pts2 = pts[1000:3500].copy()                          # a new data set: the bucket tables are rebuilt
     for e in evs:
         e.SetEvalPoints(pts2)
@@ -619,7 +624,7 @@ def test_runtime_specialised_kernels_match_the_decoded_program_and_the_oracle(na
     results = []
     for rtc, order in ((True, False), (True, True), (False, False)):
         group.SetRuntimeKernels(rtc)
-        group.SetOrdering(order)
+        group.SetOrdering(order, force=True)
         group.EvalAsync(False)
         group.EvalFinished()
         results.append(([e.GetBins() for e in evs], norms.get()))
@@ -641,16 +646,21 @@ def test_runtime_specialised_sparse_runs_kernel():
     evs, tabs, lut, norms, pbuf = build_group(rng, [150001, 60001], nobs, nb, systs, params, nfields=nfields, points=pts,
                                               lo=-0.05, hi=1.05)
     group = nll.EvalGroup(evs)
-    info = group.LaunchInfo()
-    assert "program=runtime" in info and "table=bucketed+runs(runtime)" in info, info
     out = {}
-    for sparse in (True, False):
-        group.SetSparse(sparse)
-        lut.set(np.full(lut.size, 777.0, np.float32))
-        group.EvalAsync(True)
-        group.EvalFinished()
-        out[sparse] = (lut.get(), norms.get())
-    assert np.array_equal(out[True][0].view(np.uint32), out[False][0].view(np.uint32))
+    for order, kind in ((False, "bucketed"), (True, "ordered")):      # (ordered: c, the observable with the fewest bins)
+        group.SetOrdering(order, force=True)
+        info = group.LaunchInfo()
+        assert "program=runtime" in info and "table=%s+runs(runtime)" % kind in info and "failed" not in info, info
+        for sparse in (True, False):
+            group.SetSparse(sparse)
+            lut.set(np.full(lut.size, 777.0, np.float32))
+            group.EvalAsync(True)
+            group.EvalFinished()
+            out[(sparse, order)] = (lut.get(), norms.get())
+    for k in list(out):
+        assert np.array_equal(out[k][0].view(np.uint32), out[(False, False)][0].view(np.uint32)), k
+        assert np.array_equal(out[k][1], out[(False, False)][1]), k
+    out = {True: out[(True, True)], False: out[(False, False)]}
     for j, t in enumerate(tabs):
         o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nb, systs, params, points=pts, dataset=j % 2)
         assert_same_bits(out[True][0].reshape(2, -1)[j], o["out"])
@@ -728,7 +738,7 @@ def test_random_programs_every_path_matches_the_oracle(seed):
                                (False, False, False)):
         group.SetBucketing(bucket)
         group.SetRuntimeKernels(rtc)
-        group.SetOrdering(order)
+        group.SetOrdering(order, force=True)
         info = group.LaunchInfo()
         assert "failed" not in info, info
         lut.set(np.full(lut.size, 777.0, np.float32))

@@ -24,6 +24,8 @@ def op(type_, obs_slot, extra_slot=0, npars=0):
     (1, 3, 1, 5, 0, [op(SHIFT, 2), op(SCALE, 0), op(RES, 0, 1)]),                      # C3 bucketed, r ordered
     (0, 1, 1, 5, 0, [op(SHIFT, 0)]),                                                   # bench_pdfz ordered: nothing streamed
     (2, 4, 1, 5, 0, [op(CTSCALE, 3), op(SCALE, 3), op(SCALE, 0), op(RES, 1, 2)]),      # two ops on the ordered observable
+    (1, 3, 0, 5, 1, [op(SHIFT, 2), op(SCALE, 0), op(RES, 0, 1)]),                      # C5, r ordered: sparse counting over runs
+    (1, 3, 0, 5, 0, [op(SHIFT, 2), op(SCALE, 0), op(RES, 0, 1)]),                      # ... and its dense evaluation
 ])
 def test_runtime_specialisation_compiles_without_a_gpu(nobs, nslot, lds, prew, runs, ops):
     lib = capi.load()
