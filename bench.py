@@ -504,9 +504,10 @@ def main():
                     help="fake experiments for the ensemble leg (fake data + MCMC + intervals), sharded k mod N; "
                          "-1 = eight per rank, 0 = skip")
     ap.add_argument("--exp-steps", type=int, default=2000, help="MCMC steps per fake experiment in the ensemble leg")
-    ap.add_argument("--exp-lockstep", type=int, default=4,
-                    help="ensemble leg, second pass: chains per lockstep set (one fill pass per step for the set); 0 = skip")
-    ap.add_argument("--exp-sets", type=int, default=2, help="lockstep sets in flight per GPU (one stream each)")
+    ap.add_argument("--exp-lockstep", type=int, default=2,
+                    help="ensemble leg, second pass: chains per lockstep set (one fill pass per step for the set); 0 = skip."
+                         "  2 (default): with the ordered fill two chains leave LDS for two replicas of each histogram")
+    ap.add_argument("--exp-sets", type=int, default=4, help="lockstep sets in flight per GPU (one stream each)")
     ap.add_argument("--exp-concurrent", type=int, default=4,
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
