@@ -561,7 +561,7 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
                                            std::vector<Systematic>& systematics, std::vector<Observable>& observables,
                                            unsigned nsteps, float burnin_fraction, unsigned nconcurrent,
                                            float cl = 0.9f, unsigned sync_interval = 10000, unsigned graph_steps = 0,
-                                           unsigned lockstep_chains = 2, unsigned lockstep_sets = 4) {
+                                           unsigned lockstep_chains = 4, unsigned lockstep_sets = 2) {
   const size_t G = devices.size();
   if (G == 0 || tables.size() != signals.size()) throw pdfz::Error("ensemble_multi_gpu: bad arguments");
   size_t P = sources.size();
