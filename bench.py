@@ -316,8 +316,13 @@ class Leg:
                 traffic = t["bytes_per_launch"]
         except (OSError, ValueError):
             pass
+        info = m.group.LaunchInfo()
+        kname = ("fill_ordered_kernel" if "table=ordered" in info and "+runs" not in info
+                 else "fill_sparse_kernel" if "+runs" in info and not args.no_sparse else "fill_kernel")
         return {
-            "bound": "hbm", "kernel": "fill_kernel (histogram fill, all signals batched)",
+            "bound": "hbm", "kernel": kname + " (histogram fill, all signals batched; rocprofv3 lists run-time "
+                                              "compiled kernels as sx_rtc_fill)",
+            "launch_plan": info.strip().split("\n"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
