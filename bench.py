@@ -165,7 +165,7 @@ class Leg:
     figures of its fill kernel and the parity check against the oracle."""
 
     def __init__(self, args, torch, dev, name, form, lut_output, seed, exp_seed, scale=None, events=None,
-                 keep_host="none"):
+                 keep_host="none", lookahead=False):
         from sxmc_amd import capi
         from sxmc_amd.mcmc import MCMC
         self.args, self.torch, self.name, self.form, self.lut_output = args, torch, name, form, lut_output
@@ -212,6 +212,8 @@ class Leg:
         m.group.SetSparse(not args.no_sparse)
         self.graph_state = {"steps_per_graph": args.graph_steps if form == "graph" else 0, "fallback": None}
         self.tuned_threads = 0
+        # the look-ahead walk: two evaluations per pass over the tables (needs histograms in LDS, event classes)
+        self.lookahead = bool(lookahead) and form == "graph" and not lut_output and name.lower() in ("c3", "c1")
 
     def setup(self, steps, warmup):
         from sxmc_amd import capi
@@ -225,6 +227,11 @@ class Leg:
         if self.form == "graph":
             m.step()                     # brings the launch plan up to date; recording cannot
             m.flush()
+        self.la = None
+        if self.lookahead:
+            from sxmc_amd.mcmc import LookaheadWalk
+            self.la = LookaheadWalk(m, threads=1024 if args.launch == "0,0" else 0)
+            self.la.bind()
         # untimed: clocks and graph replay settle over the first few hundred steps, whatever --warmup says
         for lo in range(0, args.prewarm, 100):
             self.run_steps(min(100, args.prewarm - lo, max(steps, 1)))
@@ -250,6 +257,10 @@ class Leg:
     def run_steps(self, n):
         from sxmc_amd import capi
         m, gstate = self.m, self.graph_state
+        if self.la is not None:
+            # look-ahead walk: passes (two evaluations each) until the chain has advanced by exactly n steps
+            self.la.steps(n, graph_passes=gstate["steps_per_graph"])
+            return
         ne = self.eager_share(n)
         if n > ne and gstate["steps_per_graph"] > 0:
             try:
@@ -309,7 +320,8 @@ class Leg:
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else "") +
-                                       ("_no_order" if args.no_order and not args.no_bucket else ""))
+                                       ("_no_order" if args.no_order and not args.no_bucket else "") +
+                                       ("_lookahead" if self.la is not None else ""))
             if args.extra_ctscale or args.no_sparse:
                 t = None
             if t and self.scale == 1.0 and args.nsyst < 0:
@@ -319,6 +331,9 @@ class Leg:
         info = m.group.LaunchInfo()
         kname = ("fill_ordered_kernel" if "table=ordered" in info and "+runs" not in info
                  else "fill_sparse_kernel" if "+runs" in info and not args.no_sparse else "fill_kernel")
+        neval = 2 if self.la is not None else 1
+        if self.la is not None:
+            kname = "sx_rtc_fill = " + kname.replace("_kernel", "_body") + " for two parameter vectors (look-ahead pass)"
         return {
             "bound": "hbm", "kernel": kname + " (histogram fill, all signals batched; rocprofv3 lists run-time "
                                               "compiled kernels as sx_rtc_fill)",
@@ -327,6 +342,10 @@ class Leg:
             "traffic": traffic,
             "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
             "avg_launch_ms": fill_ms, "launches_timed": self.nfill,
+            # a look-ahead pass fills the histograms of TWO evaluations from one pass over the tables: `achieved` and
+            # `frac` count the bytes the launch must stream once; per evaluation it is half of that
+            "evaluations_per_launch": neval,
+            "achieved_counting_every_evaluation": neval * achieved,
             "survey_bytes_per_launch": survey_bytes,
             "achieved_at_survey_bytes": survey_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0,
             "whole_step_algorithmic_bytes": fill_bytes + ab["event"],
@@ -334,6 +353,20 @@ class Leg:
         }
 
     def config(self):
+        w, args, m = self.w, self.args, self.m
+        la = None
+        if self.la is not None and self.la.passes_seen:
+            la = {"passes": self.la.passes_seen, "steps": self.la.steps_seen,
+                  "steps_per_pass": self.la.steps_seen / self.la.passes_seen,
+                  "note": "value counts chain steps (each one NLL evaluation the walk uses); every pass evaluates the "
+                          "likelihood twice -- at the step's proposal and at the vector the next step proposes after "
+                          "a rejection -- and decides one or two steps; the chain is the sequential one bit for bit "
+                          "(tests/test_gpu_nll.py: test_lookahead_walk_is_the_sequential_chain)"}
+        cfg = self._config_plain()
+        cfg["lookahead"] = la
+        return cfg
+
+    def _config_plain(self):
         w, args, m = self.w, self.args, self.m
         return {
             "workload": "%s: %s" % (w.name, w.description),
@@ -417,6 +450,9 @@ class Leg:
         from sxmc_amd import capi
         m = self.m
         capi.synchronize()
+        if getattr(self, "la", None) is not None:
+            self.la.close()              # (the multigroup goes before its groups)
+            self.la = None
         if m._graph is not None:
             m._graph.close()
         for p in m.pdfs:
@@ -530,6 +566,10 @@ def main():
                          "of one specialised through hiprtc")
     ap.add_argument("--extra-ctscale", action="store_true",
                     help="C3 with a fourth systematic, a cos-theta scale on c: a program that is not in the table")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="walk with ONE evaluation per step.  Default (config 3): the look-ahead walk -- every pass over "
+                         "the tables evaluates the step's proposal AND the vector the next step proposes after a "
+                         "rejection; one or two steps per pass, the same chain bit for bit")
     ap.add_argument("--no-order", action="store_true",
                     help="bucketed tables without the ordered observable (every written observable is streamed)")
     ap.add_argument("--no-bucket", action="store_true",
@@ -563,7 +603,8 @@ def main():
     want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1 and not args.debug_mode
     big = args.workload.lower() == "c5" and args.scale >= 0.2
     leg = Leg(args, torch, dev, args.workload, args.form, args.lut_output, args.seed, exp_seed,
-              keep_host=("ends" if big else "all") if want_cpu else "none")
+              keep_host=("ends" if big else "all") if want_cpu else "none",
+              lookahead=not args.no_lookahead and not args.debug_mode)
     w, m = leg.w, leg.m
     leg.setup(args.steps, args.warmup)
     tuned_threads = leg.tuned_threads
@@ -738,12 +779,15 @@ def main():
     also = args.also
     if also == "auto":
         full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and world == 1 and not args.debug_mode
-        also = "c3_lut_materialized,c2,c5,cpp_host" if full_c3 and want_cpu and args.form == "graph" else "none"
+        also = ("c3_single_evaluation,c3_lut_materialized,c2,c5,cpp_host"
+                if full_c3 and want_cpu and args.form == "graph" else "none")
     if also != "none" and rank == 0:
         leg.close()
         recs = {}
         for name in [x.strip() for x in also.split(",") if x.strip()]:
-            if name == "c3_lut_materialized":
+            if name == "c3_single_evaluation":    # the walk with one evaluation per step (the headline without look-ahead)
+                recs[name] = also_record(args, torch, dev, "c3", "graph", False, args.also_steps, 20, exp_seed, "all")
+            elif name == "c3_lut_materialized":
                 recs[name] = also_record(args, torch, dev, "c3", "graph", True, args.also_steps, 20, exp_seed, "all")
             elif name == "c2":
                 recs[name] = also_record(args, torch, dev, "c2", "graph", False, args.also_steps, 20, exp_seed, "all")

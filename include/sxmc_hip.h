@@ -369,6 +369,24 @@ typedef struct sxmc_multigroup* sxmc_multigroup_t;
 int sxmc_multigroup_create(const sxmc_group_t* groups, int ngroups, sxmc_multigroup_t* out);
 int sxmc_multigroup_destroy(sxmc_multigroup_t mg);
 int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args);
+/* LOOK-AHEAD WALK: one chain, two likelihood evaluations per pass over the tables.  A Metropolis step that rejects
+ * (jump_decider, nll_kernels.cpp:56-86) leaves the chain where it was, and the next proposal -- current vector +
+ * jump width x the next deviates (pick_new_vector, :30-53) -- is then known BEFORE the step is decided.  A
+ * multigroup of exactly two groups over the same tables -- groups[0]'s evaluators bound to the chain's proposal
+ * (args->d_v_proposed, args->d_norms), groups[1]'s to the look-ahead vector (d_v_lookahead, d_norms_lookahead) --
+ * evaluates both in ONE fill pass (the lockstep kernel); the step end decides the step from the first and, if it
+ * rejected, the FOLLOWING step from the second at once, then writes the next proposal and the next look-ahead
+ * vector.  A pass advances the chain by 1 + P(reject) steps on average for about 1.2 x the time of a
+ * single evaluation.  The chain is the sequential one bit for bit: every row of the jump buffer, the counters, the
+ * generator states (pre-fetching: Brockwell, J. Comput. Graph. Stat. 15 (2006)).  d_cap (device, optional): the
+ * value of *args->d_counter at which the walk stops -- a pass takes its second step only below it and does
+ * nothing at or beyond it, so a caller that needs exactly n steps launches passes until the counter says n.
+ * Needs the lookup table off (sxmc_group_set_lut_output(g, 0)), histograms in LDS and at most 256 parameters.
+ * sxmc_lookahead_begin: the first look-ahead vector of a walk, from the state sxmc_launch_pick_new_vector left. */
+int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args,
+                                         double* d_v_lookahead, const unsigned* d_norms_lookahead, const int* d_cap);
+int sxmc_lookahead_begin(sxmc_stream_t s, int nparameters, const sxmc_rng_state* d_rng, const float* d_jump_width,
+                         const double* d_v_current, double* d_v_lookahead);
 /* Kernels launched by the last sxmc_group_step_async (2 or 3, see there; +1 when the histograms had to be
  * zeroed first). */
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches);

@@ -121,6 +121,8 @@ SIGNATURES = {
     "sxmc_multigroup_create": [_vp, _i, _pvp],
     "sxmc_multigroup_destroy": [_vp],
     "sxmc_multigroup_step_async": [_vp, _vp, _vp],
+    "sxmc_multigroup_lookahead_step_async": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "sxmc_lookahead_begin": [_vp, _i, _vp, _vp, _vp, _vp],
     "sxmc_group_finish_step_async": [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz,
                                      _vp, _vp, _vp, _vp, _vp, _i],
     "sxmc_group_synchronize": [_vp],

@@ -159,7 +159,8 @@ __device__ __forceinline__ double block_sum(size_t n, const double* sums, double
 // Vectors longer than kStage fall back to the plain sequential form.
 constexpr int kStage = 256;
 
-__device__ __forceinline__ void finish_step_device(size_t npartial_sums, const double* sums, size_t nsignals,
+// Returns (to every thread) whether the proposal was accepted.
+__device__ __forceinline__ bool finish_step_device(size_t npartial_sums, const double* sums, size_t nsignals,
                                                    size_t nsources, const double* means, const double* sigmas,
                                                    sxmc_rng_state* rng, double* nll_current,
                                                    double* nll_proposed, double* v_current, double* v_proposed,
@@ -187,7 +188,8 @@ __device__ __forceinline__ void finish_step_device(size_t npartial_sums, const d
     __threadfence_block();
     __syncthreads();
     pick_new_vector_device(nparameters, rng, jump_width, v_current, v_proposed);
-    return;
+    __syncthreads();
+    return nll_current[0] == nll_proposed[0];   // (long vectors: accepted, or a tie, which changes nothing)
   }
 
   // ---- phase A
@@ -263,6 +265,26 @@ __device__ __forceinline__ void finish_step_device(size_t npartial_sums, const d
     v_proposed[i] = (s_jw[i] > 0) ? cur + s_jw[i] * s_z[i] : cur;  // :40-47
   }
   if (threadIdx.x == 0) jump_buffer[row + nparameters] = (float)s_nllcur;
+  return accept;
+}
+
+// What the NEXT call of finish_step_device would propose if the step it decides were rejected -- i.e. from the
+// vector v_current as it stands: v_current + jump_width * z with the deviates that call will draw, WITHOUT
+// advancing the generators (the call itself draws them again).  Generator 0 hands the decider its uniform first.
+// The look-ahead walk evaluates this vector beside the proposal (sxmc_multigroup_lookahead_step_async).
+__device__ __forceinline__ void peek_next_proposal_device(int nparameters, const sxmc_rng_state* rng,
+                                                          const float* jump_width, const double* v_current,
+                                                          double* out) {
+  for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
+    const float jw = jump_width[i];
+    double v = v_current[i];
+    if (jw > 0) {
+      sxmc_rng_state st = rng[i];
+      if (i == 0) (void)rng_uniform(&st);
+      v = v + jw * rng_normal(&st);
+    }
+    out[i] = v;
+  }
 }
 
 }  // namespace sxdev

@@ -196,13 +196,14 @@ struct EvalMember {
 // (valid in thread 0).  A row is an event -- or, with `weight`, a class of events that fall into the same
 // bin of every member (the descriptors then point at the class tables and carry no lookup-table output):
 // its log term counts weight[row] times.
-__device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict__ descs, int nsig,
-                                                 unsigned long long npoints, const unsigned* __restrict__ weight,
-                                                 const double* __restrict__ pars,
-                                                 const double* __restrict__ nexpected,
-                                                 const unsigned* __restrict__ n_mc,
-                                                 const short* __restrict__ source_id,
-                                                 const unsigned* __restrict__ norms, double* sh) {
+__device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                      unsigned long long npoints, const unsigned* __restrict__ weight,
+                                                      const double* __restrict__ pars,
+                                                      const double* __restrict__ nexpected,
+                                                      const unsigned* __restrict__ n_mc,
+                                                      const short* __restrict__ source_id,
+                                                      const unsigned* __restrict__ norms, double* sh,
+                                                      unsigned block_index, unsigned nblocks) {
   double* s_wave = sh;  // [16] wave sums, then nsig EvalMember records
   EvalMember* s_mem = reinterpret_cast<EvalMember*>(sh + 16);
 
@@ -211,7 +212,7 @@ __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict_
   // below are fetched and staged.
   constexpr int U = 16;
   int rb[U];
-  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long i = (unsigned long long)block_index * blockDim.x + threadIdx.x;
   // (clamped indices, no branches: all U table addresses are fetched together, then all U loads issued)
   auto load_read_bins = [&](unsigned long long ev, int j0) {
     const unsigned long long evc = ev < npoints ? ev : npoints - 1;
@@ -240,7 +241,7 @@ __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict_
 
   double sum = 0.0;
   bool requested = true;
-  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long step = (unsigned long long)nblocks * blockDim.x;
   for (; i < npoints; i += step) {
     double s = 0.0;
     for (int j0 = 0; j0 < nsig; j0 += U) {
@@ -275,6 +276,17 @@ __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict_
     for (int w = 0; w < (int)(blockDim.x / kWave); w++) t += s_wave[w];
   }
   return t;
+}
+
+__device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                 unsigned long long npoints, const unsigned* __restrict__ weight,
+                                                 const double* __restrict__ pars,
+                                                 const double* __restrict__ nexpected,
+                                                 const unsigned* __restrict__ n_mc,
+                                                 const short* __restrict__ source_id,
+                                                 const unsigned* __restrict__ norms, double* sh) {
+  return eval_nll_block_part(descs, nsig, npoints, weight, pars, nexpected, n_mc, source_id, norms, sh, blockIdx.x,
+                             gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void eval_nll_kernel(const SxSignalDesc* __restrict__ descs, int nsig,
@@ -324,6 +336,95 @@ __global__ __launch_bounds__(256) void eval_nll_finish_kernel(const SxSignalDesc
                             a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
                             a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
                             a.debug_mode != 0);
+}
+
+// LOOK-AHEAD WALK (sxmc_multigroup_lookahead_step_async).  A Metropolis step that rejects leaves the chain where it
+// was, and the NEXT proposal -- current vector + jump width x the next deviates -- is then known before the
+// step is decided.  One pass over the tables (the lockstep fill of two chains) evaluates the likelihood at BOTH
+// the step's proposal A and that look-ahead vector B; the step end below decides the step from A and, if it
+// rejected, the following step from B at once: 1 + P(reject) steps per pass, the chain -- every row of the
+// jump buffer, every generator state -- exactly the sequential one (pre-fetching, Brockwell 2006).
+// Lookup + event sums of both candidates in one launch: the first half of the grid works on A, the second on B.
+__global__ __launch_bounds__(256) void eval_nll2_kernel(const SxSignalDesc* __restrict__ descs_a,
+                                                        const SxSignalDesc* __restrict__ descs_b, int nsig,
+                                                        unsigned long long npoints,
+                                                        const unsigned* __restrict__ weight_a,
+                                                        const unsigned* __restrict__ weight_b,
+                                                        const double* __restrict__ pars_a,
+                                                        const double* __restrict__ pars_b,
+                                                        const double* __restrict__ nexpected,
+                                                        const unsigned* __restrict__ n_mc,
+                                                        const short* __restrict__ source_id,
+                                                        const unsigned* __restrict__ norms_a,
+                                                        const unsigned* __restrict__ norms_b,
+                                                        double* __restrict__ sums_a, double* __restrict__ sums_b,
+                                                        unsigned half) {
+  extern __shared__ double sh[];
+  const bool second = blockIdx.x >= half;
+  // (eval_nll_block strides by gridDim.x: give each half its own picture of the grid)
+  const double t = eval_nll_block_part(second ? descs_b : descs_a, nsig, npoints, second ? weight_b : weight_a,
+                                       second ? pars_b : pars_a, nexpected, n_mc, source_id,
+                                       second ? norms_b : norms_a, sh, second ? blockIdx.x - half : blockIdx.x, half);
+  if (threadIdx.x == 0 && !isnan(t)) (second ? sums_b : sums_a)[second ? blockIdx.x - half : blockIdx.x] = t;
+}
+
+// Step end of the look-ahead walk + the clearing for the next pass.  Workgroup 0: finish_nll_jump_pick_combo for
+// the step (candidate A = a.v_proposed) and, if that rejected and the walk may go on (the step count stays below
+// *cap), for the next step: its proposal -- written into a.v_proposed by the first call -- IS the look-ahead
+// vector (same current vector, same deviates, same arithmetic), so the second call runs on the same buffers with
+// B's event sums and normalisations.  Then the next look-ahead vector is written to v_b.  The other workgroups
+// clear both candidates' histograms.
+__global__ __launch_bounds__(256) void finish2_zero_kernel(const SxSignalDesc* __restrict__ descs_a,
+                                                           const SxSignalDesc* __restrict__ descs_b, int nsig,
+                                                           unsigned zblocks, size_t npartial, const double* sums_a,
+                                                           const double* sums_b, const unsigned* norms_b, double* v_b,
+                                                           const int* cap, SxStepArgs a) {
+  if (blockIdx.x == 0) {
+    __shared__ int s_before;
+    if (threadIdx.x == 0) s_before = a.counter[0];
+    __syncthreads();
+    const int limit = cap ? cap[0] : 0x7FFFFFFF;
+    if (s_before < limit) {      // (a pass launched after the walk reached its stop: nothing to do)
+      const bool accepted =
+          sxdev::finish_step_device(npartial, sums_a, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                                    a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                                    a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
+                                    a.debug_mode != 0);
+      __syncthreads();
+      if (!accepted && s_before + 1 < limit) {
+        sxdev::finish_step_device(npartial, sums_b, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                                  a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                                  a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, norms_b,
+                                  a.debug_mode != 0);
+        __syncthreads();
+      }
+      sxdev::peek_next_proposal_device(a.nparameters, a.rng, a.jump_width, a.v_current, v_b);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nsig; j += blockDim.x) {
+      *descs_a[j].norm = 0u;
+      *descs_b[j].norm = 0u;
+    }
+    return;
+  }
+  const unsigned b = blockIdx.x - 1u;
+  const unsigned which = b / (zblocks * (unsigned)nsig);
+  const unsigned bb = b - which * zblocks * (unsigned)nsig;
+  const SxSignalDesc& d = (which ? descs_b : descs_a)[bb / zblocks];
+  const unsigned chunk = bb % zblocks;
+  unsigned* bins = d.bins;
+  const unsigned n = (unsigned)d.total_nbins;
+  const unsigned n4 = n >> 2;
+  uint4* b4 = reinterpret_cast<uint4*>(bins);
+  const unsigned stride = zblocks * blockDim.x;
+  for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
+}
+
+// first look-ahead vector of a walk (the state as sxmc_launch_pick_new_vector left it)
+__global__ void peek_next_proposal_kernel(int nparameters, const sxmc_rng_state* rng, const float* jump_width,
+                                          const double* v_current, double* out) {
+  sxdev::peek_next_proposal_device(nparameters, rng, jump_width, v_current, out);
 }
 
 // The whole end of an MCMC step in ONE workgroup: lookup + event sum over the rows (events, or classes of events
@@ -735,6 +836,36 @@ hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsi
   const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
   hipLaunchKernelGGL(eval_nll_finish_kernel, dim3(grid), dim3(block), shmem, s, d_descs, nsig, npoints, weight, sums,
                      ticket, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_eval_nll2(const SxSignalDesc* descs_a, const SxSignalDesc* descs_b, int nsig,
+                               unsigned long long npoints, const unsigned* weight_a, const unsigned* weight_b,
+                               const double* pars_a, const double* pars_b, const double* nexpected,
+                               const unsigned* n_mc, const short* source_id, const unsigned* norms_a,
+                               const unsigned* norms_b, double* sums_a, double* sums_b, int half, int block,
+                               hipStream_t s) {
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
+  hipLaunchKernelGGL(eval_nll2_kernel, dim3(2 * half), dim3(block), shmem, s, descs_a, descs_b, nsig, npoints, weight_a,
+                     weight_b, pars_a, pars_b, nexpected, n_mc, source_id, norms_a, norms_b, sums_a, sums_b,
+                     (unsigned)half);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_finish2_zero(const SxSignalDesc* descs_a, const SxSignalDesc* descs_b, int nsig, int max_bins,
+                                  size_t npartial, const double* sums_a, const double* sums_b, const unsigned* norms_b,
+                                  double* v_b, const int* cap, const SxStepArgs& a, int block, hipStream_t s) {
+  int zb = (max_bins / 4 + block - 1) / block;
+  if (zb < 1) zb = 1;
+  if (zb > 1024) zb = 1024;
+  hipLaunchKernelGGL(finish2_zero_kernel, dim3(1 + 2u * (unsigned)zb * (unsigned)nsig), dim3(block), 0, s, descs_a,
+                     descs_b, nsig, (unsigned)zb, npartial, sums_a, sums_b, norms_b, v_b, cap, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_peek_next_proposal(int nparameters, const sxmc_rng_state* rng, const float* jump_width,
+                                        const double* v_current, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(peek_next_proposal_kernel, dim3(1), dim3(256), 0, s, nparameters, rng, jump_width, v_current, out);
   return hipGetLastError();
 }
 

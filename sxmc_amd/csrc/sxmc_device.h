@@ -76,6 +76,17 @@ hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_
 hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
                                       const unsigned* weight, double* sums, unsigned* ticket, const SxStepArgs& a,
                                       int grid, int block, hipStream_t s);
+hipError_t sx_launch_eval_nll2(const SxSignalDesc* descs_a, const SxSignalDesc* descs_b, int nsig,
+                               unsigned long long npoints, const unsigned* weight_a, const unsigned* weight_b,
+                               const double* pars_a, const double* pars_b, const double* nexpected,
+                               const unsigned* n_mc, const short* source_id, const unsigned* norms_a,
+                               const unsigned* norms_b, double* sums_a, double* sums_b, int half, int block,
+                               hipStream_t s);
+hipError_t sx_launch_finish2_zero(const SxSignalDesc* descs_a, const SxSignalDesc* descs_b, int nsig, int max_bins,
+                                  size_t npartial, const double* sums_a, const double* sums_b, const unsigned* norms_b,
+                                  double* v_b, const int* cap, const SxStepArgs& a, int block, hipStream_t s);
+hipError_t sx_launch_peek_next_proposal(int nparameters, const sxmc_rng_state* rng, const float* jump_width,
+                                        const double* v_current, double* out, hipStream_t s);
 hipError_t sx_launch_tail_step(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,
                                const unsigned* weight, const SxStepArgs& a, hipStream_t s);
 hipError_t sx_launch_fill(const SxLaunchShape& shape, const SxSignalDesc* d_descs, const SxSegment* d_segs,

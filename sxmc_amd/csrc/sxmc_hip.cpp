@@ -2765,6 +2765,118 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
   return SXMC_OK;
 }
 
+// The look-ahead walk's pass (see finish2_zero_kernel): groups[0] evaluates the step's proposal (its evaluators are
+// bound to a->d_v_proposed / a->d_norms), groups[1] the look-ahead vector (bound to d_v_lookahead / d_norms_lookahead).
+int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* a,
+                                         double* d_v_lookahead, const unsigned* d_norms_lookahead, const int* d_cap) {
+  SX_REQUIRE(mg && a && d_v_lookahead && d_norms_lookahead, "null argument");
+  SX_REQUIRE(mg->groups.size() == 2, "the look-ahead walk steps exactly two groups: the proposal's and the look-ahead's");
+  SX_REQUIRE(a->d_means && a->d_sigmas && a->d_rng && a->d_nll_current && a->d_nll_proposed && a->d_v_current &&
+                 a->d_v_proposed && a->d_accepted && a->d_counter && a->d_jump_buffer && a->d_jump_width &&
+                 a->d_nexpected && a->d_n_mc && a->d_source_id && a->d_norms && a->nparameters > 0,
+             "null argument");
+  SX_REQUIRE(a->nparameters <= 256, "the look-ahead walk stages its vectors in LDS: at most 256 parameters");
+  hipStream_t st = (hipStream_t)s;
+  bool replan = mg->seen.size() != 2;
+  for (size_t c = 0; c < 2; c++) {
+    sxmc_group* g = mg->groups[c];
+    int rc = group_refresh(g);
+    if (rc) return rc;
+    if (!replan && mg->seen[c] != g->plan_generation) replan = true;
+    rc = group_check_bound(g, true);
+    if (rc) return rc;
+    if (!g->same_points) return fail(SXMC_ERR_STATE, "members do not share one set of evaluation points");
+    if (g->cfg_lut) return fail(SXMC_ERR_STATE, "the look-ahead walk sums over event classes: switch the lookup table off");
+    if (g->sparse_ready && g->cfg_sparse) return fail(SXMC_ERR_STATE, "the look-ahead walk needs histograms that fit LDS");
+    rc = ensure_event_classes(g, false);
+    if (rc) return rc;
+    g->last_stream = st;
+  }
+  sxmc_group *ga = mg->groups[0], *gb = mg->groups[1];
+  SX_REQUIRE(ga->members.size() == gb->members.size() && ga->members.size() <= 1024 && ga->ec[0].K == gb->ec[0].K,
+             "the two groups must hold the same members over the same data");
+  if (replan) {
+    if (t_capturing) return fail(SXMC_ERR_STATE, "the chains' plans are out of date: step once before recording a graph");
+    mg->seen.resize(2);
+    for (size_t c = 0; c < 2; c++) mg->seen[c] = mg->groups[c]->plan_generation;
+    if (!multigroup_prepare(mg)) {
+      mg->seen.clear();
+      return fail(SXMC_ERR_STATE, "these groups cannot share a fill pass: " + mg->why_not);
+    }
+  }
+  for (size_t c = 0; c < 2; c++) {
+    sxmc_group* g = mg->groups[c];
+    const bool zero_launched = g->prezeroed != 1;
+    int rc = group_prepare_fill(g, st, false);
+    if (rc) return rc;
+    g->last_step_launches = zero_launched ? 1 : 0;
+  }
+  for (size_t i = 0; i < ga->classes.size(); i++) {
+    const LaunchClass& c0 = ga->classes[i];
+    if (c0.shape.grid <= 0) continue;
+    SxChainDescsHost ch{};
+    ch.d[0] = ga->classes[i].d_descs;
+    ch.d[1] = gb->classes[i].d_descs;
+    const bool rec = ga->prof && !t_capturing && ga->prof_n < (int)ga->ev0.size();
+    if (rec) SX_HIP(hipEventRecord(ga->ev0[ga->prof_n], st));
+    SX_HIP(sx_rtc_launch_multi(mg->fill_fn[i], c0.shape.grid, c0.shape.threads, mg->lds_bytes[i], ch, c0.d_segs,
+                               c0.d_blk_off, mg->fill_w[i], st));
+    if (rec) {
+      SX_HIP(hipEventRecord(ga->ev1[ga->prof_n], st));
+      ga->prof_n++;
+    }
+  }
+  const sxmc_group::EventClasses &ea = ga->ec[0], &eb = gb->ec[0];
+  const unsigned long long ne = ea.K;
+  const int block = 128;
+  const int half = (int)std::min<unsigned long long>(512, std::max<unsigned long long>(1, (ne + block - 1) / block));
+  SX_HIP(sx_launch_eval_nll2(ea.d_descs, eb.d_descs, (int)ga->members.size(), ne, ea.d_weight, eb.d_weight,
+                             a->d_v_proposed, d_v_lookahead, a->d_nexpected, a->d_n_mc, a->d_source_id, a->d_norms,
+                             d_norms_lookahead, ga->d_step_sums, gb->d_step_sums, half, block, st));
+  SxStepArgs k;
+  k.nsignals = ga->members.size();
+  k.nsources = a->nsources;
+  k.means = a->d_means;
+  k.sigmas = a->d_sigmas;
+  k.rng = a->d_rng;
+  k.nll_current = a->d_nll_current;
+  k.nll_proposed = a->d_nll_proposed;
+  k.v_current = a->d_v_current;
+  k.v_proposed = a->d_v_proposed;
+  k.accepted = a->d_accepted;
+  k.counter = a->d_counter;
+  k.jump_buffer = a->d_jump_buffer;
+  k.nparameters = a->nparameters;
+  k.debug_mode = a->debug_mode;
+  k.jump_width = a->d_jump_width;
+  k.nexpected = a->d_nexpected;
+  k.n_mc = a->d_n_mc;
+  k.source_id = a->d_source_id;
+  k.norms = a->d_norms;
+  SX_HIP(sx_launch_finish2_zero(ga->d_descs, gb->d_descs, (int)ga->members.size(), std::max(ga->max_bins, gb->max_bins),
+                                (size_t)half, ga->d_step_sums, gb->d_step_sums, d_norms_lookahead, d_v_lookahead, d_cap, k,
+                                128, st));
+  for (size_t c = 0; c < 2; c++) {
+    sxmc_group* g = mg->groups[c];
+    g->last_step_launches += (int)ga->classes.size() + 2;
+    g->prezeroed = 1;
+    for (sxmc_hist* h : g->members) {
+      h->bins_valid = false;
+      h->cleared_by = g;
+    }
+  }
+  return SXMC_OK;
+}
+
+// The first look-ahead vector of a walk: what the step after the pending one would propose if the pending one
+// were rejected (current vector + jump width x the deviates that step end will draw; generators untouched).
+int sxmc_lookahead_begin(sxmc_stream_t s, int nparameters, const sxmc_rng_state* d_rng, const float* d_jump_width,
+                         const double* d_v_current, double* d_v_lookahead) {
+  SX_REQUIRE(d_rng && d_jump_width && d_v_current && d_v_lookahead && nparameters > 0, "null argument");
+  SX_HIP(sx_launch_peek_next_proposal(nparameters, d_rng, d_jump_width, d_v_current, d_v_lookahead, (hipStream_t)s));
+  return SXMC_OK;
+}
+
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches) {
   SX_REQUIRE(g && launches, "null argument");
   *launches = g->last_step_launches;

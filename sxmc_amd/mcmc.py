@@ -310,6 +310,104 @@ class MCMC:
         return np.concatenate(chunks, axis=0), accepted
 
 
+class LookaheadWalk:
+    """ONE chain stepped with two likelihood evaluations per pass over the tables (the look-ahead walk,
+    sxmc_multigroup_lookahead_step_async): besides the step's proposal, the vector the NEXT step would propose if this
+    one rejects -- known in advance, because a rejection leaves the chain where it was -- is evaluated in the same
+    fill pass, and the step end decides one or two steps.  The chain is the sequential walk's, bit for bit.
+    chain: an MCMC(lut_output=False, consume=True, stream=...) after setup(); a shadow set of evaluators over the
+    same tables is created here."""
+
+    def __init__(self, chain, threads=1024):
+        assert chain.consume and chain.stream is not None, "the look-ahead walk needs consume=True and a created stream"
+        self.chain = chain
+        self.shadow = MCMC(chain.w, seed=1, fused=True, stream=chain.stream, share_with=chain, lut_output=False,
+                           consume=True)
+        self._threads = threads
+        self.cap = DeviceArray.zeros(1, np.int32)
+        self._graph, self._graph_passes = None, 0
+        self.mg = None
+        self.passes = 0                       # passes launched (each: one fill of the tables, two evaluations)
+        self.steps_seen, self.passes_seen = 0, 0
+
+    def bind(self, data=None):
+        """After chain.setup(): the shadow evaluators get the same data; (re)starts the look-ahead."""
+        c, s = self.chain, self.shadow
+        self.drop_graph()
+        s.setup(data, sync_interval=8)
+        for g in (c.group, s.group):
+            if self._threads:
+                g.SetLaunchConfig(self._threads, 1)     # (a pass of two evaluations is bound by vector issue and LDS)
+        if self.mg is None:
+            self.mg = nll.MultiGroup([c, s])
+        self.restart()
+
+    def restart(self):
+        """The look-ahead vector for the chain's present state (after setup, a re-tuning of the jump widths, ...)."""
+        c, s = self.chain, self.shadow
+        capi.call("sxmc_lookahead_begin", capi.ptr(c.stream), c.nparameters, capi.ptr(c.rngs), capi.ptr(c.jump_width),
+                  capi.ptr(c.current_vector), capi.ptr(s.proposed_vector))
+
+    def one_pass(self, debug_mode=False):
+        self.mg.LookaheadStepAsync(self.chain.stream, self.shadow.proposed_vector, self.shadow.normalizations, self.cap,
+                                   debug_mode)
+        self.passes += 1
+
+    def drop_graph(self):
+        if self._graph is not None:
+            self._graph.close()
+        self._graph = None
+
+    def steps(self, n, graph_passes=0, debug_mode=False, count0=None):
+        """Exactly n more steps of the chain: passes are launched in rounds of about what is still needed, the
+        jump counter read back after each round (a pass advances the chain by one or two steps; passes launched
+        beyond the stop do nothing).  count0: the jump counter now, if the caller knows it."""
+        c = self.chain
+        if count0 is None:
+            capi.call("sxmc_stream_synchronize", capi.ptr(c.stream))
+            count0 = int(c.jump_counter.get()[0])
+        target = count0 + n
+        self.cap.set(np.array([target], np.int32))
+        done = count0
+        while done < target:
+            need = target - done
+            # a pass advances the chain by 1 + P(reject) steps: aim a little short of what is needed (a pass beyond
+            # the stop still streams the tables), finish with what the counter says is left
+            rate = min(2.0, 1.03 * self.steps_seen / self.passes_seen) if self.passes_seen >= 16 else 1.75
+            k = npass = max(1, int(need / rate))
+            before, pdone = done, self.passes
+            if graph_passes > 0 and k >= graph_passes:
+                if self._graph is None or self._graph_passes != graph_passes:
+                    self.drop_graph()
+                    self.one_pass(debug_mode)                            # (plans in place before recording)
+                    k -= 1
+                    with capi.Graph.capture(c.stream) as g:
+                        for _ in range(graph_passes):
+                            self.one_pass(debug_mode)
+                    self.passes -= graph_passes
+                    self._graph, self._graph_passes = g, graph_passes
+                reps = k // graph_passes
+                if reps:
+                    self._graph.launch(reps)
+                    self.passes += reps * graph_passes
+                    k -= reps * graph_passes
+            for _ in range(k):
+                self.one_pass(debug_mode)
+            capi.call("sxmc_stream_synchronize", capi.ptr(c.stream))
+            done = int(c.jump_counter.get()[0])
+            self.steps_seen += done - before
+            self.passes_seen += self.passes - pdone
+        return done
+
+    def close(self):
+        self.drop_graph()
+        if self.mg is not None:
+            self.mg.close()
+        for p in self.shadow.pdfs:
+            p.close()
+        self.shadow.group.close()
+
+
 class LockstepChains:
     """2-4 chains over the same sample tables (MCMC(..., share_with=base), all on ONE stream) advanced together:
     every step is one fill pass over the tables for all of them (nll.MultiGroup / sxmc_multigroup_step_async)

@@ -220,6 +220,21 @@ class MultiGroup:
             a.debug_mode = int(bool(debug_mode))
         capi.call("sxmc_multigroup_step_async", self._mg, ptr(stream), C.cast(self._args, C.c_void_p))
 
+    def LookaheadStepAsync(self, stream, v_lookahead, norms_lookahead, cap=None, debug_mode=False):
+        """One pass of the look-ahead walk (sxmc_multigroup_lookahead_step_async): chains[0] is THE chain, chains[1]'s
+        evaluators are bound to v_lookahead / norms_lookahead.  cap: device int32, the jump counter at which to stop."""
+        a, m = self._args[0], self.chains[0]
+        a.d_means, a.d_sigmas, a.d_rng = ptr(m.parameter_means).value, ptr(m.parameter_sigma).value, ptr(m.rngs).value
+        a.d_nll_current, a.d_nll_proposed = ptr(m.current_nll).value, ptr(m.proposed_nll).value
+        a.d_v_current, a.d_v_proposed = ptr(m.current_vector).value, ptr(m.proposed_vector).value
+        a.d_accepted, a.d_counter = ptr(m.accept_counter).value, ptr(m.jump_counter).value
+        a.d_jump_buffer, a.nparameters, a.nsources = ptr(m.jump_buffer).value, m.nparameters, m.nsources
+        a.d_jump_width, a.d_nexpected, a.d_n_mc = ptr(m.jump_width).value, ptr(m.nexpected).value, ptr(m.n_mc).value
+        a.d_source_id, a.d_norms = ptr(m.source_id).value, ptr(m.normalizations).value
+        a.debug_mode = int(bool(debug_mode))
+        capi.call("sxmc_multigroup_lookahead_step_async", self._mg, ptr(stream), C.cast(self._args, C.c_void_p),
+                  ptr(v_lookahead), ptr(norms_lookahead), ptr(cap) if cap is not None else None)
+
     def close(self):
         if getattr(self, "_mg", None):
             capi.load().sxmc_multigroup_destroy(self._mg)

@@ -330,6 +330,50 @@ def test_lockstep_chains_walk_what_they_walk_alone(nchains, graph_steps):
     ls.close()
 
 
+@pytest.mark.parametrize("graph_passes,threads", [(0, 0), (6, 0), (4, 1024)])
+def test_lookahead_walk_is_the_sequential_chain(graph_passes, threads):
+    """sxmc_multigroup_lookahead_step_async: one pass over the tables evaluates the step's proposal AND the vector the
+    next step would propose after a rejection; the step end decides one or two steps.  Every row of the jump buffer,
+    the accept count and the chain's continuation must be those of the walk stepped one evaluation at a time --
+    in pieces of odd lengths (the stop is honoured exactly), eager and replayed from graphs."""
+    from sxmc_amd.mcmc import LookaheadWalk
+    w = workloads.config3(0.004, nevents=3000)
+    nsteps = 150
+    plain = MCMC(w, seed=77, lut_output=False, consume=True, stream=capi.new_stream())
+    plain.setup(sync_interval=256)
+    want_rows, want_acc = plain.run(nsteps)
+    assert 0 < want_acc < nsteps
+    m = MCMC(w, seed=77, lut_output=False, consume=True, stream=capi.new_stream())
+    m.setup(sync_interval=256)
+    la = LookaheadWalk(m, threads=threads)
+    la.bind()
+    done = 0
+    for piece in (17, 1, 2, 40, 23, 67):
+        done = la.steps(piece, graph_passes=graph_passes, count0=done)
+        assert done == sum((17, 1, 2, 40, 23, 67)[: (17, 1, 2, 40, 23, 67).index(piece) + 1])
+    rows, nacc = m.flush()
+    assert rows.shape[0] == nsteps and nacc == want_acc
+    assert np.array_equal(rows, want_rows)
+    assert la.passes < nsteps                    # rejections were decided two steps per pass
+    # the chain goes on identically stepped the ordinary way (generator states, current vector, proposal)
+    more_plain, _ = plain.run(10)
+    more, _ = m.run(10)
+    assert np.array_equal(more, more_plain)
+    # debug mode accepts everything: every pass is one step, still the same chain
+    p2 = MCMC(w, seed=5, lut_output=False, consume=True, stream=capi.new_stream())
+    p2.setup(sync_interval=64)
+    want2, _ = p2.run(12, debug_mode=True)
+    m2 = MCMC(w, seed=5, lut_output=False, consume=True, stream=capi.new_stream())
+    m2.setup(sync_interval=64)
+    la2 = LookaheadWalk(m2, threads=threads)
+    la2.bind()
+    la2.steps(12, debug_mode=True, count0=0)
+    got2, _ = m2.flush()
+    assert np.array_equal(got2, want2) and la2.passes == 12
+    la.close()
+    la2.close()
+
+
 def test_lockstep_refuses_chains_that_cannot_share_a_pass():
     from sxmc_amd.mcmc import LockstepChains
     w = workloads.config3(0.002, nevents=500)

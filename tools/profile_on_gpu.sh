@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 # traced runs: the timed region only (no CPU baseline, no ensemble leg -- its concurrent chains launch the same
 # kernels on other data sets and would be averaged into the per-kernel statistics)
-B="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --experiments 0 $@"
+B="python3 bench.py --steps 150 --warmup 10 --no-cpu-baseline --experiments 0 $@"
 timeout -k 10 400 python3 bench.py "$@" > $OUT/bench.json.log 2>&1 || { tail -5 $OUT/bench.json.log; exit 1; }
 tail -1 $OUT/bench.json.log > $OUT/bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1 || exit 2
