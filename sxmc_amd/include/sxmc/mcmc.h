@@ -172,6 +172,11 @@ class MCMC {
                                     //!< allocates, uploads, rebuilds launch plans, records its graph and frees
                                     //!< (calls the runtime refuses beside another thread's recording); it is
                                     //!< released while the walk only launches and waits on its own stream
+  bool lookahead = false;       //!< batched, consuming form, one chain: the LOOK-AHEAD WALK.  Every pass over the tables
+                                //!< evaluates the step's proposal AND the vector the next step proposes after a rejection
+                                //!< (a second set of evaluators over the same tables), and the step end decides one or two
+                                //!< steps (sxmc_multigroup_lookahead_step_async).  Same chain bit for bit, ~25 % more
+                                //!< steps per second at BASELINE config 3.
   bool lut_output = false;      //!< materialise the lookup table in the batched step (nothing reads it; when
                                 //!< false the event sum runs over distinct event-bin tuples, see sxmc_hip.h)
   unsigned long long seed = 0;  //!< gRandom->GetSeed() in the reference (mcmc.cpp:125)
@@ -358,6 +363,48 @@ class MCMC {
     // accessors, which go through the legacy default stream) and the batched form.
     const bool in_lockstep = lockstep && batched && reevaluate && consume;
     const unsigned gsteps = (batched && reevaluate && !in_lockstep) ? graph_steps : 0;
+
+    // ---- look-ahead walk: a shadow set of evaluators over the same tables, bound to the look-ahead vector
+    const bool ahead = lookahead && batched && reevaluate && consume && !in_lockstep && !lut_output && nparameters <= 256;
+    std::vector<std::unique_ptr<pdfz::EvalHist>> shadow;
+    sxmc_group_t shadow_group = nullptr;
+    sxmc_multigroup_t pair = nullptr;
+    pdfz::Array<double> ahead_vector(nparameters, true);
+    pdfz::Array<unsigned> ahead_norms(nsignals, true);
+    pdfz::Array<float> ahead_lut(ahead ? nevents * nsignals : 1, true);
+    pdfz::Array<int> ahead_stop(1, true);
+    struct AheadGuard {   // (the multigroup goes before its groups, the group before its evaluators)
+      sxmc_multigroup_t* pair;
+      sxmc_group_t* group;
+      ~AheadGuard() {
+        if (*pair) sxmc_multigroup_destroy(*pair);
+        if (*group) sxmc_group_destroy(*group);
+      }
+    } ahead_guard{&pair, &shadow_group};
+    if (ahead) {
+      ahead_vector.writeOnlyHostPtr();
+      ahead_norms.writeOnlyHostPtr();
+      ahead_lut.writeOnlyHostPtr();
+      std::vector<sxmc_hist_t> handles;
+      for (size_t i = 0; i < pdfs.size(); i++) {
+        pdfz::EvalHist* base = dynamic_cast<pdfz::EvalHist*>(pdfs[i]);
+        shadow.emplace_back(new pdfz::EvalHist(*base, pdfz::EvalHist::SharedSamples{}));
+        pdfz::EvalHist* p = shadow.back().get();
+        p->SetEvalPoints(data);
+        p->SetPDFValueBuffer(&ahead_lut, (int)(i * nevents), 1);
+        p->SetNormalizationBuffer(&ahead_norms, (int)i);
+        p->SetParameterBuffer(&ahead_vector, (int)nsources);
+        p->Bind();
+        handles.push_back(p->Handle());
+      }
+      check(sxmc_group_create(handles.data(), (int)handles.size(), &shadow_group));
+      check(sxmc_group_set_lut_output(shadow_group, 0));
+      // a pass of two evaluations is bound by vector issue and LDS, not by the stream: all the waves a CU holds
+      check(sxmc_group_set_launch_config(group, 1024, 1));
+      check(sxmc_group_set_launch_config(shadow_group, 1024, 1));
+      sxmc_group_t both[2] = {group, shadow_group};
+      check(sxmc_multigroup_create(both, 2, &pair));
+    }
     sxmc_stream_t strm = stream;
     sxmc_graph_t graph = nullptr;
     const bool own_stream = gsteps > 0 && !strm;
@@ -446,7 +493,7 @@ class MCMC {
       while (!flush_due(f)) f++;
       unsigned n = f - i + 1;
       resolve();
-      if (gsteps > 0 && i > 0 && n >= gsteps) {
+      if (!ahead && gsteps > 0 && i > 0 && n >= gsteps) {
         if (!graph) {  // record gsteps steps once; the launch plan is current after the eager step 0
           check(sxmc_graph_begin_capture(strm));
           try {
@@ -488,6 +535,75 @@ class MCMC {
         lockstep->advance(lockstep_index, group, a, n, graph_steps);
         n = 0;
       }
+      if (ahead && n > 0) {
+        // exactly n more steps, taken one or two per pass: passes in rounds of about what is still needed, the step
+        // counter read back after each round; a pass beyond the stop does nothing (the counter was 0 at the flush)
+        sxmc_step_args a;
+        std::memset(&a, 0, sizeof a);
+        a.d_means = d.means;
+        a.d_sigmas = d.sigmas;
+        a.d_rng = reinterpret_cast<sxmc_rng_state*>(d.rng);
+        a.d_nll_current = d.nll_current;
+        a.d_nll_proposed = d.nll_proposed;
+        a.d_v_current = d.current;
+        a.d_v_proposed = d.proposed;
+        a.d_accepted = d.accepted;
+        a.d_counter = d.counter;
+        a.d_jump_buffer = d.jump_buffer;
+        a.nparameters = (int)nparameters;
+        a.nsources = nsources;
+        a.d_jump_width = d.jump_width;
+        a.d_nexpected = d.nexpected;
+        a.d_n_mc = d.n_mc;
+        a.d_source_id = d.source_id;
+        a.d_norms = d.norms;
+        a.debug_mode = debug_mode ? 1 : 0;
+        ahead_stop.writeOnlyHostPtr()[0] = (int)n;
+        const int* d_stop = ahead_stop.readOnlyPtr();
+        double* d_ahead = ahead_vector.ptr();
+        const unsigned* d_anorms = ahead_norms.ptr();
+        // the look-ahead vector for the chain as it stands (new widths after a re-tuning included)
+        check(sxmc_lookahead_begin(strm, (int)nparameters, reinterpret_cast<const sxmc_rng_state*>(d.rng), d.jump_width,
+                                   d.current, d_ahead));
+        auto one_pass = [&]() {
+          check(sxmc_multigroup_lookahead_step_async(pair, strm, &a, d_ahead, d_anorms, d_stop));
+          ahead_passes++;
+        };
+        unsigned done = 0;
+        while (done < n) {
+          const unsigned need = n - done;
+          const double rate = ahead_passes_seen >= 16 ? std::min(2.0, 1.03 * ahead_steps_seen / ahead_passes_seen) : 1.75;
+          unsigned k = std::max(1u, (unsigned)(need / rate));
+          const size_t p0 = ahead_passes;
+          if (gsteps > 0 && k > gsteps) {
+            if (!graph) {
+              one_pass();   // (plans in place before recording)
+              k--;
+              check(sxmc_graph_begin_capture(strm));
+              try {
+                for (unsigned q = 0; q < gsteps; q++) one_pass();
+              } catch (...) {
+                sxmc_graph_end_capture(strm, &graph);
+                throw;
+              }
+              check(sxmc_graph_end_capture(strm, &graph));
+              ahead_passes -= gsteps;
+            }
+            if (excl.owns_lock()) excl.unlock();
+            check(sxmc_graph_launch(graph, strm, (int)(k / gsteps)));
+            ahead_passes += (size_t)(k / gsteps) * gsteps;
+            k %= gsteps;
+          }
+          for (unsigned q = 0; q < k; q++) one_pass();
+          (void)jump_counter.ptr();   // (the device side changed behind the mirror's back: the host copy is stale)
+          const unsigned now = (unsigned)jump_counter.readOnlyHostPtr()[0];   // (a blocking copy on the chain's stream)
+          if (now <= done && now < n) throw pdfz::Error("look-ahead walk: the chain did not advance");
+          ahead_steps_seen += now - done;
+          ahead_passes_seen += ahead_passes - p0;
+          done = now;
+        }
+        n = 0;
+      }
       for (unsigned k = 0; k < n; k++) one_step();
 
       // Flush the jump buffer (mcmc.cpp:351-377); the host reads go through blocking copies
@@ -508,6 +624,7 @@ class MCMC {
     // the evaluators borrowed this walk's arrays (lookup table, normalisations, parameter vectors): un-bind them
     // before they die, or the next evaluation of an evaluator would touch destroyed arrays
     for (pdfz::Eval* p : pdfs) p->ForgetBuffers();
+    for (auto& p : shadow) p->ForgetBuffers();
     if (exclusive && !excl.owns_lock()) excl.lock();  // tear-down frees device memory
     if (graph) check(sxmc_graph_destroy(graph));
     if (own_stream) check(sxmc_stream_destroy(strm));
@@ -520,6 +637,8 @@ class MCMC {
   }
 
   size_t NumParameters() const { return nparameters; }
+  /** Look-ahead walk: passes over the tables launched so far (each evaluates twice and takes one or two steps). */
+  size_t LookaheadPasses() const { return ahead_passes; }
 
  protected:
   /** MCMC::nll (mcmc.cpp:390-415): three launches over an evaluated lookup table. */
@@ -564,6 +683,8 @@ class MCMC {
   std::vector<pdfz::Eval*> pdfs;
   sxmc_group_t group = nullptr;
   bool optimized = false;
+  size_t ahead_passes = 0, ahead_passes_seen = 0;   //!< look-ahead walk: passes launched / counted in the rate below
+  double ahead_steps_seen = 0;
 };
 
 }  // namespace sxmc

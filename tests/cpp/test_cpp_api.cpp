@@ -440,6 +440,26 @@ TEST_F(SmallFit, GraphReplayedStepsWalkTheSameChain) {
   EXPECT_TRUE(same);
 }
 
+TEST_F(SmallFit, LookaheadWalkIsTheSequentialChain) {
+  // the look-ahead walk: two evaluations per pass over the tables, one or two steps per pass -- the same chain bit
+  // for bit, across re-tuning points (the look-ahead vector is formed anew with the new widths), jump-buffer
+  // flushes (an exact stop at every one) and graph replays, in fewer passes than steps
+  sxmc::MCMC a(sources, signals, systematics, observables, 7);
+  sxmc::Chain ca = a(data, 333, 0.2f, false, 100);
+  for (unsigned gs : {0u, 6u}) {
+    sxmc::MCMC b(sources, signals, systematics, observables, 7);
+    b.lookahead = true;
+    b.graph_steps = gs;
+    sxmc::Chain cb = b(data, 333, 0.2f, false, 100);
+    EXPECT_EQ(ca.nrows(), cb.nrows());
+    EXPECT_EQ(ca.accepted, cb.accepted);
+    bool same = ca.rows.size() == cb.rows.size();
+    for (size_t k = 0; same && k < ca.rows.size(); k++) same = ca.rows[k] == cb.rows[k];
+    EXPECT_TRUE(same);
+    EXPECT_TRUE(b.LookaheadPasses() > 0 && b.LookaheadPasses() < 333);
+  }
+}
+
 TEST(NllLaunch, ReferenceSpelling) {
   // the launch macro with the reference's argument order (mcmc.cpp:396-414)
   const size_t ne = 5, ns = 2, np = 2;
