@@ -195,13 +195,31 @@ class MCMC:
         """Fresh generator states (a new experiment on the same evaluators)."""
         self.rngs = nll.make_rngs(self.nparameters, seed, self.stream)
 
-    def walk(self, data, nsteps, burnin_fraction, debug_mode=False, sync_interval=10000, graph_steps=0):
+    def walk(self, data, nsteps, burnin_fraction, debug_mode=False, sync_interval=10000, graph_steps=0,
+             lookahead=False):
         """MCMC::operator() (mcmc.cpp:143-387): start at the means, walk nsteps, re-tune the proposal
         widths from the chain's spread at burnin_steps and 2 * burnin_steps (dropping the steps so far
         unless debug_mode).  Returns (chain [nkept, P + 1] float32, accepted).
         graph_steps = K > 0 replays a HIP graph of K recorded steps wherever K steps fit between two
         points that need the host (re-tuning, jump-buffer flush); the chain is the same."""
         self.walk_begin(data, nsteps, burnin_fraction, debug_mode, sync_interval)
+        if lookahead:
+            # the look-ahead walk (LookaheadWalk below): two evaluations per pass over the tables, one or two steps
+            # per pass; needs consume=True, lut_output=False and a created stream.  The same chain.
+            la = LookaheadWalk(self)
+            la.bind(data)
+            i = 0
+            try:
+                for f in self.flush_schedule():
+                    self._retune_if_due(i)
+                    la.restart()              # (the look-ahead vector with the widths as they now are)
+                    la.steps(f - i + 1, graph_passes=graph_steps, debug_mode=self._debug, count0=0)
+                    self._flush_if_due(f)
+                    i = f + 1
+            finally:
+                self.lookahead_passes = la.passes
+                la.close()
+            return self.walk_end()
         if graph_steps <= 0:
             for i in range(nsteps):
                 self.walk_advance(i)

@@ -374,6 +374,19 @@ def test_lookahead_walk_is_the_sequential_chain(graph_passes, threads):
     la2.close()
 
 
+def test_whole_walk_with_lookahead_is_the_same_walk():
+    """MCMC.walk(lookahead=True): burn-in re-tunings (the look-ahead vector is formed anew with the new widths),
+    jump-buffer flushes (exact stops) and graph replays -- the chain and the accept count of the ordinary walk."""
+    w = workloads.config3(0.004, nevents=3000)
+    plain = MCMC(w, seed=41, lut_output=False, consume=True, stream=capi.new_stream())
+    want = plain.walk(w.events, 260, 0.15, sync_interval=70)
+    for gs in (0, 5):
+        m = MCMC(w, seed=41, lut_output=False, consume=True, stream=capi.new_stream())
+        got = m.walk(w.events, 260, 0.15, sync_interval=70, graph_steps=gs, lookahead=True)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0]), gs
+        assert 0 < m.lookahead_passes < 260
+
+
 def test_lockstep_refuses_chains_that_cannot_share_a_pass():
     from sxmc_amd.mcmc import LockstepChains
     w = workloads.config3(0.002, nevents=500)
