@@ -374,6 +374,34 @@ def test_lookahead_walk_is_the_sequential_chain(graph_passes, threads):
     la2.close()
 
 
+@pytest.mark.parametrize("width_scale", [0.05, 12.0])
+def test_lookahead_walk_at_high_and_low_acceptance(width_scale):
+    """Nearly every step accepted (every pass one step) and nearly every step rejected (every pass two steps,
+    incl. a negative rate -> the 1e18 penalty): the same chain as stepping one evaluation at a time."""
+    from sxmc_amd.mcmc import LookaheadWalk
+    w = workloads.config3(0.003, nevents=2000)
+    nsteps = 120
+    chains = []
+    for look in (False, True):
+        m = MCMC(w, seed=91, lut_output=False, consume=True, stream=capi.new_stream())
+        jw = (m.initial_jump_widths() * np.float32(width_scale)).astype(np.float32)
+        m.setup(sync_interval=256, jump_width=jw)
+        if look:
+            la = LookaheadWalk(m, threads=0)
+            la.bind()
+            la.steps(nsteps, graph_passes=5, count0=0)
+            passes = la.passes
+            rows, nacc = m.flush()
+            la.close()
+        else:
+            rows, nacc = m.run(nsteps)
+        chains.append((rows, nacc))
+    assert chains[0][1] == chains[1][1] and np.array_equal(chains[0][0], chains[1][0])
+    frac = chains[0][1] / nsteps
+    assert (frac > 0.8) if width_scale < 1 else (frac < 0.5), frac
+    assert (passes > 0.8 * nsteps) if width_scale < 1 else (passes < 0.85 * nsteps), passes
+
+
 def test_whole_walk_with_lookahead_is_the_same_walk():
     """MCMC.walk(lookahead=True): burn-in re-tunings (the look-ahead vector is formed anew with the new widths),
     jump-buffer flushes (exact stops) and graph replays -- the chain and the accept count of the ordinary walk."""
