@@ -230,7 +230,8 @@ class Leg:
         self.la = None
         if self.lookahead:
             from sxmc_amd.mcmc import LookaheadWalk
-            self.la = LookaheadWalk(m, threads=1024 if args.launch == "0,0" else 0)
+            lt, lb = (int(x) for x in args.launch.split(","))
+            self.la = LookaheadWalk(m, threads=lt if lt else 1024, blocks_per_cu=lb if lt else 1)
             self.la.bind()
         # untimed: clocks and graph replay settle over the first few hundred steps, whatever --warmup says
         for lo in range(0, args.prewarm, 100):
