@@ -225,9 +225,11 @@ def projection_interval(values, cl=0.9, nbins=100):
 
 # ------------------------------------------------------------------------------------ the ensemble
 def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_interval=10000, mcmc=None,
-                   form="fused", graph_steps=0):
+                   form="fused", graph_steps=0, lookahead=False):
     """One iteration of the loop in sxmc.cpp:59-145: fake data -> MCMC -> intervals.
     Reuses `mcmc` (evaluators with the MC tables resident in HBM) across experiments when given.
+    lookahead: walk with two evaluations per pass over the tables (MCMC.walk(lookahead=True): the same chain, about a
+    quarter more steps per second when one experiment has the GPU to itself; `mcmc` then needs a created stream).
     Returns (intervals float32 [P, 4], chain, accepted)."""
     rng = np.random.default_rng(seed)
     if mcmc is None:
@@ -236,7 +238,8 @@ def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_int
     else:
         mcmc.reseed(seed & 0xFFFFFFFF)
     data, _ = make_fake_dataset(rng, workload, mcmc.pdfs, poisson=True)
-    chain, accepted = mcmc.walk(data, nsteps, burnin_fraction, sync_interval=sync_interval, graph_steps=graph_steps)
+    chain, accepted = mcmc.walk(data, nsteps, burnin_fraction, sync_interval=sync_interval, graph_steps=graph_steps,
+                                lookahead=lookahead and mcmc.stream is not None and mcmc.consume)
     return contour_intervals(chain, cl), chain, accepted
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from sxmc_amd import ensemble, workloads
+from sxmc_amd import capi, ensemble, workloads
 from sxmc_amd.mcmc import MCMC
 
 pytestmark = pytest.mark.gpu
@@ -114,6 +114,22 @@ def test_one_fake_experiment_end_to_end():
     # a second experiment on the same evaluators (tables stay resident) gives a different data set
     iv2, chain2, _ = ensemble.run_experiment(w, seed=99, nsteps=300, burnin_fraction=0.1, mcmc=m)
     assert chain2.shape[0] == 300 - 60 and not np.array_equal(iv, iv2)
+
+
+def test_fake_experiment_with_the_lookahead_walk_gives_the_same_intervals():
+    """run_experiment(lookahead=True): same fake data (same seed), same chain, same intervals, fewer passes."""
+    w = workloads.config3(0.003, nevents=100)
+    for s in w.signals:
+        s.nexpected = 400.0
+    out = []
+    for look in (False, True):
+        m = MCMC(w, seed=3, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
+        iv, chain, acc = ensemble.run_experiment(w, seed=4321, nsteps=600, burnin_fraction=0.2, mcmc=m,
+                                                 sync_interval=250, graph_steps=4 if look else 0, lookahead=look)
+        out.append((iv, chain, acc))
+        if look:
+            assert 0 < m.lookahead_passes < 600
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
 
 
 def test_run_config_end_to_end(tmp_path):
