@@ -32,6 +32,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+ROOFLINE_LAUNCHES = 100    # event-timed fill launches behind `roofline` (after the timed region, whatever --steps is)
+
+
+def source_fingerprints():
+    """sha256 (16 hex digits) of the sources that decide what a fill launch reads and writes: the kernels and the
+    host planner.  profiles/traffic.json keeps the pair its PMC passes were taken with (tools/update_traffic.py); a
+    line whose sources differ says `traffic_stale` instead of passing an old measurement off as this code's."""
+    import hashlib
+    csrc = os.path.join(ROOT, "sxmc_amd", "csrc")
+
+    def digest(names):
+        h = hashlib.sha256()
+        for n in names:
+            path = os.path.join(csrc, n)
+            if os.path.exists(path):
+                h.update(n.encode() + b"\0" + open(path, "rb").read())
+        return h.hexdigest()[:16]
+    return {"kernels": digest(["fill_kernels.inc.h", "pdfz_kernels.hip", "sxmc_device_types.h"]),
+            "planner": digest(["sxmc_hip.cpp", "sxmc_plan.h"])}
 
 
 def make_c3_on_gpu(torch, dev, scale, seed, nevents):
@@ -292,10 +311,31 @@ class Leg:
         elapsed = time.perf_counter() - t0
         if collective:
             elapsed = dist.max_over_ranks(elapsed)
-        self.fill_ms_total, self.nfill = m.group.ProfileRead()
+        self.fill_ms_region, self.nfill_region = m.group.ProfileRead()
         m.group.Profile(False, 0)
         self._launches = m.group.LastStepLaunches() if (m.consume and m.tail and self.form != "pdfz") else None
         self.elapsed, self.steps = elapsed, steps
+        # ---- the roofline sample, decoupled from --steps: AFTER the timed region (ms_per_step comes from the timed
+        # steps alone) the walk goes on for ROOFLINE_LAUNCHES more steps launched one by one, each fill bracketed by
+        # HIP events on the stream it is launched on, from the state the chain has reached
+        n = max(ROOFLINE_LAUNCHES, 0)
+        self.fill_ms_total, self.nfill = self.fill_ms_region, self.nfill_region
+        self.roofline_sample = "inside the timed region: the %d steps launched one by one" % self.nfill_region
+        if n > 0:
+            m.flush()
+            m.group.Profile(True, n + 8)
+            if self.la is not None:
+                self.la.steps(n, graph_passes=0)
+            else:
+                for _ in range(n):
+                    self.one_step()
+            torch.cuda.synchronize()
+            post_ms, post_n = m.group.ProfileRead()
+            m.group.Profile(False, 0)
+            m.flush()
+            if post_n >= self.nfill_region:
+                self.fill_ms_total, self.nfill = post_ms, post_n
+                self.roofline_sample = "post-timed, %d launches" % post_n
         return elapsed
 
     def launches_per_step(self):
@@ -317,7 +357,7 @@ class Leg:
         survey_bytes = 4.0 * (w.nobs + len(extra_fields)) * w.nsamples_total + ab["hist"]
         # HBM bytes of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc
         # passes (tools/profile_on_gpu.sh), corrected as MI355X_MICROARCH.md prescribes, kept per workload
-        traffic = None
+        traffic, traffic_note = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else "") +
@@ -327,6 +367,14 @@ class Leg:
                 t = None
             if t and self.scale == 1.0 and args.nsyst < 0:
                 traffic = t["bytes_per_launch"]
+                now, then = source_fingerprints(), t.get("profiled_sources")
+                stale = [k for k in now if not then or then.get(k) != now[k]]
+                traffic_note = {"from": t.get("source"), "profiled_sources": then, "current_sources": now,
+                                "stale": bool(stale),
+                                "warning": ("profiles/traffic.json was measured before the last change to the %s source(s): "
+                                            "`traffic` is that older build's figure until the PMC passes are repeated "
+                                            "(tools/profile_on_gpu.sh + tools/update_traffic.py)" % " and ".join(stale))
+                                if stale else None}
         except (OSError, ValueError):
             pass
         info = m.group.LaunchInfo()
@@ -340,9 +388,11 @@ class Leg:
                                               "compiled kernels as sx_rtc_fill)",
             "launch_plan": info.strip().split("\n"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
+            "traffic": traffic, "traffic_provenance": traffic_note,
             "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
-            "avg_launch_ms": fill_ms, "launches_timed": self.nfill,
+            "avg_launch_ms": fill_ms, "launches_timed": self.nfill, "sample": self.roofline_sample,
+            "in_timed_region": {"launches": self.nfill_region,
+                                "avg_launch_ms": self.fill_ms_region / max(self.nfill_region, 1)},
             # a look-ahead pass fills the histograms of TWO evaluations from one pass over the tables: `achieved` and
             # `frac` count the bytes the launch must stream once; per evaluation it is half of that
             "evaluations_per_launch": neval,
@@ -490,29 +540,62 @@ def also_record(args, torch, dev, name, form, lut_output, steps, warmup, exp_see
     return rec
 
 
+def run_bench_cpp(argv, timeout):
+    """tests/cpp/bench_cpp as a child process (its own HIP context; no Python in it).  Returns (records, failure):
+    the JSON lines it printed, and None or a description of what went wrong -- a bench_cpp that crashes, faults or
+    exits non-zero is a FAILURE of this bench, not a skipped leg."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "bench_cpp")
+    if not os.path.exists(exe):
+        return [], {"failed": "tests/cpp/bench_cpp is not built (__graft_entry__.build() builds it)"}
+    try:
+        r = subprocess.run([exe] + [str(a) for a in argv], capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as exc:
+        return [], {"failed": "tests/cpp/bench_cpp did not finish within %d s" % timeout,
+                    "stderr": (exc.stderr or b"")[-600:].decode(errors="replace") if isinstance(exc.stderr, bytes)
+                    else (exc.stderr or "")[-600:]}
+    lines = [json.loads(x) for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    if r.returncode != 0:
+        return lines, {"failed": "tests/cpp/bench_cpp exited with %d" % r.returncode, "stderr": r.stderr[-600:]}
+    return lines, None
+
+
 def cpp_host_record(args, nsteps=4000):
     """BASELINE config 3 at full size walked entirely by the C++ host layer (tests/cpp/bench_cpp: sxmc::build_pdfz +
     sxmc::MCMC over the C ABI, graph-replayed steps, no Python in that process): the north star's "host code stays
     C++".  The walk includes its set-up, both burn-in re-tunings and the jump-buffer flushes."""
-    import subprocess
-    exe = os.path.join(ROOT, "tests", "cpp", "bench_cpp")
-    if not os.path.exists(exe):
-        return {"skipped": "tests/cpp/bench_cpp is not built (__graft_entry__.build() builds it)"}
     t0 = time.perf_counter()
-    try:
-        r = subprocess.run([exe, "1.0", str(nsteps), str(args.graph_steps), "8", "2000", "4", "2"], capture_output=True,
-                           text=True, timeout=300)
-    except subprocess.TimeoutExpired:
-        return {"skipped": "tests/cpp/bench_cpp did not finish within 300 s"}
-    if r.returncode != 0:
-        return {"skipped": "tests/cpp/bench_cpp failed: " + r.stderr[-300:]}
-    lines = [json.loads(x) for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    lines, failure = run_bench_cpp(["--scale", "1.0", "--steps", nsteps, "--graph-steps", args.graph_steps,
+                                    "--experiments", 8, "--exp-steps", 2000, "--chains", 4, "--sets", 2], 300)
+    if failure:
+        return failure
     rec = lines[0]
     if len(lines) > 1:
         rec["ensemble_lockstep"] = lines[1]     # 8 whole fake experiments as 2 lockstep sets of 4 chains
     rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
     rec["leg_seconds"] = time.perf_counter() - t0
     rec["note"] = "whole walk of %d steps including set-up, re-tuning and flushes; host = C++ only" % nsteps
+    return rec
+
+
+def cpp_multi_gpu_record(args, ngpus, collective):
+    """BASELINE config 4's shape from the C++ host layer, ONE process: sxmc::ensemble_multi_gpu -- a host thread per
+    GPU with its own replica of the evaluators, experiment k on device k mod G in lockstep sets, ONE RCCL all-gather
+    of the intervals (sxmc_comm_allgather_f32) -- over the full-size C3 tables.  Run by rank 0 after the Python
+    ranks have finished and released their cards.  In a rehearsal (ranks sharing a card over gloo) the device threads
+    run on the same cards as the ranks did and their blocks meet through host memory: RCCL refuses two ranks on one
+    card, and the record says "host staging (rehearsal)"."""
+    t0 = time.perf_counter()
+    nexp = 8 * ngpus if args.experiments < 0 else max(args.experiments, ngpus)
+    devices = ",".join(str(d["device_index"]) for d in collective["devices"])
+    extra = [] if collective["backend"] == "nccl" else ["--host-staging"]
+    lines, failure = run_bench_cpp(["--scale", args.scale, "--no-walk", "--graph-steps", args.graph_steps,
+                                    "--experiments", nexp, "--exp-steps", args.exp_steps, "--chains", 4, "--sets", 2,
+                                    "--device-list", devices] + extra, 900)
+    if failure:
+        return failure
+    rec = lines[-1]
+    rec["leg_seconds"] = time.perf_counter() - t0
     return rec
 
 
@@ -556,8 +639,9 @@ def main():
     ap.add_argument("--exp-concurrent", type=int, default=4,
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
-                    help="sub-records measured after the headline: comma list of c3_lut_materialized, c2, c5, cpp_host; "
-                         "auto = all of them when the headline is the full-size C3 on one GPU; none = skip")
+                    help="sub-records measured after the headline: comma list of c3_lookahead, c3_lut_materialized, c2, c5, "
+                         "cpp_host, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
+                         "GPU, cpp_multi_gpu (sxmc::ensemble_multi_gpu over the same cards) at N > 1; none = skip")
     ap.add_argument("--also-steps", type=int, default=200, help="timed steps of each sub-record (C5: a quarter)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
     ap.add_argument("--no-sparse", action="store_true", help="fill HBM-resident histograms densely (global atomics)")
@@ -585,28 +669,48 @@ def main():
                     help="roofline measurement hook (wrong results): 1 stream only, 2 compute only, 4 no histogram")
     args = ap.parse_args()
 
-    import torch
-
-    from sxmc_amd import capi, dist
-    from sxmc_amd.mcmc import MCMC
+    from sxmc_amd import dist
 
     rank, local_rank, world = dist.env_world()
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # started bare (`python bench.py --gpus N`): this process, which has made no HIP call and has not asked
+        # torch about the GPU (it does not even import torch), starts N fresh workers of the same command line
+        # -- one rank per GPU, what torch.distributed.run would start -- and relays rank 0's JSON line
+        raise SystemExit(dist.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    # the job's stdout carries ONE line, the JSON record: whatever libraries print on fd 1 meanwhile (gloo and RCCL
+    # announce themselves there) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    import torch
+
+    from sxmc_amd import capi
+    from sxmc_amd.mcmc import MCMC
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    device_index = local_rank % torch.cuda.device_count()   # one GPU per rank on the real node
+    ncards = torch.cuda.device_count()
+    backend = os.environ.get("SXMC_DIST_BACKEND") or "nccl"
+    if world > ncards and backend == "nccl":
+        raise SystemExit("--gpus %d on a box with %d GPU(s): RCCL needs one card per rank (a rehearsal of the "
+                         "multi-rank path over gloo, ranks sharing a card, is SXMC_DIST_BACKEND=gloo; its line says so)"
+                         % (world, ncards))
+    device_index = local_rank % ncards   # one GPU per rank on the real node
     torch.cuda.set_device(device_index)
     capi.call("sxmc_set_device", device_index)
     dev = torch.device("cuda", device_index)
     dist.init()
     info = capi.device_info(device_index)
+    # what the collectives of this job really run on (backend, RCCL's own rank count, every rank's card)
+    collective, rccl = dist.collective_record(device_index, info)
 
     # ---- inputs: same MC tables on every rank (replica), own data events + chain seed per rank
     exp_seed = dist.experiment_seed(args.seed, rank)
-    want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1 and not args.debug_mode
+    want_cpu = (not args.no_cpu_baseline) and rank == 0 and not args.debug_mode   # parity: rank 0 at every N
     big = args.workload.lower() == "c5" and args.scale >= 0.2
     leg = Leg(args, torch, dev, args.workload, args.form, args.lut_output, args.seed, exp_seed,
               keep_host=("ends" if big else "all") if want_cpu else "none",
@@ -623,7 +727,12 @@ def main():
     chain, accepted = m.flush()
     if chain.shape[0] == 0:
         chain = np.zeros((1, w.nparameters + 1), np.float32)
-    intervals = dist.gather_intervals(chain_intervals(chain, w.nparameters)[None], world, w.nparameters)
+    mine_iv = chain_intervals(chain, w.nparameters)[None]
+    intervals = dist.gather_intervals(mine_iv, world, w.nparameters)
+    if rccl is not None:
+        # the same exchange on librccl through the C ABI (what sxmc::ensemble_multi_gpu calls); NaN-free payload
+        via_abi = dist.gather_intervals(mine_iv, world, w.nparameters, comm=rccl)
+        collective["intervals_through_c_abi_match_torch"] = bool(np.array_equal(via_abi, intervals))
 
     # ---- ensemble leg (sxmc.cpp:59-145): whole fake experiments, experiment k on rank k mod N, the MC
     # tables stay resident; one RCCL all_gather of the per-experiment intervals at the end.  Outside the
@@ -713,7 +822,10 @@ def main():
                     c.group.close()
         best = lockstep if lockstep and "experiments_per_sec" in lockstep and \
             lockstep["experiments_per_sec"] > separate["experiments_per_sec"] else separate
-        allint = dist.gather_intervals(local, nexp, w.nparameters)
+        allint = dist.gather_intervals(local, nexp, w.nparameters, comm=rccl)
+        if collective is not None:
+            collective["experiment_intervals_gathered_by"] = ("sxmc_comm_allgather_f32 (librccl through the C ABI)"
+                                                              if rccl is not None else "torch.distributed all_gather")
         experiments = {
             "count": nexp, "steps_each": args.exp_steps, "seconds": exp_elapsed, "concurrent_per_gpu": nconc,
             "steps_per_graph": exp_graph, "separate_fills": separate, "lockstep": lockstep,
@@ -767,6 +879,7 @@ def main():
         "roofline": leg.roofline(world),
         "cpu_baseline": None,
         "parity": None,
+        "collective": collective,
         "intervals_gathered": [int(x) for x in intervals.shape],
         "experiments": experiments,
         "also": None,
@@ -774,21 +887,35 @@ def main():
 
     if want_cpu:
         # same inputs, same parameter vector: parity asserted for every workload, the oracle timed beside it
-        par, cpu = leg.parity(time_evals=args.cpu_evals)
+        # (the oracle is TIMED at N = 1 only; at N > 1 rank 0 still proves parity with one oracle evaluation)
+        par, cpu = leg.parity(time_evals=args.cpu_evals if world == 1 else 0)
         result["parity"], result["cpu_baseline"] = par, cpu
         if not par["ok"]:
-            print(json.dumps(result))
+            print(json.dumps(result), file=json_out, flush=True)
             raise SystemExit("PARITY FAILURE: GPU result differs from the CPU oracle")
 
     # ---- sub-records: the other single-GPU configurations and the lookup-table-materialising step form,
     # measured in the same run so that their numbers carry the driver's clock too
     also = args.also
     if also == "auto":
-        full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and world == 1 and not args.debug_mode
-        also = ("c3_lookahead,c3_lut_materialized,c2,c5,cpp_host"
-                if full_c3 and want_cpu and args.form == "graph" else "none")
-    if also != "none" and rank == 0:
+        full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and not args.debug_mode
+        also = "none"
+        if full_c3 and want_cpu and args.form == "graph" and world == 1:
+            also = "c3_lookahead,c3_lut_materialized,c2,c5,cpp_host"
+        elif full_c3 and args.form == "graph" and world > 1:
+            also = "cpp_multi_gpu"        # the C++ one-process runner over the same N cards
+    if world > 1:
+        # every rank lets go of its card before rank 0 starts the C++ runner on all of them
         leg.close()
+        if rccl is not None:
+            rccl.close()
+        torch.cuda.empty_cache()
+        dist.barrier()
+        dist.shutdown()
+    failed_leg = None
+    if also != "none" and rank == 0:
+        if world == 1:
+            leg.close()
         recs = {}
         for name in [x.strip() for x in also.split(",") if x.strip()]:
             if name == "c3_lookahead":            # the same walk taken one or two steps per pass (two evaluations per pass)
@@ -803,13 +930,21 @@ def main():
                                          exp_seed, "ends")
             elif name == "cpp_host":
                 recs[name] = cpp_host_record(args)
+            elif name == "cpp_multi_gpu":
+                recs[name] = cpp_multi_gpu_record(args, world, collective)
             else:
                 raise SystemExit("unknown --also entry %r" % name)
+            if isinstance(recs[name], dict) and "failed" in recs[name]:
+                failed_leg = name
         result["also"] = recs
 
     if rank == 0:
-        print(json.dumps(result))
-    dist.shutdown()
+        print(json.dumps(result), file=json_out, flush=True)
+    if world == 1:
+        dist.shutdown()
+    if failed_leg:
+        raise SystemExit("bench.py: the %s leg FAILED (its record says how): %s"
+                         % (failed_leg, result["also"][failed_leg].get("failed")))
 
 
 if __name__ == "__main__":

@@ -64,6 +64,8 @@ int sxmc_set_device(int device);
 int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes,
                      int* lds_bytes_per_cu, int* clock_khz);
 int sxmc_device_synchronize(void);
+/* PCI bus id of a device ("0000:05:00.0"): tells two ranks on ONE card from two ranks on two cards of the same name. */
+int sxmc_device_pci_bus_id(int device, char* out, size_t out_bytes);
 /* Free and total device memory in bytes (hipMemGetInfo). */
 int sxmc_mem_info(size_t* free_bytes, size_t* total_bytes);
 
@@ -86,6 +88,9 @@ int sxmc_stream_create(sxmc_stream_t* s);
 int sxmc_stream_create_nonblocking(sxmc_stream_t* s);
 int sxmc_stream_destroy(sxmc_stream_t s);
 int sxmc_stream_synchronize(sxmc_stream_t s);
+/* *done = 1 when everything queued on `s` has finished, 0 while work is pending (hipStreamQuery): lets a host thread
+ * wait for a collective WITHOUT blocking inside the runtime, so that it can give up when a peer has failed. */
+int sxmc_stream_query(sxmc_stream_t s, int* done);
 
 /* HIP-graph capture of a launch sequence (the per-step sequence of mcmc.cpp:264-348 is the
  * same launches with the same arguments every step, so it can be recorded once and replayed).
@@ -474,6 +479,15 @@ int sxmc_comm_init_all(const int* devices, int ndevices, sxmc_comm_t* out);
 int sxmc_comm_unique_id(char* id, size_t id_bytes);
 int sxmc_comm_init_rank(const char* id, size_t id_bytes, int nranks, int rank, sxmc_comm_t* out);
 int sxmc_comm_rank(sxmc_comm_t c, int* rank, int* nranks);
+/* Rank, rank count and device AS THE COMMUNICATOR REPORTS THEM (ncclCommUserRank / ncclCommCount / ncclCommCuDevice),
+ * not what the caller passed in: what a bench line records to show how many ranks RCCL really joined.  Any of the
+ * three pointers may be null. */
+int sxmc_comm_query(sxmc_comm_t c, int* rank, int* nranks, int* device);
+/* *failed = 1 when the communicator has recorded an asynchronous error (a peer died, a link failed). */
+int sxmc_comm_async_error(sxmc_comm_t c, int* failed);
+/* Fail-fast tear-down: ncclCommAbort -- ends a collective that is still waiting for a peer that will never arrive
+ * (instead of sxmc_comm_destroy, which would wait for it) and frees the handle. */
+int sxmc_comm_abort(sxmc_comm_t c);
 /* d_recv[r * count .. (r + 1) * count) = rank r's d_send[0 .. count) on every rank; device buffers; asynchronous
  * on `s` of the communicator's device. */
 int sxmc_comm_allgather_f32(sxmc_comm_t c, const float* d_send, float* d_recv, size_t count, sxmc_stream_t s);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "sxmc_set_device": [_i],
     "sxmc_device_info": [_i, C.c_char_p, _pi, _psz, _pi, _pi],
     "sxmc_device_synchronize": [],
+    "sxmc_device_pci_bus_id": [_i, C.c_char_p, _sz],
     "sxmc_mem_info": [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "sxmc_malloc": [_pvp, _sz],
     "sxmc_free": [_vp],
@@ -66,6 +67,7 @@ SIGNATURES = {
     "sxmc_stream_create_nonblocking": [_pvp],
     "sxmc_stream_destroy": [_vp],
     "sxmc_stream_synchronize": [_vp],
+    "sxmc_stream_query": [_vp, _pi],
     "sxmc_graph_begin_capture": [_vp],
     "sxmc_graph_end_capture": [_vp, _pvp],
     "sxmc_graph_launch": [_vp, _vp, _i],
@@ -141,6 +143,9 @@ SIGNATURES = {
     "sxmc_comm_unique_id": [C.c_char_p, _sz],
     "sxmc_comm_init_rank": [C.c_char_p, _sz, _i, _i, _pvp],
     "sxmc_comm_rank": [_vp, _pi, _pi],
+    "sxmc_comm_query": [_vp, _pi, _pi, _pi],
+    "sxmc_comm_async_error": [_vp, _pi],
+    "sxmc_comm_abort": [_vp],
     "sxmc_comm_allgather_f32": [_vp, _vp, _vp, _sz, _vp],
     "sxmc_comm_destroy": [_vp],
     "sxmc_debug_pow_int": [_vp, _i, _i, _vp],
@@ -212,8 +217,10 @@ def device_info(device=0):
     cus, lds, clk = C.c_int(0), C.c_int(0), C.c_int(0)
     hbm = C.c_size_t(0)
     call("sxmc_device_info", device, name, C.byref(cus), C.byref(hbm), C.byref(lds), C.byref(clk))
+    bus = C.create_string_buffer(64)
+    pci = bus.value.decode() if load().sxmc_device_pci_bus_id(device, bus, 64) == OK else None
     return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=hbm.value,
-                lds_bytes_per_cu=lds.value, clock_khz=clk.value)
+                lds_bytes_per_cu=lds.value, clock_khz=clk.value, pci_bus_id=pci)
 
 
 def synchronize():

@@ -125,7 +125,7 @@ struct SampleGeom {
 __global__ __launch_bounds__(256) void random_sample_kernel(const unsigned* __restrict__ cdf, unsigned nbins_total,
                                                             SampleGeom g, unsigned long long seed,
                                                             unsigned long long n, float dataset,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, unsigned* __restrict__ exhausted) {
   const unsigned total = cdf[nbins_total - 1];
   const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += step) {
@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256) void random_sample_kernel(const unsigned* __re
         if (g.has_cuts) ok = ok && !(x[k] > g.cut_hi[k] || x[k] < g.cut_lo[k]);
       }
       if (ok) break;
+      // the reference redraws until the point passes the cuts (pdfz.cpp:838-905); a point that has not passed after
+      // 1024 draws is reported to the host, which fails the call -- never handed on as an event
+      if (attempt == 1023) atomicAdd(exhausted, 1u);
     }
     for (int k = 0; k < g.nobs; k++) out[e * (unsigned long long)(g.nobs + 1) + k] = x[k];
     out[e * (unsigned long long)(g.nobs + 1) + g.nobs] = dataset;
@@ -243,7 +246,7 @@ hipError_t sx_hist_cdf(const unsigned* d_bins, unsigned* d_cdf, int nbins_total,
 
 hipError_t sx_random_sample(const unsigned* d_cdf, int nbins_total, int nobs, const int* nbins, const double* lower,
                             const double* upper, const float* cut_lo, const float* cut_hi, unsigned long long seed,
-                            unsigned long long n, float dataset, float* d_out, hipStream_t s) {
+                            unsigned long long n, float dataset, float* d_out, unsigned* d_exhausted, hipStream_t s) {
   if (n == 0) return hipSuccess;
   SampleGeom g{};
   g.nobs = nobs;
@@ -256,6 +259,6 @@ hipError_t sx_random_sample(const unsigned* d_cdf, int nbins_total, int nobs, co
     g.cut_hi[k] = cut_hi ? cut_hi[k] : 0.0f;
   }
   hipLaunchKernelGGL(random_sample_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, s, d_cdf, (unsigned)nbins_total, g, seed,
-                     n, dataset, d_out);
+                     n, dataset, d_out, d_exhausted);
   return hipGetLastError();
 }

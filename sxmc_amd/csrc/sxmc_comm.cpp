@@ -74,8 +74,47 @@ int sxmc_comm_init_rank(const char* id, size_t id_bytes, int nranks, int rank, s
 
 int sxmc_comm_rank(sxmc_comm_t c, int* rank, int* nranks) {
   if (!c || !rank || !nranks) return comm_fail(SXMC_ERR_INVALID, "null argument");
-  *rank = c->rank;
-  *nranks = c->nranks;
+  return sxmc_comm_query(c, rank, nranks, nullptr);
+}
+
+int sxmc_comm_query(sxmc_comm_t c, int* rank, int* nranks, int* device) {
+  if (!c || !c->comm) return comm_fail(SXMC_ERR_INVALID, "null communicator");
+  // asked of the communicator itself, not of what the caller passed in when it was made
+  int v = 0;
+  ncclResult_t r;
+  if (rank) {
+    if ((r = ncclCommUserRank(c->comm, &v)) != ncclSuccess)
+      return comm_fail(SXMC_ERR_HIP, std::string("ncclCommUserRank: ") + ncclGetErrorString(r));
+    *rank = v;
+  }
+  if (nranks) {
+    if ((r = ncclCommCount(c->comm, &v)) != ncclSuccess)
+      return comm_fail(SXMC_ERR_HIP, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+    *nranks = v;
+  }
+  if (device) {
+    if ((r = ncclCommCuDevice(c->comm, &v)) != ncclSuccess)
+      return comm_fail(SXMC_ERR_HIP, std::string("ncclCommCuDevice: ") + ncclGetErrorString(r));
+    *device = v;
+  }
+  return SXMC_OK;
+}
+
+int sxmc_comm_async_error(sxmc_comm_t c, int* failed) {
+  if (!c || !c->comm || !failed) return comm_fail(SXMC_ERR_INVALID, "null argument");
+  ncclResult_t state = ncclSuccess;
+  ncclResult_t r = ncclCommGetAsyncError(c->comm, &state);
+  if (r != ncclSuccess) return comm_fail(SXMC_ERR_HIP, std::string("ncclCommGetAsyncError: ") + ncclGetErrorString(r));
+  *failed = (state != ncclSuccess && state != ncclInProgress) ? 1 : 0;
+  if (*failed) t_comm_error = std::string("asynchronous RCCL error: ") + ncclGetErrorString(state);
+  return SXMC_OK;
+}
+
+int sxmc_comm_abort(sxmc_comm_t c) {
+  if (!c) return SXMC_OK;
+  // frees the communicator AND ends any collective of it that is still waiting for a peer that will not come
+  if (c->comm) (void)ncclCommAbort(c->comm);
+  delete c;
   return SXMC_OK;
 }
 

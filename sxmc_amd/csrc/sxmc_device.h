@@ -118,7 +118,7 @@ hipError_t sx_bucket_gather(const float* cols, unsigned long long pitch, int nco
 hipError_t sx_hist_cdf(const unsigned* d_bins, unsigned* d_cdf, int nbins_total, hipStream_t s);
 hipError_t sx_random_sample(const unsigned* d_cdf, int nbins_total, int nobs, const int* nbins, const double* lower,
                             const double* upper, const float* cut_lo, const float* cut_hi, unsigned long long seed,
-                            unsigned long long n, float dataset, float* d_out, hipStream_t s);
+                            unsigned long long n, float dataset, float* d_out, unsigned* d_exhausted, hipStream_t s);
 hipError_t sx_launch_eval_pdf(const SxSignalDesc* d_descs, int nsig, unsigned long long max_points,
                               hipStream_t s);
 hipError_t sx_launch_eval_nll(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,

@@ -1629,6 +1629,12 @@ int sxmc_device_synchronize(void) {
   return SXMC_OK;
 }
 
+int sxmc_device_pci_bus_id(int device, char* out, size_t out_bytes) {
+  SX_REQUIRE(out && out_bytes >= 16, "buffer of at least 16 bytes");
+  SX_HIP(hipDeviceGetPCIBusId(out, (int)out_bytes, device));
+  return SXMC_OK;
+}
+
 int sxmc_mem_info(size_t* free_bytes, size_t* total_bytes) {
   SX_REQUIRE(free_bytes && total_bytes, "null argument");
   SX_HIP(hipMemGetInfo(free_bytes, total_bytes));
@@ -1700,6 +1706,22 @@ int sxmc_stream_synchronize(sxmc_stream_t s) {
   SX_HIP(hipStreamSynchronize((hipStream_t)s));
   return SXMC_OK;
 }
+int sxmc_stream_query(sxmc_stream_t s, int* done) {
+  SX_REQUIRE(done, "null argument");
+  const hipError_t e = hipStreamQuery((hipStream_t)s);
+  if (e == hipSuccess) {
+    *done = 1;
+    return SXMC_OK;
+  }
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();   // (not an error: clear the sticky code)
+    *done = 0;
+    return SXMC_OK;
+  }
+  SX_HIP(e);
+  return SXMC_OK;
+}
+
 int sxmc_graph_begin_capture(sxmc_stream_t s) {
   SX_REQUIRE(s, "the legacy default stream cannot be captured: pass a created stream");
   SX_REQUIRE(!t_capturing, "a capture is already in progress on this thread");
@@ -2112,10 +2134,20 @@ int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long 
   SX_REQUIRE(total > 0, "cannot sample an empty histogram");
   const size_t row = (size_t)h->nobs + 1;
   DevBuf out;
-  SX_HIP(out.alloc(sizeof(float) * nobserved * row));
+  SX_HIP(out.alloc(sizeof(float) * nobserved * row + sizeof(unsigned)));   // + the count of points never accepted
+  unsigned* d_exhausted = reinterpret_cast<unsigned*>(out.as<float>() + nobserved * row);
+  SX_HIP(hipMemsetAsync(d_exhausted, 0, sizeof(unsigned), h->stream));
   SX_HIP(sx_random_sample(h->d_cdf, h->total_nbins, h->nobs, h->nbins.data(), h->lower.data(), h->upper.data(), lowers,
-                          uppers, seed, nobserved, (float)h->dataset, out.as<float>(), h->stream));
+                          uppers, seed, nobserved, (float)h->dataset, out.as<float>(), d_exhausted, h->stream));
   SX_HIP(hipStreamSynchronize(h->stream));
+  unsigned exhausted = 0;
+  SX_HIP(hipMemcpy(&exhausted, d_exhausted, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (exhausted) {
+    return fail(SXMC_ERR_STATE, std::to_string(exhausted) + " of " + std::to_string(nobserved) +
+                                    " events could not be drawn inside the cuts in 1024 attempts each (the reference "
+                                    "would redraw for ever, pdfz.cpp:838-905): the cuts leave (almost) none of the "
+                                    "histogram's content");
+  }
   SX_HIP(hipMemcpy(h_events, out.p, sizeof(float) * nobserved * row, hipMemcpyDeviceToHost));
   return SXMC_OK;
 }

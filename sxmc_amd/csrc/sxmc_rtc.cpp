@@ -104,7 +104,8 @@ bool compile(const SxRtcSpec& k, std::vector<char>& code, std::string& err) {
     return false;
   }
   // the flags of the library's own build (Makefile): double add/mul must round separately (bit-exact bin indices)
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+  // (SXMC_ARCH: the Makefile's ARCH, so that the run-time kernels are built for what the library was built for)
+  const char* opts[] = {"--offload-arch=" SXMC_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
   r = hiprtcCompileProgram(prog, 5, opts);
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;

@@ -39,6 +39,149 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def spawn_ranks(nranks, argv, env=None, poll_seconds=0.2, grace_seconds=10.0, out=None, err=None):
+    """`python bench.py --gpus N` started BARE: the parent -- which has made no HIP call and has not asked torch
+    about the GPU, and never does -- starts N fresh worker processes of `argv` (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, what torch.distributed.run would set), relays rank 0's
+    stdout as its own and sends the other ranks' stdout to stderr.  Children, never a re-exec: a process that has
+    touched the GPU must not be replaced.  The first rank to fail ends the job: the others are terminated (their own
+    PIDs, SIGTERM then SIGKILL after `grace_seconds`) and its exit code is returned.  Returns 0 when every rank did."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = out if out is not None else sys.stdout
+    err = err if err is not None else sys.stderr
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL between processes needs on this pool
+    base.update(WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                SXMC_LAUNCHED_BY="bench.py")
+    procs = []
+    for rank in range(nranks):
+        e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), GROUP_RANK="0")
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=out if rank == 0 else err, stderr=err))
+    code = 0
+    live = set(range(nranks))
+    while live and code == 0:
+        time.sleep(poll_seconds)
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                code = rc if rc > 0 else 128 - rc
+                print("bench launcher: rank %d exited with %d; ending the other ranks" % (r, rc), file=err, flush=True)
+                break
+    if live:
+        for r in live:
+            procs[r].terminate()
+        deadline = time.time() + grace_seconds
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    return code
+
+
+class RcclComm:
+    """One process per GPU: this rank's RCCL communicator made through the C ABI (sxmc_comm_unique_id on rank 0,
+    the 128-byte id handed round over the torch.distributed process group that already exists, sxmc_comm_init_rank
+    everywhere) -- the same entry points the C++ runner uses.  `query()` asks the communicator itself."""
+
+    def __init__(self):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import capi
+        rank, _, world = env_world()
+        box = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            capi.call("sxmc_comm_unique_id", buf, 128)
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0)
+        h = C.c_void_p(0)
+        rc = capi.load().sxmc_comm_init_rank(box[0], 128, world, rank, C.byref(h))
+        if rc != capi.OK:
+            raise capi.SxmcError(rc, capi.load().sxmc_comm_last_error().decode())
+        self.h = h
+
+    def query(self):
+        import ctypes as C
+
+        from . import capi
+        r, n, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        rc = capi.load().sxmc_comm_query(self.h, C.byref(r), C.byref(n), C.byref(d))
+        if rc != capi.OK:
+            raise capi.SxmcError(rc, capi.load().sxmc_comm_last_error().decode())
+        return r.value, n.value, d.value
+
+    def allgather_f32(self, block):
+        """block: float32 numpy array, same size on every rank -> [world, block.size] (through device buffers)."""
+        from . import capi
+        _, n, _ = self.query()
+        block = np.ascontiguousarray(block, np.float32).ravel()
+        send = capi.DeviceArray(block)
+        recv = capi.DeviceArray.empty(n * block.size, np.float32)
+        st = capi.new_stream()
+        rc = capi.load().sxmc_comm_allgather_f32(self.h, capi.ptr(send), capi.ptr(recv), block.size, capi.ptr(st))
+        if rc != capi.OK:
+            raise capi.SxmcError(rc, capi.load().sxmc_comm_last_error().decode())
+        capi.call("sxmc_stream_synchronize", capi.ptr(st))
+        out = recv.get().reshape(n, block.size)
+        capi.call("sxmc_stream_destroy", capi.ptr(st))
+        return out
+
+    def close(self):
+        from . import capi
+        if self.h:
+            capi.load().sxmc_comm_destroy(self.h)
+            self.h = None
+
+
+def collective_record(device_index, device_info):
+    """What the job's collectives really ran on, for the bench line: the backend torch.distributed uses, its world
+    size, the rank count RCCL reports (from a communicator, not from the environment), an all-reduce of ones over
+    the process group, and every rank's device (index, name, PCI bus id, pid, host) -- so a line tells eight ranks on
+    eight cards from two ranks rehearsed over gloo on one.  Collective: every rank must call it.  None at world 1."""
+    rank, local_rank, world = env_world()
+    if world == 1:
+        return None, None
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    t = torch.ones(1, dtype=torch.float64, device=_device_for_collectives())
+    dist.all_reduce(t)
+    mine = {"rank": rank, "local_rank": local_rank, "device_index": int(device_index), "name": device_info.get("name"),
+            "pci_bus_id": device_info.get("pci_bus_id"), "pid": os.getpid(), "host": socket.gethostname()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    cards = {(d["host"], d["pci_bus_id"]) for d in everyone}
+    comm, nranks, comm_device, note = None, None, None, None
+    if backend == "nccl":
+        comm = RcclComm()
+        _, nranks, comm_device = comm.query()
+    else:
+        note = ("rehearsal: the ranks' collectives ran over %s (SXMC_DIST_BACKEND), not RCCL; %d rank(s) share a card"
+                % (backend, world - len(cards)))
+    rec = {"backend": backend, "library": "RCCL (torch.distributed 'nccl' on ROCm) + librccl through the C ABI "
+           "(sxmc_comm_*)" if backend == "nccl" else backend,
+           "world_size": dist.get_world_size(), "rccl_nranks": nranks, "rccl_device_of_rank0": comm_device,
+           "allreduce_of_ones": float(t.item()), "distinct_cards": len(cards), "devices": everyone, "note": note,
+           "launched_by": os.environ.get("SXMC_LAUNCHED_BY", "torch.distributed.run")}
+    return rec, comm
+
+
 def shutdown():
     _, _, world = env_world()
     if world > 1:
@@ -100,10 +243,12 @@ def sum_over_ranks(value):
     return float(t.item())
 
 
-def gather_intervals(local, nexperiments, nparameters):
+def gather_intervals(local, nexperiments, nparameters, comm=None):
     """local: float32 [len(experiments_of_rank), nparameters, 4] in the rank's experiment order.
     Returns float32 [nexperiments, nparameters, 4] in experiment order on every rank (all_gather of
-    equal-size padded blocks: ~61 KB at 256 experiments x 15 parameters, latency-bound)."""
+    equal-size padded blocks: ~61 KB at 256 experiments x 15 parameters, latency-bound).
+    comm: an RcclComm -- the exchange then runs on librccl through the C ABI (sxmc_comm_allgather_f32, what the
+    C++ runner calls) instead of torch.distributed's all_gather."""
     rank, _, world = env_world()
     local = np.ascontiguousarray(local, dtype=np.float32).reshape(-1, nparameters, INTERVAL_FIELDS)
     assert local.shape[0] == len(experiments_of_rank(nexperiments, rank, world))
@@ -114,12 +259,15 @@ def gather_intervals(local, nexperiments, nparameters):
     per = (nexperiments + world - 1) // world
     pad = np.full((per, nparameters, INTERVAL_FIELDS), np.nan, dtype=np.float32)
     pad[: local.shape[0]] = local
-    dev = _device_for_collectives()
-    mine = torch.from_numpy(pad).to(dev)
-    out = torch.empty((world,) + pad.shape, dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), mine.view(-1)) if dist.get_backend() == "nccl" else \
-        dist.all_gather(list(out.unbind(0)), mine)
-    blocks = out.cpu().numpy()
+    if comm is not None:
+        blocks = comm.allgather_f32(pad).reshape((world,) + pad.shape)
+    else:
+        dev = _device_for_collectives()
+        mine = torch.from_numpy(pad).to(dev)
+        out = torch.empty((world,) + pad.shape, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), mine.view(-1)) if dist.get_backend() == "nccl" else \
+            dist.all_gather(list(out.unbind(0)), mine)
+        blocks = out.cpu().numpy()
     full = np.empty((nexperiments, nparameters, INTERVAL_FIELDS), dtype=np.float32)
     for r in range(world):
         ks = experiments_of_rank(nexperiments, r, world)

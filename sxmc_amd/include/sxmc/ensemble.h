@@ -19,7 +19,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <exception>
+#include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <limits>
@@ -359,14 +362,14 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
                                        std::vector<Signal>& signals, std::vector<Systematic>& systematics,
                                        std::vector<Observable>& observables, unsigned nsteps, float burnin_fraction,
                                        float cl, unsigned sync_interval, unsigned graph_steps = 0,
-                                       sxmc_stream_t stream = nullptr, std::mutex* exclusive = nullptr,
+                                       sxmc_stream_t stream = nullptr, SetupLock* exclusive = nullptr,
                                        LockstepSet* lockstep = nullptr, size_t lockstep_index = 0) {
   const unsigned long long x = experiment_seed(base_seed, k);
   std::mt19937_64 rng(x);
   // `exclusive` (one chain per host thread): held over everything that allocates, copies through the
   // legacy stream or synchronises the device -- see MCMC::exclusive
-  std::unique_lock<std::mutex> lock;
-  if (exclusive) lock = std::unique_lock<std::mutex>(*exclusive);
+  std::unique_lock<SetupLock> lock;
+  if (exclusive) lock = std::unique_lock<SetupLock>(*exclusive);
   std::vector<float> data = make_fake_dataset(rng, signals, systematics, observables, true);
   std::unique_ptr<MCMC> mcmc(new MCMC(sources, signals, systematics, observables, x, stream));
   mcmc->graph_steps = graph_steps;
@@ -413,14 +416,14 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
                                                          std::vector<Observable>& observables, unsigned nsteps,
                                                          float burnin_fraction, unsigned nconcurrent, float cl = 0.9f,
                                                          unsigned sync_interval = 10000, unsigned graph_steps = 0,
-                                                         int device = -1, std::mutex* process_exclusive = nullptr) {
+                                                         int device = -1, SetupLock* device_exclusive = nullptr) {
   const size_t lanes = std::max<size_t>(1, std::min<size_t>(nconcurrent, experiments.size()));
   std::vector<ExperimentResult> out(experiments.size());
   std::vector<std::exception_ptr> errors(lanes);
-  // set-up, graph recording and tear-down of the lanes, one at a time (process-wide when several GPUs are driven
-  // from one process: ensemble_multi_gpu passes its mutex)
-  std::mutex own_exclusive;
-  std::mutex& exclusive = process_exclusive ? *process_exclusive : own_exclusive;
+  // set-up, graph recording and tear-down of the lanes of this device, one at a time (ensemble_multi_gpu passes the
+  // device's lock so that lanes of the same card started from different calls still take turns)
+  SetupLock own_exclusive;
+  SetupLock& exclusive = device_exclusive ? *device_exclusive : own_exclusive;
   std::vector<std::thread> threads;
   for (size_t t = 0; t < lanes; t++) {
     threads.emplace_back([&, t]() {
@@ -429,7 +432,7 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
       try {
         if (device >= 0) check(sxmc_set_device(device));   // (the current device is a per-thread setting)
         {
-          std::lock_guard<std::mutex> lock(exclusive);
+          std::lock_guard<SetupLock> lock(exclusive);
           check(sxmc_stream_create_nonblocking(&strm));
           transfer_stream() = strm;
           for (const Signal& s : signals) mine.push_back(share_pdfz(s));
@@ -445,7 +448,7 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
         errors[t] = std::current_exception();
       }
       {
-        std::lock_guard<std::mutex> lock(exclusive);
+        std::lock_guard<SetupLock> lock(exclusive);
         for (Signal& s : mine) delete s.histogram;
         transfer_stream() = nullptr;
         if (strm) sxmc_stream_destroy(strm);
@@ -473,12 +476,12 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
                                                        float burnin_fraction, unsigned chains_per_set, unsigned nsets,
                                                        float cl = 0.9f, unsigned sync_interval = 10000,
                                                        unsigned graph_steps = 10, int device = -1,
-                                                       std::mutex* process_exclusive = nullptr) {
+                                                       SetupLock* device_exclusive = nullptr) {
   const size_t L = std::max(2u, std::min(4u, chains_per_set)), S = std::max(1u, nsets), lanes = L * S;
   const size_t usable = experiments.size() / lanes * lanes;
   std::vector<ExperimentResult> out(experiments.size());
-  std::mutex own_exclusive;
-  std::mutex& exclusive = process_exclusive ? *process_exclusive : own_exclusive;
+  SetupLock own_exclusive;
+  SetupLock& exclusive = device_exclusive ? *device_exclusive : own_exclusive;
   if (usable) {
     std::vector<std::unique_ptr<LockstepSet>> sets;
     std::vector<sxmc_stream_t> streams(S, nullptr);
@@ -496,7 +499,7 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
         try {
           if (device >= 0) check(sxmc_set_device(device));
           {
-            std::lock_guard<std::mutex> lock(exclusive);
+            std::lock_guard<SetupLock> lock(exclusive);
             transfer_stream() = set.stream;
             for (const Signal& s : signals) mine.push_back(share_pdfz(s));
           }
@@ -517,7 +520,7 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
           errors[t] = std::current_exception();
           set.abandon("a chain of the set failed");
         }
-        std::lock_guard<std::mutex> lock(exclusive);
+        std::lock_guard<SetupLock> lock(exclusive);
         for (Signal& s : mine) delete s.histogram;
         transfer_stream() = nullptr;
       });
@@ -539,55 +542,138 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
   return out;
 }
 
+
+/** How the device threads of ensemble_multi_gpu meet before the collective: every thread arrives exactly once, with
+ *  "my part went well" or not, and all of them learn whether EVERY part went well.  A collective is entered by all
+ *  ranks or by none -- a rank that failed on the way must never leave its peers waiting inside ncclAllGather. */
+class Rendezvous {
+ public:
+  explicit Rendezvous(size_t n_) : n(n_) {}
+  bool arrive(bool ok) {
+    std::unique_lock<std::mutex> lock(m);
+    all_ok = all_ok && ok;
+    if (++arrived == n) {
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return arrived == n; });
+    }
+    return all_ok;
+  }
+
+ private:
+  std::mutex m;
+  std::condition_variable cv;
+  size_t n, arrived = 0;
+  bool all_ok = true;
+};
+
+struct MultiGpuOptions {
+  float cl = 0.9f;
+  unsigned sync_interval = 10000;
+  unsigned graph_steps = 0;
+  unsigned nconcurrent = 4;       //!< experiments in flight per device when lockstep_chains < 2 (ensemble_concurrent)
+  unsigned lockstep_chains = 4;   //!< >= 2: per device, lockstep sets of this many chains (ensemble_lockstep) ...
+  unsigned lockstep_sets = 2;     //!< ... this many sets in flight
+  /** How the per-device blocks of intervals meet.  RCCL: one ncclAllGather over xGMI -- the product path.
+   *  HOST_STAGING: every device thread's block is copied into rank 0's buffer by the host.  It exists so that the
+   *  G-thread logic (sharding, per-thread replicas, rendezvous, result order, medians, failure handling) can be
+   *  rehearsed on a box with fewer cards than ranks -- RCCL refuses two ranks on one card -- and is never chosen by
+   *  default. */
+  enum Exchange { RCCL, HOST_STAGING } exchange = RCCL;
+  double exchange_timeout_seconds = 120.0;   //!< a collective still pending after this long is aborted (fail fast)
+  /** Called by every device thread (argument: its rank) when its experiments are done, before the rendezvous.
+   *  May throw: the tests inject a failing rank with it. */
+  std::function<void(size_t)> before_exchange;
+};
+
 struct MultiGpuEnsemble {
   std::vector<ExperimentResult> results;  //!< one per experiment, in experiment order (computed on its own GPU)
   std::vector<float> gathered;            //!< [nexperiments][nparameters][4] = point_estimate, lower, upper, coverage:
                                           //!< what rank 0 received through the RCCL all-gather, in experiment order
   std::vector<float> median_upper;        //!< per parameter: median over the experiments of the upper limit
   size_t nparameters = 0;
+  int rccl_nranks = 0;                    //!< ncclCommCount of rank 0's communicator (0: host staging)
+  std::vector<int> rccl_devices;          //!< ncclCommCuDevice of every rank's communicator
+  std::vector<double> rank_seconds;       //!< per rank: replica set-up + its experiments, wall clock
+  std::vector<double> rank_setup_seconds; //!< per rank: building its replica of the evaluators (upload + layout)
+  /** per distinct device: the set-up lock of that card -- seconds its users waited for it (summed over the threads
+   *  that asked), seconds it was held, acquisitions.  waited / (lanes x wall) is the serialised share of the run. */
+  struct LockUse {
+    int device;
+    double waited_seconds, held_seconds;
+    unsigned long long acquisitions;
+  };
+  std::vector<LockUse> setup_locks;
 };
 
 /** The ensemble of sxmc.cpp:44-145 over the GPUs of one node, driven from one process: a host thread per
- *  device; every device builds its own replica of the evaluators from the host tables (`tables[j]` = signal j's
- *  row-major samples, what build_pdfz takes); experiment k runs on device k mod G with `nconcurrent` experiments
- *  in flight per device (ensemble_concurrent); no data-path collective.  At the end each device contributes its
- *  experiments' intervals to ONE RCCL all-gather (sxmc_comm_allgather_f32: interval.h:22-27 as 4 floats per
- *  parameter, padded to equal blocks), and rank 0's copy gives the medians (sxmc.cpp:126-145).
- *  `signals`: name, dataset, source, nexpected of every signal (histogram ignored). */
+ *  rank, rank r on devices[r]; every rank builds its own replica of the evaluators from the host tables
+ *  (`tables[j]` = signal j's row-major samples, what build_pdfz takes); experiment k runs on rank k mod G, several in
+ *  flight per device (lockstep sets or ensemble_concurrent); no data-path collective.  At the end each rank
+ *  contributes its experiments' intervals to ONE RCCL all-gather (sxmc_comm_allgather_f32: interval.h:22-27 as
+ *  4 floats per parameter, padded to equal blocks), and rank 0's copy gives the medians (sxmc.cpp:126-145,
+ *  utils.h:76-90).  `signals`: name, dataset, source, nexpected of every signal (histogram ignored).
+ *
+ *  Failure: the ranks meet on the host before the collective (Rendezvous).  If any rank failed -- a bad table, an
+ *  experiment that threw, an allocation -- NO rank enters the all-gather and the first error is rethrown.  A rank
+ *  whose collective does not complete (a peer lost after the rendezvous, exchange_timeout_seconds, an asynchronous
+ *  RCCL error) aborts its communicator (ncclCommAbort) instead of waiting: the call returns an error, never hangs.
+ *  Locking: set-up, graph recording and tear-down take the lock of THEIR device only (SetupLock, one per card). */
 inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsigned nexperiments,
                                            unsigned long long base_seed, std::vector<Source>& sources,
                                            const std::vector<Signal>& signals,
                                            const std::vector<const std::vector<float>*>& tables, int nfields,
                                            std::vector<Systematic>& systematics, std::vector<Observable>& observables,
-                                           unsigned nsteps, float burnin_fraction, unsigned nconcurrent,
-                                           float cl = 0.9f, unsigned sync_interval = 10000, unsigned graph_steps = 0,
-                                           unsigned lockstep_chains = 4, unsigned lockstep_sets = 2) {
+                                           unsigned nsteps, float burnin_fraction, const MultiGpuOptions& opt) {
+  typedef std::chrono::steady_clock Clock;
   const size_t G = devices.size();
   if (G == 0 || tables.size() != signals.size()) throw pdfz::Error("ensemble_multi_gpu: bad arguments");
   size_t P = sources.size();
   for (const Systematic& s : systematics) P += s.npars;
   const size_t per = (nexperiments + G - 1) / G, block = per * P * 4;
+  const bool rccl = opt.exchange == MultiGpuOptions::RCCL;
   std::vector<sxmc_comm_t> comms(G, nullptr);
-  check(sxmc_comm_init_all(devices.data(), (int)G, comms.data()));
+  if (rccl && sxmc_comm_init_all(devices.data(), (int)G, comms.data()) != SXMC_OK) {
+    throw pdfz::Error(std::string("ensemble_multi_gpu: RCCL communicators: ") + sxmc_comm_last_error());
+  }
   MultiGpuEnsemble out;
   out.nparameters = P;
   out.results.resize(nexperiments);
+  out.rank_seconds.assign(G, 0.0);
+  out.rank_setup_seconds.assign(G, 0.0);
+  if (rccl) {
+    out.rccl_devices.assign(G, -1);
+    for (size_t r = 0; r < G; r++) {
+      int rk = -1, n = 0, dv = -1;
+      if (sxmc_comm_query(comms[r], &rk, &n, &dv) == SXMC_OK) {
+        out.rccl_devices[r] = dv;
+        if (r == 0) out.rccl_nranks = n;
+      }
+    }
+  }
   std::vector<float> rank0((size_t)G * block, std::numeric_limits<float>::quiet_NaN());
   std::vector<std::exception_ptr> errors(G);
-  std::mutex exclusive;   // graph recording on one device does not tolerate allocation on another thread
+  std::map<int, SetupLock> locks;   // one per card (ranks rehearsed on one card share it)
+  for (int d : devices) (void)locks[d];
+  Rendezvous meet(G);
+  std::atomic<bool> give_up{false};   // a rank abandoned the exchange: the others stop waiting for it
   std::vector<std::thread> threads;
   for (size_t r = 0; r < G; r++) {
     threads.emplace_back([&, r]() {
       std::vector<Signal> mine;
       float *d_send = nullptr, *d_recv = nullptr;
       sxmc_stream_t strm = nullptr;
+      SetupLock& exclusive = locks[devices[r]];
+      std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());
+      bool ok = true;
+      const Clock::time_point t0 = Clock::now();
       try {
         check(sxmc_set_device(devices[r]));
         std::vector<Systematic> sys = systematics;
         std::vector<Observable> obs = observables;
         std::vector<Source> src = sources;
         {
-          std::lock_guard<std::mutex> lock(exclusive);
+          std::lock_guard<SetupLock> lock(exclusive);
           for (size_t j = 0; j < signals.size(); j++) {
             Signal s = signals[j];
             s.histogram = nullptr;
@@ -596,18 +682,18 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
             mine.push_back(s);
           }
         }
+        out.rank_setup_seconds[r] = std::chrono::duration<double>(Clock::now() - t0).count();
         std::vector<unsigned> ks;
         for (unsigned k = (unsigned)r; k < nexperiments; k += (unsigned)G) ks.push_back(k);
         // per device: experiments in flight either as lockstep sets (one pass over the tables per step and set)
         // or each with its own fill
         std::vector<ExperimentResult> res =
-            lockstep_chains >= 2
-                ? ensemble_lockstep(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, lockstep_chains,
-                                    lockstep_sets, cl, sync_interval, graph_steps ? graph_steps : 10, devices[r],
-                                    &exclusive)
-                : ensemble_concurrent(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, nconcurrent, cl,
-                                      sync_interval, graph_steps, devices[r], &exclusive);
-        std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());
+            opt.lockstep_chains >= 2
+                ? ensemble_lockstep(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, opt.lockstep_chains,
+                                    opt.lockstep_sets, opt.cl, opt.sync_interval,
+                                    opt.graph_steps ? opt.graph_steps : 10, devices[r], &exclusive)
+                : ensemble_concurrent(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, opt.nconcurrent,
+                                      opt.cl, opt.sync_interval, opt.graph_steps, devices[r], &exclusive);
         for (size_t i = 0; i < res.size(); i++) {
           out.results[ks[i]] = res[i];
           for (size_t p = 0; p < P && p < res[i].intervals.size(); p++) {
@@ -619,23 +705,61 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
             at[3] = iv.coverage;
           }
         }
-        {
-          std::lock_guard<std::mutex> lock(exclusive);
+        out.rank_seconds[r] = std::chrono::duration<double>(Clock::now() - t0).count();
+        if (rccl) {
+          std::lock_guard<SetupLock> lock(exclusive);
           check(sxmc_malloc((void**)&d_send, sizeof(float) * std::max<size_t>(block, 1)));
           check(sxmc_malloc((void**)&d_recv, sizeof(float) * std::max<size_t>(G * block, 1)));
           check(sxmc_stream_create_nonblocking(&strm));
           check(sxmc_memcpy_h2d(d_send, send.data(), sizeof(float) * block));
         }
-        // the one exchange of the multi-GPU path
-        if (sxmc_comm_allgather_f32(comms[r], d_send, d_recv, block, strm) != SXMC_OK) {
-          throw pdfz::Error(std::string("all-gather of the intervals: ") + sxmc_comm_last_error());
-        }
-        check(sxmc_stream_synchronize(strm));
-        if (r == 0) check(sxmc_memcpy_d2h(rank0.data(), d_recv, sizeof(float) * G * block));
+        if (opt.before_exchange) opt.before_exchange(r);
       } catch (...) {
         errors[r] = std::current_exception();
+        ok = false;
       }
-      std::lock_guard<std::mutex> lock(exclusive);
+      // ---- every rank arrives here, failed or not; the collective is entered by all ranks or by none
+      const bool go = meet.arrive(ok);
+      if (go) {
+        try {
+          if (rccl) {
+            // the one exchange of the multi-GPU path
+            if (sxmc_comm_allgather_f32(comms[r], d_send, d_recv, block, strm) != SXMC_OK) {
+              throw pdfz::Error(std::string("all-gather of the intervals: ") + sxmc_comm_last_error());
+            }
+            // wait WITHOUT blocking inside the runtime: a peer that gave up, an asynchronous RCCL error or the
+            // time limit end the wait
+            const Clock::time_point w0 = Clock::now();
+            for (;;) {
+              int done = 0, failed = 0;
+              check(sxmc_stream_query(strm, &done));
+              if (done) break;
+              if (give_up.load()) throw pdfz::Error("all-gather of the intervals: abandoned, another rank failed in it");
+              if (sxmc_comm_async_error(comms[r], &failed) == SXMC_OK && failed) {
+                throw pdfz::Error(std::string("all-gather of the intervals: ") + sxmc_comm_last_error());
+              }
+              if (std::chrono::duration<double>(Clock::now() - w0).count() > opt.exchange_timeout_seconds) {
+                throw pdfz::Error("all-gather of the intervals: not complete after " +
+                                  std::to_string(opt.exchange_timeout_seconds) + " s (rank " + std::to_string(r) + ")");
+              }
+              std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            if (r == 0) check(sxmc_memcpy_d2h(rank0.data(), d_recv, sizeof(float) * G * block));
+          } else {
+            std::copy(send.begin(), send.end(), rank0.begin() + (std::ptrdiff_t)(r * block));   // (disjoint blocks)
+          }
+        } catch (...) {
+          errors[r] = std::current_exception();
+          give_up.store(true);
+          // end the pending collective on this rank's device BEFORE its stream and buffers are released (releasing
+          // them would wait for a kernel that waits for a peer)
+          if (comms[r]) {
+            sxmc_comm_abort(comms[r]);
+            comms[r] = nullptr;
+          }
+        }
+      }
+      std::lock_guard<SetupLock> lock(exclusive);
       for (Signal& s : mine) delete s.histogram;
       if (d_send) sxmc_free(d_send);
       if (d_recv) sxmc_free(d_recv);
@@ -643,9 +767,24 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
     });
   }
   for (std::thread& th : threads) th.join();
-  for (sxmc_comm_t c : comms) sxmc_comm_destroy(c);
-  for (std::exception_ptr& e : errors)
-    if (e) std::rethrow_exception(e);
+  for (sxmc_comm_t c : comms)
+    if (c) sxmc_comm_destroy(c);
+  for (auto& kv : locks) {
+    out.setup_locks.push_back({kv.first, kv.second.waited_seconds(), kv.second.held_seconds(), kv.second.count()});
+  }
+  for (size_t r = 0; r < G; r++) {
+    if (!errors[r]) continue;
+    // the first failing rank's error, said which rank
+    try {
+      std::rethrow_exception(errors[r]);
+    } catch (const pdfz::Error& e) {
+      throw pdfz::Error("ensemble_multi_gpu: rank " + std::to_string(r) + " (device " + std::to_string(devices[r]) +
+                        "): " + e.msg);
+    } catch (const std::exception& e) {
+      throw pdfz::Error("ensemble_multi_gpu: rank " + std::to_string(r) + " (device " + std::to_string(devices[r]) +
+                        "): " + e.what());
+    }
+  }
   // rank r's block holds its experiments r, r + G, ... in that order
   out.gathered.assign((size_t)nexperiments * P * 4, 0.0f);
   for (unsigned k = 0; k < nexperiments; k++) {
@@ -660,6 +799,26 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
     out.median_upper.push_back(ups.empty() ? 0.0f : median(ups));
   }
   return out;
+}
+
+/** The same with the options spelled out as arguments (round 2's signature). */
+inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsigned nexperiments,
+                                           unsigned long long base_seed, std::vector<Source>& sources,
+                                           const std::vector<Signal>& signals,
+                                           const std::vector<const std::vector<float>*>& tables, int nfields,
+                                           std::vector<Systematic>& systematics, std::vector<Observable>& observables,
+                                           unsigned nsteps, float burnin_fraction, unsigned nconcurrent,
+                                           float cl = 0.9f, unsigned sync_interval = 10000, unsigned graph_steps = 0,
+                                           unsigned lockstep_chains = 4, unsigned lockstep_sets = 2) {
+  MultiGpuOptions opt;
+  opt.cl = cl;
+  opt.sync_interval = sync_interval;
+  opt.graph_steps = graph_steps;
+  opt.nconcurrent = nconcurrent;
+  opt.lockstep_chains = lockstep_chains;
+  opt.lockstep_sets = lockstep_sets;
+  return ensemble_multi_gpu(devices, nexperiments, base_seed, sources, signals, tables, nfields, systematics,
+                            observables, nsteps, burnin_fraction, opt);
 }
 
 }  // namespace sxmc

@@ -3,8 +3,8 @@
 //   Source      src/source.h:13-58        Observable  src/observable.h:22-42
 //   Systematic  src/systematic.h:23-49    Signal      src/signal.h (name, dataset, source, nexpected,
 //                                                       n_mc, histogram)
-// Config parsing (config.cpp) and ROOT ntuple ingestion (signal.cpp:11-109, io/ttree_io.cpp) are out
-// of scope; callers fill these structs directly.
+// Callers fill these structs directly, or sxmc::load_config (config.h: the reference's JSON schema, config.cpp:19-297,
+// and ROOT-free sample tables in place of io/ttree_io.cpp) fills them from a fit configuration.
 #pragma once
 
 #include <cstddef>
@@ -38,6 +38,9 @@ struct Observable {
 
 struct Systematic {
   std::string name;
+  std::string title;
+  std::string observable_field;  //!< Name of the field the systematic acts on (systematic.h)
+  std::string truth_field;       //!< resolution_scale: name of the field holding the true value
   size_t observable_field_index = 0;
   size_t truth_field_index = 0;
   size_t npars = 1;            //!< Number of parameters in power series
@@ -50,10 +53,13 @@ struct Systematic {
 
 struct Signal {
   std::string name;
+  std::string title;
+  std::string filename;                       //!< where the samples came from (signal.h)
+  std::vector<std::string> systematic_names;  //!< the systematics this signal lists in the configuration
   unsigned dataset = 0;
   Source source;
   double nexpected = 0;
-  size_t n_mc = 0;
+  size_t n_mc = 0;  //!< number of MC samples BEFORE cuts (signal.cpp:28); build_pdfz fills it in when it is 0
   pdfz::Eval* histogram = nullptr;  //!< borrowed by the driver, as in the reference
   // keeps the parameter-index arrays alive (the reference leaks them, signal.cpp:139)
   std::vector<std::shared_ptr<pdfz::Array<short>>> par_arrays;
@@ -72,7 +78,8 @@ inline void build_pdfz(Signal& sig, const std::vector<float>& samples, int nfiel
   }
   pdfz::EvalHist* h = new pdfz::EvalHist(samples, nfields, (int)observables.size(), lower, upper, nbins, sig.dataset);
   sig.histogram = h;
-  sig.n_mc = samples.size() / (size_t)nfields;
+  // (a table loaded through load_config has been cut: n_mc is then the row count before the cuts, set by the loader)
+  if (sig.n_mc == 0) sig.n_mc = samples.size() / (size_t)nfields;
   for (Systematic& s : systematics) {
     auto pars = std::make_shared<pdfz::Array<short>>(s.npars, true);
     for (size_t i = 0; i < s.pidx.size(); i++) pars->writeOnlyHostPtr()[i] = s.pidx[i];

@@ -13,6 +13,8 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -36,6 +38,38 @@ struct Chain {
   float at(size_t row, size_t col) const { return rows[row * names.size() + col]; }
 };
 
+/** The lock that serialises set-up, graph recording and tear-down of the chains that share a DEVICE (allocation,
+ *  uploads through the legacy stream, launch-plan rebuilds and device-wide synchronisation are calls the runtime
+ *  refuses, or stalls, beside another thread's recording on that device).  A std::mutex that also keeps the time its
+ *  users spent waiting for it and holding it: with G devices x lanes host threads that is the Amdahl term of an
+ *  ensemble, and a run reports it instead of guessing (bench_cpp: "setup_lock").  One per device: chains on
+ *  different devices never contend. */
+class SetupLock {
+ public:
+  void lock() {
+    const auto t0 = std::chrono::steady_clock::now();
+    m.lock();
+    since = std::chrono::steady_clock::now();
+    waited_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(since - t0).count(),
+                        std::memory_order_relaxed);
+    acquisitions.fetch_add(1, std::memory_order_relaxed);
+  }
+  void unlock() {
+    held_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                          std::chrono::steady_clock::now() - since).count(),
+                      std::memory_order_relaxed);
+    m.unlock();
+  }
+  double waited_seconds() const { return 1e-9 * (double)waited_ns.load(); }   //!< summed over all the threads that asked
+  double held_seconds() const { return 1e-9 * (double)held_ns.load(); }
+  unsigned long long count() const { return acquisitions.load(); }
+
+ private:
+  std::mutex m;
+  std::chrono::steady_clock::time_point since;   // (written and read by the holder only)
+  std::atomic<unsigned long long> waited_ns{0}, held_ns{0}, acquisitions{0};
+};
+
 /** Chains advanced TOGETHER (sxmc_multigroup_step_async): one fill pass over the shared sample tables per step for
  *  all of them, then every chain's own step end.  Shared by the MCMC objects of one lockstep set, each walking on
  *  its own host thread and on the set's ONE stream: a chain that is ready for its next run of steps leaves its
@@ -45,7 +79,7 @@ struct Chain {
 class LockstepSet {
  public:
   /** exclusive: the mutex that serialises set-up, graph recording and tear-down in this process (may be null). */
-  LockstepSet(size_t nchains, sxmc_stream_t stream_, std::mutex* exclusive_ = nullptr)
+  LockstepSet(size_t nchains, sxmc_stream_t stream_, SetupLock* exclusive_ = nullptr)
       : stream(stream_), exclusive(exclusive_), groups(nchains, nullptr), args(nchains) {}
   ~LockstepSet() {
     if (graph) sxmc_graph_destroy(graph);
@@ -107,8 +141,8 @@ class LockstepSet {
     if (graph_steps > 0 && stepped && nsteps >= graph_steps) {
       if (!graph || recorded != graph_steps) {
         // recording does not tolerate another thread's allocations: under the process's set-up mutex
-        std::unique_lock<std::mutex> excl;
-        if (exclusive) excl = std::unique_lock<std::mutex>(*exclusive);
+        std::unique_lock<SetupLock> excl;
+        if (exclusive) excl = std::unique_lock<SetupLock>(*exclusive);
         if (graph) sxmc_graph_destroy(graph);
         graph = nullptr;
         int rc = sxmc_graph_begin_capture(stream);
@@ -132,8 +166,8 @@ class LockstepSet {
     for (unsigned k = 0; k < nsteps; k++) {
       // the first step of a new set of chains builds launch plans (allocations, a device-wide synchronisation),
       // which another set's recording does not tolerate: under the process's set-up mutex, like the recording
-      std::unique_lock<std::mutex> excl;
-      if (!stepped && exclusive) excl = std::unique_lock<std::mutex>(*exclusive);
+      std::unique_lock<SetupLock> excl;
+      if (!stepped && exclusive) excl = std::unique_lock<SetupLock>(*exclusive);
       int rc = sxmc_multigroup_step_async(mg, stream, args.data());
       if (rc) return rc;
       stepped = true;   // (the launch plans are in place once a step has been launched: recording may follow)
@@ -143,7 +177,7 @@ class LockstepSet {
 
   std::mutex m;
   std::condition_variable cv;
-  std::mutex* exclusive;
+  SetupLock* exclusive;
   std::vector<sxmc_group_t> groups;
   std::vector<sxmc_step_args> args;
   sxmc_multigroup_t mg = nullptr;
@@ -168,7 +202,7 @@ class MCMC {
   bool consume = true;          //!< batched form: the step end also clears histograms and normalisations for the
                                 //!< next step (sxmc_group_step_async: 2 launches per step; nothing reads them
                                 //!< between the steps of a walk)
-  std::mutex* exclusive = nullptr;  //!< with one chain per host thread: the mutex this walk holds while it
+  SetupLock* exclusive = nullptr;   //!< with one chain per host thread: the lock this walk holds while it
                                     //!< allocates, uploads, rebuilds launch plans, records its graph and frees
                                     //!< (calls the runtime refuses beside another thread's recording); it is
                                     //!< released while the walk only launches and waits on its own stream
@@ -287,8 +321,8 @@ class MCMC {
   /** MCMC::operator() (mcmc.cpp:143-387).  data: rows of nobservables+1 floats (last = dataset id). */
   Chain operator()(std::vector<float>& data, unsigned nsteps, float burnin_fraction,
                    const bool debug_mode = false, unsigned sync_interval = 10000) {
-    std::unique_lock<std::mutex> excl;  // (first local: released last, after the arrays below are freed)
-    if (exclusive) excl = std::unique_lock<std::mutex>(*exclusive);
+    std::unique_lock<SetupLock> excl;  // (first local: released last, after the arrays below are freed)
+    if (exclusive) excl = std::unique_lock<SetupLock>(*exclusive);
     // array transfers of this walk are ordered on the chain's stream (a blocking copy through the legacy
     // default stream would neither wait for a non-blocking stream nor leave other chains alone)
     struct TransferGuard {
@@ -405,6 +439,7 @@ class MCMC {
       sxmc_group_t both[2] = {group, shadow_group};
       check(sxmc_multigroup_create(both, 2, &pair));
     }
+    bool ahead_planned = false;   // the look-ahead pair has launched once: its plans exist
     sxmc_stream_t strm = stream;
     sxmc_graph_t graph = nullptr;
     const bool own_stream = gsteps > 0 && !strm;
@@ -508,8 +543,9 @@ class MCMC {
         n %= gsteps;
       }
       // set-up is over once the first run of steps after step 0 has its graph (or needs none); a lockstep chain
-      // must not hold the lock while it waits for its partners, who need it for their own set-up
-      if ((i > 0 || in_lockstep) && excl.owns_lock()) excl.unlock();
+      // must not hold the lock while it waits for its partners, who need it for their own set-up.  The look-ahead
+      // walk builds its plans in its first pass and records its graph further down: it keeps the lock until then.
+      if ((i > 0 || in_lockstep) && !ahead && excl.owns_lock()) excl.unlock();
       if (in_lockstep) {
         // this run of steps together with the other chains of the set (recorded and replayed there)
         sxmc_step_args a;
@@ -575,9 +611,21 @@ class MCMC {
           const double rate = ahead_passes_seen >= 16 ? std::min(2.0, 1.03 * ahead_steps_seen / ahead_passes_seen) : 1.75;
           unsigned k = std::max(1u, (unsigned)(need / rate));
           const size_t p0 = ahead_passes;
+          // The pair's first pass builds its launch plans (allocations, a module load, a device-wide synchronisation)
+          // and the recording must not meet another thread's allocation: both under the set-up lock, like the
+          // sequential walk's recording.  Every other round only launches and waits on this chain's stream.
+          const bool records = gsteps > 0 && k > gsteps && !graph;
+          if (exclusive) {
+            if (!ahead_planned || records) {
+              if (!excl.owns_lock()) excl.lock();
+            } else if (i > 0 && excl.owns_lock()) {
+              excl.unlock();
+            }
+          }
           if (gsteps > 0 && k > gsteps) {
             if (!graph) {
               one_pass();   // (plans in place before recording)
+              ahead_planned = true;
               k--;
               check(sxmc_graph_begin_capture(strm));
               try {
@@ -588,13 +636,19 @@ class MCMC {
               }
               check(sxmc_graph_end_capture(strm, &graph));
               ahead_passes -= gsteps;
+              if (i > 0 && excl.owns_lock()) excl.unlock();
             }
-            if (excl.owns_lock()) excl.unlock();
             check(sxmc_graph_launch(graph, strm, (int)(k / gsteps)));
             ahead_passes += (size_t)(k / gsteps) * gsteps;
             k %= gsteps;
           }
-          for (unsigned q = 0; q < k; q++) one_pass();
+          for (unsigned q = 0; q < k; q++) {
+            one_pass();
+            if (!ahead_planned) {
+              ahead_planned = true;
+              if (i > 0 && excl.owns_lock()) excl.unlock();
+            }
+          }
           (void)jump_counter.ptr();   // (the device side changed behind the mirror's back: the host copy is stale)
           const unsigned now = (unsigned)jump_counter.readOnlyHostPtr()[0];   // (a blocking copy on the chain's stream)
           if (now <= done && now < n) throw pdfz::Error("look-ahead walk: the chain did not advance");

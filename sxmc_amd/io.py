@@ -116,11 +116,11 @@ def load_config(path_or_text, base_dir=None):
     assert fc.nexperiments > 0 and fc.nsteps > 0
     fc.error_type = fit.get("error_type", "contour")
     assert fc.error_type in ("contour", "projection")
-    fc.burnin_fraction = float(fit.get("burnin_fraction", 0.1))
+    fc.burnin_fraction = float(np.float32(fit.get("burnin_fraction", 0.1)))     # (floats in the reference: asFloat())
     fc.debug_mode = bool(fit.get("debug_mode", False))
     fc.output_prefix = fit.get("output_prefix", "lspace")
     fc.seed = int(fit.get("seed", 0))
-    fc.confidence = float(fit.get("confidence", 0.683))
+    fc.confidence = float(np.float32(fit.get("confidence", 0.683)))
     fc.signal_name = fit.get("signal_name", "")
 
     def observable(name):
@@ -132,10 +132,13 @@ def load_config(path_or_text, base_dir=None):
     fc.cuts = [observable(n) for n in fit.get("cuts", [])]
     assert not {o["name"] for o in fc.observables} & {c["name"] for c in fc.cuts}
 
-    # systematics and sources: union over the signals, in signal order (config.cpp:99-151)
+    # systematics and sources: union over the signals (config.cpp:97-151).  The reference walks the JSON object
+    # `signals` with jsoncpp 0.6's iterator, i.e. in KEY order (a std::map compared with strcmp), not in file order:
+    # the numbering of the sources and of the systematic parameters -- the layout of the parameter vector -- follows it
     fc.systematics, fc.sources = [], []
     pidx = 0
-    for sname, sconf in sig_params.items():
+    for sname in sorted(sig_params, key=lambda k: k.encode()):
+        sconf = sig_params[sname]
         for sys_name in sconf.get("systematics", []):
             if any(s["name"] == sys_name for s in fc.systematics):
                 continue
@@ -186,7 +189,9 @@ def load_config(path_or_text, base_dir=None):
         src_name = c.get("source", name)
         fc.signals.append(dict(
             name=name, dataset=int(c["dataset"]), filename=c["filename"],
-            rate=float(c["rate"]) if "rate" in c else None, scale=float(c["scale"]) if "scale" in c else None,
+            # config.cpp:216-222: both go through a float
+            rate=float(np.float32(c["rate"])) if "rate" in c else None,
+            scale=float(np.float32(c["scale"])) if "scale" in c else None,
             systematics=[s for s in c.get("systematics", [])],
             source=next(s for s in fc.sources if s["name"] == src_name)))
     fc.data = {int(k): [dict(filename=row["filename"], title=row.get("title", "")) for row in rows]
@@ -205,7 +210,9 @@ def build_workload(fc):
     for s in fc.signals:
         table, fields = read_table(os.path.join(fc.base_dir, s["filename"]))
         n_mc = table.shape[0]                                    # before cuts (signal.cpp:28)
-        nexpected = s["rate"] if s["rate"] is not None else n_mc / s["scale"]   # signal.cpp:31-35
+        # config.cpp:221 keeps -1 / scale in a float, signal.cpp:31-35 multiplies it by -n_mc in double
+        nexpected = s["rate"] if s["rate"] is not None else \
+            float(np.float32(-1.0) / np.float32(s["scale"])) * (-1.0 * n_mc)
         samples = read_dataset_to_samples(table, fields, s["dataset"], fc.sample_fields, cuts)
         sig = workloads.Signal(samples, nfields, nexpected, s["source"]["index"], dataset=s["dataset"])
         sig.n_mc_total = n_mc

@@ -1,15 +1,81 @@
-// bench_cpp.cpp -- the C++ host layer on BASELINE config 3's shape: builds the 12 signals through
-// sxmc::build_pdfz, walks one chain with sxmc::MCMC (the caller of the hot path, mcmc.cpp:143-387) and prints
-// MCMC steps (= NLL evaluations) per second.  Usage: bench_cpp [scale=1.0] [nsteps=2000] [graph_steps=10]
-//   [experiments=0] [steps_each=2000] [chains_per_fill=4] [sets=2]   (the last four: an ensemble leg in lockstep sets)
+// bench_cpp.cpp -- the C++ host layer on BASELINE config 3's shape, no Python in the process: builds the 12 signals
+// through sxmc::build_pdfz, walks one chain with sxmc::MCMC (the caller of the hot path, mcmc.cpp:143-387) and
+// prints MCMC steps (= NLL evaluations) per second; optionally whole fake experiments (sxmc.cpp:59-145) as lockstep
+// sets on one GPU, or sharded over the GPUs of the node with sxmc::ensemble_multi_gpu (BASELINE config 4: a host
+// thread per GPU, ONE RCCL all-gather of the intervals).  One JSON line per leg on stdout.
+//
+//   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk]
+//             [--experiments 0] [--exp-steps 2000] [--chains 4] [--sets 2]
+//             [--devices G | --device-list 0,0] [--host-staging] [--config fit.json]
+//
+// --devices G: the ensemble leg runs on devices 0..G-1 through ensemble_multi_gpu (needs --experiments).
+// --host-staging: the blocks meet through host memory instead of RCCL (rehearsal of G ranks on fewer cards).
+// --config: signals, observables, systematics, rates and sample tables come from a fit configuration
+//   (sxmc::load_config, the reference's JSON schema: config.cpp:19-297) instead of the synthetic C3 generator.
 // Synthetic inputs as SURVEY.md 8(d) C3 describes them (not bit-identical to bench.py's generator).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
+#include <string>
 #include <thread>
 
+#include "../../sxmc_amd/include/sxmc/config.h"
 #include "../../sxmc_amd/include/sxmc/ensemble.h"
+
+namespace {
+struct Options {
+  double scale = 1.0;
+  unsigned nsteps = 2000, graph_steps = 10;
+  bool walk = true;
+  unsigned nexp = 0, esteps = 2000, L = 4, S = 2;
+  std::vector<int> devices;
+  bool host_staging = false;
+  std::string config;
+};
+
+std::vector<int> parse_list(const char* s) {
+  std::vector<int> v;
+  for (const char* p = s; *p;) {
+    v.push_back(std::atoi(p));
+    while (*p && *p != ',') p++;
+    if (*p == ',') p++;
+  }
+  return v;
+}
+
+Options parse(int argc, char** argv) {
+  Options o;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    auto next = [&]() -> const char* {
+      if (i + 1 >= argc) throw std::runtime_error("missing value after " + a);
+      return argv[++i];
+    };
+    if (a == "--scale") o.scale = std::atof(next());
+    else if (a == "--steps") o.nsteps = (unsigned)std::atoi(next());
+    else if (a == "--graph-steps") o.graph_steps = (unsigned)std::atoi(next());
+    else if (a == "--no-walk") o.walk = false;
+    else if (a == "--experiments") o.nexp = (unsigned)std::atoi(next());
+    else if (a == "--exp-steps") o.esteps = (unsigned)std::atoi(next());
+    else if (a == "--chains") o.L = (unsigned)std::atoi(next());
+    else if (a == "--sets") o.S = (unsigned)std::atoi(next());
+    else if (a == "--devices") {
+      const int g = std::atoi(next());
+      for (int d = 0; d < g; d++) o.devices.push_back(d);
+    } else if (a == "--device-list") o.devices = parse_list(next());
+    else if (a == "--host-staging") o.host_staging = true;
+    else if (a == "--config") o.config = next();
+    else throw std::runtime_error("unknown argument " + a);
+  }
+  return o;
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+}  // namespace
 
 static int run(int argc, char** argv);
 int main(int argc, char** argv) {
@@ -24,127 +90,219 @@ int main(int argc, char** argv) {
 }
 
 static int run(int argc, char** argv) {
-  const double scale = argc > 1 ? std::atof(argv[1]) : 1.0;
-  const unsigned nsteps = argc > 2 ? (unsigned)std::atoi(argv[2]) : 2000;
-  const unsigned graph_steps = argc > 3 ? (unsigned)std::atoi(argv[3]) : 10;
-  const size_t S = 12, F = 5, E = 100000;
-  const size_t per_signal = (size_t)(1e8 * scale) / S;
-
-  std::vector<sxmc::Observable> observables(3);
-  const float lo[3] = {0, 0, -1}, hi[3] = {10, 6, 1};
-  for (size_t k = 0; k < 3; k++) {
-    observables[k].field_index = k;
-    observables[k].bins = 20;
-    observables[k].lower = lo[k];
-    observables[k].upper = hi[k];
-  }
-  std::vector<sxmc::Systematic> systematics(3);
-  systematics[0].name = "r_shift"; systematics[0].type = pdfz::Systematic::SHIFT;
-  systematics[0].observable_field_index = 1; systematics[0].sigmas = {0.05};
-  systematics[1].name = "e_scale"; systematics[1].type = pdfz::Systematic::SCALE;
-  systematics[1].observable_field_index = 0; systematics[1].sigmas = {0.01};
-  systematics[2].name = "e_res"; systematics[2].type = pdfz::Systematic::RESOLUTION_SCALE;
-  systematics[2].observable_field_index = 0; systematics[2].truth_field_index = 3; systematics[2].sigmas = {0.05};
-  for (size_t q = 0; q < 3; q++) {
-    systematics[q].means = {0.0};
-    systematics[q].pidx = {(short)q};
-  }
-
-  // the tables are generated by one host thread per signal (10^8 samples are ~4 10^8 random draws), then handed to
-  // build_pdfz one by one
-  std::vector<std::vector<float>> tabs(S);
-  {
-    std::vector<std::thread> gen;
-    for (size_t j = 0; j < S; j++) {
-      gen.emplace_back([&, j]() {
-        std::mt19937_64 rng(3 + 1000 * j);
-        std::normal_distribution<float> gauss(0.0f, 1.0f);
-        std::uniform_real_distribution<float> uni(0.0f, 1.0f);
-        std::vector<float>& tab = tabs[j];
-        tab.resize(per_signal * F);
-        for (size_t i = 0; i < per_signal; i++) {
-          const float e_true = 2.0f + 0.5f * j + 1.2f * gauss(rng);
-          tab[i * F + 0] = e_true + 0.3f * gauss(rng);
-          tab[i * F + 1] = 6.0f * std::cbrt(uni(rng));
-          tab[i * F + 2] = 2.0f * uni(rng) - 1.0f;
-          tab[i * F + 3] = e_true;
-          tab[i * F + 4] = 0.0f;
-        }
-      });
-    }
-    for (std::thread& t : gen) t.join();
-  }
-  std::mt19937_64 rng(3);
+  const Options o = parse(argc, argv);
+  std::vector<sxmc::Observable> observables;
+  std::vector<sxmc::Systematic> systematics;
   std::vector<sxmc::Source> sources;
-  std::vector<sxmc::Signal> signals;
-  std::vector<float> data;
-  for (size_t j = 0; j < S; j++) {
-    std::vector<float>& tab = tabs[j];
-    sxmc::Signal sig;
-    sig.name = "signal" + std::to_string(j);
-    sig.source = sxmc::Source("source" + std::to_string(j), j, 1.0f, 0.0f, false);
-    sig.nexpected = (double)E / S;
-    sxmc::build_pdfz(sig, tab, (int)F, observables, systematics);
-    signals.push_back(sig);
-    sources.push_back(sig.source);
-    for (size_t e = 0; e < E / S; e++) {  // data events: samples of the mixture
-      const size_t i = rng() % per_signal;
-      data.push_back(tab[i * F + 0]);
-      data.push_back(tab[i * F + 1]);
-      data.push_back(tab[i * F + 2]);
-      data.push_back(0.0f);
-    }
-    tab.clear();
-    tab.shrink_to_fit();
-  }
+  std::vector<sxmc::Signal> signals;          // name, source, nexpected (histograms are built below)
+  std::vector<std::vector<float>> tabs;       // row-major host tables, one per signal
+  std::vector<float> data;                    // data events for the single walk: rows of D + 1 floats
+  size_t F = 5;
+  unsigned long long base_seed = 77;
+  float burnin = 0.1f, cl = 0.9f;
+  Options run_opt = o;
 
-  sxmc_stream_t strm = nullptr;
-  sxmc::check(sxmc_stream_create_nonblocking(&strm));
-  // SXMC_BENCH_LOOKAHEAD=0: one evaluation per step; default: the look-ahead walk (two evaluations per pass)
-  const char* la_env = std::getenv("SXMC_BENCH_LOOKAHEAD");
-  const bool lookahead = !(la_env && la_env[0] == '0');
-  for (int pass = 0; pass < 2; pass++) {  // pass 0 warms up (clocks, launch plan); pass 1 is timed
-    sxmc::MCMC mcmc(sources, signals, systematics, observables, 1234 + pass, strm);
-    mcmc.graph_steps = graph_steps;
-    mcmc.lookahead = lookahead;
-    const auto t0 = std::chrono::steady_clock::now();
-    sxmc::Chain chain = mcmc(data, pass == 0 ? std::min(nsteps, 500u) : nsteps, 0.1f, false, 10000);
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (pass == 1) {
-      std::fflush(stdout);
-      std::printf("{\"driver\": \"sxmc::MCMC (C++)\", \"nsamples_total\": %zu, \"nsignals\": %zu, \"nevents\": %zu, "
-                  "\"steps\": %u, \"steps_per_graph\": %u, \"seconds\": %.4f, \"steps_per_sec\": %.1f, "
-                  "\"accepted\": %zu, \"rows_kept\": %zu, \"lookahead\": %s, \"passes\": %zu}\n",
-                  per_signal * S, S, data.size() / 4, nsteps, graph_steps, sec, nsteps / sec, chain.accepted,
-                  chain.nrows(), lookahead ? "true" : "false", mcmc.LookaheadPasses());
+  if (!o.config.empty()) {
+    // ---- inputs from a fit configuration: the reference's control file + ROOT-free sample tables
+    sxmc::FitConfig fc = sxmc::load_config(o.config);
+    observables = fc.observables;
+    systematics = fc.systematics;
+    sources = fc.sources;
+    signals = fc.signals;
+    tabs = std::move(fc.tables);
+    F = fc.nfields;
+    burnin = fc.burnin_fraction;
+    cl = fc.confidence;
+    if (fc.seed) base_seed = fc.seed;
+    if (run_opt.nexp == 0) run_opt.nexp = fc.nexperiments;
+    run_opt.esteps = fc.nsteps;
+    run_opt.walk = false;
+    std::printf("{\"driver\": \"sxmc::load_config (C++)\", \"config\": \"%s\", \"signals\": %zu, \"observables\": %zu, "
+                "\"systematics\": %zu, \"nfields\": %zu, \"rows_total\": %zu, \"experiments\": %u, \"steps\": %u}\n",
+                o.config.c_str(), signals.size(), observables.size(), systematics.size(), F, fc.rows_total(),
+                run_opt.nexp, run_opt.esteps);
+  } else {
+    const size_t S = 12, E = 100000;
+    const size_t per_signal = (size_t)(1e8 * o.scale) / S;
+    observables.resize(3);
+    const float lo[3] = {0, 0, -1}, hi[3] = {10, 6, 1};
+    for (size_t k = 0; k < 3; k++) {
+      observables[k].field_index = k;
+      observables[k].bins = 20;
+      observables[k].lower = lo[k];
+      observables[k].upper = hi[k];
     }
-  }
-  sxmc_stream_destroy(strm);
-  // optional ensemble leg: argv[4] experiments of argv[5] steps as lockstep sets of argv[6] chains (argv[7] sets);
-  // whole fake experiments (fake data drawn on the device, walk with burn-in re-tuning, contour intervals)
-  const unsigned nexp = argc > 4 ? (unsigned)std::atoi(argv[4]) : 0;
-  if (nexp > 0) {
-    const unsigned esteps = argc > 5 ? (unsigned)std::atoi(argv[5]) : 2000;
-    const unsigned L = argc > 6 ? (unsigned)std::atoi(argv[6]) : 4, S = argc > 7 ? (unsigned)std::atoi(argv[7]) : 2;
-    std::vector<unsigned> ks;
-    for (unsigned k = 0; k < nexp; k++) ks.push_back(k);
-    for (sxmc::Signal& sg : signals) sg.nexpected = 8000.0;   // ~1e5 events per fake data set
-    for (int pass = 0; pass < 2; pass++) {   // pass 0 (one round) compiles the lockstep kernel and warms up
-      std::vector<unsigned> run(ks.begin(), pass == 0 ? ks.begin() + std::min<size_t>(ks.size(), L * S) : ks.end());
-      const auto t0 = std::chrono::steady_clock::now();
-      std::vector<sxmc::ExperimentResult> res = sxmc::ensemble_lockstep(
-          run, 77, sources, signals, systematics, observables, pass == 0 ? 300 : esteps, 0.1f, L, S, 0.9f, esteps,
-          graph_steps);
-      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (pass == 1) {
-        std::printf("{\"driver\": \"sxmc::ensemble_lockstep (C++)\", \"experiments\": %zu, \"steps_each\": %u, "
-                    "\"chains_per_fill\": %u, \"sets\": %u, \"seconds\": %.4f, \"experiments_per_sec\": %.4f, "
-                    "\"steps_per_sec_inside\": %.1f, \"nevents_first\": %zu}\n",
-                    res.size(), esteps, L, S, sec, res.size() / sec, res.size() * (double)esteps / sec,
-                    res.empty() ? (size_t)0 : res[0].nevents);
+    systematics.resize(3);
+    systematics[0].name = "r_shift"; systematics[0].type = pdfz::Systematic::SHIFT;
+    systematics[0].observable_field_index = 1; systematics[0].sigmas = {0.05};
+    systematics[1].name = "e_scale"; systematics[1].type = pdfz::Systematic::SCALE;
+    systematics[1].observable_field_index = 0; systematics[1].sigmas = {0.01};
+    systematics[2].name = "e_res"; systematics[2].type = pdfz::Systematic::RESOLUTION_SCALE;
+    systematics[2].observable_field_index = 0; systematics[2].truth_field_index = 3; systematics[2].sigmas = {0.05};
+    for (size_t q = 0; q < 3; q++) {
+      systematics[q].means = {0.0};
+      systematics[q].pidx = {(short)q};
+    }
+    // the tables are generated by one host thread per signal (10^8 samples are ~4 10^8 random draws)
+    tabs.resize(S);
+    {
+      std::vector<std::thread> gen;
+      for (size_t j = 0; j < S; j++) {
+        gen.emplace_back([&, j]() {
+          std::mt19937_64 rng(3 + 1000 * j);
+          std::normal_distribution<float> gauss(0.0f, 1.0f);
+          std::uniform_real_distribution<float> uni(0.0f, 1.0f);
+          std::vector<float>& tab = tabs[j];
+          tab.resize(per_signal * F);
+          for (size_t i = 0; i < per_signal; i++) {
+            const float e_true = 2.0f + 0.5f * j + 1.2f * gauss(rng);
+            tab[i * F + 0] = e_true + 0.3f * gauss(rng);
+            tab[i * F + 1] = 6.0f * std::cbrt(uni(rng));
+            tab[i * F + 2] = 2.0f * uni(rng) - 1.0f;
+            tab[i * F + 3] = e_true;
+            tab[i * F + 4] = 0.0f;
+          }
+        });
+      }
+      for (std::thread& t : gen) t.join();
+    }
+    std::mt19937_64 rng(3);
+    for (size_t j = 0; j < S; j++) {
+      sxmc::Signal sig;
+      sig.name = "signal" + std::to_string(j);
+      sig.source = sxmc::Source("source" + std::to_string(j), j, 1.0f, 0.0f, false);
+      sig.nexpected = (double)E / S;
+      signals.push_back(sig);
+      sources.push_back(sig.source);
+      for (size_t e = 0; e < E / S; e++) {  // data events: samples of the mixture
+        const size_t i = rng() % per_signal;
+        data.push_back(tabs[j][i * F + 0]);
+        data.push_back(tabs[j][i * F + 1]);
+        data.push_back(tabs[j][i * F + 2]);
+        data.push_back(0.0f);
       }
     }
   }
-  for (sxmc::Signal& s : signals) delete s.histogram;
+  const Options& opt = run_opt;
+  const bool multi = !opt.devices.empty();
+  size_t rows_total = 0;
+  for (const std::vector<float>& t : tabs) rows_total += t.size() / F;
+
+  // ---- evaluators on the current device (the single walk and the one-GPU ensemble leg)
+  if (opt.walk || (opt.nexp > 0 && !multi)) {
+    for (size_t j = 0; j < signals.size(); j++) sxmc::build_pdfz(signals[j], tabs[j], (int)F, observables, systematics);
+  }
+
+  if (opt.walk) {
+    sxmc_stream_t strm = nullptr;
+    sxmc::check(sxmc_stream_create_nonblocking(&strm));
+    // SXMC_BENCH_LOOKAHEAD=0: one evaluation per step; default: the look-ahead walk (two evaluations per pass)
+    const char* la_env = std::getenv("SXMC_BENCH_LOOKAHEAD");
+    const bool lookahead = !(la_env && la_env[0] == '0');
+    for (int pass = 0; pass < 2; pass++) {  // pass 0 warms up (clocks, launch plan); pass 1 is timed
+      sxmc::MCMC mcmc(sources, signals, systematics, observables, 1234 + pass, strm);
+      mcmc.graph_steps = opt.graph_steps;
+      mcmc.lookahead = lookahead;
+      const auto t0 = std::chrono::steady_clock::now();
+      sxmc::Chain chain = mcmc(data, pass == 0 ? std::min(opt.nsteps, 500u) : opt.nsteps, 0.1f, false, 10000);
+      const double sec = seconds_since(t0);
+      if (pass == 1) {
+        std::printf("{\"driver\": \"sxmc::MCMC (C++)\", \"nsamples_total\": %zu, \"nsignals\": %zu, \"nevents\": %zu, "
+                    "\"steps\": %u, \"steps_per_graph\": %u, \"seconds\": %.4f, \"steps_per_sec\": %.1f, "
+                    "\"accepted\": %zu, \"rows_kept\": %zu, \"lookahead\": %s, \"passes\": %zu}\n",
+                    rows_total, signals.size(), data.size() / (observables.size() + 1), opt.nsteps, opt.graph_steps, sec,
+                    opt.nsteps / sec, chain.accepted, chain.nrows(), lookahead ? "true" : "false",
+                    mcmc.LookaheadPasses());
+        std::fflush(stdout);
+      }
+    }
+    sxmc_stream_destroy(strm);
+  }
+
+  // ---- ensemble leg: whole fake experiments (fake data drawn on the device, walk with burn-in re-tuning, contour
+  // intervals), in lockstep sets of L chains (S sets in flight per GPU)
+  if (opt.nexp > 0 && !multi) {
+    std::vector<unsigned> ks;
+    for (unsigned k = 0; k < opt.nexp; k++) ks.push_back(k);
+    if (opt.config.empty())
+      for (sxmc::Signal& sg : signals) sg.nexpected = 8000.0;   // ~1e5 events per fake data set
+    for (int pass = 0; pass < 2; pass++) {   // pass 0 (one round) compiles the lockstep kernel and warms up
+      std::vector<unsigned> part(ks.begin(),
+                                 pass == 0 ? ks.begin() + std::min<size_t>(ks.size(), opt.L * opt.S) : ks.end());
+      sxmc::SetupLock lock;
+      const auto t0 = std::chrono::steady_clock::now();
+      std::vector<sxmc::ExperimentResult> res = sxmc::ensemble_lockstep(
+          part, base_seed, sources, signals, systematics, observables, pass == 0 ? std::min(300u, opt.esteps) : opt.esteps,
+          burnin, opt.L, opt.S, cl, opt.esteps, opt.graph_steps, -1, &lock);
+      const double sec = seconds_since(t0);
+      if (pass == 1) {
+        std::printf("{\"driver\": \"sxmc::ensemble_lockstep (C++)\", \"experiments\": %zu, \"steps_each\": %u, "
+                    "\"chains_per_fill\": %u, \"sets\": %u, \"seconds\": %.4f, \"experiments_per_sec\": %.4f, "
+                    "\"steps_per_sec_inside\": %.1f, \"nevents_first\": %zu, "
+                    "\"setup_lock\": {\"waited_seconds_summed_over_lanes\": %.4f, \"held_seconds\": %.4f, "
+                    "\"acquisitions\": %llu, \"lanes\": %u}}\n",
+                    res.size(), opt.esteps, opt.L, opt.S, sec, res.size() / sec, res.size() * (double)opt.esteps / sec,
+                    res.empty() ? (size_t)0 : res[0].nevents, lock.waited_seconds(), lock.held_seconds(), lock.count(),
+                    opt.L * opt.S);
+        std::fflush(stdout);
+      }
+    }
+  }
+  for (sxmc::Signal& s : signals) {
+    delete s.histogram;
+    s.histogram = nullptr;
+  }
+
+  // ---- the same experiments sharded over the GPUs of the node: a host thread per device, its own replica of the
+  // evaluators, experiment k on device k mod G, ONE RCCL all-gather of the intervals at the end
+  if (opt.nexp > 0 && multi) {
+    if (opt.config.empty())
+      for (sxmc::Signal& sg : signals) sg.nexpected = 8000.0;
+    std::vector<const std::vector<float>*> tp;
+    for (const std::vector<float>& t : tabs) tp.push_back(&t);
+    sxmc::MultiGpuOptions mo;
+    mo.cl = cl;
+    mo.sync_interval = opt.esteps;
+    mo.graph_steps = opt.graph_steps;
+    mo.lockstep_chains = opt.L;
+    mo.lockstep_sets = opt.S;
+    mo.nconcurrent = std::max(1u, opt.L * opt.S);
+    if (opt.host_staging) mo.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
+    const size_t G = opt.devices.size();
+    for (int pass = 0; pass < 2; pass++) {   // pass 0: one round per device (kernel compilation, clocks)
+      const unsigned n = pass == 0 ? (unsigned)std::min<size_t>(opt.nexp, G * std::max(1u, opt.L * opt.S)) : opt.nexp;
+      const auto t0 = std::chrono::steady_clock::now();
+      sxmc::MultiGpuEnsemble mg =
+          sxmc::ensemble_multi_gpu(opt.devices, n, base_seed, sources, signals, tp, (int)F, systematics, observables,
+                                   pass == 0 ? std::min(300u, opt.esteps) : opt.esteps, burnin, mo);
+      const double sec = seconds_since(t0);
+      if (pass == 0) continue;
+      double setup_max = 0, rank_max = 0;
+      for (double s : mg.rank_setup_seconds) setup_max = std::max(setup_max, s);
+      for (double s : mg.rank_seconds) rank_max = std::max(rank_max, s);
+      const double inside = std::max(rank_max - setup_max, 1e-9);
+      std::string locks = "[", devs = "[", rdevs = "[";
+      for (size_t i = 0; i < mg.setup_locks.size(); i++) {
+        char b[256];
+        std::snprintf(b, sizeof b, "%s{\"device\": %d, \"waited_seconds_summed_over_lanes\": %.4f, \"held_seconds\": %.4f, "
+                      "\"acquisitions\": %llu}", i ? ", " : "", mg.setup_locks[i].device, mg.setup_locks[i].waited_seconds,
+                      mg.setup_locks[i].held_seconds, mg.setup_locks[i].acquisitions);
+        locks += b;
+      }
+      for (size_t i = 0; i < G; i++) devs += (i ? ", " : "") + std::to_string(opt.devices[i]);
+      for (size_t i = 0; i < mg.rccl_devices.size(); i++) rdevs += (i ? ", " : "") + std::to_string(mg.rccl_devices[i]);
+      std::printf("{\"driver\": \"sxmc::ensemble_multi_gpu (C++)\", \"ranks\": %zu, \"devices\": %s], "
+                  "\"exchange\": \"%s\", \"rccl_nranks\": %d, \"rccl_devices\": %s], \"experiments\": %u, "
+                  "\"steps_each\": %u, \"chains_per_fill\": %u, \"sets\": %u, \"seconds\": %.4f, "
+                  "\"replica_setup_seconds_max\": %.4f, \"experiments_per_sec\": %.4f, "
+                  "\"experiments_per_sec_after_setup\": %.4f, \"steps_per_sec_inside\": %.1f, "
+                  "\"median_upper_limit_source0\": %.6g, \"gathered_floats\": %zu, \"setup_locks\": %s]}\n",
+                  G, devs.c_str(), opt.host_staging ? "host staging (rehearsal)" : "ncclAllGather (RCCL)",
+                  mg.rccl_nranks, rdevs.c_str(), n, opt.esteps, opt.L, opt.S, sec, setup_max, n / sec, n / inside,
+                  n * (double)opt.esteps / inside, mg.median_upper.empty() ? 0.0 : (double)mg.median_upper[0],
+                  mg.gathered.size(), locks.c_str());
+      std::fflush(stdout);
+    }
+  }
   return 0;
 }

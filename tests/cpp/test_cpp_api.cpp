@@ -690,6 +690,106 @@ TEST_F(SmallFit, MultiGpuRunnerGathersTheIntervalsThroughRccl) {
   EXPECT_EQ(2.5f, sxmc::median(std::vector<float>{1.0f, 4.0f, 2.0f, 3.0f}));   // utils.h:76-90: mean of the two middle ones
 }
 
+TEST_F(SmallFit, MultiGpuRunnerWithTwoLogicalRanksOnOneCard) {
+  // G = 2 device threads, both on card 0, through everything but the RCCL call (RCCL refuses two ranks on one card;
+  // MultiGpuOptions::HOST_STAGING stands in for the all-gather): sharding k mod G, a replica of the evaluators per
+  // thread, the rendezvous, the order of the results, the medians.  Three ranks as well (uneven shares, padded blocks).
+  for (int G : {2, 3}) {
+    const unsigned N = 7;
+    std::vector<unsigned> ks;
+    for (unsigned k = 0; k < N; k++) ks.push_back(k);
+    std::vector<sxmc::ExperimentResult> seq =
+        sxmc::ensemble(ks, 21, sources, signals, systematics, observables, 300, 0.2f, 0.9f, 100);
+    std::vector<const std::vector<float>*> tabs;
+    for (const std::vector<float>& t : tables) tabs.push_back(&t);
+    sxmc::MultiGpuOptions opt;
+    opt.sync_interval = 100;
+    opt.graph_steps = 8;
+    opt.lockstep_chains = 2;
+    opt.lockstep_sets = 1;
+    opt.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
+    sxmc::MultiGpuEnsemble mg = sxmc::ensemble_multi_gpu(std::vector<int>((size_t)G, 0), N, 21, sources, signals, tabs, 4,
+                                                         systematics, observables, 300, 0.2f, opt);
+    EXPECT_EQ(0, mg.rccl_nranks);
+    EXPECT_EQ((size_t)1, mg.setup_locks.size());   // one card, one lock, shared by the ranks
+    EXPECT_TRUE(mg.setup_locks[0].acquisitions > 0 && mg.setup_locks[0].held_seconds > 0);
+    EXPECT_EQ((size_t)G, mg.rank_seconds.size());
+    for (unsigned k = 0; k < N; k++) {
+      EXPECT_EQ(k, mg.results[k].index);
+      EXPECT_EQ(seq[k].accepted, mg.results[k].accepted);
+      for (size_t p = 0; p < 5; p++) {
+        const float* g = &mg.gathered[((size_t)k * 5 + p) * 4];
+        EXPECT_EQ(seq[k].intervals[p].point_estimate, g[0]);
+        EXPECT_EQ(seq[k].intervals[p].lower, g[1]);
+        EXPECT_EQ(seq[k].intervals[p].upper, g[2]);
+        EXPECT_EQ(seq[k].intervals[p].coverage, g[3]);
+      }
+    }
+    for (size_t p = 0; p < 5; p++) {
+      std::vector<float> ups;
+      for (unsigned k = 0; k < N; k++) ups.push_back(seq[k].intervals[p].upper);
+      EXPECT_EQ(sxmc::median(ups), mg.median_upper[p]);   // utils.h:76-90
+    }
+  }
+}
+
+TEST_F(SmallFit, MultiGpuRunnerFailsFastWhenOneRankFails) {
+  // a rank that fails before the exchange must not leave the others waiting in it: the ranks meet on the host first,
+  // nobody enters the collective, the failing rank's error comes back -- with host staging (2 ranks on one card) and
+  // on the real RCCL path (the ranks this box has)
+  std::vector<const std::vector<float>*> tabs;
+  for (const std::vector<float>& t : tables) tabs.push_back(&t);
+  int ndev = 0;
+  ASSERT_EQ(SXMC_OK, sxmc_device_count(&ndev));
+  for (int pass = 0; pass < 2; pass++) {
+    sxmc::MultiGpuOptions opt;
+    opt.sync_interval = 100;
+    opt.graph_steps = 8;
+    opt.lockstep_chains = 0;
+    opt.nconcurrent = 2;
+    opt.exchange = pass == 0 ? sxmc::MultiGpuOptions::HOST_STAGING : sxmc::MultiGpuOptions::RCCL;
+    std::vector<int> devices;
+    if (pass == 0) devices = {0, 0};
+    else for (int d = 0; d < ndev && d < 8; d++) devices.push_back(d);
+    const size_t bad = devices.size() - 1;
+    opt.before_exchange = [bad](size_t r) {
+      if (r == bad) throw pdfz::Error("injected failure");
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    bool threw = false;
+    std::string msg;
+    try {
+      sxmc::ensemble_multi_gpu(devices, 4, 21, sources, signals, tabs, 4, systematics, observables, 200, 0.2f, opt);
+    } catch (const pdfz::Error& e) {
+      threw = true;
+      msg = e.msg;
+    }
+    EXPECT_TRUE(threw);
+    EXPECT_TRUE(msg.find("injected failure") != std::string::npos);
+    EXPECT_TRUE(msg.find("rank " + std::to_string(bad)) != std::string::npos);
+    EXPECT_TRUE(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 60.0);
+  }
+  // a failure while the replicas are built (a table that is not rows of nfields floats): same outcome
+  {
+    std::vector<float> broken(tables[0].begin(), tables[0].begin() + 4 * 100 + 1);
+    std::vector<const std::vector<float>*> tabs2 = tabs;
+    tabs2[1] = &broken;
+    sxmc::MultiGpuOptions opt;
+    opt.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
+    ASSERT_THROW(sxmc::ensemble_multi_gpu({0, 0}, 4, 21, sources, signals, tabs2, 4, systematics, observables, 200, 0.2f,
+                                          opt),
+                 pdfz::Error);
+  }
+  // and the runner still works afterwards (nothing was left locked, recording or half torn down)
+  sxmc::MultiGpuOptions opt;
+  opt.sync_interval = 100;
+  opt.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
+  sxmc::MultiGpuEnsemble mg =
+      sxmc::ensemble_multi_gpu({0, 0}, 2, 21, sources, signals, tabs, 4, systematics, observables, 200, 0.2f, opt);
+  EXPECT_EQ((size_t)2, mg.results.size());
+  EXPECT_EQ(1u, mg.results[1].index);
+}
+
 int main(int argc, char** argv) {
   int ndev = 0;
   if (sxmc_device_count(&ndev) != SXMC_OK || ndev < 1) {

@@ -1,0 +1,36 @@
+"""GPU box (one card): `python bench.py --gpus 2` started BARE, rehearsed over gloo with both ranks on the one card
+(SXMC_DIST_BACKEND=gloo).  What the driver's multi-GPU run does, minus RCCL between processes: the launcher starts
+two fresh workers, each walks its chain and its share of the fake experiments, rank 0 proves parity against the
+oracle, the line carries `collective` (and says it was a rehearsal), and the C++ one-process runner follows."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bare_two_rank_bench_over_gloo():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SXMC_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--prewarm", "20", "--scale", "0.02", "--events", "5000", "--experiments", "4", "--exp-steps", "300",
+                        "--also", "cpp_multi_gpu"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    c = rec["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["rccl_nranks"] is None and c["launched_by"] == "bench.py"
+    assert c["distinct_cards"] == 1 and "rehearsal" in c["note"]
+    assert [d["rank"] for d in c["devices"]] == [0, 1] and all(d["pci_bus_id"] for d in c["devices"])
+    assert rec["parity"]["ok"] and rec["parity"]["bins_and_norms_bit_exact"]      # rank 0, also at N > 1
+    assert rec["cpu_baseline"] is None                                            # timed at N = 1 only
+    assert rec["roofline"]["launches_timed"] >= 100 and rec["roofline"]["sample"].startswith("post-timed")
+    assert rec["experiments"]["count"] == 4 and rec["experiments"]["gathered_shape"] == [4, 15, 4]
+    cpp = rec["also"]["cpp_multi_gpu"]
+    assert cpp["ranks"] == 2 and cpp["exchange"].startswith("host staging") and cpp["experiments"] == 4

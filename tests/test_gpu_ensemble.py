@@ -58,6 +58,13 @@ def test_device_random_sample_is_reproducible_and_respects_cuts():
     cut = ev.RandomSample(3000, 5, lowers=[1.0, 2.0, -0.5], uppers=[4.0, 5.0, 0.5])
     assert np.all((cut[:, 0] >= 1.0) & (cut[:, 0] <= 4.0) & (cut[:, 1] >= 2.0) & (cut[:, 1] <= 5.0) &
                   (np.abs(cut[:, 2]) <= 0.5))
+    # cuts that leave nothing of the histogram: the reference would redraw for ever (pdfz.cpp:838-905); here the call
+    # FAILS after 1024 attempts per event -- it does not hand out points that are outside the cuts
+    with pytest.raises(capi.SxmcError) as err:
+        ev.RandomSample(100, 5, lowers=[20.0, 2.0, -0.5], uppers=[30.0, 5.0, 0.5])
+    assert "could not be drawn inside the cuts" in str(err.value)
+    again = ev.RandomSample(5000, 77)
+    assert np.array_equal(again, a)                      # and the evaluator is as usable as before
     # a second and third data set on the same evaluators: descriptors are patched, results are those of a fresh chain
     for seed in (3, 4):
         data, _ = ensemble.make_fake_dataset(np.random.default_rng(seed), w, m.pdfs, poisson=True)

@@ -45,7 +45,8 @@ def test_comments_are_stripped_outside_strings():
 
 def test_config_schema_field_order_and_parameter_indices():
     fc = io.load_config(EXAMPLE)
-    assert fc.nsteps == 1000 and fc.confidence == 0.9 and fc.error_type == "contour"
+    # (confidence, burnin_fraction, rates and scales are floats in the reference: asFloat())
+    assert fc.nsteps == 1000 and fc.confidence == float(np.float32(0.9)) and fc.error_type == "contour"
     # sample fields: observables, extra truth fields, DATASET (config.cpp:153-194)
     assert fc.sample_fields == ["energy", "mc_energy", "DATASET"]
     es, er = fc.systematics
@@ -92,9 +93,197 @@ def test_workload_from_config(tmp_path):
     assert w.nobs == 1 and w.nbins == [10] and w.nsources == 2 and w.nparameters == 5
     a, b = w.signals
     assert a.nfields == 3 and a.samples.shape[0] < 1000 and a.n_mc == 1000        # n_mc counts events before cuts
-    assert b.nexpected == 2000 / 20.0                                             # scale -> nexpected (signal.cpp:31-35)
+    # scale -> nexpected: -1 / scale kept in a FLOAT (config.cpp:221), times -n_mc in double (signal.cpp:31-35)
+    assert b.nexpected == float(np.float32(-1.0) / np.float32(20.0)) * -2000.0 and abs(b.nexpected - 100.0) < 1e-5
     assert np.all(a.samples[:, 2] == 0) and a.samples[:, 0].max() > 15            # observables are not cuts for MC
     assert w.systematics[1] == dict(type="resolution_scale", obs=0, true_obs=1, pars=[1, 2])
     assert list(w.parameter_sigmas()) == [0.0, 0.25, 0.01, 0.001, 0.0]
     assert w.parameter_names == ["sig_a", "shared", "energy_scale_0", "energy_resolution_0", "energy_resolution_1",
                                  "likelihood"]
+
+
+# ---- the C++ input layer (sxmc_amd/include/sxmc/config.h) against this one, on the same files --------------------
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "tests", "cpp", "config_dump")
+DUMP_ASAN = os.path.join(ROOT, "tests", "cpp", "config_dump_asan")
+
+# signals named so that KEY order (what jsoncpp 0.6 iterates in: config.cpp:97) differs from file order and from
+# fit.signals order; different systematics lists; a source shared by two signals; a cut; two data sets; mixed dtypes
+KEYED = """
+{
+  "fit": {"nexperiments": 3, "nsteps": 500, "seed": 1234567890123, "confidence": 0.9, "error_type": "projection",
+          "signals": ["zeta", "alpha", "Mid"], "observables": ["energy", "radius"], "cuts": ["fitvalid"],
+          "signal_name": "alpha", "debug_mode": true},
+  "pdfs": {
+    "observables": {
+      "energy": {"title": "E", "field": "e", "bins": 12, "min": 0.1, "max": 10.3},
+      "radius": {"title": "R", "field": "r", "bins": 7, "min": 0.0, "max": 6.0},
+      "fitvalid": {"title": "ok", "field": "valid", "bins": 1, "min": 0.5, "max": 1.5}
+    },
+    "systematics": {
+      "r_shift": {"title": "s", "type": "shift", "observable_field": "r", "mean": [0.0], "sigma": [0.05]},
+      "e_scale": {"title": "s", "type": "scale", "observable_field": "e", "mean": [0.0, 0.1], "sigma": [0.01, 0.0], "fixed": true},
+      "e_res": {"title": "s", "type": "resolution_scale", "observable_field": "e", "truth_field": "e_true", "mean": [0.0]},
+      "c_ct": {"title": "s", "type": "ctscale", "observable_field": "r", "mean": [0.0], "sigma": [0.3]}
+    }
+  },
+  "signals": {
+    "zeta": {"title": "Z", "filename": "z.npz", "dataset": 1, "rate": 12.3, "systematics": ["r_shift", "e_res"]},
+    "alpha": {"title": "A", "filename": "a.npz", "dataset": 0, "scale": 3.0, "source": "common",
+              "systematics": ["e_scale", "r_shift"]},
+    "Mid": {"title": "M", "filename": "m.npz", "dataset": 0, "rate": 7, "source": "common", "mean": 2.0,
+            "systematics": ["c_ct"]}
+  },
+  "sources": {"common": {"mean": 1.5, "sigma": 0.1}},
+  "data": {"1": [{"title": "d1", "filename": "d1.npz"}], "0": [{"title": "d0", "filename": "d0.npz"}, {"title": "d0b", "filename": "z.npz"}]}
+}
+"""
+
+
+def _write_keyed_files(tmp_path):
+    rng = np.random.default_rng(5)
+    for name, n in (("z.npz", 700), ("a.npz", 1300), ("m.npz", 10), ("d1.npz", 90), ("d0.npz", 60)):
+        e_true = rng.uniform(0, 11, n)
+        # the archive's field order differs from the sample-field order; dtypes: double, float, int, bool
+        np.savez(tmp_path / name, valid=rng.integers(0, 3, n), r=rng.uniform(-0.5, 6.5, n).astype(np.float32),
+                 e_true=e_true, junk=rng.integers(0, 2, n).astype(bool), e=(e_true + rng.normal(0, 0.4, n)))
+    (tmp_path / "fit.json").write_text(KEYED)
+    return str(tmp_path / "fit.json")
+
+
+def _python_summary(path):
+    fc = io.load_config(path)
+    out = {"sample_fields": fc.sample_fields, "nexperiments": fc.nexperiments, "nsteps": fc.nsteps, "seed": fc.seed,
+           "error_type": fc.error_type, "confidence": fc.confidence, "burnin_fraction": fc.burnin_fraction,
+           "debug_mode": fc.debug_mode, "signal_name": fc.signal_name,
+           "sources": [(s["name"], s["index"], float(s["mean"]), float(s["sigma"]), s["fixed"]) for s in fc.sources],
+           # (type as pdfz::Systematic::Type numbers it, pdfz.h:109-116: SHIFT, SCALE, RESOLUTION_SCALE, CTSCALE)
+           "systematics": [(s["name"], {"shift": 0, "scale": 1, "resolution_scale": 2, "ctscale": 3}[s["type"]],
+                            s["observable_field_index"],
+                            s["truth_field_index"], s["npars"], s["fixed"], s["pidx"], s["means"], s["sigmas"])
+                           for s in fc.systematics],
+           "observables": [(o["name"], o["field_index"], o["bins"], float(o["lower"]), float(o["upper"]))
+                           for o in fc.observables]}
+    cuts = [(c["field"], c["lower"], c["upper"]) for c in fc.cuts]
+    sigs = []
+    for s in fc.signals:
+        table, fields = io.read_table(os.path.join(fc.base_dir, s["filename"]))
+        n_mc = table.shape[0]
+        samples = io.read_dataset_to_samples(table, fields, s["dataset"], fc.sample_fields, cuts)
+        nexp = s["rate"] if s["rate"] is not None else float(np.float32(-1.0) / np.float32(s["scale"])) * (-1.0 * n_mc)
+        sigs.append((s["name"], s["dataset"], s["source"]["index"], nexp, n_mc, _fingerprint(samples)))
+    out["signals"] = sigs
+    return out, fc
+
+
+def _fingerprint(a):
+    flat = np.ascontiguousarray(a, np.float32).ravel()
+    total = 0.0
+    for x in flat.astype(np.float64):          # (the C++ side adds in index order, in double)
+        total += x
+    return (int(a.shape[0]), total, int(np.bitwise_xor.reduce(flat.view(np.uint32))) if flat.size else 0)
+
+
+@pytest.mark.parametrize("exe", [DUMP, DUMP_ASAN])
+def test_cpp_load_config_matches_python_on_the_same_files(tmp_path, exe):
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp is not built")
+    path = _write_keyed_files(tmp_path)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe, path], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cpp = json.loads(r.stdout)
+    py, fc = _python_summary(path)
+    # key order: Mid < alpha < zeta (strcmp), so the union numbers c_ct first; sources: common (Mid), then zeta
+    assert [s["name"] for s in cpp["systematics"]] == ["c_ct", "e_scale", "r_shift", "e_res"]
+    assert [s["pidx"] for s in cpp["systematics"]] == [[0], [1, 2], [3], [4]]
+    assert [(s["name"], s["index"]) for s in cpp["sources"]] == [("common", 0), ("zeta", 1)]
+    assert cpp["sample_fields"] == py["sample_fields"] == ["e", "r", "e_true", "DATASET"]
+    for k in ("nexperiments", "nsteps", "seed", "error_type", "debug_mode", "signal_name"):
+        assert cpp[k] == py[k], k
+    assert cpp["confidence"] == pytest.approx(py["confidence"], rel=1e-8)
+    assert [(s["name"], s["index"], s["mean"], s["sigma"], s["fixed"]) for s in cpp["sources"]] == \
+        [(n, i, pytest.approx(m, rel=1e-8), pytest.approx(sg, rel=1e-8), f) for n, i, m, sg, f in py["sources"]]
+    assert [(s["name"], s["type"], s["observable_field_index"], s["truth_field_index"], s["npars"], s["fixed"],
+             s["pidx"], s["means"], s["sigmas"]) for s in cpp["systematics"]] == [tuple(x) for x in py["systematics"]]
+    assert [(o["name"], o["field_index"], o["bins"]) for o in cpp["observables"]] == [x[:3] for x in py["observables"]]
+    for got, want in zip(cpp["signals"], py["signals"]):
+        name, dataset, src, nexp, n_mc, (rows, total, xor) = want
+        assert (got["name"], got["dataset"], got["source_index"], got["n_mc"]) == (name, dataset, src, n_mc)
+        assert got["nexpected"] == nexp                       # bit for bit, incl. the float in -1 / scale
+        assert (got["table"]["rows"], got["table"]["sum"], got["table"]["xor"]) == (rows, total, xor)
+        assert rows < n_mc                                    # the cut removed something
+    # data sets: clipped to the PDF boundaries, observables + dataset id
+    w = io.build_workload(fc)
+    data = io.load_data(fc, w)
+    for ds in (0, 1):
+        rows, total, xor = _fingerprint(data[data[:, -1] == ds])
+        t = cpp["data"][str(ds)]
+        assert (t["rows"], t["sum"], t["xor"]) == (rows, total, xor)
+    assert cpp["same_systematics_everywhere"] is False
+
+
+def test_cpp_json_reader_accepts_what_the_reference_accepts(tmp_path):
+    if not os.path.exists(DUMP_ASAN):
+        pytest.skip("tests/cpp is not built")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    doc = '{ // c\n "a": [1, -2.5e3, true, null, "x\\"y // not a comment", {"k": {}}], /* c */ "b": {"z": 1, "A": 2}\n}'
+    (tmp_path / "d.json").write_text(doc)
+    r = subprocess.run([DUMP_ASAN, "--json", str(tmp_path / "d.json")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == json.loads(io.strip_comments(doc))
+    assert list(json.loads(r.stdout)["b"]) == ["A", "z"]       # members in key order, like jsoncpp 0.6
+    # the defect of the reference's own config/example.json (a missing comma, SURVEY.md appendix C) is reported the
+    # way jsoncpp reports it, not swallowed
+    (tmp_path / "bad.json").write_text('{"a": {"x": 1 "y": 2}}')
+    r = subprocess.run([DUMP_ASAN, "--json", str(tmp_path / "bad.json")], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "missing ',' or '}' in object declaration" in r.stderr and "line 1" in r.stderr
+    for bad in ('{"a": [1, 2}', '{"a": "unterminated}', '{"a": 1} trailing', '/* open', ''):
+        (tmp_path / "bad.json").write_text(bad)
+        r = subprocess.run([DUMP_ASAN, "--json", str(tmp_path / "bad.json")], capture_output=True, text=True, env=env)
+        assert r.returncode == 1 and "JSON parse error" in r.stderr, bad
+
+
+def test_cpp_table_reader_rejects_what_it_cannot_read(tmp_path):
+    if not os.path.exists(DUMP_ASAN):
+        pytest.skip("tests/cpp is not built")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    cfg = json.loads(io.strip_comments(EXAMPLE))
+
+    def run():
+        (tmp_path / "fit.json").write_text(json.dumps(cfg))
+        return subprocess.run([DUMP_ASAN, str(tmp_path / "fit.json")], capture_output=True, text=True, env=env)
+    good = dict(energy=np.ones(4, np.float32), radius=np.ones(4, np.float32), mc_energy=np.ones(4, np.float32))
+    np.savez(tmp_path / "b.npz", **good)
+    np.savez_compressed(tmp_path / "a.npz", **good)
+    r = run()
+    assert r.returncode == 1 and "compressed" in r.stderr
+    np.savez(tmp_path / "a.npz", energy=np.ones(4), radius=np.ones(5), mc_energy=np.ones(4))
+    r = run()
+    assert r.returncode == 1 and "differ in length" in r.stderr
+    np.savez(tmp_path / "a.npz", energy=np.ones((2, 2)), radius=np.ones(4), mc_energy=np.ones(4))
+    r = run()
+    assert r.returncode == 1 and "1-D" in r.stderr
+    np.savez(tmp_path / "a.npz", energy=np.ones(4), radius=np.ones(4))            # a sample field is missing
+    r = run()
+    assert r.returncode == 1 and "mc_energy" in r.stderr
+    (tmp_path / "a.npz").write_bytes(b"PK\x03\x04 truncated")
+    r = run()
+    assert r.returncode == 1
+    np.savez(tmp_path / "a.npz", **good)                                          # and the good file loads
+    r = run()
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout)["signals"][0]["n_mc"] == 4
+    # a 2-D float32 .npy with the field names in the configuration
+    np.save(tmp_path / "a.npy", np.array([[0, 1, 2], [3, 4, 5], [6, 10.5, 8], [9, 10, 11]], np.float32))
+    cfg["signals"]["sig_a"]["filename"] = "a.npy"
+    cfg["signals"]["sig_a"]["fields"] = ["energy", "radius", "mc_energy"]
+    r = run()
+    assert r.returncode == 0, r.stderr
+    t = json.loads(r.stdout)["signals"][0]["table"]
+    assert t["rows"] == 3                      # radius 10 passes (bounds inclusive), 10.5 does not
