@@ -237,7 +237,8 @@ class Leg:
     def setup(self, steps, warmup):
         from sxmc_amd import capi
         args, m = self.args, self.m
-        m.setup(sync_interval=max(steps, warmup + 1, min(args.prewarm, 100) + 1, 1))
+        # (the jump buffer holds every step between two flushes: the longest run here, the post-timed sample included)
+        m.setup(sync_interval=max(steps, warmup + 1, min(args.prewarm, 100) + 1, 2 * ROOFLINE_LAUNCHES + 8, 1))
         m.group.SetDebugMode(args.debug_mode)
         # EvalHist::Optimize's role (pdfz.cpp:622-727): a few trial launches pick the lane count per CU for this box
         if not args.no_autotune and args.launch == "0,0":
@@ -323,9 +324,9 @@ class Leg:
         self.roofline_sample = "inside the timed region: the %d steps launched one by one" % self.nfill_region
         if n > 0:
             m.flush()
-            m.group.Profile(True, n + 8)
+            m.group.Profile(True, 2 * n + 8)
             if self.la is not None:
-                self.la.steps(n, graph_passes=0)
+                self.la.steps(2 * n, graph_passes=0)      # (one or two steps per pass: at least n passes)
             else:
                 for _ in range(n):
                     self.one_step()

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsxmc_oracle.so")
+# SXMC_ORACLE_LIB selects another build of the same oracle (the ASan + UBSan build: tests/test_plan_cpu.py)
+_LIB_PATH = os.environ.get("SXMC_ORACLE_LIB") or os.path.join(_HERE, "libsxmc_oracle.so")
 
 MAX_SYST_PARS = 8
 SHIFT, SCALE, RESOLUTION_SCALE, CTSCALE = 0, 1, 2, 3   # pdfz.h:111-116

@@ -616,7 +616,11 @@ struct StaticEntry {
 #define SX_P1(NO, NS, PRE, G, GR, A) {NO, NS, 1, {A, 0, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A>>, PRE, G, GR}
 #define SX_P2(NO, NS, PRE, G, GR, A, B) {NO, NS, 2, {A, B, 0, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B>>, PRE, G, GR}
 #define SX_P3(NO, NS, PRE, G, GR, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_k<NO, NS, true, StaticProg<A, B, C>>, PRE, G, GR}
-#define SX_P0(NO) {NO, NO, 0, {0, 0, 0, 0}, launch_fill_k<NO, NO, true, StaticProg<>>, SX_NOPRE, SX_NOG, SX_NOGRAN}
+// (no systematics: EVERY observable is untouched, so the pre-binned column carries the whole flat index and no float
+// column is streamed at all -- 1 or 2 bytes per sample instead of 4 per observable)
+#define SX_P0(NO) \
+  {NO, NO, 0, {0, 0, 0, 0}, launch_fill_k<NO, NO, true, StaticProg<>>, \
+   {launch_fill_k<NO, NO, true, StaticProg<>, 1>, launch_fill_k<NO, NO, true, StaticProg<>, 2>}, SX_NOG, SX_NOGRAN}
 const StaticEntry kStaticPrograms[] = {
     // no systematics at all (BASELINE config 2)
     SX_P0(1), SX_P0(2), SX_P0(3),

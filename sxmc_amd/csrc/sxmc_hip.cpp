@@ -8,6 +8,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "sxmc_device.h"
+#include "sxmc_plan.h"
 
 extern "C" {
 hipError_t sx_nll_init_rngs(int, int, hipStream_t, int, unsigned long long, sxmc_rng_state*);
@@ -234,6 +236,7 @@ struct LaunchClass {
   int partition = 0;  // 1 sliced, 2 interleaved (what build_partition chose)
   bool light = false; // a pure stream: runs best with few waves per CU (see group_rebuild)
   bool runs_mode = false;  // bucketed tables laid out in per-wave runs; the sparse flavour runs fill_sparse_kernel
+  bool cached_loads = false;  // the class's tables fit the Infinity Cache: default-policy loads (see group_rebuild)
 };
 
 void free_class(LaunchClass& c) {
@@ -247,105 +250,22 @@ void free_class(LaunchClass& c) {
   c.d_blk_off = nullptr;
 }
 
-// Cut the class's work (units of SXMC_VEC samples) into per-workgroup segment lists.
-//  interleaved: member j gets K_j workgroups (proportional to its size, sum = grid); workgroup i of
-//    the member takes chunks i, i + K_j, ... of `threads` units: neighbouring workgroups read
-//    neighbouring chunks at the same time and every workgroup flushes one histogram once.
-//  sliced: workgroup b owns the contiguous slice [total*b/G, total*(b+1)/G) of the concatenated
-//    members: perfectly balanced, used when members outnumber workgroups or are tiny.
-// Largest-remainder apportionment of `grid` workgroups over members of `sizes` units: at least one per
-// non-empty member and never more than the member has chunks of `threads` units.  false: they do not fit.
-bool apportion_workgroups(const std::vector<unsigned long long>& sizes, int grid, int threads, std::vector<int>& K) {
-  K.assign(sizes.size(), 0);
-  unsigned long long total = 0;
-  for (unsigned long long n : sizes) total += n;
-  if (total == 0) return true;
-  int used = 0;
-  std::vector<std::pair<double, int>> frac;
-  for (size_t j = 0; j < sizes.size(); j++) {
-    if (!sizes[j]) continue;
-    const double share = (double)grid * (double)sizes[j] / (double)total;
-    const unsigned long long chunks = (sizes[j] + threads - 1) / threads;
-    K[j] = (int)std::min<unsigned long long>(chunks, std::max<unsigned long long>(1, (unsigned long long)share));
-    used += K[j];
-    frac.push_back({share - std::floor(share), (int)j});
-  }
-  std::sort(frac.begin(), frac.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-  for (size_t i = 0; used < grid && !frac.empty() && i < 4 * frac.size(); i++) {
-    const int j = frac[i % frac.size()].second;
-    const unsigned long long chunks = (sizes[(size_t)j] + threads - 1) / threads;
-    if ((unsigned long long)K[(size_t)j] < chunks) {
-      K[(size_t)j]++;
-      used++;
-    }
-  }
-  return used <= grid;
+// Who reads which units: sxmc_plan.h (apportion_workgroups, interleaved_segments, build_partition), here as thin
+// adapters from descriptors to their unit counts.
+using sxplan::apportion_workgroups;
+std::vector<unsigned long long> unit_counts(const std::vector<SxSignalDesc>& descs) {
+  std::vector<unsigned long long> nvec;
+  for (const SxSignalDesc& d : descs) nvec.push_back(d.nvec);
+  return nvec;
 }
-
-// Workgroup i of member j takes chunks i, i + K_j, ... of `threads` units of the member.
 void interleaved_segments(const std::vector<SxSignalDesc>& descs, const std::vector<int>& K, int threads, int grid,
                           std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off) {
-  segs.clear();
-  blk_off.assign(1, 0u);
-  for (size_t j = 0; j < descs.size(); j++) {
-    for (int i = 0; i < K[j]; i++) {
-      SxSegment sg{};
-      sg.sig = (int)j;
-      sg.v0 = (unsigned long long)i * threads;
-      sg.v1 = descs[j].nvec;
-      sg.step = (unsigned long long)K[j] * threads;
-      segs.push_back(sg);
-      blk_off.push_back((unsigned)segs.size());
-    }
-  }
-  while ((int)blk_off.size() < grid + 1) blk_off.push_back((unsigned)segs.size());  // idle workgroups
+  sxplan::interleaved_segments(unit_counts(descs), K, threads, grid, segs, blk_off);
 }
-
 void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threads, int want_mode,
                      std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off, int& mode_out,
                      unsigned long long align = 1) {
-  segs.clear();
-  blk_off.assign(1, 0u);
-  unsigned long long total = 0;
-  int nonempty = 0;
-  for (const SxSignalDesc& d : descs) {
-    total += d.nvec;
-    if (d.nvec) nonempty++;
-  }
-  bool interleave = want_mode == 2 || (want_mode == 0 && nonempty > 0 && grid >= 2 * nonempty &&
-                                       total >= (unsigned long long)grid * threads * 8ull);
-  if (want_mode == 2 && (nonempty == 0 || grid < nonempty)) interleave = false;
-  std::vector<int> K;
-  if (interleave) {
-    std::vector<unsigned long long> sizes;
-    for (const SxSignalDesc& d : descs) sizes.push_back(d.nvec);
-    interleave = apportion_workgroups(sizes, grid, threads, K);  // false: more non-empty members than workgroups
-  }
-  if (interleave) {
-    interleaved_segments(descs, K, threads, grid, segs, blk_off);
-    mode_out = 2;
-    return;
-  }
-  for (int b = 0; b < grid; b++) {
-    // (bucketed tables: slices start on granule boundaries; every member's unit count is a multiple of `align`)
-    unsigned long long r0 = total * (unsigned long long)b / grid / align * align;
-    const unsigned long long r1 = b + 1 == grid ? total : total * (unsigned long long)(b + 1) / grid / align * align;
-    unsigned long long start = 0;
-    for (size_t j = 0; j < descs.size() && r0 < r1; j++) {
-      const unsigned long long s0 = start, s1 = start + descs[j].nvec;
-      start = s1;
-      if (s1 <= r0) continue;
-      SxSegment sg{};
-      sg.sig = (int)j;
-      sg.v0 = r0 - s0;
-      sg.v1 = std::min(r1, s1) - s0;
-      sg.step = (unsigned long long)threads;
-      segs.push_back(sg);
-      r0 = std::min(r1, s1);
-    }
-    blk_off.push_back((unsigned)segs.size());
-  }
-  mode_out = 1;
+  sxplan::build_partition(unit_counts(descs), grid, threads, want_mode, segs, blk_off, mode_out, align);
 }
 }  // namespace
 
@@ -454,47 +374,17 @@ void free_sparse(sxmc_hist* h) {
   h->h_read_slot.clear();
 }
 
-int ceil_log2(size_t x) {
-  int b = 0;
-  while (((size_t)1 << b) < x) b++;
-  return b;
-}
+using sxplan::ceil_log2;
 
 // Sparse-counting structures of one evaluator from its event bins (host side, once per SetEvalPoints).
 int build_sparse(sxmc_hist* h, const std::vector<int>& rb) {
   free_sparse(h);
-  std::vector<unsigned> targets;
-  for (int b : rb)
-    if (b >= 0) targets.push_back((unsigned)b);
-  std::sort(targets.begin(), targets.end());
-  targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+  sxplan::SparseTables st;
+  sxplan::build_sparse_tables(rb, st);   // (sxmc_plan.h: targets, slots, filters, table)
+  const std::vector<unsigned>&targets = st.targets, &filter = st.filter, &table = st.table, &coarse = st.coarse;
+  const std::vector<int>& slot = st.slot;
   const size_t T = targets.size();
-  std::vector<int> slot(rb.size());
-  for (size_t i = 0; i < rb.size(); i++) {
-    slot[i] = rb[i] < 0 ? rb[i]
-                        : (int)(std::lower_bound(targets.begin(), targets.end(), (unsigned)rb[i]) - targets.begin());
-  }
-  const int fbits = std::min(26, std::max(16, ceil_log2(64 * std::max<size_t>(T, 1))));  // <= 1.6 % false positives
-  const int tbits = std::max(6, ceil_log2(2 * std::max<size_t>(T, 1)));                   // load <= 50 %
-  // coarse filter: two hashes per bin, >= 8 bits per bin up to 2^20 bits (128 KiB of LDS): ~3 % false
-  // positives at 1e5 event bins (one hash in 64 KiB let 19 % through, and every survivor costs L2 probes)
-  const int cbits = std::min(20, std::max(10, ceil_log2(16 * std::max<size_t>(T, 1))));
-  std::vector<unsigned> coarse((size_t)1 << (cbits - 5), 0u);
-  std::vector<unsigned> filter((size_t)1 << (fbits - 5), 0u);
-  std::vector<unsigned> table((size_t)2 << tbits, 0xFFFFFFFFu);
-  const unsigned mask = (1u << tbits) - 1u;
-  for (size_t t = 0; t < T; t++) {
-    const unsigned bin = targets[t];
-    const unsigned hb = (bin * 0x9E3779B1u) >> (32 - fbits);
-    filter[hb >> 5] |= 1u << (hb & 31u);
-    const unsigned hc = (bin * 0xC2B2AE35u) >> (32 - cbits), hd = (bin * 0x27D4EB2Fu) >> (32 - cbits);
-    coarse[hc >> 5] |= 1u << (hc & 31u);
-    coarse[hd >> 5] |= 1u << (hd & 31u);
-    unsigned hp = (bin * 0x85EBCA6Bu) >> (32 - tbits);
-    while (table[2 * (size_t)hp] != 0xFFFFFFFFu) hp = (hp + 1u) & mask;
-    table[2 * (size_t)hp] = bin;
-    table[2 * (size_t)hp + 1] = (unsigned)t;
-  }
+  const int cbits = st.cbits, fbits = st.fbits, tbits = st.tbits;
   SX_HIP(hipMalloc((void**)&h->d_cnt, sizeof(unsigned) * std::max<size_t>(T, 4)));
   SX_HIP(hipMemset(h->d_cnt, 0, sizeof(unsigned) * std::max<size_t>(T, 4)));
   SX_HIP(hipMalloc((void**)&h->d_read_slot, sizeof(int) * std::max<size_t>(slot.size(), 1)));
@@ -645,40 +535,21 @@ int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask
   std::vector<unsigned> first((size_t)nkeys + 1);
   SX_HIP(hipMemcpy(first.data(), dfirst.p, first.size() * 4, hipMemcpyDeviceToHost));
 
-  const size_t kept = first[outside] != 0xFFFFFFFFu ? first[outside] : n;
-  std::vector<unsigned> present;
-  for (unsigned k = 0; k < outside; k++)
-    if (first[k] != 0xFFFFFFFFu) present.push_back(k);
-  // logical granules: bucket by bucket, each bucket padded to whole granules
-  for (size_t i = 0; i < present.size(); i++) {
-    const size_t lo = first[present[i]], hi = i + 1 < present.size() ? first[present[i + 1]] : kept;
-    for (size_t at = lo; at < hi; at += 256) {
-      b->lsrc.push_back((unsigned)at);
-      b->lvalid.push_back((unsigned)std::min<size_t>(256, hi - at));
-      b->lwhich.push_back((unsigned)i);
-    }
-  }
-  if ((double)b->lsrc.size() * 256.0 > 1.3 * (double)kept + 16384.0) {  // mostly padding: not worth it
+  // logical granules: bucket by bucket, each bucket padded to whole granules (sxmc_plan.h)
+  sxplan::GranulePlan gp;
+  sxplan::bucket_granules(first, outside, n, gp);
+  if (!gp.worth_it) {  // mostly padding: not worth it
     (void)hipFree(b->d_rows);
     b->d_rows = nullptr;
-    b->lsrc.clear();
-    b->lvalid.clear();
-    b->lwhich.clear();
     return SXMC_OK;
   }
-  b->keys = present;
+  b->lsrc = gp.lsrc;
+  b->lvalid = gp.lvalid;
+  b->lwhich = gp.lwhich;
+  b->keys = gp.present;
   b->nkeys_total = outside;
-  b->nkept = kept;
-  b->key_pre.resize(present.size());
-  for (size_t i = 0; i < present.size(); i++) {
-    long long pre = 0;
-    for (int k = 0; k < h->nobs; k++) {
-      if (!((mask >> k) & 1u)) continue;
-      const unsigned idx = (present[i] / b->radix[k]) % ((unsigned)h->nbins[(size_t)k] + 1u);
-      pre += (long long)idx * h->stride[(size_t)k];
-    }
-    b->key_pre[i] = (unsigned)pre;
-  }
+  b->nkept = gp.kept;
+  sxplan::bucket_key_offsets(gp.present, mask, b->radix, h->nbins.data(), h->stride.data(), h->nobs, b->key_pre);
   b->rejected = false;
   *out = b;
   return SXMC_OK;
@@ -706,24 +577,10 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
   b->fields = fields;
   b->runs = runs;
   b->sort = bs;
-  const size_t L = bs->lsrc.size();
-  const unsigned outside = bs->nkeys_total;
-  const size_t T = (L + (size_t)runs - 1) / (size_t)runs, P = T * (size_t)runs, A = std::max<size_t>(P, 1);
-  std::vector<unsigned> psrc(A, 0u), pvalid(A, 0u), ppre(A, 0u), pkp(2 * A, 0u);
-  for (size_t p = 0; p < P; p++) {
-    const size_t r = p % (size_t)runs, t = p / (size_t)runs, l = r * T + t;
-    if (l < L) {
-      psrc[p] = bs->lsrc[l];
-      pvalid[p] = bs->lvalid[l];
-      ppre[p] = bs->key_pre[bs->lwhich[l]];
-      // (ordered tables: histograms in LDS, so the offset is below 2^24 and the row count rides in the top byte)
-      if (pack_rows) ppre[p] |= (bs->lvalid[l] - 1u) << 24;
-      pkp[2 * p] = bs->keys[bs->lwhich[l]];
-    } else {  // padding granule at the end of the last runs: no samples, stays in the last bucket
-      pkp[2 * p] = L ? bs->keys[bs->lwhich[L - 1]] : outside;
-    }
-    pkp[2 * p + 1] = ppre[p];
-  }
+  sxplan::BucketedLayout lay;   // physical granule order for `runs` runs (sxmc_plan.h)
+  sxplan::bucketed_layout(bs->lsrc, bs->lvalid, bs->lwhich, bs->keys, bs->key_pre, bs->nkeys_total, runs, pack_rows, lay);
+  const size_t P = lay.P, A = lay.A;
+  const std::vector<unsigned>&psrc = lay.psrc, &pvalid = lay.pvalid, &ppre = lay.ppre, &pkp = lay.pkp;
   b->ngranules = P;
   b->nkept = bs->nkept;
   b->pitch = std::max<size_t>(64, P * 256);
@@ -758,78 +615,9 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
 int build_bucket_tables(sxmc_hist* h, const SampleStore::BucketSort* bs) {
   if (h->btab_valid && h->btab_mask == bs->mask && h->btab_points_version == h->points_version) return SXMC_OK;
   free_bucket_tables(h);
-  const unsigned nkeys = bs->nkeys_total;
-  const int D = h->nobs;
-  std::vector<unsigned> dir(2 * ((size_t)nkeys + 1), 0u);
-  for (size_t k = 0; k <= nkeys; k++) dir[2 * k + 1] = SXMC_SPARSE_EMPTY;
-  // bucket keys with an index equal to nbins: their samples alias into other rows of the flat index
-  for (unsigned key = 0; key < nkeys; key++) {
-    for (int k = 0; k < D; k++) {
-      if (!((bs->mask >> k) & 1u)) continue;
-      if ((key / bs->radix[k]) % ((unsigned)h->nbins[(size_t)k] + 1u) == (unsigned)h->nbins[(size_t)k]) {
-        dir[2 * (size_t)key + 1] = SXMC_SPARSE_SLOW;
-      }
-    }
-  }
-  // event bins by bucket
-  std::vector<std::vector<std::pair<unsigned, unsigned>>> by_key;   // only for keys that have some
-  std::vector<int> where((size_t)nkeys, -1);
-  for (size_t t = 0; t < h->targets.size(); t++) {
-    const unsigned flat = h->targets[t];
-    unsigned key = 0, pre = 0;
-    for (int k = 0; k < D; k++) {
-      if (!((bs->mask >> k) & 1u)) continue;
-      const unsigned idx = (flat / (unsigned)h->stride[(size_t)k]) % (unsigned)h->nbins[(size_t)k];
-      key += idx * bs->radix[k];
-      pre += idx * (unsigned)h->stride[(size_t)k];
-    }
-    if (where[key] < 0) {
-      where[key] = (int)by_key.size();
-      by_key.emplace_back();
-    }
-    by_key[(size_t)where[key]].push_back({flat - pre, (unsigned)t});
-  }
-  std::vector<unsigned> tkeys, tslot;
-  for (unsigned key = 0; key < nkeys; key++) {
-    if (where[key] < 0) continue;
-    const auto& list = by_key[(size_t)where[key]];
-    // cells of four keys (one 16-byte LDS read per probe); load <= 25 %, or <= 50 % for the largest buckets
-    int lg = std::max(2, ceil_log2(4 * list.size()));
-    if (lg > SXMC_SPARSE_SMAX_LOG2) lg = std::max(2, ceil_log2(2 * list.size()));
-    if (lg > SXMC_SPARSE_SMAX_LOG2) {                                  // more event bins than a wave's slice holds
-      dir[2 * (size_t)key + 1] = SXMC_SPARSE_SLOW;
-      continue;
-    }
-    const size_t off = tkeys.size(), S = (size_t)1 << lg, cells = S / 4;
-    tkeys.resize(off + S, 0xFFFFFFFFu);
-    tslot.resize(off + S, 0u);
-    unsigned probes = 1;
-    for (const auto& e : list) {
-      size_t cell = lg > 2 ? (size_t)((e.first * 0x9E3779B1u) >> (34 - lg)) : 0;
-      unsigned dist = 1;
-      for (;; cell = (cell + 1) & (cells - 1), dist++) {
-        size_t at = off + 4 * cell, free_slot = 4;
-        for (size_t m = 0; m < 4; m++)
-          if (tkeys[at + m] == 0xFFFFFFFFu) {
-            free_slot = m;
-            break;
-          }
-        if (free_slot < 4) {
-          tkeys[at + free_slot] = e.first;
-          tslot[at + free_slot] = e.second;
-          break;
-        }
-      }
-      probes = std::max(probes, dist);
-    }
-    if (probes > 255) {   // (cannot happen below 100 % load; keeps the field in range)
-      dir[2 * (size_t)key + 1] = SXMC_SPARSE_SLOW;
-      continue;
-    }
-    lg |= (int)(probes << 8);
-    dir[2 * (size_t)key] = (unsigned)off;
-    dir[2 * (size_t)key + 1] = (unsigned)lg;
-  }
+  sxplan::BucketTables bt;   // directory + per-bucket tables of the event bins (sxmc_plan.h)
+  sxplan::bucket_tables(bs->nkeys_total, bs->mask, bs->radix, h->nbins.data(), h->stride.data(), h->nobs, h->targets, bt);
+  const std::vector<unsigned>&dir = bt.dir, &tkeys = bt.tkeys, &tslot = bt.tslot;
   SX_HIP(hipMalloc((void**)&h->d_bdir, sizeof(unsigned) * dir.size()));
   SX_HIP(hipMemcpy(h->d_bdir, dir.data(), sizeof(unsigned) * dir.size(), hipMemcpyHostToDevice));
   SX_HIP(hipMalloc((void**)&h->d_btkeys, sizeof(unsigned) * std::max<size_t>(tkeys.size(), 4)));
@@ -1239,6 +1027,16 @@ int group_rebuild(sxmc_group* g) {
       // a filter of more than half the LDS leaves room for one workgroup per CU: make it a full one
       if (g->cfg_threads <= 0 && c.shape.lds_bytes * 2 > (size_t)props.lds_per_cu) c.shape.threads = 1024;
     }
+    if (g->cfg_threads <= 0 && g->cfg_bpc <= 0 && c.shape.lds_hist && !bucketed && !c.runs_mode) {
+      // A SHORT launch with its histograms in LDS (BASELINE config 2: 80 MB, ~10 units per lane): the launch's fixed
+      // cost is most of it, and a large part of that is the flush -- every workgroup sends its private histogram
+      // to HBM with memory-side atomics.  ONE workgroup of 1024 per CU instead of two of 512 keeps the lanes and
+      // halves the histograms to flush: config 2, same box, 17.6 us against 21.0 (35 700 against 33 200 evals/s;
+      // 768 x 1: 18.0, 512 x 1: 21.5, 256 x 4: 27.5, 1024 x 2: 19.6; profiles/r03_c2_sweep.log).
+      double bytes = 0;
+      for (int idx : c.member_idx) bytes += (double)g->h_descs[(size_t)idx].nvec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot);
+      if (bytes < 2.0e8) c.shape.threads = 1024;
+    }
     const int threads = c.shape.threads;  // (shadows the group-wide default above)
 
     // ---- the members' descriptors; bucketed members: lay the table out now that the shape is known
@@ -1289,6 +1087,19 @@ int group_rebuild(sxmc_group* g) {
                        (c.shape.static_prog >= 0 || c.shape.rtc_fill || cls_nsyst <= 1) &&
                        stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
     c.light = light;
+    // Cache policy of the column loads (fill_kernel; kDbgCached in fill_kernels.inc.h).  A table that fits the
+    // 256 MiB Infinity Cache (config 2: 80 MB) is read again by the next evaluation, and default-policy loads could
+    // let that replay hit on die.  MEASURED (config 2, one box, every launch shape; profiles/r03_c2_sweep.log):
+    // they are SLOWER than nontemporal loads, 33 300 against 35 700 evals/s at 1024 x 1 (fill 18.6 against 17.6 us)
+    // -- the stream gains nothing from the on-die hits and pays for the allocation.  Nontemporal therefore stays the
+    // policy for every size; SXMC_LOAD_POLICY=2 switches a run to cached loads to repeat the measurement.
+    {
+      static const int forced = [] {
+        const char* e = std::getenv("SXMC_LOAD_POLICY");
+        return e ? std::atoi(e) : 0;
+      }();
+      c.cached_loads = forced == 2;
+    }
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
     const size_t lds_need = std::max(c.shape.lds_bytes, c.shape.sparse_lds_bytes);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(lds_need, 1)));
@@ -1462,50 +1273,11 @@ int ensure_event_classes(sxmc_group* g, bool sparse) {
       arr[j] = slots ? &h->h_read_slot : &h->h_read_bins;
       if (arr[j]->size() != E) return fail(SXMC_ERR_STATE, "event-bin table of a member is missing");
     }
-    // members with identical tables (one binning, one data set: the usual case) count once in the key
-    std::vector<int> rep(S);
-    std::vector<int> distinct;
-    for (size_t j = 0; j < S; j++) {
-      rep[j] = -1;
-      for (size_t q = 0; q < distinct.size(); q++) {
-        if (*arr[(size_t)distinct[q]] == *arr[j]) {
-          rep[j] = (int)q;
-          break;
-        }
-      }
-      if (rep[j] < 0) {
-        rep[j] = (int)distinct.size();
-        distinct.push_back((int)j);
-      }
-    }
-    std::vector<unsigned> order(E);
-    for (size_t i = 0; i < E; i++) order[i] = (unsigned)i;
-    auto less = [&](unsigned a, unsigned b) {
-      for (int q : distinct) {
-        const int x = (*arr[(size_t)q])[a], y = (*arr[(size_t)q])[b];
-        if (x != y) return x < y;
-      }
-      return false;
-    };
-    auto same = [&](unsigned a, unsigned b) {
-      for (int q : distinct)
-        if ((*arr[(size_t)q])[a] != (*arr[(size_t)q])[b]) return false;
-      return true;
-    };
-    std::sort(order.begin(), order.end(), less);
-    std::vector<unsigned> first, weight;
-    for (size_t i = 0; i < E; i++) {
-      if (i > 0 && same(order[i - 1], order[i])) {
-        weight.back()++;
-      } else {
-        first.push_back(order[i]);
-        weight.push_back(1u);
-      }
-    }
-    const size_t K = first.size();
-    std::vector<int> tables(std::max<size_t>(S * K, 1));
-    for (size_t j = 0; j < S; j++)
-      for (size_t k = 0; k < K; k++) tables[j * K + k] = (*arr[j])[first[k]];
+    sxplan::EventClasses cls;   // distinct tuples of event bins + multiplicities (sxmc_plan.h)
+    sxplan::event_classes(arr, E, cls);
+    const size_t K = cls.K;
+    const std::vector<int>& tables = cls.tables;
+    const std::vector<unsigned>& weight = cls.weight;
     if (tables.size() > ec.cap_rb) {
       if (ec.d_rb) SX_HIP(hipFree(ec.d_rb));
       ec.d_rb = nullptr;
@@ -1573,7 +1345,7 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
   for (LaunchClass& c : g->classes) {
     const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
-    c.shape.debug_mode = g->debug_mode;
+    c.shape.debug_mode = g->debug_mode | (c.cached_loads ? 8 : 0);
     if (sparse && c.d_descs_sparse && c.shape.sparse_runs) {
       SX_HIP(sx_launch_fill_sparse_runs(c.shape, c.d_descs_sparse, c.d_segs, c.d_blk_off, s));
     } else {
@@ -1978,24 +1750,9 @@ int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints
   SX_REQUIRE(n <= (size_t)INT_MAX, "too many evaluation points");
   // pdfz.cpp:264-301: the bin of each point never changes between evaluations, so it is
   // resolved once on the host (NaN coordinates count as outside the domain).
-  std::vector<int> rb(n);
-  const int D = h->nobs;
-  for (size_t ip = 0; ip < n; ip++) {
-    bool in_domain = true;
-    int bin_id = 0;
-    for (int k = 0; k < D; k++) {
-      const double element = points[row * ip + (size_t)k];
-      if (!(element >= h->lower[(size_t)k] && element < h->upper[(size_t)k])) {
-        in_domain = false;
-        break;
-      }
-      bin_id += (int)((element - h->lower[(size_t)k]) * h->scale[(size_t)k]) * h->stride[(size_t)k];
-    }
-    // an index rounded up past the end (the reference would read one-past-the-end in eval_pdf): outside
-    if (in_domain && (unsigned)bin_id >= (unsigned)h->total_nbins) in_domain = false;
-    if (points[row * ip + (size_t)D] != (float)h->dataset) bin_id = -2;  // pdfz.cpp:289-293
-    rb[ip] = in_domain ? bin_id : -1;
-  }
+  std::vector<int> rb;
+  sxplan::eval_point_bins(points, n, h->nobs, h->lower.data(), h->upper.data(), h->scale.data(), h->stride.data(),
+                          h->total_nbins, h->dataset, rb);
   // The caller has finished with the evaluator's previous evaluations (pdfz.h:354-357), so the table is
   // replaced in place: no device-wide synchronisation, and no hipFree / hipMalloc (both stall every stream of
   // the device) unless the new data set outgrows the buffer -- other chains on the GPU keep running.
@@ -2310,11 +2067,11 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
     char line[512];
     const char* kind = c.shape.rtc_fill ? "runtime" : c.shape.static_prog >= 0 ? "builtin" : c.shape.nobs ? "decoded" : "generic";
     std::snprintf(line, sizeof line,
-                  "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d\n",
+                  "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d loads=%s\n",
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
                   c.shape.pre_width == 5 ? "ordered" : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
-                  c.shape.grid, c.partition);
+                  c.shape.grid, c.partition, c.cached_loads ? "cached" : "nt");
     text += line;
   }
   if (!g->rtc_note.empty()) text += "runtime specialisation failed: " + g->rtc_note.substr(0, 300) + "\n";

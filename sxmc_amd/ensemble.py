@@ -188,15 +188,21 @@ def projection_interval(values, cl=0.9, nbins=100):
     walk outwards from the mean's bin until cl / 2 of the samples lie on either side (or one-sided from the low
     edge when less than cl / 2 lies below the mean).  Returns (point_estimate, lower, upper, coverage, one_sided)."""
     values = np.asarray(values, np.float64)
-    lo, hi = values.min(), values.max()
+    lo, hi = float(values.min()), float(values.max())
     if hi <= lo:
         return float(lo), float(lo), float(hi), 1.0, False
-    counts, edges = np.histogram(values, bins=nbins, range=(lo, hi))
+    # TH1 conventions (TAxis::FindBin, GetBinCenter, GetBinLowEdge): bin = 1 + int(nbins (x - xmin) / (xmax - xmin)),
+    # the maximum counted in the last bin (see the docstring: the range is ours, not TTree::Draw's)
+    width = (hi - lo) / nbins
+    idx = np.minimum((nbins * (values - lo) / (hi - lo)).astype(np.int64), nbins - 1)
+    counts = np.bincount(idx, minlength=nbins)
     total = counts.sum()
-    centers = 0.5 * (edges[:-1] + edges[1:])
+    centers = lo + (np.arange(nbins) + 0.5) * width
+    edges = lo + np.arange(nbins + 1) * width
     fit = gaus_fit(centers, counts)
     mu = fit[1] if fit is not None else float(centers[np.argmax(counts)])     # (no fit: the mode's bin)
-    imax = int(np.searchsorted(edges, mu, side="right"))                        # 1-based bin of the mode
+    # 1-based bin of the mean (TH1::FindBin): 0 below the range, nbins + 1 at or beyond its end
+    imax = 0 if mu < lo else nbins + 1 if mu >= hi else 1 + int(nbins * (mu - lo) / (hi - lo))
     if imax < 1:                                                               # projection.cpp:28-31
         imax, mu = 1, float(edges[0])
     imax = min(imax, nbins)
@@ -220,7 +226,8 @@ def projection_interval(values, cl=0.9, nbins=100):
                 break
     ihi = max(ihi, ilo) if ihi else nbins
     coverage = (csum[ihi] - csum[ilo - 1]) / total
-    return float(mu), float(edges[ilo - 1]), float(edges[ihi]), float(coverage), one_sided
+    # projection.cpp:72-73: GetBinLowEdge(ilo); GetBinLowEdge(ihi) + GetBinWidth(ihi)
+    return float(mu), float(edges[ilo - 1]), float(edges[ihi - 1] + width), float(coverage), one_sided
 
 
 # ------------------------------------------------------------------------------------ the ensemble

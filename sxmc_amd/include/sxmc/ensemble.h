@@ -233,7 +233,8 @@ inline Interval projection_interval(const std::vector<float>& values, float cl =
   }
   const double width = (hi - lo) / nbins;
   std::vector<double> counts((size_t)nbins, 0.0), centers((size_t)nbins), csum((size_t)nbins + 1, 0.0);
-  for (float v : values) counts[(size_t)std::min<long>(nbins - 1, (long)((v - lo) / width))] += 1;
+  // TH1 conventions (TAxis::FindBin): bin = 1 + int(nbins (x - xmin) / (xmax - xmin)); the maximum counts in the last bin
+  for (float v : values) counts[(size_t)std::min<long>(nbins - 1, (long)(nbins * ((double)v - lo) / (hi - lo)))] += 1;
   for (int i = 0; i < nbins; i++) centers[(size_t)i] = lo + (i + 0.5) * width;
   double total = 0;
   for (int i = 0; i < nbins; i++) csum[(size_t)i + 1] = (total += counts[(size_t)i]);   // csum[i] = bins 1..i
@@ -241,8 +242,8 @@ inline Interval projection_interval(const std::vector<float>& values, float cl =
   if (!gaus_fit(centers, counts, a, mu, sigma)) {
     mu = centers[(size_t)(std::max_element(counts.begin(), counts.end()) - counts.begin())];
   }
-  long imax = (long)std::floor((mu - lo) / width) + 1;   // 1-based bin of the mean (TH1::FindBin)
-  if (mu >= hi) imax = nbins + 1;
+  // 1-based bin of the mean (TH1::FindBin): 0 below the range, nbins + 1 at or beyond its end
+  long imax = mu < lo ? 0 : mu >= hi ? nbins + 1 : 1 + (long)(nbins * (mu - lo) / (hi - lo));
   if (imax < 1) {                                         // projection.cpp:28-31
     imax = 1;
     mu = lo;
@@ -273,7 +274,7 @@ inline Interval projection_interval(const std::vector<float>& values, float cl =
   iv.point_estimate = (float)mu;
   iv.coverage = (float)((csum[(size_t)ihi] - csum[(size_t)ilo - 1]) / total);
   iv.lower = (float)(lo + (ilo - 1) * width);
-  iv.upper = (float)(lo + ihi * width);
+  iv.upper = (float)(lo + (ihi - 1) * width + width);   // projection.cpp:73: GetBinLowEdge(ihi) + GetBinWidth(ihi)
   return iv;
 }
 

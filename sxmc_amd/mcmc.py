@@ -121,6 +121,7 @@ class MCMC:
         self._graph = None                      # recorded steps hold the old evaluation-point tables
         self.nevents = data.size // (w.nobs + 1)
         self.sync_interval = sync_interval
+        self._since_flush = 0                   # steps launched since the jump buffer was last read back
         self.jump_buffer = DeviceArray.zeros(sync_interval * (self.nparameters + 1), np.float32)
         jw = self.initial_jump_widths() if jump_width is None else np.asarray(jump_width, np.float32)
         self.jump_width = DeviceArray(jw)
@@ -152,6 +153,7 @@ class MCMC:
     def step(self, debug_mode=False):
         """One pass of the hot path = one NLL evaluation at the proposed vector + the fused
         accept/reject/propose (mcmc.cpp:264-271, 314-348).  Asynchronous."""
+        self._launching(1)
         if self.fused == "step":
             self.group.McmcStepAsync(self.stream, self.parameter_means, self.parameter_sigma, self.rngs,
                                      self.current_nll, self.proposed_nll, self.current_vector,
@@ -190,6 +192,17 @@ class MCMC:
                                        self.jump_counter, self.jump_buffer, self.nparameters, self.jump_width,
                                        self.nexpected, self.n_mc, self.source_id, self.normalizations,
                                        debug_mode)
+
+    def _launching(self, n):
+        """Every step appends a row to the jump buffer (sync_interval rows, jump_decider nll_kernels.cpp:78-84, which
+        does not check): refuse on the host what would run past its end."""
+        if getattr(self, "_recording", False):
+            return
+        if self._since_flush + n > self.sync_interval:
+            raise RuntimeError("%d step(s) after %d since the last flush do not fit the jump buffer of %d rows: "
+                               "flush() first, or setup(sync_interval=...) for longer runs"
+                               % (n, self._since_flush, self.sync_interval))
+        self._since_flush += n
 
     def reseed(self, seed):
         """Fresh generator states (a new experiment on the same evaluators)."""
@@ -243,9 +256,13 @@ class MCMC:
         run since the last change to the evaluators; the graph is dropped by setup()."""
         if self.stream is None:
             raise ValueError("graph capture needs a created stream (MCMC(stream=capi.new_stream()))")
-        with capi.Graph.capture(self.stream) as g:
-            for _ in range(k):
-                self.step(debug_mode)
+        self._recording = True                  # (recorded steps run, and are counted, when the graph is launched)
+        try:
+            with capi.Graph.capture(self.stream) as g:
+                for _ in range(k):
+                    self.step(debug_mode)
+        finally:
+            self._recording = False
         return g
 
     def steps(self, n, graph_steps=0, debug_mode=False):
@@ -253,6 +270,7 @@ class MCMC:
         if graph_steps > 0 and n >= graph_steps:
             if self._graph is None or self._graph_steps != graph_steps:
                 self._graph, self._graph_steps = self.capture_steps(graph_steps, debug_mode), graph_steps
+            self._launching((n // graph_steps) * graph_steps)
             self._graph.launch(n // graph_steps)
             n %= graph_steps
         for _ in range(n):
@@ -314,6 +332,7 @@ class MCMC:
         rows = self.jump_buffer.get()[: njumps * (self.nparameters + 1)].reshape(njumps, self.nparameters + 1)
         self.jump_counter.set(np.zeros(1, np.int32))
         self.accept_counter.set(np.zeros(1, np.int32))
+        self._since_flush = 0
         return rows.copy(), nacc
 
     def run(self, nsteps, debug_mode=False):
@@ -388,6 +407,10 @@ class LookaheadWalk:
             capi.call("sxmc_stream_synchronize", capi.ptr(c.stream))
             count0 = int(c.jump_counter.get()[0])
         target = count0 + n
+        if target > c.sync_interval:
+            raise RuntimeError("%d more steps after %d in the jump buffer do not fit its %d rows: flush() first"
+                               % (n, count0, c.sync_interval))
+        c._since_flush = target
         self.cap.set(np.array([target], np.int32))
         done = count0
         while done < target:
@@ -441,8 +464,12 @@ class LockstepChains:
         assert all(c.consume for c in self.chains), "lockstep chains clear for the next step (consume=True)"
         self.mg = nll.MultiGroup(self.chains)
         self._graph, self._graph_steps = None, 0
+        self._recording = False
 
     def step(self, debug_mode=False):
+        if not self._recording:
+            for c in self.chains:
+                c._launching(1)      # (every chain's jump buffer must hold the run)
         self.mg.StepAsync(self.stream, debug_mode)
 
     def drop_graph(self):
@@ -455,10 +482,16 @@ class LockstepChains:
         if graph_steps > 0 and n >= graph_steps:
             if self._graph is None or self._graph_steps != graph_steps:
                 self.drop_graph()
-                with capi.Graph.capture(self.stream) as g:
-                    for _ in range(graph_steps):
-                        self.step(debug_mode)
+                self._recording = True
+                try:
+                    with capi.Graph.capture(self.stream) as g:
+                        for _ in range(graph_steps):
+                            self.step(debug_mode)
+                finally:
+                    self._recording = False
                 self._graph, self._graph_steps = g, graph_steps
+            for c in self.chains:
+                c._launching((n // graph_steps) * graph_steps)
             self._graph.launch(n // graph_steps)
             n %= graph_steps
         for _ in range(n):

@@ -258,16 +258,19 @@ def test_free_chain_runs_and_accepts_some():
     assert np.all(np.isfinite(chain))
 
 
-@pytest.mark.parametrize("make,scale", [(workloads.config2, 1.0), (workloads.config3, 0.25)])
-def test_baseline_configs_at_size_against_the_oracle(make, scale):
-    """BASELINE config 2 at its full size (10^7 samples) and config 3 at a quarter (2.5 10^7; its full size is
-    asserted by every bench.py run, see the `parity` object of the bench line): one whole MCMC step in the walk's
-    default form (bucketed table, event classes, graph-recorded launches) against the oracle -- every bin, the
-    norms, the lookup table bits and the NLL."""
+@pytest.mark.parametrize("make,scale,plan", [(workloads.config2, 1.0, "table=prebinned"),
+                                             (workloads.config3, 1.0, "table=ordered")])
+def test_baseline_configs_at_size_against_the_oracle(make, scale, plan):
+    """BASELINE config 2 (10^7 samples) and config 3 (10^8 samples, 12 signals, shift + scale + resolution_scale), both
+    at their FULL size and through the kernels the bench measures (config 3: the bucketed table with the shifted
+    observable ordered, fill_ordered_kernel -- the headline kernel at the headline size): one whole MCMC step in the
+    walk's default form (event classes, graph-recorded launches) against the oracle -- every bin, the norms, the
+    lookup table bits and the NLL."""
     w = make(scale, nevents=100000)
     m = MCMC(w, seed=31, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
     m.setup(sync_interval=8)
     capi.synchronize()                           # (the first proposal is drawn on the chain's non-blocking stream)
+    assert plan in m.group.LaunchInfo(), m.group.LaunchInfo()
     proposal = m.proposed_vector.get()
     m.step(debug_mode=True)
     m.steps(4, graph_steps=2, debug_mode=True)

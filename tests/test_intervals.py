@@ -1,0 +1,116 @@
+"""Interval extraction three ways on the SAME chain: the Python form (sxmc_amd/ensemble.py),
+the C++ form (sxmc_amd/include/sxmc/ensemble.h through tests/cpp/intervals_dump) and the brute-force restatement of
+contour.cpp:30-69 / likelihood.cpp:90-102 / projection.cpp:14-77 in oracle/intervals.py -- on synthetic chains here
+(CPU) and on a chain walked on the GPU (-m gpu), the printed-offset regime |lmin| ~ 3e5 of BASELINE config 3 included.
+Contour intervals must agree bit for bit (they are minima and maxima of chain values once the same rows are
+selected); projection limits and coverages exactly, the fitted mean to 1e-6 (three different minimisers of one chi2).
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import intervals as ref
+from sxmc_amd import ensemble
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "tests", "cpp", "intervals_dump")
+
+
+def cpp_intervals(chain, cl, tmp_path):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "intervals_dump"])
+    path = os.path.join(str(tmp_path), "chain.f32")
+    np.ascontiguousarray(chain, np.float32).tofile(path)
+    r = subprocess.run([DUMP, path, str(chain.shape[1]), repr(float(cl))], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout)
+
+
+def compare_three_ways(chain, cl, tmp_path):
+    chain = np.ascontiguousarray(chain, np.float32)
+    P = chain.shape[1] - 1
+    cl32 = float(np.float32(cl))                         # `float cl` in the reference (error_estimator.h)
+    cpp = cpp_intervals(chain, cl32, tmp_path)
+    py = ensemble.contour_intervals(chain, cl32)
+    try:
+        want = ref.contour_intervals(chain, cl32)
+    except AssertionError:
+        # the reference itself stops here (assert at likelihood.cpp:99: with this |lmin| the printed offset is so far
+        # off that no row passes).  Product code falls back to the exact offset; Python and C++ must agree on that.
+        like = chain[:, -1].astype(np.float64)
+        exact = chain[chain[:, -1] - chain[:, -1].min() < np.float32(0.5 * ref.chisquare_quantile_1dof(np.float32(cl32)))]
+        want = [(float(py[p, 0]), float(exact[:, p].min()), float(exact[:, p].max()), -999.0) for p in range(P)]
+    for p in range(P):
+        for k in range(3):                                # point estimate, lower, upper: bit for bit
+            assert np.float32(want[p][k]) == py[p, k] == np.float32(cpp["contour"][p][k]), (p, k, want[p], py[p], cpp["contour"][p])
+        assert py[p, 3] == -999 and cpp["contour"][p][3] == -999
+    for p in range(P):
+        w = ref.projection_interval(chain[:, p], cl32)
+        a = ensemble.projection_interval(chain[:, p], cl32)
+        c = cpp["projection"][p]
+        scale = max(abs(w[0]), float(np.ptp(chain[:, p])), 1e-30)
+        assert abs(a[0] - w[0]) <= 1e-6 * scale and abs(c[0] - w[0]) <= 2e-6 * scale, (p, w, a, c)    # fitted mean
+        assert a[1] == w[1] and a[2] == w[2] and a[3] == w[3] and a[4] == w[4], (p, w, a)             # limits, coverage
+        assert np.float32(w[1]) == np.float32(c[1]) and np.float32(w[2]) == np.float32(c[2]), (p, w, c)
+        assert abs(c[3] - w[3]) < 1e-6 and c[4] == w[4]
+    return want
+
+
+def synthetic_chain(seed, n, nll_offset, spread=3.0):
+    """A Metropolis-looking chain: correlated Gaussian parameters with repeated rows, likelihood = offset + chi2 / 2."""
+    rng = np.random.default_rng(seed)
+    P = 4
+    mean = np.array([1.0, 0.02, -0.5, 250.0])
+    sig = np.array([0.1, 0.01, 0.2, 30.0])
+    x = mean + sig * rng.standard_normal((n, P))
+    x[:, 1] += 0.3 * (x[:, 0] - mean[0]) * sig[1] / sig[0]
+    keep = rng.random(n) < 0.4                            # rejected steps repeat the previous row
+    for i in range(1, n):
+        if not keep[i]:
+            x[i] = x[i - 1]
+    nll = nll_offset + 0.5 * np.sum(((x - mean) / sig) ** 2, axis=1) * spread / 3.0
+    return np.concatenate([x, nll[:, None]], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("offset", [12.5, -348086.3, 3.2e5, -7.123456e6])
+@pytest.mark.parametrize("cl", [0.9, 0.683])
+def test_python_cpp_and_restatement_agree_on_synthetic_chains(tmp_path, offset, cl):
+    chain = synthetic_chain(int(abs(offset)) % 1000 + int(cl * 100), 4000, offset)
+    compare_three_ways(chain, cl, tmp_path)
+
+
+def test_printed_offset_changes_the_contour_at_config3_magnitudes(tmp_path):
+    """With |lmin| = 348 086.3 the text "likelihood+348086<1.35277" applies an offset that is off by 0.3: the contour
+    the reference selects is NOT the exact Delta-NLL contour, and all three implementations follow the reference."""
+    chain = synthetic_chain(7, 4000, -348086.3)
+    got = compare_three_ways(chain, 0.9, tmp_path)
+    like = chain[:, -1].astype(np.float64)
+    delta = 0.5 * ref.chisquare_quantile_1dof(np.float32(0.9))
+    exact = chain[like - like.min() < delta]
+    assert float(got[0][2]) != float(exact[:, 0].max()) or float(got[0][1]) != float(exact[:, 0].min())
+    # a one-sided projection: a parameter piled up at its lower bound
+    rng = np.random.default_rng(3)
+    col = np.abs(rng.standard_normal(5000)).astype(np.float32) * 0.1
+    w = ref.projection_interval(col, float(np.float32(0.9)))
+    a = ensemble.projection_interval(col, float(np.float32(0.9)))
+    assert w[4] is True and a[4] is True and a[1:4] == w[1:4]
+
+
+@pytest.mark.gpu
+def test_intervals_of_a_gpu_chain_three_ways(tmp_path):
+    """A chain walked on the GPU (BASELINE config 3's shape at 1 % of the samples, 10^5 events: |lmin| of a few 1e5,
+    the printed-offset regime) through Contour and Projection in Python and C++, against the restatement."""
+    from sxmc_amd import workloads
+    from sxmc_amd.mcmc import MCMC
+    w = workloads.config3(0.01, nevents=100000)
+    m = MCMC(w, seed=11, fused=True, lut_output=False, consume=True)
+    chain, accepted = m.walk(w.events, 1500, 0.2, sync_interval=500)
+    assert chain.shape[0] > 800 and 0 < accepted < 1500
+    assert abs(float(chain[:, -1].min())) > 1e5          # six printed digits cannot hold this offset
+    compare_three_ways(chain, 0.9, tmp_path)
+    compare_three_ways(chain, 0.683, tmp_path)
+    for p in m.pdfs:
+        p.close()
+    m.group.close()
