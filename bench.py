@@ -184,9 +184,11 @@ class Leg:
     figures of its fill kernel and the parity check against the oracle."""
 
     def __init__(self, args, torch, dev, name, form, lut_output, seed, exp_seed, scale=None, events=None,
-                 keep_host="none", lookahead=False):
+                 keep_host="none", lookahead=False, overrides=None):
         from sxmc_amd import capi
         from sxmc_amd.mcmc import MCMC
+        if overrides:                      # (a sub-record measured with other switches than the headline's)
+            args = argparse.Namespace(**dict(vars(args), **overrides))
         self.args, self.torch, self.name, self.form, self.lut_output = args, torch, name, form, lut_output
         a = argparse.Namespace(**vars(args))
         a.workload = name
@@ -248,6 +250,8 @@ class Leg:
             m.step()                     # brings the launch plan up to date; recording cannot
             m.flush()
         self.la = None
+        if self.lookahead and not m.group.LookaheadSupported():
+            self.lookahead = False       # (config 1: its step ends in the one-workgroup form; it walks sequentially)
         if self.lookahead:
             from sxmc_amd.mcmc import LookaheadWalk
             lt, lb = (int(x) for x in args.launch.split(","))
@@ -337,7 +341,30 @@ class Leg:
             if post_n >= self.nfill_region:
                 self.fill_ms_total, self.nfill = post_ms, post_n
                 self.roofline_sample = "post-timed, %d launches" % post_n
+        self.event_bracket_ms = self.empty_bracket_ms()
         return elapsed
+
+    def empty_bracket_ms(self, n=50):
+        """What two HIP events measure with NOTHING between them, on the walk's stream (mean of n): the part of every
+        event-timed duration that is not the kernel.  Negligible against config 3's 130 us fill; a fifth of config 2's
+        (rocprofv3 --kernel-trace on the same command reads that much lower: profiles/r03_c2_*)."""
+        import ctypes as C
+
+        from sxmc_amd import capi
+        e0, e1 = C.c_void_p(0), C.c_void_p(0)
+        capi.call("sxmc_event_create", C.byref(e0))
+        capi.call("sxmc_event_create", C.byref(e1))
+        total, ms = 0.0, C.c_float(0)
+        st = capi.ptr(self.m.stream)
+        for _ in range(n):
+            capi.call("sxmc_event_record", e0, st)
+            capi.call("sxmc_event_record", e1, st)
+            capi.call("sxmc_event_synchronize", e1)
+            capi.call("sxmc_event_elapsed_ms", e0, e1, C.byref(ms))
+            total += ms.value
+        capi.call("sxmc_event_destroy", e0)
+        capi.call("sxmc_event_destroy", e1)
+        return total / n
 
     def launches_per_step(self):
         if getattr(self, "_launches", None):
@@ -392,6 +419,8 @@ class Leg:
             "traffic": traffic, "traffic_provenance": traffic_note,
             "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
             "avg_launch_ms": fill_ms, "launches_timed": self.nfill, "sample": self.roofline_sample,
+            # two events with nothing between them: what every event-timed duration carries besides the kernel
+            "empty_event_bracket_ms": self.event_bracket_ms,
             "in_timed_region": {"launches": self.nfill_region,
                                 "avg_launch_ms": self.fill_ms_region / max(self.nfill_region, 1)},
             # a look-ahead pass fills the histograms of TWO evaluations from one pass over the tables: `achieved` and
@@ -518,12 +547,12 @@ class Leg:
 
 
 def also_record(args, torch, dev, name, form, lut_output, steps, warmup, exp_seed, keep_host, share=None,
-                lookahead=False):
+                lookahead=False, overrides=None):
     """A sub-record of the default run: another workload (or another step form of the headline workload)
     measured the same way -- evals/s, the fill kernel's time and roofline fraction, parity."""
     t0 = time.perf_counter()
     leg = Leg(args, torch, dev, name, form, lut_output, args.seed, exp_seed, scale=1.0, keep_host=keep_host,
-              lookahead=lookahead)
+              lookahead=lookahead, overrides=overrides)
     leg.setup(steps, warmup)
     elapsed = leg.timed(steps, collective=False)
     rf = leg.roofline()
@@ -641,7 +670,7 @@ def main():
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
                     help="sub-records measured after the headline: comma list of c3_lookahead, c3_lut_materialized, c2, c5, "
-                         "cpp_host, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
+                         "c2_float_columns, cpp_host, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
                          "GPU, cpp_multi_gpu (sxmc::ensemble_multi_gpu over the same cards) at N > 1; none = skip")
     ap.add_argument("--also-steps", type=int, default=200, help="timed steps of each sub-record (C5: a quarter)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
@@ -902,7 +931,7 @@ def main():
         full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and not args.debug_mode
         also = "none"
         if full_c3 and want_cpu and args.form == "graph" and world == 1:
-            also = "c3_lookahead,c3_lut_materialized,c2,c5,cpp_host"
+            also = "c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,cpp_host"
         elif full_c3 and args.form == "graph" and world > 1:
             also = "cpp_multi_gpu"        # the C++ one-process runner over the same N cards
     if world > 1:
@@ -926,6 +955,9 @@ def main():
                 recs[name] = also_record(args, torch, dev, "c3", "graph", True, args.also_steps, 20, exp_seed, "all")
             elif name == "c2":
                 recs[name] = also_record(args, torch, dev, "c2", "graph", False, args.also_steps, 20, exp_seed, "all")
+            elif name == "c2_float_columns":      # config 2 with both observables streamed as floats (no pre-binned column)
+                recs[name] = also_record(args, torch, dev, "c2", "graph", False, args.also_steps, 20, exp_seed, "all",
+                                         overrides={"no_prebin": True})
             elif name == "c5":
                 recs[name] = also_record(args, torch, dev, "c5", "graph", False, max(10, args.also_steps // 4), 10,
                                          exp_seed, "ends")

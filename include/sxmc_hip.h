@@ -390,6 +390,11 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
  * sxmc_lookahead_begin: the first look-ahead vector of a walk, from the state sxmc_launch_pick_new_vector left. */
 int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args,
                                          double* d_v_lookahead, const unsigned* d_norms_lookahead, const int* d_cap);
+/* *ok = 1 when a walk over this group (evaluation points set, buffers bound) can be taken by the look-ahead pass and
+ * stay the sequential chain bit for bit.  0: histograms beyond LDS, a materialised lookup table, members with
+ * different points -- or a problem so small (at most 256 look-ups per step) that the sequential step ends in the
+ * one-workgroup form, whose event sum is partitioned differently: walk sequentially then. */
+int sxmc_group_lookahead_supported(sxmc_group_t g, int* ok);
 int sxmc_lookahead_begin(sxmc_stream_t s, int nparameters, const sxmc_rng_state* d_rng, const float* d_jump_width,
                          const double* d_v_current, double* d_v_lookahead);
 /* Kernels launched by the last sxmc_group_step_async (2 or 3, see there; +1 when the histograms had to be

@@ -125,6 +125,7 @@ SIGNATURES = {
     "sxmc_multigroup_step_async": [_vp, _vp, _vp],
     "sxmc_multigroup_lookahead_step_async": [_vp, _vp, _vp, _vp, _vp, _vp],
     "sxmc_lookahead_begin": [_vp, _i, _vp, _vp, _vp, _vp],
+    "sxmc_group_lookahead_supported": [_vp, _pi],
     "sxmc_group_finish_step_async": [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz,
                                      _vp, _vp, _vp, _vp, _vp, _i],
     "sxmc_group_synchronize": [_vp],

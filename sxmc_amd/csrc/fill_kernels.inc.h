@@ -243,19 +243,20 @@ __device__ __forceinline__ void run_static(double (&f)[NSLOT][SXMC_VEC], const d
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load per lane
 
-// How the sample columns are read.  NT = nontemporal: right for a table far larger than the 256 MiB Infinity Cache,
-// which is streamed once per evaluation and would only evict itself (+3 % at BASELINE config 3).  A table that FITS
-// (config 2: 80 MB) is read again by the next evaluation, and default-policy loads let that replay hit on die
-// (MI355X_MICROARCH.md: "nt gives up what a back-to-back replay of the same launch gains from default-policy loads").
-// MEASURED at config 2 (profiles/r03_c2_sweep.log): cached loads are 5-7 % SLOWER than nontemporal ones for that
-// table too, at every launch shape, so the host never sets the bit by itself; it stays as a measurement switch
-// (SXMC_LOAD_POLICY=2 -> kDbgCached in the launch's `dbg` word, tested once per workgroup outside the sample loop).
-template <bool NT, typename T>
+// How the sample columns are read: NONTEMPORAL loads.  Right for a table far larger than the 256 MiB Infinity Cache,
+// which is streamed once per evaluation and would only evict itself (+3 % at BASELINE config 3) -- and, MEASURED, also
+// for one that fits (config 2: 80 MB, read again by the next evaluation): default-policy loads, which could let that
+// replay hit on die, were 5-7 % SLOWER at every launch shape (profiles/r03_c2_sweep_policy_x_shape.log: 33 300
+// against 35 700 evals/s at 1024 x 1).  A library built with -DSXMC_CACHED_LOADS=1 (make VARIANT=_cached
+// EXTRA=-DSXMC_CACHED_LOADS=1; SXMC_HIP_LIB selects it) repeats that measurement.
+#ifndef SXMC_CACHED_LOADS
+#define SXMC_CACHED_LOADS 0
+#endif
+template <typename T>
 __device__ __forceinline__ T stream_load(gptr<const T> p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p);
-  else return *p;
+  if constexpr (SXMC_CACHED_LOADS) return *p;
+  else return __builtin_nontemporal_load(p);
 }
-constexpr unsigned kDbgCached = 8u;   // dbg bit 3: default-policy (cacheable) column loads
 
 // SPARSE COUNTING.  A histogram too large for LDS costs one scattered HBM atomic per sample plus zeroing
 // the whole array, but the likelihood only ever looks it up at the data events' bins.  When an evaluation
@@ -327,7 +328,7 @@ constexpr unsigned pre_sentinel() {
   return PREW == 1 ? 0xFFu : PREW == 2 ? 0xFFFFu : 0xFFFFFFFFu;
 }
 
-template <int NOBS, int NSLOT, int PREW, typename PROG, bool NT = true>
+template <int NOBS, int NSLOT, int PREW, typename PROG>
 __device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr<const vfloat4> (&col)[NSLOT],
                                              gptr<const typename PreVec<PREW>::type> pre, unsigned long long v) {
   // Issue order is pinned (sched_barrier): the wait-counter bookkeeping at the loop header merges
@@ -337,8 +338,7 @@ __device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr
   for (int k = 0; k < NSLOT; k++) {
     if constexpr (true) {
       if (slot_loaded<NOBS, PREW, PROG>(k)) {
-        // NT: streamed once per evaluation and far larger than the caches (+3 % measured); else see stream_load
-        c.v[k] = stream_load<NT, vfloat4>(&col[k][v]);
+        c.v[k] = stream_load<vfloat4>(&col[k][v]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -347,7 +347,7 @@ __device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr
     c.pre = pre[v >> 6];   // one word per granule: every lane of the wave asks for the same address
     __builtin_amdgcn_sched_barrier(0);
   } else if constexpr (PREW != 0) {
-    c.pre = stream_load<NT, typename PreVec<PREW>::type>(&pre[v]);
+    c.pre = stream_load<typename PreVec<PREW>::type>(&pre[v]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -418,12 +418,7 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
     const unsigned long long vlast = v1 - 1;
     const unsigned long long vfirst = v0 + tid;
     Columns<NSLOT, PREW> bufA;
-    const bool cached = (dbg & kDbgCached) != 0u;   // wave-uniform: a kernel argument
-    if (cached) {
-      load_columns<NOBS, NSLOT, PREW, PROG, false>(bufA, col, precol, vfirst < v1 ? vfirst : vlast);
-    } else {
-      load_columns<NOBS, NSLOT, PREW, PROG, true>(bufA, col, precol, vfirst < v1 ? vfirst : vlast);
-    }
+    load_columns<NOBS, NSLOT, PREW, PROG>(bufA, col, precol, vfirst < v1 ? vfirst : vlast);
 
     if (!lds_clean) {
       // whole LDS histogram (sized for the largest member), once per workgroup
@@ -461,11 +456,12 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
     // under them.  ONE unit in flight per lane, on purpose: HBM delivers most when a CU keeps about 32 KiB
     // of loads in flight (tools/hbm_probe.hip: 7.1 TB/s there, 5.5-6.5 TB/s at twice that), and 512 lanes
     // per CU x 3-4 columns x 16 bytes is that much; a second unit in flight (tried: a two-deep register
-    // ring) or more waves per CU only queue up behind the memory system (-8 %).  Loads are unconditional
+    // ring) or more waves per CU only queue up behind the memory system (-8 %); for SHORT launches too (config 2,
+    // ~10 units per lane: two units in flight changed nothing, profiles/r03_c2_sweep_two_units_in_flight.log --
+    // such a launch is bound by its fixed cost, not by a lane's chain of round trips).  Loads are unconditional
     // (index clamped into the slice) so the wait counters stay exact; lanes past the end of the slice
     // are treated like out-of-domain samples.
-    auto stage = [&](auto NTc, Columns<NSLOT, PREW>& buf, const unsigned long long vc) {
-      constexpr bool NT = decltype(NTc)::value != 0;
+    auto stage = [&](Columns<NSLOT, PREW>& buf, const unsigned long long vc) {
       double f[NSLOT][SXMC_VEC];
 #pragma unroll
       for (int k = 0; k < NSLOT; k++) {
@@ -495,7 +491,7 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
       //   bit 0: skip the arithmetic and the histogram -> the HBM stream alone
       //   bit 2: skip only the histogram update
       const unsigned long long vl = vc + step;
-      load_columns<NOBS, NSLOT, PREW, PROG, NT>(buf, col, precol, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
+      load_columns<NOBS, NSLOT, PREW, PROG>(buf, col, precol, (vl < v1 && !(dbg & 2u)) ? vl : vlast);
       if (dbg & 1u) {
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
@@ -591,12 +587,7 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
     // wave-uniform trip count: every lane runs the same number of stages
     unsigned long long v = vfirst;
     const unsigned long long niter = (v1 - v0 + step - 1) / step;
-    // (the two loops differ in the cache policy of their loads and in nothing else)
-    if (cached) {
-      for (unsigned long long it = 0; it < niter; ++it, v += step) stage(IntC<0>{}, bufA, v);
-    } else {
-      for (unsigned long long it = 0; it < niter; ++it, v += step) stage(IntC<1>{}, bufA, v);
-    }
+    for (unsigned long long it = 0; it < niter; ++it, v += step) stage(bufA, v);
 
     // ---- in-domain count: lane registers -> wave -> workgroup -> one global atomic
 #pragma unroll

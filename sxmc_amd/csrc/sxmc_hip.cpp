@@ -236,7 +236,6 @@ struct LaunchClass {
   int partition = 0;  // 1 sliced, 2 interleaved (what build_partition chose)
   bool light = false; // a pure stream: runs best with few waves per CU (see group_rebuild)
   bool runs_mode = false;  // bucketed tables laid out in per-wave runs; the sparse flavour runs fill_sparse_kernel
-  bool cached_loads = false;  // the class's tables fit the Infinity Cache: default-policy loads (see group_rebuild)
 };
 
 void free_class(LaunchClass& c) {
@@ -1032,10 +1031,12 @@ int group_rebuild(sxmc_group* g) {
       // cost is most of it, and a large part of that is the flush -- every workgroup sends its private histogram
       // to HBM with memory-side atomics.  ONE workgroup of 1024 per CU instead of two of 512 keeps the lanes and
       // halves the histograms to flush: config 2, same box, 17.6 us against 21.0 (35 700 against 33 200 evals/s;
-      // 768 x 1: 18.0, 512 x 1: 21.5, 256 x 4: 27.5, 1024 x 2: 19.6; profiles/r03_c2_sweep.log).
+      // 768 x 1: 18.0, 512 x 1: 21.5, 256 x 4: 27.5, 1024 x 2: 19.6; profiles/r03_c2_sweep_policy_x_shape.log).
       double bytes = 0;
       for (int idx : c.member_idx) bytes += (double)g->h_descs[(size_t)idx].nvec * SXMC_VEC * 4.0 * std::max(1, c.shape.nslot);
-      if (bytes < 2.0e8) c.shape.threads = 1024;
+      if (bytes < 2.0e8) {
+        c.shape.threads = 1024;
+      }
     }
     const int threads = c.shape.threads;  // (shadows the group-wide default above)
 
@@ -1087,19 +1088,6 @@ int group_rebuild(sxmc_group* g) {
                        (c.shape.static_prog >= 0 || c.shape.rtc_fill || cls_nsyst <= 1) &&
                        stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
     c.light = light;
-    // Cache policy of the column loads (fill_kernel; kDbgCached in fill_kernels.inc.h).  A table that fits the
-    // 256 MiB Infinity Cache (config 2: 80 MB) is read again by the next evaluation, and default-policy loads could
-    // let that replay hit on die.  MEASURED (config 2, one box, every launch shape; profiles/r03_c2_sweep.log):
-    // they are SLOWER than nontemporal loads, 33 300 against 35 700 evals/s at 1024 x 1 (fill 18.6 against 17.6 us)
-    // -- the stream gains nothing from the on-die hits and pays for the allocation.  Nontemporal therefore stays the
-    // policy for every size; SXMC_LOAD_POLICY=2 switches a run to cached loads to repeat the measurement.
-    {
-      static const int forced = [] {
-        const char* e = std::getenv("SXMC_LOAD_POLICY");
-        return e ? std::atoi(e) : 0;
-      }();
-      c.cached_loads = forced == 2;
-    }
     int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
     const size_t lds_need = std::max(c.shape.lds_bytes, c.shape.sparse_lds_bytes);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(lds_need, 1)));
@@ -1345,7 +1333,7 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
   for (LaunchClass& c : g->classes) {
     const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
-    c.shape.debug_mode = g->debug_mode | (c.cached_loads ? 8 : 0);
+    c.shape.debug_mode = g->debug_mode;
     if (sparse && c.d_descs_sparse && c.shape.sparse_runs) {
       SX_HIP(sx_launch_fill_sparse_runs(c.shape, c.d_descs_sparse, c.d_segs, c.d_blk_off, s));
     } else {
@@ -2071,7 +2059,7 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
                   c.shape.pre_width == 5 ? "ordered" : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
-                  c.shape.grid, c.partition, c.cached_loads ? "cached" : "nt");
+                  c.shape.grid, c.partition, "nt");
     text += line;
   }
   if (!g->rtc_note.empty()) text += "runtime specialisation failed: " + g->rtc_note.substr(0, 300) + "\n";
@@ -2260,6 +2248,21 @@ int sxmc_group_finish_step_async(sxmc_group_t g, sxmc_stream_t s, size_t npartia
 namespace {
 // The end of a step after the fill: lookup + event sum + finish_nll_jump_pick_combo + the clearing for the next
 // evaluation -- one workgroup in one launch where that is small, two launches otherwise (see sxmc_group_step_async).
+// Does the end of a step over `ne` rows take the one-workgroup form (tail_step_kernel)?  One rule, asked by the
+// sequential step and by the look-ahead walk (which must partition its event sum exactly like the sequential step,
+// or the two could round the NLL differently and part ways at an accept boundary).
+bool step_end_takes_tail(const sxmc_group* g, bool sparse, unsigned long long ne) {
+  unsigned long long words = 0;
+  const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
+  for (const SxSignalDesc& d : flavour) words += (unsigned long long)d.total_nbins;
+  const unsigned long long gathers = ne * g->members.size();
+  return gathers <= 256ull && words <= (1ull << 16) && g->cfg_tail != 0;
+}
+// workgroups of 128 rows the event sum of a step is cut into (eval_nll_kernel; eval_nll2_kernel per candidate)
+int step_sum_blocks(unsigned long long ne) {
+  return (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + 127) / 128));
+}
+
 int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDesc* descs, unsigned long long ne,
                     const unsigned* weight, const SxStepArgs& a) {
   // How much the end of the step has to touch decides its shape.  One workgroup doing all of it in one launch
@@ -2267,17 +2270,13 @@ int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDe
   // (~8000 rows x 12 members) one CU needs 59 us for what ~60 workgroups + the step-end launch do in 15.6 us, and
   // at config 2 (~2500 x 6) 16 us against 9, at the bench_pdfz shape (1000 x 1) 8 us against 7; config 1 (10 x 2)
   // gains 0.6 us of 14.7.  Only the smallest problems take it.
-  unsigned long long words = 0;
-  const std::vector<SxSignalDesc>& flavour = sparse ? g->h_descs_sparse : g->h_descs;
-  for (const SxSignalDesc& d : flavour) words += (unsigned long long)d.total_nbins;
-  const unsigned long long gathers = ne * g->members.size();
-  if (gathers <= 256ull && words <= (1ull << 16) && g->cfg_tail != 0) {
+  if (step_end_takes_tail(g, sparse, ne)) {
     SX_HIP(sx_launch_tail_step(descs, (int)g->members.size(), ne, weight, a, st));
     g->last_step_launches += 1;
   } else {
     g->last_step_launches += 2;
     const int block = 128;
-    const int grid = (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + block - 1) / block));
+    const int grid = step_sum_blocks(ne);
     SX_HIP(sx_launch_eval_nll(descs, (int)g->members.size(), ne, weight, a.v_proposed, a.nexpected, a.n_mc, a.source_id,
                               a.norms, g->d_step_sums, grid, block, st));
     SX_HIP(sx_launch_finish_zero(sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
@@ -2584,6 +2583,12 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
   sxmc_group *ga = mg->groups[0], *gb = mg->groups[1];
   SX_REQUIRE(ga->members.size() == gb->members.size() && ga->members.size() <= 1024 && ga->ec[0].K == gb->ec[0].K,
              "the two groups must hold the same members over the same data");
+  if (step_end_takes_tail(ga, false, ga->ec[0].K)) {
+    return fail(SXMC_ERR_STATE,
+                "the look-ahead walk is not offered for this shape: the sequential step ends in the one-workgroup form "
+                "(at most 256 look-ups), whose event sum is partitioned differently -- walk sequentially "
+                "(sxmc_group_lookahead_supported says so beforehand)");
+  }
   if (replan) {
     if (t_capturing) return fail(SXMC_ERR_STATE, "the chains' plans are out of date: step once before recording a graph");
     mg->seen.resize(2);
@@ -2618,7 +2623,9 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
   const sxmc_group::EventClasses &ea = ga->ec[0], &eb = gb->ec[0];
   const unsigned long long ne = ea.K;
   const int block = 128;
-  const int half = (int)std::min<unsigned long long>(512, std::max<unsigned long long>(1, (ne + block - 1) / block));
+  // each candidate's event sum is cut exactly like the sequential step's (group_step_tail): the same blocks of 128
+  // rows, the same cap, so the partial sums and their reduction round identically
+  const int half = step_sum_blocks(ne);
   SX_HIP(sx_launch_eval_nll2(ea.d_descs, eb.d_descs, (int)ga->members.size(), ne, ea.d_weight, eb.d_weight,
                              a->d_v_proposed, d_v_lookahead, a->d_nexpected, a->d_n_mc, a->d_source_id, a->d_norms,
                              d_norms_lookahead, ga->d_step_sums, gb->d_step_sums, half, block, st));
@@ -2654,6 +2661,33 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
       h->cleared_by = g;
     }
   }
+  return SXMC_OK;
+}
+
+int sxmc_group_lookahead_supported(sxmc_group_t g, int* ok) {
+  SX_REQUIRE(g && ok, "null argument");
+  *ok = 0;
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  if (!g->same_points || g->cfg_lut || (g->sparse_ready && g->cfg_sparse) || g->members.empty()) return SXMC_OK;
+  if (!g->members[0]->has_points) return SXMC_OK;
+  rc = ensure_event_classes(g, false);
+  if (rc) return rc;
+  if (step_end_takes_tail(g, false, g->ec[0].K)) return SXMC_OK;
+  // the pass keeps TWO histograms per member in LDS (the proposal's and the look-ahead's): what multigroup_prepare
+  // will require of every launch of the plan
+  DeviceProps props;
+  if (get_props(props)) return SXMC_OK;
+  for (const LaunchClass& c : g->classes) {
+    if (!c.shape.lds_hist || !c.prog_simple ||
+        !(c.shape.pre_width == 0 || c.shape.pre_width == 3 || c.shape.pre_width == 5) ||
+        (c.shape.nobs == 0 && c.shape.pre_width != 5)) {
+      return SXMC_OK;
+    }
+    const size_t words = c.shape.pre_width == 5 ? (size_t)(c.shape.lds_layout & 0xFFFFFFu) : c.shape.lds_bytes / 4 - 4 - 64;
+    if ((4 + 2 * words + 64) * 4 > (size_t)props.lds_per_cu) return SXMC_OK;
+  }
+  *ok = 1;
   return SXMC_OK;
 }
 

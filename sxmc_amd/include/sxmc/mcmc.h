@@ -399,7 +399,14 @@ class MCMC {
     const unsigned gsteps = (batched && reevaluate && !in_lockstep) ? graph_steps : 0;
 
     // ---- look-ahead walk: a shadow set of evaluators over the same tables, bound to the look-ahead vector
-    const bool ahead = lookahead && batched && reevaluate && consume && !in_lockstep && !lut_output && nparameters <= 256;
+    bool ahead = lookahead && batched && reevaluate && consume && !in_lockstep && !lut_output && nparameters <= 256;
+    if (ahead) {
+      // not every shape is offered the look-ahead pass (histograms beyond LDS; problems so small that the sequential
+      // step ends in the one-workgroup form, whose event sum is partitioned differently): those walk sequentially
+      int ok = 0;
+      check(sxmc_group_lookahead_supported(group, &ok));
+      ahead = ok != 0;
+    }
     std::vector<std::unique_ptr<pdfz::EvalHist>> shadow;
     sxmc_group_t shadow_group = nullptr;
     sxmc_multigroup_t pair = nullptr;

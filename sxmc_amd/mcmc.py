@@ -216,7 +216,9 @@ class MCMC:
         graph_steps = K > 0 replays a HIP graph of K recorded steps wherever K steps fit between two
         points that need the host (re-tuning, jump-buffer flush); the chain is the same."""
         self.walk_begin(data, nsteps, burnin_fraction, debug_mode, sync_interval)
-        if lookahead:
+        self.lookahead_passes = 0
+        # (a shape the look-ahead pass is not offered for -- see Group.LookaheadSupported -- walks sequentially)
+        if lookahead and self.group.LookaheadSupported():
             # the look-ahead walk (LookaheadWalk below): two evaluations per pass over the tables, one or two steps
             # per pass; needs consume=True, lut_output=False and a created stream.  The same chain.
             la = LookaheadWalk(self)

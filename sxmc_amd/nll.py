@@ -107,6 +107,14 @@ class EvalGroup:
         """Specialise the fill kernel through hiprtc for programs of systematics that are not built in (default on)."""
         capi.call("sxmc_group_set_runtime_kernels", self._g, int(bool(enable)))
 
+    def LookaheadSupported(self):
+        """Can a walk over this group be taken by the look-ahead pass and stay the sequential chain bit for bit?
+        (sxmc_group_lookahead_supported: not for histograms beyond LDS, a materialised lookup table, or problems of at
+        most 256 look-ups per step, whose sequential step ends in the one-workgroup form.)"""
+        ok = C.c_int(0)
+        capi.call("sxmc_group_lookahead_supported", self._g, C.byref(ok))
+        return bool(ok.value)
+
     def LaunchInfo(self):
         buf = C.create_string_buffer(8192)
         capi.call("sxmc_group_launch_info", self._g, buf, len(buf))

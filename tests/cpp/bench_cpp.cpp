@@ -105,10 +105,15 @@ static int run(int argc, char** argv) {
   if (!o.config.empty()) {
     // ---- inputs from a fit configuration: the reference's control file + ROOT-free sample tables
     sxmc::FitConfig fc = sxmc::load_config(o.config);
+    if (!sxmc::same_systematics_everywhere(fc)) {
+      throw std::runtime_error("the batched drivers (one launch for all signals) need every signal to list every "
+                               "systematic of the fit, in the same order");
+    }
     observables = fc.observables;
     systematics = fc.systematics;
     sources = fc.sources;
     signals = fc.signals;
+    const size_t rows_loaded = fc.rows_total();
     tabs = std::move(fc.tables);
     F = fc.nfields;
     burnin = fc.burnin_fraction;
@@ -119,7 +124,7 @@ static int run(int argc, char** argv) {
     run_opt.walk = false;
     std::printf("{\"driver\": \"sxmc::load_config (C++)\", \"config\": \"%s\", \"signals\": %zu, \"observables\": %zu, "
                 "\"systematics\": %zu, \"nfields\": %zu, \"rows_total\": %zu, \"experiments\": %u, \"steps\": %u}\n",
-                o.config.c_str(), signals.size(), observables.size(), systematics.size(), F, fc.rows_total(),
+                o.config.c_str(), signals.size(), observables.size(), systematics.size(), F, rows_loaded,
                 run_opt.nexp, run_opt.esteps);
   } else {
     const size_t S = 12, E = 100000;

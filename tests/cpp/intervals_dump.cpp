@@ -27,11 +27,17 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i + 1 < ncol; i++) chain.names.push_back("p" + std::to_string(i));
     chain.names.push_back("likelihood");
     const std::vector<sxmc::Interval> c = sxmc::contour_intervals(chain, cl), p = sxmc::projection_intervals(chain, cl);
-    auto dump = [](const char* name, const std::vector<sxmc::Interval>& v) {
+    auto num = [](float x) {   // (JSON has no inf / nan: a fit that ran away prints as null)
+      char b[40];
+      if (std::isfinite(x)) std::snprintf(b, sizeof b, "%.9g", (double)x);
+      else std::snprintf(b, sizeof b, "null");
+      return std::string(b);
+    };
+    auto dump = [&](const char* name, const std::vector<sxmc::Interval>& v) {
       std::printf("\"%s\": [", name);
       for (size_t i = 0; i < v.size(); i++) {
-        std::printf("%s[%.9g, %.9g, %.9g, %.9g, %s]", i ? ", " : "", (double)v[i].point_estimate, (double)v[i].lower,
-                    (double)v[i].upper, (double)v[i].coverage, v[i].one_sided ? "true" : "false");
+        std::printf("%s[%s, %s, %s, %s, %s]", i ? ", " : "", num(v[i].point_estimate).c_str(), num(v[i].lower).c_str(),
+                    num(v[i].upper).c_str(), num(v[i].coverage).c_str(), v[i].one_sided ? "true" : "false");
       }
       std::printf("]");
     };

@@ -377,6 +377,64 @@ def test_lookahead_walk_is_the_sequential_chain(graph_passes, threads):
     la2.close()
 
 
+def test_lookahead_event_sum_is_partitioned_like_the_sequential_step():
+    """the look-ahead pass must cut its event sum exactly like the sequential step, or the two round the NLL
+    differently and the chains part at an accept boundary.  (a) MORE than 65 536 event classes -- beyond the cap the
+    look-ahead sum used to have (512 blocks of 128 rows per candidate against the sequential step's 1 024): four data
+    sets, so that the members' event-bin tables differ and the distinct tuples of event bins outnumber the bins of
+    one histogram (two of which must fit LDS for the look-ahead pass).  (b) a problem so small that the sequential step ends in the one-workgroup form: the look-ahead pass is
+    not offered, says so, and a walk asked to look ahead falls back to the sequential chain."""
+    from sxmc_amd.mcmc import LookaheadWalk
+    rng = np.random.default_rng(12)
+    nb, lower, upper = [26, 26, 26], [0.0, 0.0, -1.0], [10.0, 6.0, 1.0]          # 17 576 bins: two histograms fit LDS
+    signals = []
+    for j in range(4):
+        n = 200000
+        e_true = rng.uniform(0, 10, n).astype(np.float32)
+        tab = np.stack([e_true + rng.normal(0, 0.2, n).astype(np.float32), rng.uniform(0, 6, n).astype(np.float32),
+                        rng.uniform(-1, 1, n).astype(np.float32), e_true, np.full(n, j, np.float32)], axis=1)
+        signals.append(workloads.Signal(np.ascontiguousarray(tab, np.float32), 5, 4000.0 + 500 * j, j, dataset=j))
+    nev = 260000
+    events = np.zeros((nev, 4), np.float32)
+    events[:, 0] = rng.uniform(0, 10, nev)
+    events[:, 1] = rng.uniform(0, 6, nev)
+    events[:, 2] = rng.uniform(-1, 1, nev)
+    events[:, 3] = rng.integers(0, 4, nev)
+    w = workloads.Workload("four-datasets", 3, lower, upper, nb, signals, workloads.C3_SYSTS, workloads.C3_SIGMAS, events,
+                           "many event classes")
+    nsteps = 40
+    plain = MCMC(w, seed=3, lut_output=False, consume=True, stream=capi.new_stream())
+    plain.setup(sync_interval=64)
+    want_rows, want_acc = plain.run(nsteps)
+    m = MCMC(w, seed=3, lut_output=False, consume=True, stream=capi.new_stream())
+    m.setup(sync_interval=64)
+    assert m.group.LookaheadSupported()
+    la = LookaheadWalk(m, threads=0)
+    la.bind()
+    la.steps(nsteps, graph_passes=4, count0=0)
+    rows, nacc = m.flush()
+    # the classes really outnumber the old cap (K distinct tuples = the occupied bins of every data set)
+    geom = oracle.HistGeometry(lower, upper, nb)
+    K = sum(np.unique(oracle.set_eval_points(geom, events, j)[events[:, 3] == j]).size for j in range(4))
+    assert K > 65536, K
+    assert 0 < want_acc < nsteps and nacc == want_acc and np.array_equal(rows, want_rows)
+    la.close()
+    # (b) config 1: 10 bins x 2 signals -> at most 20 look-ups per step
+    w1 = workloads.config1()
+    seq = MCMC(w1, seed=9, lut_output=False, consume=True, stream=capi.new_stream())
+    chain_seq, acc_seq = seq.walk(w1.events, 300, 0.1, sync_interval=100, graph_steps=4)
+    ahead = MCMC(w1, seed=9, lut_output=False, consume=True, stream=capi.new_stream())
+    chain_la, acc_la = ahead.walk(w1.events, 300, 0.1, sync_interval=100, graph_steps=4, lookahead=True)
+    assert not ahead.group.LookaheadSupported() and ahead.lookahead_passes == 0
+    assert acc_la == acc_seq and np.array_equal(chain_la, chain_seq)
+    la1 = LookaheadWalk(ahead, threads=0)
+    la1.bind()
+    with pytest.raises(capi.SxmcError) as err:
+        la1.one_pass()
+    assert "not offered for this shape" in str(err.value)
+    la1.close()
+
+
 @pytest.mark.parametrize("width_scale", [0.05, 12.0])
 def test_lookahead_walk_at_high_and_low_acceptance(width_scale):
     """Nearly every step accepted (every pass one step) and nearly every step rejected (every pass two steps,

@@ -25,7 +25,10 @@ def cpp_intervals(chain, cl, tmp_path):
     np.ascontiguousarray(chain, np.float32).tofile(path)
     r = subprocess.run([DUMP, path, str(chain.shape[1]), repr(float(cl))], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    return json.loads(r.stdout)
+    try:
+        return json.loads(r.stdout)
+    except ValueError:
+        raise AssertionError("intervals_dump printed something that is not JSON: " + r.stdout[:3000])
 
 
 def compare_three_ways(chain, cl, tmp_path):
@@ -102,13 +105,18 @@ def test_printed_offset_changes_the_contour_at_config3_magnitudes(tmp_path):
 def test_intervals_of_a_gpu_chain_three_ways(tmp_path):
     """A chain walked on the GPU (BASELINE config 3's shape at 1 % of the samples, 10^5 events: |lmin| of a few 1e5,
     the printed-offset regime) through Contour and Projection in Python and C++, against the restatement."""
-    from sxmc_amd import workloads
+    from sxmc_amd import capi, workloads
     from sxmc_amd.mcmc import MCMC
     w = workloads.config3(0.01, nevents=100000)
-    m = MCMC(w, seed=11, fused=True, lut_output=False, consume=True)
-    chain, accepted = m.walk(w.events, 1500, 0.2, sync_interval=500)
-    assert chain.shape[0] > 800 and 0 < accepted < 1500
+    for s in w.signals:
+        s.nexpected = 100000.0 / w.nsignals               # rates that describe the data: the walk starts near the truth
+    m = MCMC(w, seed=11, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
+    # long enough for both re-tunings of the proposal (mcmc.cpp:274-311) to take: the kept half samples the posterior
+    chain, accepted = m.walk(w.events, 12000, 0.25, sync_interval=1000, graph_steps=8)
+    assert chain.shape[0] == 6000 and 300 < accepted < 11000
     assert abs(float(chain[:, -1].min())) > 1e5          # six printed digits cannot hold this offset
+    for p in range(w.nparameters):                        # every parameter moved: the projections are real histograms
+        assert np.unique(chain[:, p]).size > 50
     compare_three_ways(chain, 0.9, tmp_path)
     compare_three_ways(chain, 0.683, tmp_path)
     for p in m.pdfs:

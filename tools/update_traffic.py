@@ -6,7 +6,6 @@ profiled library was built from -- bench.py compares them with the sources it ru
 
   update_traffic.py <key> <pmc_summary.csv> <kernel name prefix> <committed copy under profiles/> [note]
 """
-import csv
 import json
 import os
 import sys
@@ -20,13 +19,14 @@ def main():
     note = sys.argv[5] if len(sys.argv) > 5 else ""
     from bench import source_fingerprints
     fetch = write = None
-    for r in csv.DictReader(open(summary)):
-        if not r["kernel"].startswith(prefix):
+    for line in open(summary).read().splitlines()[1:]:
+        kernel, counter, _, mean = line.rsplit(",", 3)      # (kernel names contain commas)
+        if not kernel.startswith(prefix):
             continue
-        if r["counter"] == "FETCH_SIZE":
-            fetch = float(r["mean_per_launch"])
-        if r["counter"] == "WRITE_SIZE":
-            write = float(r["mean_per_launch"])
+        if counter == "FETCH_SIZE":
+            fetch = float(mean)
+        if counter == "WRITE_SIZE":
+            write = float(mean)
     if fetch is None or write is None:
         raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for %r in %s" % (prefix, summary))
     path = os.path.join(ROOT, "profiles", "traffic.json")
