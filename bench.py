@@ -744,7 +744,7 @@ def main():
     big = args.workload.lower() == "c5" and args.scale >= 0.2
     leg = Leg(args, torch, dev, args.workload, args.form, args.lut_output, args.seed, exp_seed,
               keep_host=("ends" if big else "all") if want_cpu else "none",
-              lookahead=args.lookahead and not args.debug_mode)
+              lookahead=args.lookahead)
     w, m = leg.w, leg.m
     leg.setup(args.steps, args.warmup)
     tuned_threads = leg.tuned_threads

@@ -66,7 +66,8 @@ struct SxChainDescsHost {
   const SxSignalDesc* d[4];
 };
 hipError_t sx_rtc_launch_multi(void* fn, int grid, int threads, size_t lds_bytes, const SxChainDescsHost& chains,
-                               const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, hipStream_t s);
+                               const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, unsigned dbg,
+                               hipStream_t s);
 hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, const SxSignalDesc* descs,
                          const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s);
 

@@ -2507,7 +2507,7 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
     const bool rec = g0->prof && !t_capturing && g0->prof_n < (int)g0->ev0.size();
     if (rec) SX_HIP(hipEventRecord(g0->ev0[g0->prof_n], st));
     SX_HIP(sx_rtc_launch_multi(mg->fill_fn[i], c0.shape.grid, c0.shape.threads, mg->lds_bytes[i], ch, c0.d_segs,
-                               c0.d_blk_off, mg->fill_w[i], st));
+                               c0.d_blk_off, mg->fill_w[i], (unsigned)mg->groups[0]->debug_mode, st));
     if (rec) {
       SX_HIP(hipEventRecord(g0->ev1[g0->prof_n], st));
       g0->prof_n++;
@@ -2614,7 +2614,7 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
     const bool rec = ga->prof && !t_capturing && ga->prof_n < (int)ga->ev0.size();
     if (rec) SX_HIP(hipEventRecord(ga->ev0[ga->prof_n], st));
     SX_HIP(sx_rtc_launch_multi(mg->fill_fn[i], c0.shape.grid, c0.shape.threads, mg->lds_bytes[i], ch, c0.d_segs,
-                               c0.d_blk_off, mg->fill_w[i], st));
+                               c0.d_blk_off, mg->fill_w[i], (unsigned)mg->groups[0]->debug_mode, st));
     if (rec) {
       SX_HIP(hipEventRecord(ga->ev1[ga->prof_n], st));
       ga->prof_n++;

@@ -54,8 +54,8 @@ std::string kernel_source(const SxRtcSpec& k) {
                               std::to_string(k.nchain > 1 ? k.nchain : 1);
     if (k.nchain > 1) {
       s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(SxChainDescs chains, "
-           "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w) {\n";
-      s += "  fill_ordered_body<" + targs + ">(chains, segs, blk_off, w, 0u);\n}\n";
+           "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";
+      s += "  fill_ordered_body<" + targs + ">(chains, segs, blk_off, w, dbg);\n}\n";
     } else {
       s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(const SxSignalDesc* __restrict__ descs, "
            "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";
@@ -66,7 +66,7 @@ std::string kernel_source(const SxRtcSpec& k) {
   }
   if (k.nchain > 1) {
     s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(SxChainDescs chains, "
-         "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w) {\n";
+         "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned) {\n";
     s += "  fill_multi_body<" + std::to_string(k.nobs) + ", " + std::to_string(k.nslot) + ", " + prog + ", " +
          std::to_string(k.pre_width) + ", " + std::to_string(k.nchain) + ">(chains, segs, blk_off, w);\n}\n";
     return s;
@@ -187,9 +187,10 @@ hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, cons
 }
 
 hipError_t sx_rtc_launch_multi(void* fn, int grid, int threads, size_t lds_bytes, const SxChainDescsHost& chains,
-                               const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, hipStream_t s) {
+                               const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, unsigned dbg,
+                               hipStream_t s) {
   SxChainDescsHost c = chains;
-  void* args[] = {(void*)&c, (void*)&segs, (void*)&blk_off, (void*)&hist_words};
+  void* args[] = {(void*)&c, (void*)&segs, (void*)&blk_off, (void*)&hist_words, (void*)&dbg};
   return hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds_bytes, s,
                                args, nullptr);
 }
