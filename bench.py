@@ -975,7 +975,8 @@ def main():
         print(json.dumps(result), file=json_out, flush=True)
     if world == 1:
         dist.shutdown()
-    if failed_leg:
+    # (at N > 1 the failed leg is the extra C++ runner: its record says so, the job's own measurement stands)
+    if failed_leg and world == 1:
         raise SystemExit("bench.py: the %s leg FAILED (its record says how): %s"
                          % (failed_leg, result["also"][failed_leg].get("failed")))
 

@@ -158,10 +158,13 @@ void* sx_rtc_get(const SxRtcSpec& k, std::string* err) {
     if (err) *err = bad->second;
     return nullptr;
   }
-  std::vector<char> code;
+  // the code object is compiled once per process and specialisation (every GPU of the node is a gfx950); each
+  // device loads its own module from it
+  static std::map<std::string, std::vector<char>> g_code;
   std::string e;
   hipFunction_t fn = nullptr;
-  if (compile(k, code, e)) {
+  std::vector<char>& code = g_code[spec_key(k)];
+  if (!code.empty() || compile(k, code, e)) {
     hipModule_t mod = nullptr;
     hipError_t he = hipModuleLoadData(&mod, code.data());
     if (he == hipSuccess) he = hipModuleGetFunction(&fn, mod, "sx_rtc_fill");

@@ -169,8 +169,23 @@ def collective_record(device_index, device_info):
     cards = {(d["host"], d["pci_bus_id"]) for d in everyone}
     comm, nranks, comm_device, note = None, None, None, None
     if backend == "nccl":
-        comm = RcclComm()
-        _, nranks, comm_device = comm.query()
+        # librccl through the C ABI, beside torch's own communicator.  Should it fail on some rank (it has never been
+        # run on more than one card: no multi-GPU box was available to the builder), every rank learns of it and the
+        # job goes on with torch.distributed's all_gather alone -- and says so in the line -- instead of stopping
+        try:
+            comm = RcclComm()
+            _, nranks, comm_device = comm.query()
+            mine_ok, why = 1.0, None
+        except Exception as exc:      # noqa: BLE001 (whatever it is, the other ranks must hear of it)
+            comm, mine_ok, why = None, 0.0, "%s: %s" % (type(exc).__name__, exc)
+        ok = torch.tensor([mine_ok], dtype=torch.float64, device=_device_for_collectives())
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            if comm is not None:
+                comm.close()
+            comm, nranks, comm_device = None, None, None
+            note = "the C-ABI RCCL communicator could not be made on every rank (%s); intervals gathered by " \
+                   "torch.distributed's all_gather" % (why or "another rank failed")
     else:
         note = ("rehearsal: the ranks' collectives ran over %s (SXMC_DIST_BACKEND), not RCCL; %d rank(s) share a card"
                 % (backend, world - len(cards)))
