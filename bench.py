@@ -345,9 +345,12 @@ class Leg:
         return elapsed
 
     def empty_bracket_ms(self, n=50):
-        """What two HIP events measure with NOTHING between them, on the walk's stream (mean of n): the part of every
-        event-timed duration that is not the kernel.  Negligible against config 3's 130 us fill; a fifth of config 2's
-        (rocprofv3 --kernel-trace on the same command reads that much lower: profiles/r03_c2_*)."""
+        """What two hipEventRecord calls measure with NOTHING between them, on the walk's stream (mean of n).  The fill's
+        own durations do NOT contain it: profiled fills are launched through hipExtLaunchKernelGGL /
+        hipExtModuleLaunchKernel with a start and a stop event, which carry the dispatch's own begin and end timestamps
+        -- the duration rocprofv3 --kernel-trace reports.  (Round 2 recorded an event before and after the launch: that
+        also timed the packets in between, ~2.5 us per launch, a fifth of config 2's fill.)  Reported so that the
+        difference is on record."""
         import ctypes as C
 
         from sxmc_amd import capi
@@ -419,7 +422,9 @@ class Leg:
             "traffic": traffic, "traffic_provenance": traffic_note,
             "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
             "avg_launch_ms": fill_ms, "launches_timed": self.nfill, "sample": self.roofline_sample,
-            # two events with nothing between them: what every event-timed duration carries besides the kernel
+            "timing": "HIP events stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop events) on the stream the "
+                      "fill is launched on: the kernel's own duration, as rocprofv3 --kernel-trace reports it",
+            # two hipEventRecord calls with nothing between them (NOT part of avg_launch_ms, see empty_bracket_ms)
             "empty_event_bracket_ms": self.event_bracket_ms,
             "in_timed_region": {"launches": self.nfill_region,
                                 "avg_launch_ms": self.fill_ms_region / max(self.nfill_region, 1)},

@@ -16,6 +16,9 @@
 // -ffp-contract=off plus the pragma below), in the reference's operation order, so bin
 // indices are bit-identical to the reference CPU loop.  x^i of the polynomial systematics is
 // rounded once (pow_step in fill_kernels.inc.h), like libm's pow for these exponents.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
 #include "nll_device.h"
 
 #include "fill_kernels.inc.h"
@@ -549,6 +552,18 @@ __global__ __launch_bounds__(256) void untranspose_obs_kernel(const float* __res
   }
 }
 
+// A fill launch; with the launch shape's two profiling events set, through hipExtLaunchKernelGGL, which stamps them
+// with the dispatch's own begin and end (what rocprofv3 --kernel-trace reports as the kernel's duration).
+template <typename K, typename... A>
+void launch_fill(const SxLaunchShape& sh, K k, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
+  if (sh.ev_start && sh.ev_stop) {
+    hipExtLaunchKernelGGL(k, grid, block, (std::uint32_t)lds, s, (hipEvent_t)sh.ev_start, (hipEvent_t)sh.ev_stop, 0u,
+                          args...);
+  } else {
+    hipLaunchKernelGGL(k, grid, block, lds, s, args...);
+  }
+}
+
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW = 0>
 hipError_t launch_fill_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                          const unsigned* blk_off, hipStream_t s) {
@@ -561,8 +576,8 @@ hipError_t launch_fill_k(const SxLaunchShape& sh, const SxSignalDesc* descs, con
   // LDS: 4 header words + hist_words + 64 trash words
   // LDS-histogram launches: hist_words bins + 64 trash words; others: room for the sparse coarse filter
   const unsigned hist_words = (unsigned)(sh.lds_bytes / 4 - 4 - (LDS_HIST ? 64 : 0));
-  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, hist_words,
-                     (unsigned)sh.debug_mode);
+  launch_fill(sh, k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, hist_words,
+              (unsigned)sh.debug_mode);
   return hipGetLastError();
 }
 
@@ -580,8 +595,8 @@ hipError_t launch_fill_sparse_k(const SxLaunchShape& sh, const SxSignalDesc* des
   }
   const unsigned nwaves = (unsigned)sh.threads / 64u;
   const unsigned smax = (unsigned)(sh.sparse_lds_bytes / 4 / nwaves / 2);   // entries per wave (keys + counts)
-  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.sparse_lds_bytes, s, descs, segs, blk_off, smax,
-                     (unsigned)sh.debug_mode);
+  launch_fill(sh, k, dim3(sh.grid), dim3(sh.threads), sh.sparse_lds_bytes, s, descs, segs, blk_off, smax,
+              (unsigned)sh.debug_mode);
   return hipGetLastError();
 }
 
@@ -666,8 +681,8 @@ hipError_t launch_fill_ordered_k(const SxLaunchShape& sh, const SxSignalDesc* de
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, sh.lds_layout,
-                     (unsigned)sh.debug_mode);
+  launch_fill(sh, k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, sh.lds_layout,
+              (unsigned)sh.debug_mode);
   return hipGetLastError();
 }
 struct OrderedEntry {
@@ -719,7 +734,7 @@ hipError_t sx_launch_fill_sparse_runs(const SxLaunchShape& sh, const SxSignalDes
   if (sh.rtc_sparse) {
     const unsigned smax = (unsigned)(sh.sparse_lds_bytes / 4 / ((unsigned)sh.threads / 64u) / 2);
     return sx_rtc_launch(sh.rtc_sparse, sh.grid, sh.threads, sh.sparse_lds_bytes, descs, segs, blk_off, smax,
-                         (unsigned)sh.debug_mode, s);
+                         (unsigned)sh.debug_mode, s, sh.ev_start, sh.ev_stop);
   }
   if (!sx_fill_static_supports_sparse_runs(sh.static_prog)) return hipErrorInvalidValue;
   return kStaticPrograms[sh.static_prog].fn_sruns(sh, descs, segs, blk_off, s);
@@ -767,7 +782,7 @@ hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, co
     const unsigned hist_words = sh.pre_width == kPreOrdered ? sh.lds_layout
                                                             : (unsigned)(sh.lds_bytes / 4 - 4 - (sh.lds_hist ? 64 : 0));
     return sx_rtc_launch(sh.rtc_fill, sh.grid, sh.threads, sh.lds_bytes, descs, segs, blk_off, hist_words,
-                         (unsigned)sh.debug_mode, s);
+                         (unsigned)sh.debug_mode, s, sh.ev_start, sh.ev_stop);
   }
   if (sh.static_prog >= 0 && sh.static_prog < kNumStatic) {
     const StaticEntry& e = kStaticPrograms[sh.static_prog];
@@ -797,11 +812,10 @@ hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, co
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off,
-                       (unsigned)(sh.lds_bytes / 4 - 4 - 64));
+    launch_fill(sh, k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off,
+                (unsigned)(sh.lds_bytes / 4 - 4 - 64));
   } else {
-    hipLaunchKernelGGL(fill_kernel_generic<false>, dim3(sh.grid), dim3(sh.threads), 64, s, descs, segs,
-                       blk_off, 0u);
+    launch_fill(sh, fill_kernel_generic<false>, dim3(sh.grid), dim3(sh.threads), (size_t)64, s, descs, segs, blk_off, 0u);
   }
   return hipGetLastError();
 }

@@ -51,6 +51,12 @@ struct SxLaunchShape {
   int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none, 3 = bucketed table (one
                     // bin offset per 256-sample granule), 5 = bucketed table with an ordered observable
                     // (fill_ordered_kernel; static_prog then indexes the ordered programs built in)
+  // profiling (sxmc_group_profile): when set, the fill is launched through hipExtLaunchKernelGGL /
+  // hipExtModuleLaunchKernel with these two HIP events, which then carry the DISPATCH's own begin and end timestamps
+  // -- the kernel's duration as rocprofv3 --kernel-trace reports it.  (Two hipEventRecord calls around the launch
+  // also time the packets between them: +2.5-3 us per launch, a fifth of BASELINE config 2's fill.)
+  void* ev_start = nullptr;
+  void* ev_stop = nullptr;
 };
 
 // A fill kernel specialised at run time (sxmc_rtc.cpp): the template arguments of fill_body / fill_sparse_body.
@@ -67,9 +73,10 @@ struct SxChainDescsHost {
 };
 hipError_t sx_rtc_launch_multi(void* fn, int grid, int threads, size_t lds_bytes, const SxChainDescsHost& chains,
                                const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, unsigned dbg,
-                               hipStream_t s);
+                               hipStream_t s, void* ev_start = nullptr, void* ev_stop = nullptr);
 hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, const SxSignalDesc* descs,
-                         const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s);
+                         const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s,
+                         void* ev_start = nullptr, void* ev_stop = nullptr);
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
 hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,

@@ -1331,8 +1331,10 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
   int rc = group_prepare_fill(g, s, sparse);
   if (rc) return rc;
   for (LaunchClass& c : g->classes) {
-    const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
-    if (rec) SX_HIP(hipEventRecord(g->ev0[g->prof_n], s));
+    // profiled launches (sxmc_group_profile) carry two events stamped with the dispatch's own begin and end
+    const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size() && c.shape.grid > 0;
+    c.shape.ev_start = rec ? (void*)g->ev0[g->prof_n] : nullptr;
+    c.shape.ev_stop = rec ? (void*)g->ev1[g->prof_n] : nullptr;
     c.shape.debug_mode = g->debug_mode;
     if (sparse && c.d_descs_sparse && c.shape.sparse_runs) {
       SX_HIP(sx_launch_fill_sparse_runs(c.shape, c.d_descs_sparse, c.d_segs, c.d_blk_off, s));
@@ -1340,10 +1342,8 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
       SX_HIP(sx_launch_fill(c.shape, (sparse && c.d_descs_sparse) ? c.d_descs_sparse : c.d_descs, c.d_segs,
                             c.d_blk_off, s));
     }
-    if (rec) {
-      SX_HIP(hipEventRecord(g->ev1[g->prof_n], s));
-      g->prof_n++;
-    }
+    c.shape.ev_start = c.shape.ev_stop = nullptr;
+    if (rec) g->prof_n++;
   }
   return SXMC_OK;
 }
@@ -2505,13 +2505,10 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
     SxChainDescsHost ch{};
     for (size_t c = 0; c < C; c++) ch.d[c] = mg->groups[c]->classes[i].d_descs;
     const bool rec = g0->prof && !t_capturing && g0->prof_n < (int)g0->ev0.size();
-    if (rec) SX_HIP(hipEventRecord(g0->ev0[g0->prof_n], st));
     SX_HIP(sx_rtc_launch_multi(mg->fill_fn[i], c0.shape.grid, c0.shape.threads, mg->lds_bytes[i], ch, c0.d_segs,
-                               c0.d_blk_off, mg->fill_w[i], (unsigned)mg->groups[0]->debug_mode, st));
-    if (rec) {
-      SX_HIP(hipEventRecord(g0->ev1[g0->prof_n], st));
-      g0->prof_n++;
-    }
+                               c0.d_blk_off, mg->fill_w[i], (unsigned)mg->groups[0]->debug_mode, st,
+                               rec ? (void*)g0->ev0[g0->prof_n] : nullptr, rec ? (void*)g0->ev1[g0->prof_n] : nullptr));
+    if (rec) g0->prof_n++;
   }
   // every chain's own step end
   for (size_t c = 0; c < C; c++) {
@@ -2612,13 +2609,10 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
     ch.d[0] = ga->classes[i].d_descs;
     ch.d[1] = gb->classes[i].d_descs;
     const bool rec = ga->prof && !t_capturing && ga->prof_n < (int)ga->ev0.size();
-    if (rec) SX_HIP(hipEventRecord(ga->ev0[ga->prof_n], st));
     SX_HIP(sx_rtc_launch_multi(mg->fill_fn[i], c0.shape.grid, c0.shape.threads, mg->lds_bytes[i], ch, c0.d_segs,
-                               c0.d_blk_off, mg->fill_w[i], (unsigned)mg->groups[0]->debug_mode, st));
-    if (rec) {
-      SX_HIP(hipEventRecord(ga->ev1[ga->prof_n], st));
-      ga->prof_n++;
-    }
+                               c0.d_blk_off, mg->fill_w[i], (unsigned)mg->groups[0]->debug_mode, st,
+                               rec ? (void*)ga->ev0[ga->prof_n] : nullptr, rec ? (void*)ga->ev1[ga->prof_n] : nullptr));
+    if (rec) ga->prof_n++;
   }
   const sxmc_group::EventClasses &ea = ga->ec[0], &eb = gb->ec[0];
   const unsigned long long ne = ea.K;

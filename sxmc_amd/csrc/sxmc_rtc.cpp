@@ -7,6 +7,7 @@
 // launches it through the module API.  A program that cannot be compiled (no hiprtc, a compilation error) falls
 // back to the kernel that decodes the program at run time: same results, slower.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
 
 #include <map>
@@ -183,17 +184,26 @@ void* sx_rtc_get(const SxRtcSpec& k, std::string* err) {
 }
 
 hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, const SxSignalDesc* descs,
-                         const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s) {
+                         const SxSegment* segs, const unsigned* blk_off, unsigned w, unsigned dbg, hipStream_t s,
+                         void* ev_start, void* ev_stop) {
   void* args[] = {(void*)&descs, (void*)&segs, (void*)&blk_off, (void*)&w, (void*)&dbg};
+  if (ev_start && ev_stop) {   // profiled launch: the two events carry the dispatch's own begin and end
+    return hipExtModuleLaunchKernel((hipFunction_t)fn, (unsigned)grid * (unsigned)threads, 1, 1, (unsigned)threads, 1, 1,
+                                    lds_bytes, s, args, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0);
+  }
   return hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds_bytes, s,
                                args, nullptr);
 }
 
 hipError_t sx_rtc_launch_multi(void* fn, int grid, int threads, size_t lds_bytes, const SxChainDescsHost& chains,
                                const SxSegment* segs, const unsigned* blk_off, unsigned hist_words, unsigned dbg,
-                               hipStream_t s) {
+                               hipStream_t s, void* ev_start, void* ev_stop) {
   SxChainDescsHost c = chains;
   void* args[] = {(void*)&c, (void*)&segs, (void*)&blk_off, (void*)&hist_words, (void*)&dbg};
+  if (ev_start && ev_stop) {
+    return hipExtModuleLaunchKernel((hipFunction_t)fn, (unsigned)grid * (unsigned)threads, 1, 1, (unsigned)threads, 1, 1,
+                                    lds_bytes, s, args, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0);
+  }
   return hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds_bytes, s,
                                args, nullptr);
 }

@@ -290,6 +290,14 @@ inline std::vector<Interval> projection_intervals(const Chain& chain, float cl =
   return out;
 }
 
+/** error_estimator.h: how the intervals are taken from the sampled likelihood space (fit.error_type). */
+enum ErrorType { ERROR_CONTOUR, ERROR_PROJECTION };
+
+/** LikelihoodSpace::extract_best_fit (likelihood.cpp:104-137): every parameter's interval by the chosen estimator. */
+inline std::vector<Interval> extract_intervals(const Chain& chain, float cl, ErrorType error_type) {
+  return error_type == ERROR_PROJECTION ? projection_intervals(chain, cl) : contour_intervals(chain, cl);
+}
+
 /** RandomSample on a flat row-major histogram (1-3 D). */
 inline void random_sample(std::mt19937_64& rng, const std::vector<unsigned>& bins, const std::vector<Observable>& obs,
                           size_t nobserved, unsigned dataset, std::vector<float>& events) {
@@ -364,7 +372,8 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
                                        std::vector<Observable>& observables, unsigned nsteps, float burnin_fraction,
                                        float cl, unsigned sync_interval, unsigned graph_steps = 0,
                                        sxmc_stream_t stream = nullptr, SetupLock* exclusive = nullptr,
-                                       LockstepSet* lockstep = nullptr, size_t lockstep_index = 0) {
+                                       LockstepSet* lockstep = nullptr, size_t lockstep_index = 0,
+                                       ErrorType error_type = ERROR_CONTOUR) {
   const unsigned long long x = experiment_seed(base_seed, k);
   std::mt19937_64 rng(x);
   // `exclusive` (one chain per host thread): held over everything that allocates, copies through the
@@ -385,7 +394,7 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   if (exclusive) lock.unlock();
   ExperimentResult r;
   r.index = k;
-  r.intervals = contour_intervals(chain, cl);
+  r.intervals = extract_intervals(chain, cl, error_type);
   r.accepted = chain.accepted;
   r.nevents = data.size() / (observables.size() + 1);
   return r;
@@ -396,11 +405,11 @@ inline std::vector<ExperimentResult> ensemble(const std::vector<unsigned>& exper
                                               std::vector<Systematic>& systematics,
                                               std::vector<Observable>& observables, unsigned nsteps,
                                               float burnin_fraction, float cl = 0.9f, unsigned sync_interval = 10000,
-                                              unsigned graph_steps = 0) {
+                                              unsigned graph_steps = 0, ErrorType error_type = ERROR_CONTOUR) {
   std::vector<ExperimentResult> out;
   for (unsigned k : experiments) {
     out.push_back(run_experiment(k, base_seed, sources, signals, systematics, observables, nsteps, burnin_fraction,
-                                 cl, sync_interval, graph_steps));
+                                 cl, sync_interval, graph_steps, nullptr, nullptr, nullptr, 0, error_type));
   }
   return out;
 }
@@ -417,7 +426,8 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
                                                          std::vector<Observable>& observables, unsigned nsteps,
                                                          float burnin_fraction, unsigned nconcurrent, float cl = 0.9f,
                                                          unsigned sync_interval = 10000, unsigned graph_steps = 0,
-                                                         int device = -1, SetupLock* device_exclusive = nullptr) {
+                                                         int device = -1, SetupLock* device_exclusive = nullptr,
+                                                         ErrorType error_type = ERROR_CONTOUR) {
   const size_t lanes = std::max<size_t>(1, std::min<size_t>(nconcurrent, experiments.size()));
   std::vector<ExperimentResult> out(experiments.size());
   std::vector<std::exception_ptr> errors(lanes);
@@ -443,7 +453,7 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
         std::vector<Observable> obs = observables;
         for (size_t i = t; i < experiments.size(); i += lanes) {
           out[i] = run_experiment(experiments[i], base_seed, src, mine, sys, obs, nsteps, burnin_fraction, cl,
-                                  sync_interval, graph_steps, strm, &exclusive);
+                                  sync_interval, graph_steps, strm, &exclusive, nullptr, 0, error_type);
         }
       } catch (...) {
         errors[t] = std::current_exception();
@@ -477,7 +487,8 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
                                                        float burnin_fraction, unsigned chains_per_set, unsigned nsets,
                                                        float cl = 0.9f, unsigned sync_interval = 10000,
                                                        unsigned graph_steps = 10, int device = -1,
-                                                       SetupLock* device_exclusive = nullptr) {
+                                                       SetupLock* device_exclusive = nullptr,
+                                                       ErrorType error_type = ERROR_CONTOUR) {
   const size_t L = std::max(2u, std::min(4u, chains_per_set)), S = std::max(1u, nsets), lanes = L * S;
   const size_t usable = experiments.size() / lanes * lanes;
   std::vector<ExperimentResult> out(experiments.size());
@@ -509,7 +520,7 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
           std::vector<Observable> obs = observables;
           for (size_t i = t; i < usable; i += lanes) {
             out[i] = run_experiment(experiments[i], base_seed, src, mine, sys, obs, nsteps, burnin_fraction, cl,
-                                    sync_interval, graph_steps, set.stream, &exclusive, &set, t % L);
+                                    sync_interval, graph_steps, set.stream, &exclusive, &set, t % L, error_type);
           }
         } catch (const pdfz::Error& e) {
           errors[t] = std::current_exception();
@@ -537,7 +548,7 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
     std::vector<unsigned> rest(experiments.begin() + (std::ptrdiff_t)usable, experiments.end());
     std::vector<ExperimentResult> r = ensemble_concurrent(rest, base_seed, sources, signals, systematics, observables,
                                                           nsteps, burnin_fraction, (unsigned)lanes, cl, sync_interval,
-                                                          graph_steps, device, &exclusive);
+                                                          graph_steps, device, &exclusive, error_type);
     for (size_t i = 0; i < r.size(); i++) out[usable + i] = r[i];
   }
   return out;
@@ -582,6 +593,7 @@ struct MultiGpuOptions {
    *  default. */
   enum Exchange { RCCL, HOST_STAGING } exchange = RCCL;
   double exchange_timeout_seconds = 120.0;   //!< a collective still pending after this long is aborted (fail fast)
+  ErrorType error_type = ERROR_CONTOUR;      //!< fit.error_type: contour or projection intervals
   /** Called by every device thread (argument: its rank) when its experiments are done, before the rendezvous.
    *  May throw: the tests inject a failing rank with it. */
   std::function<void(size_t)> before_exchange;
@@ -692,9 +704,9 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
             opt.lockstep_chains >= 2
                 ? ensemble_lockstep(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, opt.lockstep_chains,
                                     opt.lockstep_sets, opt.cl, opt.sync_interval,
-                                    opt.graph_steps ? opt.graph_steps : 10, devices[r], &exclusive)
+                                    opt.graph_steps ? opt.graph_steps : 10, devices[r], &exclusive, opt.error_type)
                 : ensemble_concurrent(ks, base_seed, src, mine, sys, obs, nsteps, burnin_fraction, opt.nconcurrent,
-                                      opt.cl, opt.sync_interval, opt.graph_steps, devices[r], &exclusive);
+                                      opt.cl, opt.sync_interval, opt.graph_steps, devices[r], &exclusive, opt.error_type);
         for (size_t i = 0; i < res.size(); i++) {
           out.results[ks[i]] = res[i];
           for (size_t p = 0; p < P && p < res[i].intervals.size(); p++) {

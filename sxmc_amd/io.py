@@ -278,7 +278,11 @@ def run_config(path, out_dir=None, nexperiments=None, nsteps=None):
             events = data
         m.reseed(((fc.seed << 20) + i) & 0xFFFFFFFF)
         chain, _ = m.walk(events, nsteps, fc.burnin_fraction, debug_mode=fc.debug_mode)
-        iv = ensemble.contour_intervals(chain, fc.confidence)
+        if fc.error_type == "projection":                       # likelihood.cpp:104-137: the chosen estimator
+            cols = [ensemble.projection_interval(chain[:, p], fc.confidence) for p in range(chain.shape[1] - 1)]
+            iv = np.array([c[:4] for c in cols], np.float32)
+        else:
+            iv = ensemble.contour_intervals(chain, fc.confidence)
         allint.append(iv)
         if fc.signal_name in w.parameter_names:
             limits.append(float(iv[w.parameter_names.index(fc.signal_name), 2]))

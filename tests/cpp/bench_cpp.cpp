@@ -100,6 +100,7 @@ static int run(int argc, char** argv) {
   size_t F = 5;
   unsigned long long base_seed = 77;
   float burnin = 0.1f, cl = 0.9f;
+  sxmc::ErrorType error_type = sxmc::ERROR_CONTOUR;
   Options run_opt = o;
 
   if (!o.config.empty()) {
@@ -118,6 +119,7 @@ static int run(int argc, char** argv) {
     F = fc.nfields;
     burnin = fc.burnin_fraction;
     cl = fc.confidence;
+    error_type = fc.error_type == "projection" ? sxmc::ERROR_PROJECTION : sxmc::ERROR_CONTOUR;
     if (fc.seed) base_seed = fc.seed;
     if (run_opt.nexp == 0) run_opt.nexp = fc.nexperiments;
     run_opt.esteps = fc.nsteps;
@@ -238,7 +240,7 @@ static int run(int argc, char** argv) {
       const auto t0 = std::chrono::steady_clock::now();
       std::vector<sxmc::ExperimentResult> res = sxmc::ensemble_lockstep(
           part, base_seed, sources, signals, systematics, observables, pass == 0 ? std::min(300u, opt.esteps) : opt.esteps,
-          burnin, opt.L, opt.S, cl, opt.esteps, opt.graph_steps, -1, &lock);
+          burnin, opt.L, opt.S, cl, opt.esteps, opt.graph_steps, -1, &lock, error_type);
       const double sec = seconds_since(t0);
       if (pass == 1) {
         std::printf("{\"driver\": \"sxmc::ensemble_lockstep (C++)\", \"experiments\": %zu, \"steps_each\": %u, "
@@ -272,6 +274,7 @@ static int run(int argc, char** argv) {
     mo.lockstep_chains = opt.L;
     mo.lockstep_sets = opt.S;
     mo.nconcurrent = std::max(1u, opt.L * opt.S);
+    mo.error_type = error_type;
     if (opt.host_staging) mo.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
     const size_t G = opt.devices.size();
     for (int pass = 0; pass < 2; pass++) {   // pass 0: one round per device (kernel compilation, clocks)
