@@ -13,7 +13,7 @@
 // as the reference's jsoncpp accepts them, README.md:64-65).  Objects remember their members in KEY ORDER (strcmp), as
 // jsoncpp 0.6's std::map does: FitConfig walks `signals` that way when it numbers sources and systematic parameters
 // (config.cpp:97-151), so the parameter order of a fit depends on it.
-// The Python counterpart is sxmc_amd/io.py; tests/test_io_cpu.py + tests/cpp/test_config.cpp check the two against
+// The Python counterpart is sxmc_amd/io.py; tests/test_io_cpu.py (through tests/cpp/config_dump.cpp) checks the two against
 // each other on the same files.
 #pragma once
 
@@ -73,7 +73,7 @@ class Value {
   float asFloat(const char* what = "value") const { return (float)asDouble(what); }
   long long asInt(const char* what = "value") const {
     const double d = asDouble(what);
-    if (d != std::floor(d)) throw ConfigError(std::string(what) + ": not an integer");
+    if (!(d == std::floor(d)) || !(std::fabs(d) < 9.0e18)) throw ConfigError(std::string(what) + ": not an integer");
     return (long long)d;
   }
   bool asBool(const char* what = "value") const {
@@ -106,6 +106,7 @@ class Parser {
  private:
   const std::string& text;
   size_t pos = 0;
+  int depth = 0;   // nesting of the value being read (a document is refused beyond 256 levels: the reader recurses)
 
   [[noreturn]] void fail(const std::string& msg) const {
     size_t line = 1, col = 1;
@@ -134,6 +135,12 @@ class Parser {
     }
   }
   Value value() {
+    struct Depth {
+      int& d;
+      explicit Depth(int& x) : d(x) { d++; }
+      ~Depth() { d--; }
+    } guard(depth);
+    if (depth > 256) fail("nested too deeply");
     skip();
     if (pos >= text.size()) fail("unexpected end of text");
     const char c = text[pos];
@@ -314,25 +321,37 @@ inline NpyView parse_npy(const unsigned char* p, size_t n, const std::string& wh
   NpyView v;
   auto field = [&](const char* key) -> size_t {
     const size_t k = h.find(std::string("'") + key + "'");
-    if (k == std::string::npos) throw ConfigError(what + ": .npy header has no '" + key + "'");
-    return h.find(':', k) + 1;
+    const size_t c = k == std::string::npos ? k : h.find(':', k);
+    if (c == std::string::npos) throw ConfigError(what + ": .npy header has no '" + key + "'");
+    return c + 1;
   };
   {
-    size_t a = h.find('\'', field("descr"));
-    const size_t b = h.find('\'', a + 1);
+    const size_t a = h.find('\'', field("descr"));
+    const size_t b = a == std::string::npos ? a : h.find('\'', a + 1);
     if (a == std::string::npos || b == std::string::npos) throw ConfigError(what + ": structured dtypes are not supported");
     v.descr = h.substr(a + 1, b - a - 1);
   }
-  v.fortran = h.compare(h.find_first_not_of(' ', field("fortran_order")), 4, "True") == 0;
   {
-    size_t a = h.find('(', field("shape"));
-    const size_t b = h.find(')', a);
-    std::string s = h.substr(a + 1, b - a - 1);
-    for (char& c : s)
+    const size_t a = h.find_first_not_of(' ', field("fortran_order"));
+    v.fortran = a != std::string::npos && h.compare(a, 4, "True") == 0;
+  }
+  {
+    const size_t a = h.find('(', field("shape"));
+    const size_t b = a == std::string::npos ? a : h.find(')', a);
+    if (a == std::string::npos || b == std::string::npos) throw ConfigError(what + ": .npy header has no shape");
+    std::string sh = h.substr(a + 1, b - a - 1);
+    for (char& c : sh)
       if (c == ',') c = ' ';
-    std::istringstream is(s);
-    size_t d;
-    while (is >> d) v.shape.push_back(d);
+    std::istringstream is(sh);
+    unsigned long long d;
+    size_t total = 1;
+    while (is >> d) {
+      // (a shape whose product does not fit the file is caught below; one that overflows size_t here)
+      if (d != 0 && total > (size_t)-1 / (size_t)d) throw ConfigError(what + ": .npy shape overflows");
+      total *= (size_t)d;
+      v.shape.push_back((size_t)d);
+    }
+    if (v.shape.size() > 8) throw ConfigError(what + ": .npy shape has too many dimensions");
   }
   v.data = p + hoff + hlen;
   v.nbytes = n - hoff - hlen;
@@ -347,8 +366,11 @@ inline void npy_to_float(const NpyView& v, float* out, size_t stride, const std:
   }
   const char kind = d[1];
   const int width = std::atoi(d.c_str() + 2);
+  if (width != 1 && width != 2 && width != 4 && width != 8) {
+    throw ConfigError(what + ": dtype " + d + " is not supported (int / float / double / bool only)");
+  }
   const size_t n = v.count();
-  if (v.nbytes < n * (size_t)width) throw ConfigError(what + ": truncated data");
+  if (n > v.nbytes / (size_t)width) throw ConfigError(what + ": truncated data");
   const unsigned char* p = v.data;
   for (size_t i = 0; i < n; i++, p += width) {
     float f;
@@ -401,35 +423,45 @@ inline std::vector<ZipMember> zip_members(const unsigned char* z, size_t n, cons
   uint64_t count = le16(z + eocd + 10), cd_off = le32(z + eocd + 16);
   if ((count == 0xFFFF || cd_off == 0xFFFFFFFFu) && eocd >= 20 && le32(z + eocd - 20) == 0x07064b50u) {
     const uint64_t z64 = le64(z + eocd - 20 + 8);   // zip64 end-of-central-directory record
-    if (z64 + 56 > n || le32(z + z64) != 0x06064b50u) throw ConfigError(what + ": bad zip64 record");
+    if (z64 > n || n - z64 < 56 || le32(z + z64) != 0x06064b50u) throw ConfigError(what + ": bad zip64 record");
     count = le64(z + z64 + 32);
     cd_off = le64(z + z64 + 48);
   }
   std::vector<ZipMember> out;
+  if (cd_off > n) throw ConfigError(what + ": bad ZIP central directory offset");
   size_t p = (size_t)cd_off;
   for (uint64_t k = 0; k < count; k++) {
-    if (p + 46 > n || le32(z + p) != 0x02014b50u) throw ConfigError(what + ": bad ZIP central directory");
+    if (n - p < 46 || le32(z + p) != 0x02014b50u) throw ConfigError(what + ": bad ZIP central directory");
     const unsigned method = le16(z + p + 10);
     uint64_t csize = le32(z + p + 20), usize = le32(z + p + 24), lho = le32(z + p + 42);
     const size_t nlen = le16(z + p + 28), xlen = le16(z + p + 30), clen = le16(z + p + 32);
+    if (p + 46 + nlen + xlen + clen > n) throw ConfigError(what + ": ZIP central directory entry runs past the end of the file");
     ZipMember m;
     m.name.assign((const char*)z + p + 46, nlen);
     // zip64 extra field: the values that did not fit, in this order
-    for (size_t x = p + 46 + nlen; x + 4 <= p + 46 + nlen + xlen;) {
+    const size_t xend = p + 46 + nlen + xlen;
+    for (size_t x = p + 46 + nlen; x + 4 <= xend;) {
       const unsigned id = le16(z + x), len = le16(z + x + 2);
+      if (x + 4 + len > xend) throw ConfigError(what + ": bad ZIP extra field");
       if (id == 0x0001) {
         size_t q = x + 4;
-        if (usize == 0xFFFFFFFFu) { usize = le64(z + q); q += 8; }
-        if (csize == 0xFFFFFFFFu) { csize = le64(z + q); q += 8; }
-        if (lho == 0xFFFFFFFFu) { lho = le64(z + q); q += 8; }
+        const size_t qend = x + 4 + len;
+        auto take = [&](uint64_t& v) {
+          if (q + 8 > qend) throw ConfigError(what + ": truncated zip64 extra field");
+          v = le64(z + q);
+          q += 8;
+        };
+        if (usize == 0xFFFFFFFFu) take(usize);
+        if (csize == 0xFFFFFFFFu) take(csize);
+        if (lho == 0xFFFFFFFFu) take(lho);
       }
       x += 4 + len;
     }
     if (method != 0) throw ConfigError(what + ": member " + m.name + " is compressed (write it with numpy.savez, not savez_compressed)");
-    if (lho + 30 > n || le32(z + lho) != 0x04034b50u) throw ConfigError(what + ": bad ZIP local header");
+    if (lho > n || n - lho < 30 || le32(z + lho) != 0x04034b50u) throw ConfigError(what + ": bad ZIP local header");
     m.offset = (size_t)lho + 30 + le16(z + lho + 26) + le16(z + lho + 28);
     m.size = (size_t)usize;
-    if (m.offset + m.size > n) throw ConfigError(what + ": member " + m.name + " runs past the end of the file");
+    if (m.offset > n || m.size > n - m.offset) throw ConfigError(what + ": member " + m.name + " runs past the end of the file");
     (void)csize;
     out.push_back(m);
     p += 46 + nlen + xlen + clen;

@@ -243,7 +243,7 @@ def test_cpp_json_reader_accepts_what_the_reference_accepts(tmp_path):
     (tmp_path / "bad.json").write_text('{"a": {"x": 1 "y": 2}}')
     r = subprocess.run([DUMP_ASAN, "--json", str(tmp_path / "bad.json")], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "missing ',' or '}' in object declaration" in r.stderr and "line 1" in r.stderr
-    for bad in ('{"a": [1, 2}', '{"a": "unterminated}', '{"a": 1} trailing', '/* open', ''):
+    for bad in ('{"a": [1, 2}', '{"a": "unterminated}', '{"a": 1} trailing', '/* open', '', "[" * 100000, '{"a":' * 5000):
         (tmp_path / "bad.json").write_text(bad)
         r = subprocess.run([DUMP_ASAN, "--json", str(tmp_path / "bad.json")], capture_output=True, text=True, env=env)
         assert r.returncode == 1 and "JSON parse error" in r.stderr, bad
@@ -287,3 +287,53 @@ def test_cpp_table_reader_rejects_what_it_cannot_read(tmp_path):
     assert r.returncode == 0, r.stderr
     t = json.loads(r.stdout)["signals"][0]["table"]
     assert t["rows"] == 3                      # radius 10 passes (bounds inclusive), 10.5 does not
+
+
+def test_cpp_input_layer_survives_damaged_files_under_asan(tmp_path):
+    """Byte-level damage to a valid configuration and to valid .npz / .npy tables (truncation, flipped bytes, overwritten
+    length fields): sxmc::load_config must either load or refuse with a message -- under AddressSanitizer +
+    UndefinedBehaviorSanitizer never read out of bounds, overflow or crash."""
+    if not os.path.exists(DUMP_ASAN):
+        pytest.skip("tests/cpp is not built")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1")
+    rng = np.random.default_rng(99)
+    cfg = json.loads(io.strip_comments(EXAMPLE))
+    good = dict(energy=np.linspace(5, 15, 64).astype(np.float32), radius=np.linspace(0, 12, 64), mc_energy=np.arange(64))
+    np.savez(tmp_path / "b.npz", **good)
+    np.savez(tmp_path / "a.npz", **good)
+    (tmp_path / "fit.json").write_text(json.dumps(cfg))
+    r = subprocess.run([DUMP_ASAN, str(tmp_path / "fit.json")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    pristine = {"fit.json": (tmp_path / "fit.json").read_bytes(), "a.npz": (tmp_path / "a.npz").read_bytes()}
+    np.save(tmp_path / "a.npy", np.arange(30, dtype=np.float32).reshape(10, 3))
+    pristine["a.npy"] = (tmp_path / "a.npy").read_bytes()
+    outcomes = {0: 0, 1: 0}
+    for trial in range(240):
+        name = ("fit.json", "a.npz", "a.npy")[trial % 3]
+        data = bytearray(pristine[name])
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            data = data[: rng.integers(0, len(data))]                       # truncated
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 6))):
+                data[rng.integers(0, len(data))] = rng.integers(0, 256)     # flipped bytes
+        elif kind == 2:
+            at = rng.integers(0, max(1, len(data) - 8))
+            data[at:at + 4] = (0xFFFFFFFF if rng.integers(0, 2) else int(rng.integers(0, 1 << 31))).to_bytes(4, "little")
+        else:
+            at = rng.integers(0, len(data))
+            data[at:at] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))   # inserted bytes
+        for k, v in pristine.items():
+            (tmp_path / k).write_bytes(bytes(data) if k == name else v)
+        if name == "a.npy":          # (the .npy is only read when the configuration points at it)
+            c2 = json.loads(pristine["fit.json"])
+            c2["signals"]["sig_a"].update(filename="a.npy", fields=["energy", "radius", "mc_energy"])
+            (tmp_path / "fit.json").write_text(json.dumps(c2))
+        r = subprocess.run([DUMP_ASAN, str(tmp_path / "fit.json")], capture_output=True, text=True, env=env, timeout=60,
+                           errors="replace")      # (a damaged file's bytes may come back in the message)
+        assert r.returncode in (0, 1), (trial, name, kind, r.returncode, r.stderr[-1500:])
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (trial, name, kind, r.stderr[-1500:])
+        if r.returncode == 1:
+            assert r.stderr.startswith("config_dump: ")                      # refused with a message
+        outcomes[r.returncode] += 1
+    assert outcomes[1] > 60 and outcomes[0] > 5, outcomes       # most damage is noticed; harmless damage still loads
