@@ -745,22 +745,27 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
     };
     load(vfirst < v1 ? vfirst : vlast);
 
+    // The host sends this kernel only geometries whose bin counts AND strides are below 2^23 (sxmc_hip.cpp:
+    // group_rebuild, `narrow`), so idx * stride + bin is ONE v_mad_i32_i24 (24-bit signed operands, 32-bit result);
+    // round 2 formed it from two 24-bit products of a split stride: 5 vector instructions per observable and sample.
     double lo[NOBS], hi[NOBS], sc[NOBS];
-    int sth[NOBS], stl[NOBS];
+    int stv[NOBS];
     unsigned nb[NOBS];
 #pragma unroll
     for (int k = 0; k < NOBS; k++) {
       lo[k] = d.lower[k];
       hi[k] = d.upper[k];
       sc[k] = d.scale[k];
-      sth[k] = d.bin_stride[k] >> 12;
-      stl[k] = d.bin_stride[k] & 4095;
+      stv[k] = d.bin_stride[k];
+      asm volatile("" : "+v"(stv[k]));   // (in a vector register: the multiply-add takes one scalar operand)
       nb[k] = (unsigned)d.nbins[k];
     }
 
     // ordered observable: geometry, and the codes of the wave's next 64 granules (one per lane)
     const double olo = d.lower[ORDERED ? NOBS : 0], ohi = d.upper[ORDERED ? NOBS : 0], osc = d.scale[ORDERED ? NOBS : 0];
-    const int osth = d.bin_stride[ORDERED ? NOBS : 0] >> 12, ostl = d.bin_stride[ORDERED ? NOBS : 0] & 4095;
+    const int ost = d.bin_stride[ORDERED ? NOBS : 0];
+    int ostv = ost;
+    asm volatile("" : "+v"(ostv));
     const unsigned onb = (unsigned)d.nbins[ORDERED ? NOBS : 0];
     gptr<const vfloat2> edges = to_global(reinterpret_cast<const vfloat2*>(d.edges));
     const unsigned long long vwave = v0 + (tid - lane);
@@ -807,7 +812,7 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
           // (an index equal to nbins -- one ulp below the upper edge -- aliases into the next row of the flat
           // index: such granules take the per-sample path, which knows how to deal with it)
           const bool mixedg = nan || e0 != e1 || (!outside && (unsigned)e0 >= onb);
-          const unsigned cst = (unsigned)((__mul24(e0, osth) << 12) + __mul24(e0, ostl));
+          const unsigned cst = (unsigned)__mul24(e0, ost);
           codes = !live ? kOrdSkip : mixedg ? kOrdMixed : outside ? kOrdSkip : cst;
         }
         code = (unsigned)__builtin_amdgcn_readlane((int)codes, j);
@@ -880,40 +885,38 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
         run_static<NSLOT>(f, craw, PROG{}, Seq{});
       }
 
-      const unsigned dead = (v < v1) ? 0u : 1u;
+      // The per-sample part, written for the vector unit's instruction count (this kernel is co-bound by vector issue
+      // and the stream): domain tests are compares into scalar mask registers combined on the scalar unit (NaN
+      // fails), the in-domain count is an add-with-carry from that mask.  pdfz.cpp:388-398.
+      const bool live = v < v1;   // lanes past the end of the slice hold clamped duplicates
       unsigned p2[SXMC_VEC];
       bool fast[SXMC_VEC], slow[SXMC_VEC];
       const bool table_here = cur_info <= SXMC_SPARSE_SMAX_LOG2;
       const bool all_slow = cur_info == SXMC_SPARSE_SLOW;
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
-        unsigned bad = dead, alias = 0u;
+        bool ind = live, alias = false;
         int bin = (ORDERED && !mixed) ? (int)code : 0;
         if (mixed) {
           const double x = f[ORD][q];
-          bad += !(x >= olo) ? 1u : 0u;
-          bad += !(x < ohi) ? 1u : 0u;
+          ind = ind & (x >= olo) & (x < ohi);
           const int idx = (int)((x - olo) * osc);
-          alias += ((unsigned)idx >= onb) ? 1u : 0u;
-          bin += (__mul24(idx, osth) << 12) + __mul24(idx, ostl);
+          alias = alias | ((unsigned)idx >= onb);
+          bin = mad24(idx, ostv, bin);
         }
 #pragma unroll
         for (int k = 0; k < NOBS; k++) {
           const double x = f[k][q];
-          bad += !(x >= lo[k]) ? 1u : 0u;
-          bad += !(x < hi[k]) ? 1u : 0u;
+          ind = ind & (x >= lo[k]) & (x < hi[k]);
           const int idx = (int)((x - lo[k]) * sc[k]);
-          alias += ((unsigned)idx >= nb[k]) ? 1u : 0u;
-          // idx * stride without the quarter-rate 32-bit multiply: two 24-bit ones (the host sends this kernel only
-          // problems with fewer than 2^23 bins per observable; what a sample outside the domain gives is not used)
-          bin += (__mul24(idx, sth[k]) << 12) + __mul24(idx, stl[k]);
+          alias = alias | ((unsigned)idx >= nb[k]);   // (one ulp below the upper edge the index can come out as nbins)
+          bin = mad24(idx, stv[k], bin);              // (what a sample outside the domain gives is not used)
         }
-        const bool in_domain = bad == 0u;
-        cnt += in_domain ? 1u : 0u;
+        cnt += ind ? 1u : 0u;
         p2[q] = (unsigned)bin;
-        const bool count_it = in_domain && !(dbg & 4u);
-        fast[q] = count_it && table_here && alias == 0u;
-        slow[q] = count_it && (all_slow || alias != 0u);
+        const bool count_it = ind && !(dbg & 4u);
+        fast[q] = count_it && table_here && !alias;
+        slow[q] = count_it && (all_slow || alias);
       }
       if (table_here) {
         // The table is cut into cells of four keys (one 16-byte LDS read); a key sits in its home cell or, when

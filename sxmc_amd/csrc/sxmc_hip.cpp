@@ -821,8 +821,10 @@ int group_rebuild(sxmc_group* g) {
       plans[(size_t)i].fields = fields;
       bucketed = true;
       // histograms beyond LDS, evaluated at data events: per-wave runs + event bins grouped by bucket
-      bool narrow = true;   // (the runs kernel forms idx * stride from 24-bit products)
-      for (int k = 0; k < h->nobs; k++) narrow = narrow && h->nbins[(size_t)k] < (1 << 23);
+      bool narrow = true;   // (the runs kernel forms idx * stride + bin with ONE signed 24-bit multiply-add)
+      for (int k = 0; k < h->nobs; k++) {
+        narrow = narrow && h->nbins[(size_t)k] < (1 << 23) && h->stride[(size_t)k] < (1 << 23);
+      }
       runs_mode = !lds_hist && narrow && h->has_points && h->d_table &&
                   have_kernel(cd.nobs, cd.nslot, prew, 1, prog2, sp, &rtc_sparse);
       if (runs_mode) {
@@ -845,7 +847,9 @@ int group_rebuild(sxmc_group* g) {
       // (a histogram beyond LDS: only with the event-bin counters over runs; the round-1 filter path of a table
       // left in sorted order has no ordered form)
       bool narrow_o = true;
-      for (int k = 0; k < h->nobs; k++) narrow_o = narrow_o && h->nbins[(size_t)k] < (1 << 23);
+      for (int k = 0; k < h->nobs; k++) {
+        narrow_o = narrow_o && h->nbins[(size_t)k] < (1 << 23) && h->stride[(size_t)k] < (1 << 23);
+      }
       const bool beyond_ok = !lds_hist && !g->order_blocked && narrow_o && h->has_points && h->d_table && n <= props.cus;
       if (g->cfg_order && ((lds_hist && h->total_nbins < (1 << 24)) || beyond_ok)) {
         for (int k = 0; k < d.nobs; k++) {

@@ -676,7 +676,7 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
       std::vector<Signal> mine;
       float *d_send = nullptr, *d_recv = nullptr;
       sxmc_stream_t strm = nullptr;
-      SetupLock& exclusive = locks[devices[r]];
+      SetupLock& exclusive = locks.find(devices[r])->second;   // (every key exists; find does not modify the map)
       std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());
       bool ok = true;
       const Clock::time_point t0 = Clock::now();

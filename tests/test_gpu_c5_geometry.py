@@ -135,3 +135,52 @@ def test_c5_real_geometry_walk_forms_agree(c5, sparse):
     assert np.array_equal(chain[:, :-1], want_chain[:, :-1])
     assert np.allclose(chain[:, -1], want_chain[:, -1], rtol=1e-6, atol=0)
     close_chain(m)
+
+
+def test_strides_beyond_24_bits_take_the_general_path():
+    """fill_sparse_kernel forms idx * stride + bin with ONE signed 24-bit multiply-add; the host sends it only geometries
+    whose bin counts and strides are below 2^23.  100 x 2900 x 2900 bins (8.4e8, a 3.4 GB dense histogram): the first
+    observable's stride is 8 410 000 >= 2^23, so the plan must NOT use the runs kernel -- and the lookup values,
+    normalisations and the NLL must still be the oracle's."""
+    rng = np.random.default_rng(77)
+    nb, lower, upper = [100, 2900, 2900], [0.0, 0.0, -1.0], [10.0, 6.0, 1.0]
+    signals = []
+    for j in range(2):
+        n = 300_001
+        e_true = rng.normal(4.0 + j, 1.5, n)
+        tab = np.stack([e_true + rng.normal(0, 0.3, n), 6.0 * rng.uniform(size=n) ** (1 / 3), rng.uniform(-1, 1, n),
+                        e_true, np.zeros(n)], axis=1).astype(np.float32)
+        signals.append(workloads.Signal(tab, 5, nexpected=500.0 + 100 * j, source_id=j))
+    ev = workloads._events_from_mixture(rng, signals, 3, 20000, None, None)
+    ev[::19, 1] = 7.0                                    # outside the domain
+    w = workloads.Workload("wide-strides", 3, lower, upper, nb, signals, workloads.C3_SYSTS, workloads.C3_SIGMAS, ev,
+                           "strides beyond 2^23")
+    geom = oracle.HistGeometry(lower, upper, nb)
+    assert geom.total_nbins == 841_000_000
+    m = MCMC(w, seed=4, fused=True)
+    m.setup(sync_interval=8)
+    info = m.group.LaunchInfo()
+    assert "hist=global" in info and "+runs" not in info, info
+    proposal = m.proposed_vector.get()
+    m.step(debug_mode=True)
+    rows, nacc = m.flush()
+    want, _, norms, lut = oracle_at(w, geom, proposal, keep_bins=False)
+    assert np.array_equal(m.normalizations.get(), norms)
+    assert np.array_equal(m.lut.get().view(np.uint32), lut.ravel().view(np.uint32))
+    got = m.proposed_nll.get()[0]
+    assert abs(got - want) <= 1e-12 * abs(want), (got, want)
+    close_chain(m)
+    # the same table with 8 x fewer bins in the last observable: strides fit again, the runs kernel is back
+    w2 = workloads.Workload("narrow-strides", 3, lower, upper, [100, 2900, 360], signals, workloads.C3_SYSTS,
+                            workloads.C3_SIGMAS, ev, "strides below 2^23")
+    m2 = MCMC(w2, seed=4, fused=True)
+    m2.setup(sync_interval=8)
+    assert "+runs" in m2.group.LaunchInfo(), m2.group.LaunchInfo()
+    proposal = m2.proposed_vector.get()
+    m2.step(debug_mode=True)
+    m2.flush()
+    geom2 = oracle.HistGeometry(lower, upper, [100, 2900, 360])
+    want, _, norms, lut = oracle_at(w2, geom2, proposal, keep_bins=False)
+    assert np.array_equal(m2.normalizations.get(), norms)
+    assert np.array_equal(m2.lut.get().view(np.uint32), lut.ravel().view(np.uint32))
+    close_chain(m2)
