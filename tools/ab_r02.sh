@@ -1,6 +1,10 @@
 #!/bin/bash
-# Runs ON the GPU box: the headline (config 3) from the round-2 tree (build/r02tree, exported with git archive) and
-# from this tree, alternating on the same box: is the fill as fast as it was?
+# Runs ON the GPU box: the headline (config 3) from the round-2 tree and from this tree, alternating on the same box:
+# is the fill as fast as it was?  The old tree is exported and built first, in the container (build/ is git-ignored
+# but travels with gpurun):
+#   mkdir -p build/r02tree && git archive 6ca6f10 | tar -x -C build/r02tree && make -C build/r02tree/sxmc_amd/csrc
+#   make -C build/r02tree/oracle
+# Result of round 3 (gpurun_out/r3g): old 125.1 / 132.2 us, new 131.9 / 130.4 us -- unchanged within the run-to-run spread.
 set -o pipefail
 OUT=$PWD/gpurun_out/$1; mkdir -p $OUT
 ARGS="--steps 400 --warmup 50 --also none --experiments 0 --no-cpu-baseline"
