@@ -626,7 +626,7 @@ def cpp_multi_gpu_record(args, ngpus, collective):
     extra = [] if collective["backend"] == "nccl" else ["--host-staging"]
     lines, failure = run_bench_cpp(["--scale", args.scale, "--no-walk", "--graph-steps", args.graph_steps,
                                     "--experiments", nexp, "--exp-steps", args.exp_steps, "--chains", 4, "--sets", 2,
-                                    "--device-list", devices] + extra, 900)
+                                    "--device-list", devices] + extra, 300)
     if failure:
         return failure
     rec = lines[-1]
