@@ -33,6 +33,14 @@ dist.all_gather_into_tensor(out, torch.arange(4, dtype=torch.float32, device="cu
 torch.cuda.synchronize()
 assert want[1] == got[1] and np.array_equal(want[0], got[0])
 assert out.cpu().tolist() == [0.0, 1.0, 2.0, 3.0]
+# bench.py at N > 1 also makes a communicator through the C ABI (librccl) inside this torch process, beside torch's
+# own: the id travels over the process group (sxmc_amd.dist.RcclComm), the rank count is asked of the communicator
+from sxmc_amd import dist as sd
+comm = sd.RcclComm()
+assert comm.query() == (0, 1, 0)
+block = np.arange(60, dtype=np.float32)
+assert np.array_equal(comm.allgather_f32(block), block.reshape(1, 60))
+comm.close()
 dist.destroy_process_group()
 print("rccl-graph-ok")
 """
