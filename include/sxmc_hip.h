@@ -63,6 +63,9 @@ int sxmc_set_device(int device);
 /* name: at least 256 bytes. */
 int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes,
                      int* lds_bytes_per_cu, int* clock_khz);
+/* Host-side roctx ranges around the phases of a step (launch plan, fill, step end, SetEvalPoints, graph replay), for
+ * rocprofv3 --marker-trace beside --kernel-trace.  Off by default; SXMC_ROCTX=1 in the environment turns them on too. */
+int sxmc_set_tracing(int enable);
 int sxmc_device_synchronize(void);
 /* PCI bus id of a device ("0000:05:00.0"): tells two ranks on ONE card from two ranks on two cards of the same name. */
 int sxmc_device_pci_bus_id(int device, char* out, size_t out_bytes);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "sxmc_device_count": [_pi],
     "sxmc_set_device": [_i],
     "sxmc_device_info": [_i, C.c_char_p, _pi, _psz, _pi, _pi],
+    "sxmc_set_tracing": [_i],
     "sxmc_device_synchronize": [],
     "sxmc_device_pci_bus_id": [_i, C.c_char_p, _sz],
     "sxmc_mem_info": [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +15,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include "sxmc_device.h"
 #include "sxmc_plan.h"
@@ -47,6 +50,31 @@ int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+
+// Host-side roctx ranges around the phases of a step (tracing): what rocprofv3 --marker-trace
+// shows beside the kernel trace.  Off unless SXMC_ROCTX=1 is in the environment or sxmc_set_tracing(1) was called: a
+// step makes three of them, and config 2's step is 21 us.
+std::atomic<int> g_tracing{-1};
+inline bool tracing() {
+  int t = g_tracing.load(std::memory_order_relaxed);
+  if (t < 0) {
+    const char* e = std::getenv("SXMC_ROCTX");
+    t = (e && e[0] && e[0] != '0') ? 1 : 0;
+    g_tracing.store(t, std::memory_order_relaxed);
+  }
+  return t > 0;
+}
+struct TraceRange {
+  bool on;
+  explicit TraceRange(const char* name) : on(tracing()) {
+    if (on) roctxRangePushA(name);
+  }
+  ~TraceRange() {
+    if (on) roctxRangePop();
+  }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
 
 #define SX_HIP(expr)                                                                        \
   do {                                                                                      \
@@ -674,6 +702,7 @@ void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, int no
 }
 
 int group_rebuild(sxmc_group* g) {
+  TraceRange trace("sxmc: launch plan (tables, partitions, kernels)");
   // Descriptors may still be read by kernels in flight on another stream: rebuilds are rare
   // (bindings change only during setup), so a device-wide sync is the simple safe choice.
   SX_HIP(hipDeviceSynchronize());
@@ -1331,6 +1360,7 @@ int group_prepare_fill(sxmc_group* g, hipStream_t s, bool sparse) {
 }
 
 int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
+  TraceRange trace("sxmc: fill (EvalHist of all signals)");
   sparse = sparse && g->sparse_ready && g->cfg_sparse;
   int rc = group_prepare_fill(g, s, sparse);
   if (rc) return rc;
@@ -1385,6 +1415,11 @@ int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_byt
   if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
   if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
   if (clock_khz) *clock_khz = prop.clockRate;
+  return SXMC_OK;
+}
+
+int sxmc_set_tracing(int enable) {
+  g_tracing.store(enable ? 1 : 0, std::memory_order_relaxed);
   return SXMC_OK;
 }
 
@@ -1512,6 +1547,7 @@ int sxmc_graph_end_capture(sxmc_stream_t s, sxmc_graph_t* out) {
   return SXMC_OK;
 }
 int sxmc_graph_launch(sxmc_graph_t graph, sxmc_stream_t s, int times) {
+  TraceRange trace("sxmc: graph replay");
   SX_REQUIRE(graph, "null graph");
   SX_REQUIRE(times >= 0, "negative repeat count");
   for (int i = 0; i < times; i++) SX_HIP(hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)s));
@@ -1733,6 +1769,7 @@ int sxmc_hist_add_systematic(sxmc_hist_t h, int type, int obs, int extra_field, 
 }
 
 int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints_floats) {
+  TraceRange trace("sxmc: SetEvalPoints");
   SX_REQUIRE(h, "null evaluator");
   const size_t row = (size_t)h->nobs + 1;
   SX_REQUIRE(npoints_floats % row == 0,
@@ -2269,6 +2306,7 @@ int step_sum_blocks(unsigned long long ne) {
 
 int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDesc* descs, unsigned long long ne,
                     const unsigned* weight, const SxStepArgs& a) {
+  TraceRange trace("sxmc: step end (lookup + event sum, finish_nll_jump_pick_combo + clearing)");
   // How much the end of the step has to touch decides its shape.  One workgroup doing all of it in one launch
   // saves a launch and a boundary, but a row costs S double divisions and a log: measured at BASELINE config 3
   // (~8000 rows x 12 members) one CU needs 59 us for what ~60 workgroups + the step-end launch do in 15.6 us, and
@@ -2461,6 +2499,7 @@ int sxmc_multigroup_destroy(sxmc_multigroup_t mg) {
 }
 
 int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args) {
+  TraceRange trace("sxmc: lockstep step (one fill pass for the set's chains + their step ends)");
   SX_REQUIRE(mg && args, "null argument");
   hipStream_t st = (hipStream_t)s;
   const size_t C = mg->groups.size();
@@ -2558,6 +2597,7 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
 // bound to a->d_v_proposed / a->d_norms), groups[1] the look-ahead vector (bound to d_v_lookahead / d_norms_lookahead).
 int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* a,
                                          double* d_v_lookahead, const unsigned* d_norms_lookahead, const int* d_cap) {
+  TraceRange trace("sxmc: look-ahead pass (two evaluations, one or two steps)");
   SX_REQUIRE(mg && a && d_v_lookahead && d_norms_lookahead, "null argument");
   SX_REQUIRE(mg->groups.size() == 2, "the look-ahead walk steps exactly two groups: the proposal's and the look-ahead's");
   SX_REQUIRE(a->d_means && a->d_sigmas && a->d_rng && a->d_nll_current && a->d_nll_proposed && a->d_v_current &&
