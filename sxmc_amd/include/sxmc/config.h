@@ -557,6 +557,100 @@ inline std::vector<float> read_dataset_to_samples(const std::vector<float>& data
   return out;
 }
 
+// ------------------------------------------------------------------------------------------------ chain output
+namespace detail {
+inline uint32_t crc32(const unsigned char* p, size_t n) {   // (ZIP's CRC-32, reflected 0xEDB88320)
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    ready = true;
+  }
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+inline void put16(std::string& o, unsigned v) {
+  o.push_back((char)(v & 0xFF));
+  o.push_back((char)((v >> 8) & 0xFF));
+}
+inline void put32(std::string& o, uint32_t v) {
+  put16(o, v & 0xFFFFu);
+  put16(o, v >> 16);
+}
+}  // namespace detail
+
+/** The "ls" ntuple of one experiment (sxmc.cpp:130-141, mcmc.cpp:100-114: one column per parameter + "likelihood"),
+ *  ROOT-free: an .npz with one 1-D float32 array per column -- what numpy.load and sxmc_amd/io.py read
+ *  (`write_chain` there writes the same).  names.size() columns, rows.size() / names.size() rows, row-major. */
+inline void write_chain_npz(const std::string& path, const std::vector<std::string>& names, const std::vector<float>& rows) {
+  const size_t ncol = names.size(), nrow = ncol ? rows.size() / ncol : 0;
+  if (ncol == 0 || nrow * ncol != rows.size()) throw ConfigError("write_chain_npz: rows are not a multiple of the columns");
+  std::string zip, central;
+  for (size_t c = 0; c < ncol; c++) {
+    // one .npy image per column: magic, version 1.0, header padded so that the data starts on a multiple of 64
+    std::string dict = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(nrow) + ",), }";
+    while ((10 + dict.size() + 1) % 64 != 0) dict.push_back(' ');
+    dict.push_back('\n');
+    std::string npy = "\x93NUMPY";
+    npy.push_back('\x01');
+    npy.push_back('\x00');
+    detail::put16(npy, (unsigned)dict.size());
+    npy += dict;
+    const size_t at = npy.size();
+    npy.resize(at + 4 * nrow);
+    for (size_t r = 0; r < nrow; r++) std::memcpy(&npy[at + 4 * r], &rows[r * ncol + c], 4);
+    if (npy.size() > 0xFFFFFFF0ull) throw ConfigError("write_chain_npz: a column beyond 4 GB");
+    const std::string fname = names[c] + ".npy";
+    const uint32_t crc = detail::crc32((const unsigned char*)npy.data(), npy.size()), size = (uint32_t)npy.size();
+    const uint32_t offset = (uint32_t)zip.size();
+    auto header = [&](std::string& o, bool is_central) {
+      detail::put32(o, is_central ? 0x02014b50u : 0x04034b50u);
+      if (is_central) detail::put16(o, 20);   // version made by
+      detail::put16(o, 20);                    // version needed
+      detail::put16(o, 0);                     // flags
+      detail::put16(o, 0);                     // method: stored
+      detail::put16(o, 0);                     // time
+      detail::put16(o, 0x21);                  // date: 1980-01-01
+      detail::put32(o, crc);
+      detail::put32(o, size);
+      detail::put32(o, size);
+      detail::put16(o, (unsigned)fname.size());
+      detail::put16(o, 0);                     // extra length
+      if (is_central) {
+        detail::put16(o, 0);                   // comment length
+        detail::put16(o, 0);                   // disk number
+        detail::put16(o, 0);                   // internal attributes
+        detail::put32(o, 0);                   // external attributes
+        detail::put32(o, offset);
+      }
+      o += fname;
+    };
+    header(zip, false);
+    zip += npy;
+    header(central, true);
+    if (zip.size() > 0xFFFFFFF0ull) throw ConfigError("write_chain_npz: archive beyond 4 GB");
+  }
+  const uint32_t cd_off = (uint32_t)zip.size(), cd_size = (uint32_t)central.size();
+  zip += central;
+  detail::put32(zip, 0x06054b50u);
+  detail::put16(zip, 0);
+  detail::put16(zip, 0);
+  detail::put16(zip, (unsigned)ncol);
+  detail::put16(zip, (unsigned)ncol);
+  detail::put32(zip, cd_size);
+  detail::put32(zip, cd_off);
+  detail::put16(zip, 0);
+  std::ofstream f(path.c_str(), std::ios::binary);
+  if (!f) throw ConfigError("cannot write " + path);
+  f.write(zip.data(), (std::streamsize)zip.size());
+  if (!f) throw ConfigError("short write to " + path);
+}
+
 // ------------------------------------------------------------------------------------------------ FitConfig
 /** What FitConfig::FitConfig (config.cpp:19-297) extracts, with every signal's table loaded and cut
  *  (Signal::Signal, signal.cpp:11-47): all that build_pdfz / ensemble / ensemble_multi_gpu take. */

@@ -348,6 +348,15 @@ inline std::vector<float> make_fake_dataset(std::mt19937_64& rng, std::vector<Si
   return events;
 }
 
+/** sxmc.cpp:130-141 writes every experiment's sampled likelihood space ("ls") to <output_prefix>_<i>.root.  Set this to
+ *  receive the chains (experiment index, chain) -- e.g. to write them with write_chain_npz (config.h).  Called on the
+ *  experiment's own host thread; calls are serialised.  Empty by default: chains are dropped once their intervals are
+ *  taken. */
+inline std::function<void(unsigned, const Chain&)>& chain_sink() {
+  static std::function<void(unsigned, const Chain&)> sink;
+  return sink;
+}
+
 struct ExperimentResult {
   unsigned index = 0;
   std::vector<Interval> intervals;  //!< one per parameter
@@ -392,6 +401,11 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   if (exclusive) lock.lock();
   mcmc.reset();
   if (exclusive) lock.unlock();
+  if (chain_sink()) {
+    static std::mutex sink_mutex;
+    std::lock_guard<std::mutex> guard(sink_mutex);
+    chain_sink()(k, chain);
+  }
   ExperimentResult r;
   r.index = k;
   r.intervals = extract_intervals(chain, cl, error_type);

@@ -6,12 +6,14 @@
 //
 //   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk]
 //             [--experiments 0] [--exp-steps 2000] [--chains 4] [--sets 2]
-//             [--devices G | --device-list 0,0] [--host-staging] [--config fit.json]
+//             [--devices G | --device-list 0,0] [--host-staging] [--config fit.json] [--output-dir d]
 //
 // --devices G: the ensemble leg runs on devices 0..G-1 through ensemble_multi_gpu (needs --experiments).
 // --host-staging: the blocks meet through host memory instead of RCCL (rehearsal of G ranks on fewer cards).
 // --config: signals, observables, systematics, rates and sample tables come from a fit configuration
 //   (sxmc::load_config, the reference's JSON schema: config.cpp:19-297) instead of the synthetic C3 generator.
+// --output-dir: every experiment's chain is written to <d>/<output_prefix>_<k>.npz (one float32 column per parameter
+//   + "likelihood": the "ls" ntuple of sxmc.cpp:130-141, readable by numpy.load and sxmc_amd/io.py).
 // Synthetic inputs as SURVEY.md 8(d) C3 describes them (not bit-identical to bench.py's generator).
 #include <chrono>
 #include <cstdio>
@@ -33,6 +35,7 @@ struct Options {
   std::vector<int> devices;
   bool host_staging = false;
   std::string config;
+  std::string output_dir;   // every experiment's chain as <output_dir>/<prefix>_<k>.npz (sxmc.cpp:130-141)
 };
 
 std::vector<int> parse_list(const char* s) {
@@ -67,6 +70,7 @@ Options parse(int argc, char** argv) {
     } else if (a == "--device-list") o.devices = parse_list(next());
     else if (a == "--host-staging") o.host_staging = true;
     else if (a == "--config") o.config = next();
+    else if (a == "--output-dir") o.output_dir = next();
     else throw std::runtime_error("unknown argument " + a);
   }
   return o;
@@ -101,6 +105,7 @@ static int run(int argc, char** argv) {
   unsigned long long base_seed = 77;
   float burnin = 0.1f, cl = 0.9f;
   sxmc::ErrorType error_type = sxmc::ERROR_CONTOUR;
+  std::string output_prefix = "lspace";
   Options run_opt = o;
 
   if (!o.config.empty()) {
@@ -120,6 +125,7 @@ static int run(int argc, char** argv) {
     burnin = fc.burnin_fraction;
     cl = fc.confidence;
     error_type = fc.error_type == "projection" ? sxmc::ERROR_PROJECTION : sxmc::ERROR_CONTOUR;
+    output_prefix = fc.output_prefix;
     if (fc.seed) base_seed = fc.seed;
     if (run_opt.nexp == 0) run_opt.nexp = fc.nexperiments;
     run_opt.esteps = fc.nsteps;
@@ -192,6 +198,12 @@ static int run(int argc, char** argv) {
   }
   const Options& opt = run_opt;
   const bool multi = !opt.devices.empty();
+  if (!opt.output_dir.empty()) {
+    const std::string stem = opt.output_dir + "/" + output_prefix + "_";
+    sxmc::chain_sink() = [stem](unsigned k, const sxmc::Chain& chain) {
+      sxmc::write_chain_npz(stem + std::to_string(k) + ".npz", chain.names, chain.rows);
+    };
+  }
   size_t rows_total = 0;
   for (const std::vector<float>& t : tabs) rows_total += t.size() / F;
 

@@ -71,8 +71,16 @@ int main(int argc, char** argv) {
       std::putchar('\n');
       return 0;
     }
+    if (argc == 4 && std::string(argv[1]) == "--rewrite") {
+      // read_table + write_chain_npz: the table of argv[2] written again, column by column, to argv[3]
+      std::vector<float> m;
+      std::vector<std::string> fields;
+      sxmc::read_table(argv[2], m, fields);
+      sxmc::write_chain_npz(argv[3], fields, m);
+      return 0;
+    }
     if (argc != 2) {
-      std::fprintf(stderr, "usage: config_dump <config.json>\n");
+      std::fprintf(stderr, "usage: config_dump <config.json> | --json <file> | --rewrite <in.npz> <out.npz>\n");
       return 2;
     }
     const sxmc::FitConfig fc = sxmc::load_config(argv[1]);

@@ -124,7 +124,8 @@ def test_cpp_bench_driver_from_a_fit_configuration(tmp_path):
     (tmp_path / "fit.json").write_text(FIT)
     exe = os.path.join(ROOT, "tests", "cpp", "bench_cpp")
     outs = []
-    for extra in (["--devices", "1"], ["--device-list", "0,0", "--host-staging"]):
+    (tmp_path / "out").mkdir()
+    for extra in (["--devices", "1", "--output-dir", str(tmp_path / "out")], ["--device-list", "0,0", "--host-staging"]):
         r = subprocess.run([exe, "--config", str(tmp_path / "fit.json"), "--chains", "2", "--sets", "1", "--graph-steps", "8"]
                            + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -135,6 +136,12 @@ def test_cpp_bench_driver_from_a_fit_configuration(tmp_path):
         outs.append(lines[-1])
         assert lines[-1]["experiments"] == 3 and lines[-1]["steps_each"] == 400
         assert lines[-1]["gathered_floats"] == 3 * (3 + 3) * 4   # 3 sources (bkg, bkg_a, sig) + 3 systematic parameters
+    # --output-dir: every experiment's chain as <prefix>_<k>.npz, columns = parameter names + likelihood (sxmc.cpp:130-141)
+    for k in range(3):
+        with np.load(tmp_path / "out" / ("lspace_%d.npz" % k)) as z:
+            assert list(z.files) == ["bkg_a", "bkg", "sig", "e_scale_0", "r_shift_0", "e_res_0", "likelihood"]
+            assert z["likelihood"].shape == z["sig"].shape and 100 < z["sig"].shape[0] <= 400
+            assert np.all(np.isfinite(z["likelihood"]))
     assert outs[0]["rccl_nranks"] == 1 and outs[1]["ranks"] == 2
     assert outs[0]["median_upper_limit_source0"] == outs[1]["median_upper_limit_source0"]
     # a configuration the batched drivers cannot take is refused with the reason, not walked wrongly

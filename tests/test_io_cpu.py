@@ -337,3 +337,36 @@ def test_cpp_input_layer_survives_damaged_files_under_asan(tmp_path):
             assert r.stderr.startswith("config_dump: ")                      # refused with a message
         outcomes[r.returncode] += 1
     assert outcomes[1] > 60 and outcomes[0] > 5, outcomes       # most damage is noticed; harmless damage still loads
+
+
+def test_cpp_chain_files_are_read_by_numpy_and_by_the_python_layer(tmp_path):
+    """sxmc::write_chain_npz (the "ls" ntuple of sxmc.cpp:130-141 without ROOT): numpy.load verifies every member's
+    CRC-32, so a clean load of identical columns says the archive is a well-formed .npz; and the C++ reader reads back
+    what the C++ writer wrote."""
+    if not os.path.exists(DUMP_ASAN):
+        pytest.skip("tests/cpp is not built")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    rng = np.random.default_rng(4)
+    names = ["source_a", "bkg", "e_scale_0", "likelihood"]
+    chain = rng.normal(size=(1237, 4)).astype(np.float32)
+    io.write_chain(tmp_path / "py.npz", names, chain)
+    r = subprocess.run([DUMP_ASAN, "--rewrite", str(tmp_path / "py.npz"), str(tmp_path / "cpp.npz")], capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    with np.load(tmp_path / "cpp.npz") as z:
+        assert list(z.files) == names
+        for i, n in enumerate(names):
+            assert z[n].dtype == np.float32 and np.array_equal(z[n], chain[:, i])
+    got, fields = io.read_table(tmp_path / "cpp.npz")
+    assert fields == names and np.array_equal(got, chain)
+    r = subprocess.run([DUMP_ASAN, "--rewrite", str(tmp_path / "cpp.npz"), str(tmp_path / "cpp2.npz")], capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "cpp2.npz").read_bytes() == (tmp_path / "cpp.npz").read_bytes()
+    # an empty chain (no kept rows) is still a valid file
+    io.write_chain(tmp_path / "e.npz", names, np.zeros((0, 4), np.float32))
+    r = subprocess.run([DUMP_ASAN, "--rewrite", str(tmp_path / "e.npz"), str(tmp_path / "e2.npz")], capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    with np.load(tmp_path / "e2.npz") as z:
+        assert z["likelihood"].shape == (0,)
