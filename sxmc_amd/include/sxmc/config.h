@@ -663,6 +663,7 @@ struct FitConfig {
   long long seed = 0;
   float confidence = 0.683f;
   std::string signal_name;
+  std::string samples;   //!< fit.samples: a saved chain to take the intervals from INSTEAD of walking (sxmc.cpp:84-94)
   std::vector<Observable> observables, cuts;
   std::vector<Systematic> systematics;            //!< union over the signals, parameters numbered in that order
   std::vector<Source> sources;
@@ -768,6 +769,7 @@ inline FitConfig parse_config(const std::string& text, const std::string& base_d
   fc.seed = fit.isMember("seed") ? fit["seed"].asInt("seed") : 0;
   fc.confidence = (float)fit.get("confidence", 0.683);
   fc.signal_name = fit.get("signal_name", "");
+  fc.samples = fit.get("samples", "");   // config.cpp:51
 
   // observables and cuts (config.cpp:77-95)
   for (const json::Value& v : fit["observables"].items) {

@@ -357,6 +357,19 @@ inline std::function<void(unsigned, const Chain&)>& chain_sink() {
   return sink;
 }
 
+/** A chain from a table of columns (parameter names..., "likelihood"): what read_table (config.h) returns for a file
+ *  written by write_chain_npz / sxmc_amd/io.py -- the `fit.samples` path of sxmc.cpp:84-94, where a saved likelihood
+ *  space replaces the walk. */
+inline Chain chain_from_table(const std::vector<float>& matrix, const std::vector<std::string>& fields) {
+  if (fields.empty() || fields.back() != "likelihood" || matrix.size() % fields.size() != 0 || matrix.empty()) {
+    throw pdfz::Error("a saved chain needs at least one row and \"likelihood\" as its last column");
+  }
+  Chain c;
+  c.names = fields;
+  c.rows = matrix;
+  return c;
+}
+
 struct ExperimentResult {
   unsigned index = 0;
   std::vector<Interval> intervals;  //!< one per parameter

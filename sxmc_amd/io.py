@@ -11,8 +11,8 @@
                                                        + "likelihood"; here an .npz with the same columns
 
 Config parsing and file formats are not compute; they exist so that a fit described in the reference's
-schema can be run end to end (run_config).  Plots, the `fit.samples` reload path and ROOT files are not
-supported.
+schema can be run end to end (run_config; `fit.samples` re-loads a saved chain instead of walking, as sxmc.cpp:84-94
+does).  Plots and ROOT files are not supported.
 """
 import json
 import os
@@ -122,6 +122,7 @@ def load_config(path_or_text, base_dir=None):
     fc.seed = int(fit.get("seed", 0))
     fc.confidence = float(np.float32(fit.get("confidence", 0.683)))
     fc.signal_name = fit.get("signal_name", "")
+    fc.samples = fit.get("samples", "")      # config.cpp:51: a saved chain to use INSTEAD of walking (sxmc.cpp:84-94)
 
     def observable(name):
         c = obs_params[name]
@@ -262,8 +263,18 @@ def run_config(path, out_dir=None, nexperiments=None, nsteps=None):
     (or the configured data sets), MCMC, contour intervals; chains written as <prefix>_<i>.npz.
     Returns (intervals [nexp, P, 4], limits of fit.signal_name, parameter names)."""
     from . import ensemble
-    from .mcmc import MCMC
     fc = load_config(path)
+    if fc.samples:                                               # sxmc.cpp:84-94: no walk, the saved likelihood space
+        chain, names = read_table(os.path.join(fc.base_dir, fc.samples))
+        assert names and names[-1] == "likelihood" and chain.shape[0] > 0
+        if fc.error_type == "projection":
+            iv = np.array([ensemble.projection_interval(chain[:, p], fc.confidence)[:4] for p in range(len(names) - 1)],
+                          np.float32)
+        else:
+            iv = ensemble.contour_intervals(chain, fc.confidence)
+        limits = [float(iv[names.index(fc.signal_name), 2])] if fc.signal_name in names[:-1] else []
+        return iv[None], limits, names
+    from .mcmc import MCMC
     w = build_workload(fc)
     m = MCMC(w, seed=fc.seed & 0xFFFFFFFF, fused=True, lut_output=False, consume=True)
     nexp = nexperiments or fc.nexperiments

@@ -110,7 +110,25 @@ static int run(int argc, char** argv) {
 
   if (!o.config.empty()) {
     // ---- inputs from a fit configuration: the reference's control file + ROOT-free sample tables
-    sxmc::FitConfig fc = sxmc::load_config(o.config);
+    sxmc::FitConfig fc = sxmc::load_config(o.config, /*load_tables=*/false);
+    if (fc.samples.empty()) fc = sxmc::load_config(o.config);
+    if (!fc.samples.empty()) {
+      // fit.samples (sxmc.cpp:84-94): a saved chain replaces the walk -- the intervals are taken from it and that is all
+      std::vector<float> m;
+      std::vector<std::string> fields;
+      sxmc::read_table(sxmc::detail::join_path(fc.base_dir, fc.samples), m, fields);
+      const sxmc::Chain chain = sxmc::chain_from_table(m, fields);
+      const std::vector<sxmc::Interval> iv = sxmc::extract_intervals(
+          chain, fc.confidence, fc.error_type == "projection" ? sxmc::ERROR_PROJECTION : sxmc::ERROR_CONTOUR);
+      std::printf("{\"driver\": \"fit.samples (C++)\", \"samples\": \"%s\", \"rows\": %zu, \"error_type\": \"%s\", "
+                  "\"intervals\": {", fc.samples.c_str(), chain.nrows(), fc.error_type.c_str());
+      for (size_t p = 0; p < iv.size(); p++) {
+        std::printf("%s\"%s\": [%.9g, %.9g, %.9g]", p ? ", " : "", chain.names[p].c_str(), (double)iv[p].point_estimate,
+                    (double)iv[p].lower, (double)iv[p].upper);
+      }
+      std::printf("}}\n");
+      return 0;
+    }
     if (!sxmc::same_systematics_everywhere(fc)) {
       throw std::runtime_error("the batched drivers (one launch for all signals) need every signal to list every "
                                "systematic of the fit, in the same order");

@@ -370,3 +370,29 @@ def test_cpp_chain_files_are_read_by_numpy_and_by_the_python_layer(tmp_path):
     assert r.returncode == 0, r.stderr
     with np.load(tmp_path / "e2.npz") as z:
         assert z["likelihood"].shape == (0,)
+
+
+def test_fit_samples_reloads_a_saved_chain_instead_of_walking(tmp_path):
+    """fit.samples (config.cpp:51, sxmc.cpp:84-94): the intervals come from a saved likelihood space, no walk, no
+    device -- in Python (io.run_config) and in C++ (bench_cpp --config), same numbers."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bench_cpp")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp is not built")
+    from tests.test_intervals import synthetic_chain
+    chain = synthetic_chain(3, 3000, -348086.3)
+    names = ["sig_a", "shared", "energy_scale_0", "energy_resolution_0", "likelihood"]
+    io.write_chain(tmp_path / "saved.npz", names, chain)
+    for error_type in ("contour", "projection"):
+        cfg = json.loads(io.strip_comments(EXAMPLE))
+        cfg["fit"].update(samples="saved.npz", signal_name="shared", error_type=error_type)
+        (tmp_path / "fit.json").write_text(json.dumps(cfg))
+        iv, limits, nm = io.run_config(str(tmp_path / "fit.json"))
+        assert nm == names and iv.shape == (1, 4, 4) and limits == [float(iv[0, 1, 2])]
+        r = subprocess.run([exe, "--config", str(tmp_path / "fit.json")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        rec = json.loads(r.stdout)
+        assert rec["rows"] == 3000 and rec["error_type"] == error_type
+        for p, n in enumerate(names[:-1]):
+            got = rec["intervals"][n]
+            assert np.float32(got[1]) == iv[0, p, 1] and np.float32(got[2]) == iv[0, p, 2]       # limits: bit for bit
+            assert abs(got[0] - iv[0, p, 0]) <= 2e-6 * max(abs(iv[0, p, 0]), float(np.ptp(chain[:, p])))
