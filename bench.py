@@ -809,7 +809,9 @@ def main():
         # ---- the same experiments with the chains in LOCKSTEP sets: one fill pass per step for the chains of a set
         lockstep = None
         L = args.exp_lockstep
-        if L >= 2 and form is True and len(mine) >= L:
+        # (decided from what EVERY rank holds -- the smallest share -- so that all ranks take the same path through the
+        # barriers below, whatever --experiments is)
+        if L >= 2 and form is True and nexp // world >= L:
             from sxmc_amd.mcmc import LockstepChains
             nsets = max(1, args.exp_sets)
             sets = []
