@@ -213,6 +213,10 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads);
  * contiguous slice of the concatenated members), 2 = interleaved (each member's workgroups stride
  * through it chunk by chunk, like a grid-stride copy). */
 int sxmc_group_set_partition(sxmc_group_t g, int mode);
+/* Interleaved partition of a BUCKETED table (rows sorted by bin): a member's workgroups split into `teams` teams, each
+ * over a contiguous part of the member (so a workgroup sees a fraction of the bins and flushes as few).  0 = default
+ * (one team); sxmc_group_optimize tries three on the box it runs on.  Results never depend on it. */
+int sxmc_group_set_partition_teams(sxmc_group_t g, int teams);
 /* Sparse counting (default on): a histogram too large for LDS (more than 40 832 bins) costs one scattered
  * HBM atomic per sample plus zeroing the whole array, yet an evaluation for lookup (do_eval_pdf != 0, the
  * fused evaluations, the MCMC step) reads it only at the data events' bins.  Such evaluations count into one

@@ -103,6 +103,7 @@ SIGNATURES = {
     "sxmc_group_set_launch_config": [_vp, _i, _i],
     "sxmc_group_optimize": [_vp, _vp, _pi],
     "sxmc_group_set_partition": [_vp, _i],
+    "sxmc_group_set_partition_teams": [_vp, _i],
     "sxmc_group_set_sparse": [_vp, _i],
     "sxmc_group_set_prebinning": [_vp, _i],
     "sxmc_group_set_bucketing": [_vp, _i],

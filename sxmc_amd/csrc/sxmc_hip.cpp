@@ -264,6 +264,7 @@ struct LaunchClass {
   int partition = 0;  // 1 sliced, 2 interleaved (what build_partition chose)
   bool light = false; // a pure stream: runs best with few waves per CU (see group_rebuild)
   bool runs_mode = false;  // bucketed tables laid out in per-wave runs; the sparse flavour runs fill_sparse_kernel
+  int teams = 1;           // teams of workgroups per member over a bucketed table (sxplan::interleaved_segments)
 };
 
 void free_class(LaunchClass& c) {
@@ -291,8 +292,8 @@ void interleaved_segments(const std::vector<SxSignalDesc>& descs, const std::vec
 }
 void build_partition(const std::vector<SxSignalDesc>& descs, int grid, int threads, int want_mode,
                      std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off, int& mode_out,
-                     unsigned long long align = 1) {
-  sxplan::build_partition(unit_counts(descs), grid, threads, want_mode, segs, blk_off, mode_out, align);
+                     unsigned long long align = 1, int groups = 1) {
+  sxplan::build_partition(unit_counts(descs), grid, threads, want_mode, segs, blk_off, mode_out, align, groups);
 }
 }  // namespace
 
@@ -310,6 +311,7 @@ struct sxmc_group {
   int cfg_threads = 0, cfg_bpc = 0;
   int cfg_seen_threads = -1, cfg_seen_bpc = -1;
   int cfg_partition = 0, cfg_seen_partition = -1;  // 0 auto, 1 sliced, 2 interleaved
+  int cfg_teams = 0, cfg_seen_teams = -1;          // teams per member over a bucketed table (0 = 1, the default)
   int cfg_prebin = 1, cfg_seen_prebin = -1;        // pre-bin the observables no systematic writes
   int cfg_bucket = 1, cfg_seen_bucket = -1;        // stream a bucketed copy of the table where that pays
   bool order_blocked = false;                      // a plan with ordered tables beyond LDS could not be laid out in runs
@@ -1181,7 +1183,22 @@ int group_rebuild(sxmc_group* g) {
         interleaved_segments(descs, K, threads, c.shape.grid, segs, blk_off);
         c.partition = 2;
       } else {
-        build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition, bucketed ? 64 : 1);
+        // Bucketed tables are sorted by bin, so a member's workgroups can work as TEAMS over contiguous parts of it
+        // (sxplan::interleaved_segments): a workgroup of a team of 7 sees a third of the histogram's bins, and the
+        // flush -- one memory-side atomic per non-zero bin of every workgroup, 1.3 M per launch at config 3 -- sends
+        // a third of the atomics, against a coarser interleaving of the stream.  Which wins depends on the BOX
+        // (tools/part_groups_sweep.sh, profiles/r03_c3_teams_sweep.log: 3 teams 129.4 us against 133.4-134.4 on one,
+        // 128.4 against 124.9 on another, each consistently over alternating runs), so the default is one team and
+        // sxmc_group_optimize tries three on the box it runs on (SXMC_PART_GROUPS forces a count for A/B runs).
+        static const int forced_groups = [] {
+          const char* e = std::getenv("SXMC_PART_GROUPS");
+          return e ? std::atoi(e) : 0;
+        }();
+        const int groups = (bucketed && c.shape.lds_hist)
+                               ? (forced_groups > 0 ? forced_groups : std::max(1, g->cfg_teams)) : 1;
+        c.teams = groups;
+        build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition, bucketed ? 64 : 1,
+                        groups);
       }
       SX_HIP(hipMalloc((void**)&c.d_segs, sizeof(SxSegment) * std::max<size_t>(segs.size(), 1)));
       SX_HIP(hipMalloc((void**)&c.d_blk_off, sizeof(unsigned) * blk_off.size()));
@@ -1201,6 +1218,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_threads = g->cfg_threads;
   g->cfg_seen_bpc = g->cfg_bpc;
   g->cfg_seen_partition = g->cfg_partition;
+  g->cfg_seen_teams = g->cfg_teams;
   g->cfg_seen_prebin = g->cfg_prebin;
   g->cfg_seen_bucket = g->cfg_bucket;
   g->cfg_seen_order = g->cfg_order;
@@ -1238,7 +1256,8 @@ int group_update_points(sxmc_group* g) {
 
 int group_refresh(sxmc_group* g) {
   bool stale = !g->built || g->cfg_seen_threads != g->cfg_threads || g->cfg_seen_bpc != g->cfg_bpc ||
-               g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_prebin != g->cfg_prebin ||
+               g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_teams != g->cfg_teams ||
+               g->cfg_seen_prebin != g->cfg_prebin ||
                g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc ||
                g->cfg_seen_order != g->cfg_order;
   bool points = false;
@@ -2039,14 +2058,45 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
       best_ms = ms;
     }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   // the default shape is what 0, 0 means: keep the configuration "automatic" when it won
   g->cfg_threads = (failure == SXMC_OK && best_threads != 512) ? best_threads : 0;
   g->cfg_bpc = (failure == SXMC_OK && best_threads != 512) ? 1 : 0;
+  // second choice, for bucketed tables: one team of workgroups per member or three (see group_rebuild: which is
+  // faster differs from box to box by ~3 % either way); three must win by 1.5 % to be taken
+  bool has_bucketed = false;
+  for (const LaunchClass& c : g->classes) has_bucketed = has_bucketed || ((c.shape.pre_width == 3 || c.shape.pre_width == 5) && c.shape.lds_hist);
+  if (failure == SXMC_OK && has_bucketed && g->cfg_teams == 0) {
+    float ms_of[2] = {best_ms, 1e30f};
+    for (int pass = 0; pass < 2 && failure == SXMC_OK; pass++) {
+      g->cfg_teams = pass == 0 ? 0 : 3;
+      if ((failure = group_refresh(g)) != SXMC_OK) break;
+      float ms = 1e30f;
+      for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {
+        hipError_t e = hipEventRecord(e0, st);
+        if (e == hipSuccess) failure = group_fill(g, st, false);
+        if (failure == SXMC_OK && e == hipSuccess) e = hipEventRecord(e1, st);
+        if (failure == SXMC_OK && e == hipSuccess) e = hipEventSynchronize(e1);
+        float t = 0;
+        if (failure == SXMC_OK && e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (failure == SXMC_OK && e != hipSuccess) failure = fail(SXMC_ERR_HIP, std::string("optimize: ") + hipGetErrorString(e));
+        if (rep > 0 && t < ms) ms = t;
+      }
+      ms_of[pass] = ms;
+    }
+    g->cfg_teams = (failure == SXMC_OK && ms_of[1] < 0.985f * ms_of[0]) ? 3 : 0;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   if (failure != SXMC_OK) return failure;
   if (chosen_threads) *chosen_threads = best_threads;
   return group_refresh(g);
+}
+
+int sxmc_group_set_partition_teams(sxmc_group_t g, int teams) {
+  SX_REQUIRE(g, "null group");
+  SX_REQUIRE(teams >= 0 && teams <= 64, "teams must be 0 (default: one) to 64");
+  g->cfg_teams = teams;
+  return SXMC_OK;
 }
 
 int sxmc_group_set_partition(sxmc_group_t g, int mode) {
@@ -2096,11 +2146,11 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
     char line[512];
     const char* kind = c.shape.rtc_fill ? "runtime" : c.shape.static_prog >= 0 ? "builtin" : c.shape.nobs ? "decoded" : "generic";
     std::snprintf(line, sizeof line,
-                  "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d loads=%s\n",
+                  "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d teams=%d\n",
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
                   c.shape.pre_width == 5 ? "ordered" : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
-                  c.shape.grid, c.partition, "nt");
+                  c.shape.grid, c.partition, c.teams);
     text += line;
   }
   if (!g->rtc_note.empty()) text += "runtime specialisation failed: " + g->rtc_note.substr(0, 300) + "\n";

@@ -66,19 +66,40 @@ inline bool apportion_workgroups(const std::vector<unsigned long long>& sizes, i
 }
 
 // Workgroup i of member j takes chunks i, i + K_j, ... of `threads` units of the member (nvec[j] units).
+// groups > 1 (tables whose rows are SORTED by bin -- bucketed copies): the member's workgroups are split into `groups`
+// teams, team t takes a contiguous part of the member (sized by its share of the workgroups, cut at multiples of
+// `threads` units) and interleaves inside it.  Neighbouring workgroups of a team still read neighbouring chunks at
+// the same time (DRAM locality), but a workgroup now sees only its team's part of the sorted order, i.e. a fraction
+// of the histogram's bins -- and the flush sends one memory-side atomic per NON-ZERO bin of every workgroup.
 inline void interleaved_segments(const std::vector<unsigned long long>& nvec, const std::vector<int>& K, int threads,
-                                 int grid, std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off) {
+                                 int grid, std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off,
+                                 int groups = 1) {
   segs.clear();
   blk_off.assign(1, 0u);
   for (size_t j = 0; j < nvec.size(); j++) {
-    for (int i = 0; i < K[j]; i++) {
-      SxSegment sg{};
-      sg.sig = (int)j;
-      sg.v0 = (unsigned long long)i * threads;
-      sg.v1 = nvec[j];
-      sg.step = (unsigned long long)K[j] * threads;
-      segs.push_back(sg);
-      blk_off.push_back((unsigned)segs.size());
+    const int Kj = K[j];
+    if (Kj <= 0) continue;
+    const int G = std::max(1, std::min(groups, Kj));
+    const unsigned long long chunks = (nvec[j] + (unsigned long long)threads - 1) / (unsigned long long)threads;
+    int wg0 = 0;
+    unsigned long long chunk0 = 0;
+    for (int t = 0; t < G; t++) {
+      const int wg1 = (int)((long long)Kj * (t + 1) / G);                     // workgroups [wg0, wg1) form team t
+      const unsigned long long chunk1 = t + 1 == G ? chunks : chunks * (unsigned long long)wg1 / (unsigned long long)Kj;
+      const int Kt = wg1 - wg0;
+      for (int i = 0; i < Kt; i++) {
+        SxSegment sg{};
+        sg.sig = (int)j;
+        sg.v0 = (chunk0 + (unsigned long long)i) * (unsigned long long)threads;
+        sg.v1 = std::min(nvec[j], chunk1 * (unsigned long long)threads);
+        sg.step = (unsigned long long)Kt * (unsigned long long)threads;
+        // (a team with more workgroups than chunks: the spare ones get nothing -- an empty list, not an empty segment,
+        // because the kernels clamp loads to v1 - 1)
+        if (sg.v0 < sg.v1) segs.push_back(sg);
+        blk_off.push_back((unsigned)segs.size());
+      }
+      wg0 = wg1;
+      chunk0 = chunk1;
     }
   }
   while ((int)blk_off.size() < grid + 1) blk_off.push_back((unsigned)segs.size());  // idle workgroups
@@ -88,7 +109,7 @@ inline void interleaved_segments(const std::vector<unsigned long long>& nvec, co
 // `align` units (bucketed tables: granule boundaries; every member's unit count is then a multiple of it).
 inline void build_partition(const std::vector<unsigned long long>& nvec, int grid, int threads, int want_mode,
                             std::vector<SxSegment>& segs, std::vector<unsigned>& blk_off, int& mode_out,
-                            unsigned long long align = 1) {
+                            unsigned long long align = 1, int groups = 1) {
   segs.clear();
   blk_off.assign(1, 0u);
   unsigned long long total = 0;
@@ -103,7 +124,7 @@ inline void build_partition(const std::vector<unsigned long long>& nvec, int gri
   std::vector<int> K;
   if (interleave) interleave = apportion_workgroups(nvec, grid, threads, K);  // false: more members than workgroups
   if (interleave) {
-    interleaved_segments(nvec, K, threads, grid, segs, blk_off);
+    interleaved_segments(nvec, K, threads, grid, segs, blk_off, groups);
     mode_out = 2;
     return;
   }

@@ -85,6 +85,10 @@ class EvalGroup:
         """0 automatic, 1 sliced, 2 interleaved (see include/sxmc_hip.h)."""
         capi.call("sxmc_group_set_partition", self._g, int(mode))
 
+    def SetPartitionTeams(self, teams):
+        """Teams of workgroups per member over a bucketed table (0 = default, one; see include/sxmc_hip.h)."""
+        capi.call("sxmc_group_set_partition_teams", self._g, int(teams))
+
     def SetSparse(self, enable):
         """Count only the event bins when a histogram beyond LDS capacity is evaluated for lookup (default on)."""
         capi.call("sxmc_group_set_sparse", self._g, int(bool(enable)))

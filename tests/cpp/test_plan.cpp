@@ -84,6 +84,14 @@ TEST(Plan, PartitionsCoverEveryUnitExactlyOnce) {
         // every workgroup reads ONE member: one histogram flush per workgroup
         for (int wg = 0; wg < grid; wg++) EXPECT_TRUE(blk_off[(size_t)wg + 1] - blk_off[(size_t)wg] <= 1u);
       }
+      // teams of workgroups over contiguous parts of a member (tables sorted by bin)
+      for (int groups : {2, 3, 7, 50}) {
+        sxplan::build_partition(nvec, grid, threads, mode, segs, blk_off, built, align, groups);
+        replay_partition(nvec, grid, threads, segs, blk_off, built == 2 ? std::min<unsigned long long>(align, 64) : align);
+        if (built == 2) {
+          for (int wg = 0; wg < grid; wg++) EXPECT_TRUE(blk_off[(size_t)wg + 1] - blk_off[(size_t)wg] <= 1u);
+        }
+      }
     }
   }
 }

@@ -64,6 +64,21 @@ def test_ordered_observable_gives_identical_histograms(name, nobs, nbins, systs,
                 group.EvalFinished()
                 results.append(([e.GetBins() for e in evs], norms.get(), group.AlgorithmicBytes()["fill_read"]))
         group.SetPartition(0)
+        # teams of workgroups over contiguous parts of the sorted table (what sxmc_group_optimize may choose): the
+        # same counts, whatever the team count (ordered + bucketed forms)
+        group.SetPartition(2)
+        for order in (True, False):
+            group.SetOrdering(order, force=True)
+            group.SetBucketing(True)
+            for teams in (3, 7, 64):
+                group.SetPartitionTeams(teams)
+                if order and teams == 3:
+                    assert "teams=3" in group.LaunchInfo() or "partition=1" in group.LaunchInfo()
+                group.EvalAsync(False)
+                group.EvalFinished()
+                results.append(([e.GetBins() for e in evs], norms.get(), 0.0))
+        group.SetPartitionTeams(0)
+        group.SetPartition(0)
         assert results[0][2] < results[3][2] <= results[4][2]          # fewer bytes to stream
         for j, t in enumerate(tabs):
             o = oracle_eval(t, nfields, [0.0] * nobs, [1.0] * nobs, nbins, systs, params)
