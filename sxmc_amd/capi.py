@@ -125,6 +125,7 @@ SIGNATURES = {
     "sxmc_multigroup_create": [_vp, _i, _pvp],
     "sxmc_multigroup_destroy": [_vp],
     "sxmc_multigroup_step_async": [_vp, _vp, _vp],
+    "sxmc_multigroup_set_joint_step_end": [_vp, C.c_int],
     "sxmc_multigroup_lookahead_step_async": [_vp, _vp, _vp, _vp, _vp, _vp],
     "sxmc_lookahead_begin": [_vp, _i, _vp, _vp, _vp, _vp],
     "sxmc_group_lookahead_supported": [_vp, _pi],

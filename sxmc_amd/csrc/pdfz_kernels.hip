@@ -489,6 +489,46 @@ __global__ __launch_bounds__(256) void finish_zero_kernel(const SxSignalDesc* __
   if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
 }
 
+// LOCKSTEP SETS: the step ends of all chains of a set in two launches instead of two per chain.  The chains have
+// their own events (event classes, weights), parameter vectors, generators and jump buffers, so nothing is shared
+// but the launch: chain = blockIdx.y, and inside a chain every workgroup does exactly what it does in
+// eval_nll_kernel / finish_zero_kernel launched for that chain alone (same blocks of the event sum, same order of
+// the partial sums) -- the chains stay bit-identical to chains stepped one at a time.  These kernels are a few
+// microseconds of memory latency each; C chains cost the latency once instead of C times.
+__global__ __launch_bounds__(256) void eval_nll_chains_kernel(SxChainEnds e, int nsig) {
+  extern __shared__ double sh[];
+  const SxChainEnd& c = e.c[blockIdx.y];
+  if (blockIdx.x >= c.nblocks) return;   // (uniform: a chain with fewer rows than the set's largest)
+  const double t = eval_nll_block_part(c.lookup_descs, nsig, c.nrows, c.weight, c.a.v_proposed, c.a.nexpected, c.a.n_mc,
+                                       c.a.source_id, c.a.norms, sh, blockIdx.x, c.nblocks);
+  if (threadIdx.x == 0 && !isnan(t)) c.sums[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void finish_zero_chains_kernel(SxChainEnds e, int nsig, unsigned zblocks) {
+  const SxChainEnd& c = e.c[blockIdx.y];
+  const SxStepArgs& a = c.a;
+  if (blockIdx.x == 0) {
+    sxdev::finish_step_device(c.nblocks, c.sums, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                              a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                              a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
+                              a.debug_mode != 0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nsig; j += blockDim.x) *c.hist_descs[j].norm = 0u;
+    if (threadIdx.x == 0 && c.ticket) *c.ticket = 0u;
+    return;
+  }
+  const unsigned b = blockIdx.x - 1u;
+  const SxSignalDesc& d = c.hist_descs[b / zblocks];
+  const unsigned chunk = b % zblocks;
+  unsigned* bins = d.bins;
+  const unsigned n = (unsigned)d.total_nbins;
+  const unsigned n4 = n >> 2;
+  uint4* b4 = reinterpret_cast<uint4*>(bins);
+  const unsigned stride = zblocks * blockDim.x;
+  for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
+}
+
 // ------------------------------------------------------------------------------------ pre-binning
 // Builds the pre-binned column of one evaluator: for every sample, sum_k idx_k * stride_k over the
 // observables in `mask` with the fill kernel's arithmetic (pdfz.cpp:388-398), or all ones when one of
@@ -901,6 +941,21 @@ hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(finish_zero_kernel, dim3(1 + (unsigned)zb * (unsigned)nsig), dim3(block), 0, s, d_descs, nsig,
                      (unsigned)zb, npartial, sums, ticket, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_chain_ends(const SxChainEnds& e, int nchains, int nsig, int max_bins, int block, hipStream_t s) {
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
+  unsigned widest = 1;
+  for (int c = 0; c < nchains; c++) widest = e.c[c].nblocks > widest ? e.c[c].nblocks : widest;
+  hipLaunchKernelGGL(eval_nll_chains_kernel, dim3(widest, (unsigned)nchains), dim3(block), shmem, s, e, nsig);
+  hipError_t rc = hipGetLastError();
+  if (rc != hipSuccess) return rc;
+  int zb = (max_bins / 4 + block - 1) / block;
+  if (zb < 1) zb = 1;
+  if (zb > 1024) zb = 1024;
+  hipLaunchKernelGGL(finish_zero_chains_kernel, dim3(1 + (unsigned)zb * (unsigned)nsig, (unsigned)nchains), dim3(block), 0,
+                     s, e, nsig, (unsigned)zb);
   return hipGetLastError();
 }
 

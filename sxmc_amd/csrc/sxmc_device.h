@@ -33,6 +33,23 @@ struct SxStepArgs {
   const unsigned* norms;
 };
 
+// The step ends of the chains of a lockstep set, launched together (sxmc_multigroup_step_async): per chain what
+// eval_nll_kernel and finish_zero_kernel take.  Passed by value (kernel argument); the chain is blockIdx.y.
+#define SXMC_MAX_LOCKSTEP 4
+struct SxChainEnd {
+  const SxSignalDesc* lookup_descs;  // the rows the event sum runs over (event classes, or the events themselves)
+  const SxSignalDesc* hist_descs;    // the chain's histograms and normalisations (cleared for the next evaluation)
+  unsigned long long nrows;
+  const unsigned* weight;            // events per row, or null
+  double* sums;                      // nblocks partial event sums
+  unsigned* ticket;
+  unsigned nblocks;                  // workgroups of this chain's event sum (step_sum_blocks: as in its sequential step)
+  SxStepArgs a;
+};
+struct SxChainEnds {
+  SxChainEnd c[SXMC_MAX_LOCKSTEP];
+};
+
 // Host-callable launchers implemented in the .hip files -------------------------------------
 struct SxLaunchShape {
   int nobs;
@@ -79,6 +96,7 @@ hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, cons
                          void* ev_start = nullptr, void* ev_stop = nullptr);
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
+hipError_t sx_launch_chain_ends(const SxChainEnds& e, int nchains, int nsig, int max_bins, int block, hipStream_t s);
 hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,
                                  const double* sums, unsigned* ticket, const SxStepArgs& a, int block, hipStream_t s);
 hipError_t sx_launch_eval_nll_finish(const SxSignalDesc* d_descs, int nsig, unsigned long long npoints,

@@ -2452,6 +2452,7 @@ struct sxmc_multigroup {
   std::vector<unsigned> fill_w;          // the kernels' layout argument: words per histogram, or the ordered fill's replica layout
   std::vector<unsigned long long> seen;  // the groups' plan generations the kernels were chosen for
   std::string why_not;               // set when the chains cannot be stepped together
+  bool joint_ends = true;            // the chains' step ends share two launches (sx_launch_chain_ends)
 };
 
 namespace {
@@ -2539,6 +2540,7 @@ int sxmc_multigroup_create(const sxmc_group_t* groups, int ngroups, sxmc_multigr
   for (int i = 0; i < ngroups; i++) SX_REQUIRE(groups[i], "null group");
   sxmc_multigroup* mg = new sxmc_multigroup;
   mg->groups.assign(groups, groups + ngroups);
+  if (const char* e = std::getenv("SXMC_JOINT_STEP_END")) mg->joint_ends = std::atoi(e) != 0;   // (A/B runs of whole programs)
   *out = mg;
   return SXMC_OK;
 }
@@ -2603,7 +2605,15 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
                                rec ? (void*)g0->ev0[g0->prof_n] : nullptr, rec ? (void*)g0->ev1[g0->prof_n] : nullptr));
     if (rec) g0->prof_n++;
   }
-  // every chain's own step end
+  // every chain's own step end -- in two launches for the whole set where every chain's end has the two-launch form
+  // (the chains then pay the kernels' latency once, not C times), else chain by chain
+  bool joint = mg->joint_ends;
+  for (size_t c = 0; c < C && joint; c++) {
+    const sxmc_group* g = mg->groups[c];
+    joint = g->max_bins == g0->max_bins &&
+            !step_end_takes_tail(g, false, g->cfg_lut ? g->members[0]->npoints : g->ec[0].K);
+  }
+  SxChainEnds ends{};
   for (size_t c = 0; c < C; c++) {
     sxmc_group* g = mg->groups[c];
     const sxmc_step_args& p = args[c];
@@ -2637,9 +2647,34 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
     a.n_mc = p.d_n_mc;
     a.source_id = p.d_source_id;
     a.norms = p.d_norms;
+    if (joint) {
+      SxChainEnd& e = ends.c[c];
+      e.lookup_descs = descs;
+      e.hist_descs = g->d_descs;
+      e.nrows = ne;
+      e.weight = weight;
+      e.sums = g->d_step_sums;
+      e.ticket = g->d_ticket;
+      e.nblocks = (unsigned)step_sum_blocks(ne);
+      e.a = a;
+      g->last_step_launches += 2;
+      g->prezeroed = 1;
+      for (sxmc_hist* h : g->members) {
+        h->bins_valid = false;
+        h->cleared_by = g;
+      }
+      continue;
+    }
     int rc = group_step_tail(g, st, false, descs, ne, weight, a);
     if (rc) return rc;
   }
+  if (joint) SX_HIP(sx_launch_chain_ends(ends, (int)C, (int)g0->members.size(), g0->max_bins, 128, st));
+  return SXMC_OK;
+}
+
+int sxmc_multigroup_set_joint_step_end(sxmc_multigroup_t mg, int enable) {
+  SX_REQUIRE(mg, "null multigroup");
+  mg->joint_ends = enable != 0;
   return SXMC_OK;
 }
 

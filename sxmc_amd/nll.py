@@ -220,6 +220,11 @@ class MultiGroup:
         self._mg = mg
         self._args = (capi.StepArgs * len(self.chains))()
 
+    def SetJointStepEnd(self, enable):
+        """False: the chains' step ends are launched chain by chain instead of two launches for the set (the chains are
+        the same either way; measurement / tests)."""
+        capi.call("sxmc_multigroup_set_joint_step_end", self._mg, int(bool(enable)))
+
     def StepAsync(self, stream, debug_mode=False):
         for a, m in zip(self._args, self.chains):
             a.d_means, a.d_sigmas, a.d_rng = ptr(m.parameter_means).value, ptr(m.parameter_sigma).value, ptr(m.rngs).value

@@ -301,11 +301,14 @@ def test_baseline_configs_at_size_against_the_oracle(make, scale, plan):
     assert abs(m.proposed_nll.get()[0] - want) <= NLL_RTOL * abs(want)
 
 
-@pytest.mark.parametrize("nchains,graph_steps", [(2, 0), (2, 6), (3, 4), (4, 0)])
-def test_lockstep_chains_walk_what_they_walk_alone(nchains, graph_steps):
+@pytest.mark.parametrize("nchains,graph_steps,joint_ends",
+                         [(2, 0, True), (2, 6, True), (3, 4, True), (4, 0, True), (3, 4, False), (2, 0, False)])
+def test_lockstep_chains_walk_what_they_walk_alone(nchains, graph_steps, joint_ends):
     """sxmc_multigroup_step_async: chains over the same sample tables (different seeds, different data) advanced
     together -- ONE fill pass per step bins every sample under each chain's parameters -- must walk, bit for
-    bit, the chains they walk when stepped alone (same kernels for everything but the fill; counts are integers)."""
+    bit, the chains they walk when stepped alone (same kernels for everything but the fill; counts are integers).
+    joint_ends: the chains' step ends share two launches (chain = blockIdx.y; the chains have different numbers of
+    event classes, so different numbers of workgroups in their event sums) or are launched chain by chain."""
     from sxmc_amd.mcmc import LockstepChains
     w = workloads.config3(0.004, nevents=3000)
     rng = np.random.default_rng(5)
@@ -323,6 +326,7 @@ def test_lockstep_chains_walk_what_they_walk_alone(nchains, graph_steps):
     for c, m in enumerate(chains):
         m.setup(data=datas[c], sync_interval=64)
     ls = LockstepChains(chains)
+    ls.mg.SetJointStepEnd(joint_ends)
     ls.step()                                     # (the first step is launched; recording needs the plans in place)
     ls.steps(nsteps - 1, graph_steps)
     for c, m in enumerate(chains):
