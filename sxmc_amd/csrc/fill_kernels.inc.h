@@ -1356,7 +1356,8 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
               const int idx = (int)((x - olo) * osc);
               bin = LDS_HIST ? mad24(idx, ostv, bin) : idx * ostv + bin;
             }
-            vcnt[c] += ind ? 1u : 0u;                      // (an add-with-carry straight from the compare mask)
+            vcnt[c] += ind ? 1u : 0u;                      // (an add-with-carry straight from the compare mask;
+                                                           //  a ballot + s_bcnt1 costs a v_cndmask and a v_cmp instead)
             // in domain but index out of range (the reference's one-past-the-end case) still counts in the norm
             if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
               if constexpr (LDS_HIST) {

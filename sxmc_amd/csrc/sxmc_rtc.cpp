@@ -106,8 +106,12 @@ bool compile(const SxRtcSpec& k, std::vector<char>& code, std::string& err) {
   }
   // the flags of the library's own build (Makefile): double add/mul must round separately (bit-exact bin indices)
   // (SXMC_ARCH: the Makefile's ARCH, so that the run-time kernels are built for what the library was built for)
-  const char* opts[] = {"--offload-arch=" SXMC_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
-  r = hiprtcCompileProgram(prog, 5, opts);
+  std::vector<const char*> opts = {"--offload-arch=" SXMC_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+  // (a variant build of the library -- make VARIANT=.. EXTRA=-D.. -- compiles its run-time kernels the same way)
+#if defined(SXMC_CACHED_LOADS) && SXMC_CACHED_LOADS
+  opts.push_back("-DSXMC_CACHED_LOADS=1");
+#endif
+  r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
     (void)hiprtcGetProgramLogSize(prog, &n);
