@@ -634,7 +634,8 @@ def cpp_multi_gpu_record(args, ngpus, collective):
     return rec
 
 
-def main():
+def parse_args(argv=None):
+    """The command line (argv None: sys.argv) -- also what tools/ use to build the same legs as the bench."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -702,7 +703,11 @@ def main():
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
     ap.add_argument("--debug-mode", type=int, default=0,
                     help="roofline measurement hook (wrong results): 1 stream only, 2 compute only, 4 no histogram")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
 
     from sxmc_amd import dist
 

@@ -249,6 +249,24 @@ typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load 
 // replay hit on die, were 5-7 % SLOWER at every launch shape (profiles/r03_c2_sweep_policy_x_shape.log: 33 300
 // against 35 700 evals/s at 1024 x 1).  A library built with -DSXMC_CACHED_LOADS=1 (make VARIANT=_cached
 // EXTRA=-DSXMC_CACHED_LOADS=1; SXMC_HIP_LIB selects it) repeats that measurement.
+// Measurement build only (make VARIANT=_stamps EXTRA=-DSXMC_WG_STAMPS=1, tools/wg_tail_study.py): every workgroup of
+// the ordered fill leaves the 100 MHz real-time counter at its entry, at the end of its stream and at its exit.
+#ifndef SXMC_WG_STAMPS
+#define SXMC_WG_STAMPS 0
+#endif
+#if SXMC_WG_STAMPS && !defined(__HIPCC_RTC__)
+extern "C" __device__ unsigned long long sx_wg_stamps[3 * 4096];
+#define SX_WG_STAMP(which)                                                                      \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < 4096u) {                                               \
+      sx_wg_stamps[(which)*4096 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();               \
+    }                                                                                           \
+  } while (0)
+#else
+#define SX_WG_STAMP(which) \
+  do {                     \
+  } while (0)
+#endif
 #ifndef SXMC_CACHED_LOADS
 #define SXMC_CACHED_LOADS 0
 #endif
@@ -1156,6 +1174,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   const unsigned myrep = (lane & (R - 1u)) * rstride;
 
   bool lds_clean = false;
+  SX_WG_STAMP(0);
   const unsigned seg_end = blk_off[blockIdx.x + 1];
   for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
     const SxSegment& sg = segs[si];
@@ -1382,6 +1401,10 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       }
     }
 
+#if SXMC_WG_STAMPS
+    __syncthreads();   // (measurement build: the stamp is the workgroup's last wave leaving the stream)
+    SX_WG_STAMP(1);
+#endif
     // in-domain counts: lane registers -> wave -> workgroup
 #pragma unroll
     for (int c = 0; c < NCHAIN; c++) {
@@ -1427,6 +1450,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     __syncthreads();
     lds_clean = true;
   }
+  SX_WG_STAMP(2);
 }
 
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>

@@ -529,6 +529,15 @@ __global__ __launch_bounds__(256) void finish_zero_chains_kernel(SxChainEnds e, 
   if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
 }
 
+#if SXMC_WG_STAMPS
+extern "C" {
+__device__ unsigned long long sx_wg_stamps[3 * 4096];   // (the definition; fill_kernels.inc.h declares it)
+}
+extern "C" int sxmc_debug_read_wg_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sx_wg_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
 // ------------------------------------------------------------------------------------ pre-binning
 // Builds the pre-binned column of one evaluator: for every sample, sum_k idx_k * stride_k over the
 // observables in `mask` with the fill kernel's arithmetic (pdfz.cpp:388-398), or all ones when one of
