@@ -823,6 +823,9 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
     } catch (const std::exception& e) {
       throw pdfz::Error("ensemble_multi_gpu: rank " + std::to_string(r) + " (device " + std::to_string(devices[r]) +
                         "): " + e.what());
+    } catch (...) {   // (a callback of the caller's may throw anything)
+      throw pdfz::Error("ensemble_multi_gpu: rank " + std::to_string(r) + " (device " + std::to_string(devices[r]) +
+                        "): an exception that is neither a pdfz::Error nor a std::exception");
     }
   }
   // rank r's block holds its experiments r, r + G, ... in that order
