@@ -140,3 +140,36 @@ def projection_interval(values, cl, nbins=100):
     ihi = max(ihi, ilo)
     coverage = integral(ilo, ihi) / total
     return point, low_edge(ilo), low_edge(ihi) + width, coverage, one_sided
+
+
+def correlation_matrix(chain):
+    """get_correlation_matrix, src/utils.cpp:29-77, statement by statement: float accumulators over the rows in order,
+    means = sum / nentries, the entries on and to the right of the diagonal t / sqrt(dx2 * dy2) with the square root
+    taken in double (TMath::Sqrt), everything else left at 0.  chain: [n, P + 1], last column the likelihood."""
+    chain = np.asarray(chain, np.float32)
+    n, P = chain.shape[0], chain.shape[1] - 1
+    f = np.float32
+    means = [f(0)] * P
+    for k in range(n):
+        for j in range(P):
+            means[j] = f(means[j] + chain[k, j])
+    means = [f(m / f(n)) for m in means]
+    out = [[0.0] * P for _ in range(P)]
+    for i in range(P):
+        for j in range(i, P):
+            t = dx2 = dy2 = f(0)
+            for k in range(n):
+                x1 = f(chain[k, i] - means[i])
+                x2 = f(chain[k, j] - means[j])
+                t = f(t + f(x1 * x2))
+                dx2 = f(dx2 + f(x1 * x1))
+                dy2 = f(dy2 + f(x2 * x2))
+            out[i][j] = float(f(float(t) / math.sqrt(float(f(dx2 * dy2)))))
+    return out
+
+
+def interval_text(point, lower, upper):
+    """Interval::str, src/interval.cpp:6-20, two-sided form (a string stream of its own: six significant digits)."""
+    f = np.float32
+    g = lambda x: "%g" % float(f(x))
+    return "%s -%s +%s" % (g(point), g(f(point) - f(lower)), g(f(upper) - f(point)))

@@ -135,6 +135,64 @@ def contour_intervals(chain, cl=0.9):
     return out
 
 
+def _g(x, precision=6):
+    """`ostream << float` at the stream's precision (general format)."""
+    return "%.*g" % (precision, float(np.float32(x)))
+
+
+def interval_str(row, cl=0.9, one_sided=False):
+    """Interval::str (interval.cpp:6-20) of (point_estimate, lower, upper, ...): "point -lower_error +upper_error", or
+    "point <upper (cl% CL)" for a one-sided interval (its own string stream there: always six significant digits)."""
+    point, lower, upper = (np.float32(row[k]) for k in range(3))
+    if one_sided:
+        return "%s <%s (%s%% CL)" % (_g(point), _g(upper), _g(np.float32(100) * np.float32(cl)))
+    return "%s -%s +%s" % (_g(point), _g(point - lower), _g(upper - point))
+
+
+def correlation_matrix(chain):
+    """get_correlation_matrix (utils.cpp:29-77) of the chain's parameter columns (all but the last, the likelihood):
+    float32 [P, P].  As there, sums accumulate in float32 in row order, the square root is a double's, and only the
+    diagonal and the entries to its right are computed -- the ones below stay 0."""
+    chain = np.asarray(chain, np.float32)
+    n, P = chain.shape[0], chain.shape[1] - 1
+    cols = chain[:, :P]
+
+    def fsum(v):                      # a float accumulator over the rows, in order (np.sum would add pairwise)
+        return np.cumsum(v, dtype=np.float32)[-1] if v.shape[0] else np.float32(0)
+    means = np.array([fsum(cols[:, j]) / np.float32(n) for j in range(P)], np.float32)
+    d = cols - means[None, :]
+    out = np.zeros((P, P), np.float32)
+    for i in range(P):
+        for j in range(i, P):
+            t, dx2, dy2 = fsum(d[:, i] * d[:, j]), fsum(d[:, i] * d[:, i]), fsum(d[:, j] * d[:, j])
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out[i, j] = np.float32(np.float64(t) / np.sqrt(np.float64(np.float32(dx2 * dy2))))
+    return out
+
+
+def format_best_fit(names, intervals, nll_min, cl=0.9, one_sided=None, precision=6):
+    """LikelihoodSpace::print_best_fit (likelihood.cpp:34-45): the parameters in NAME order (a std::map there: byte
+    order), then the minimum of the likelihood column.  names: the chain's parameter columns; intervals: [P, >= 3].
+    precision: the output stream's -- it reaches only the NLL line (print_correlations leaves it at 3, so from the
+    second experiment on the reference prints the NLL with three digits)."""
+    lines = ["-- Best fit --"]
+    for name, k in sorted(((n, k) for k, n in enumerate(names) if n != "likelihood"), key=lambda t: t[0].encode()):
+        lines.append(" %s: %s" % (name, interval_str(intervals[k], cl, bool(one_sided[k]) if one_sided is not None else False)))
+    lines.append(" NLL: %s" % _g(nll_min, precision))
+    return "\n".join(lines) + "\n"
+
+
+def format_correlations(names, matrix):
+    """LikelihoodSpace::print_correlations (likelihood.cpp:48-72): names in column order, right-aligned to the longest;
+    entries fixed, three decimals, eight columns wide."""
+    names = [n for n in names if n != "likelihood"]
+    width = max([len(n) for n in names] + [0])
+    lines = ["-- Correlation matrix --"]
+    for i, n in enumerate(names):
+        lines.append("%*s " % (width, n) + "".join("%8.3f" % float(matrix[i, j]) for j in range(len(names))))
+    return "\n".join(lines) + "\n"
+
+
 def gaus_fit(centers, counts, iterations=200):
     """What `TH1::Fit("gaus")` minimises (projection.cpp:22-23): chi2 = sum over the non-empty bins of
     ((n_i - A exp(-(x_i - mu)^2 / (2 sigma^2))) / sqrt(n_i))^2, the function taken at the bin centre, started

@@ -22,11 +22,14 @@
 #include <condition_variable>
 #include <exception>
 #include <functional>
+#include <iomanip>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <limits>
+#include <ostream>
 #include <random>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -298,6 +301,73 @@ inline std::vector<Interval> extract_intervals(const Chain& chain, float cl, Err
   return error_type == ERROR_PROJECTION ? projection_intervals(chain, cl) : contour_intervals(chain, cl);
 }
 
+/** Interval::str (interval.cpp:6-20): "point -lower_error +upper_error", or "point <upper (cl% CL)". */
+inline std::string interval_str(const Interval& iv) {
+  const float lower_error = iv.point_estimate - iv.lower, upper_error = iv.upper - iv.point_estimate;
+  std::ostringstream ss;
+  ss << iv.point_estimate;
+  if (iv.one_sided) ss << " <" << iv.upper << " (" << 100 * iv.cl << "% CL)";
+  else ss << " -" << lower_error << " +" << upper_error;
+  return ss.str();
+}
+
+/** get_correlation_matrix (utils.cpp:29-77) of a chain's parameter columns (every column but `likelihood`), row-major
+ *  [P][P].  As there: sums, means and products accumulate in float in row order, the square root is taken in double,
+ *  and only the diagonal and what is to the right of it is computed -- the entries below stay 0. */
+inline std::vector<float> correlation_matrix(const Chain& chain) {
+  const size_t P = chain.names.size() - 1, n = chain.nrows();
+  std::vector<float> matrix(P * P, 0.0f), means(P, 0.0f);
+  for (size_t k = 0; k < n; k++)
+    for (size_t j = 0; j < P; j++) means[j] += chain.at(k, j);
+  for (size_t j = 0; j < P; j++) means[j] /= (int)n;
+  for (size_t i = 0; i < P; i++) {
+    for (size_t j = i; j < P; j++) {
+      float t = 0, dx2 = 0, dy2 = 0;
+      for (size_t k = 0; k < n; k++) {
+        const float x1 = chain.at(k, i) - means[i], x2 = chain.at(k, j) - means[j];
+        t += x1 * x2;
+        dx2 += x1 * x1;
+        dy2 += x2 * x2;
+      }
+      matrix[i * P + j] = (float)(t / std::sqrt((double)(dx2 * dy2)));
+    }
+  }
+  return matrix;
+}
+
+/** LikelihoodSpace::print_best_fit (likelihood.cpp:34-45): the parameters in NAME order (a std::map there), then
+ *  the minimum of the likelihood column (likelihood.cpp:134). */
+inline void print_best_fit(std::ostream& os, const Chain& chain, const std::vector<Interval>& intervals) {
+  const size_t P = chain.names.size() - 1;
+  std::map<std::string, Interval> by_name;
+  for (size_t p = 0; p < P && p < intervals.size(); p++) by_name[chain.names[p]] = intervals[p];
+  os << "-- Best fit --" << std::endl;
+  for (const auto& kv : by_name) {
+    if (kv.first == "likelihood") continue;
+    os << " " << kv.first << ": " << interval_str(kv.second) << std::endl;
+  }
+  float lmin = chain.nrows() ? chain.at(0, P) : 0.0f;
+  for (size_t r = 1; r < chain.nrows(); r++) lmin = std::min(lmin, chain.at(r, P));
+  os << " NLL: " << lmin << std::endl;
+}
+
+/** LikelihoodSpace::print_correlations (likelihood.cpp:48-72): names in column order, right-aligned to the longest,
+ *  entries fixed with three decimals in eight columns. */
+inline void print_correlations(std::ostream& os, const Chain& chain) {
+  const size_t P = chain.names.size() - 1;
+  const std::vector<float> c = correlation_matrix(chain);
+  os << "-- Correlation matrix --" << std::endl;
+  int maxlen = 0;
+  for (size_t i = 0; i < P; i++) maxlen = std::max(maxlen, (int)chain.names[i].length());
+  for (size_t i = 0; i < P; i++) {
+    os << std::setw(maxlen) << chain.names[i] << " ";
+    for (size_t j = 0; j < P; j++) {
+      os << std::setiosflags(std::ios::fixed) << std::setprecision(3) << std::setw(8) << c[j + i * P];
+    }
+    os << std::resetiosflags(std::ios::fixed) << std::endl;
+  }
+}
+
 /** RandomSample on a flat row-major histogram (1-3 D). */
 inline void random_sample(std::mt19937_64& rng, const std::vector<unsigned>& bins, const std::vector<Observable>& obs,
                           size_t nobserved, unsigned dataset, std::vector<float>& events) {
@@ -354,6 +424,13 @@ inline std::vector<float> make_fake_dataset(std::mt19937_64& rng, std::vector<Si
  *  taken. */
 inline std::function<void(unsigned, const Chain&)>& chain_sink() {
   static std::function<void(unsigned, const Chain&)> sink;
+  return sink;
+}
+
+/** Set by a caller that wants what sxmc.cpp:100-101 prints for every experiment -- the text of print_best_fit followed
+ *  by print_correlations -- handed over as (experiment index, text), one call at a time. */
+inline std::function<void(unsigned, const std::string&)>& report_sink() {
+  static std::function<void(unsigned, const std::string&)> sink;
   return sink;
 }
 
@@ -424,6 +501,14 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   r.intervals = extract_intervals(chain, cl, error_type);
   r.accepted = chain.accepted;
   r.nevents = data.size() / (observables.size() + 1);
+  if (report_sink()) {
+    std::ostringstream os;
+    print_best_fit(os, chain, r.intervals);
+    print_correlations(os, chain);
+    static std::mutex report_mutex;
+    std::lock_guard<std::mutex> guard(report_mutex);
+    report_sink()(k, os.str());
+  }
   return r;
 }
 

@@ -258,20 +258,29 @@ def write_chain(path, names, chain):
     np.savez(path, **{n: np.asarray(chain)[:, i] for i, n in enumerate(names)})
 
 
-def run_config(path, out_dir=None, nexperiments=None, nsteps=None):
+def run_config(path, out_dir=None, nexperiments=None, nsteps=None, report=None):
     """ensemble() of sxmc.cpp:44-145 for a config in the reference's schema: per experiment fake data
     (or the configured data sets), MCMC, contour intervals; chains written as <prefix>_<i>.npz.
+    report: a text stream that receives, per experiment, what sxmc.cpp:100-101 prints (best fit + correlation matrix).
     Returns (intervals [nexp, P, 4], limits of fit.signal_name, parameter names)."""
     from . import ensemble
+
+    def say(names, chain, iv, one_sided=None):
+        if report is not None:
+            report.write(ensemble.format_best_fit(names, iv, np.asarray(chain, np.float32)[:, -1].min(), fc.confidence, one_sided))
+            report.write(ensemble.format_correlations(names, ensemble.correlation_matrix(chain)))
     fc = load_config(path)
     if fc.samples:                                               # sxmc.cpp:84-94: no walk, the saved likelihood space
         chain, names = read_table(os.path.join(fc.base_dir, fc.samples))
         assert names and names[-1] == "likelihood" and chain.shape[0] > 0
+        one_sided = None
         if fc.error_type == "projection":
-            iv = np.array([ensemble.projection_interval(chain[:, p], fc.confidence)[:4] for p in range(len(names) - 1)],
-                          np.float32)
+            cols = [ensemble.projection_interval(chain[:, p], fc.confidence) for p in range(len(names) - 1)]
+            iv = np.array([c[:4] for c in cols], np.float32)
+            one_sided = [bool(c[4]) for c in cols]
         else:
             iv = ensemble.contour_intervals(chain, fc.confidence)
+        say(names[:-1], chain, iv, one_sided)
         limits = [float(iv[names.index(fc.signal_name), 2])] if fc.signal_name in names[:-1] else []
         return iv[None], limits, names
     from .mcmc import MCMC
@@ -293,7 +302,9 @@ def run_config(path, out_dir=None, nexperiments=None, nsteps=None):
             cols = [ensemble.projection_interval(chain[:, p], fc.confidence) for p in range(chain.shape[1] - 1)]
             iv = np.array([c[:4] for c in cols], np.float32)
         else:
+            cols = None
             iv = ensemble.contour_intervals(chain, fc.confidence)
+        say(w.parameter_names, chain, iv, [bool(c[4]) for c in cols] if cols else None)
         allint.append(iv)
         if fc.signal_name in w.parameter_names:
             limits.append(float(iv[w.parameter_names.index(fc.signal_name), 2]))

@@ -17,6 +17,8 @@
 // Synthetic inputs as SURVEY.md 8(d) C3 describes them (not bit-identical to bench.py's generator).
 #include <chrono>
 #include <cstdio>
+#include <fstream>
+#include <iostream>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -127,6 +129,9 @@ static int run(int argc, char** argv) {
                     (double)iv[p].lower, (double)iv[p].upper);
       }
       std::printf("}}\n");
+      // what sxmc.cpp:100-101 prints for the likelihood space: best fit + correlation matrix (stderr: stdout is JSON)
+      sxmc::print_best_fit(std::cerr, chain, iv);
+      sxmc::print_correlations(std::cerr, chain);
       return 0;
     }
     if (!sxmc::same_systematics_everywhere(fc)) {
@@ -220,6 +225,11 @@ static int run(int argc, char** argv) {
     const std::string stem = opt.output_dir + "/" + output_prefix + "_";
     sxmc::chain_sink() = [stem](unsigned k, const sxmc::Chain& chain) {
       sxmc::write_chain_npz(stem + std::to_string(k) + ".npz", chain.names, chain.rows);
+    };
+    // ... and beside each chain what sxmc.cpp:100-101 prints for the experiment: best fit + correlation matrix
+    sxmc::report_sink() = [stem](unsigned k, const std::string& text) {
+      std::ofstream f(stem + std::to_string(k) + ".txt");
+      f << text;
     };
   }
   size_t rows_total = 0;

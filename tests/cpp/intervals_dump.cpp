@@ -3,14 +3,18 @@
 // chain read from a file, printed as JSON: tests/test_intervals.py compares them with the Python forms and with the
 // brute-force restatement in oracle/intervals.py on the same chain.  No device call.
 // Usage: intervals_dump <chain.f32> <ncolumns> <cl>      (row-major float32, last column = likelihood)
+//        intervals_dump <chain.f32> <ncolumns> <cl> --report name0,name1,...   the text of
+//            LikelihoodSpace::print_best_fit + print_correlations (likelihood.cpp:34-72) for that chain with those
+//            parameter names (contour intervals), as sxmc.cpp:100-101 prints them per experiment
 #include <cstdio>
 #include <fstream>
+#include <iostream>
 
 #include "../../sxmc_amd/include/sxmc/ensemble.h"
 
 int main(int argc, char** argv) {
-  if (argc != 4) {
-    std::fprintf(stderr, "usage: intervals_dump <chain.f32> <ncolumns> <cl>\n");
+  if (argc != 4 && !(argc == 6 && std::string(argv[4]) == "--report")) {
+    std::fprintf(stderr, "usage: intervals_dump <chain.f32> <ncolumns> <cl> [--report name0,name1,...]\n");
     return 2;
   }
   try {
@@ -26,6 +30,18 @@ int main(int argc, char** argv) {
     f.read(reinterpret_cast<char*>(chain.rows.data()), (std::streamsize)(chain.rows.size() * 4));
     for (size_t i = 0; i + 1 < ncol; i++) chain.names.push_back("p" + std::to_string(i));
     chain.names.push_back("likelihood");
+    if (argc == 6) {
+      std::string names = argv[5];
+      for (size_t i = 0, at = 0; i + 1 < ncol; i++) {
+        const size_t comma = names.find(',', at);
+        chain.names[i] = names.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+        at = comma == std::string::npos ? names.size() : comma + 1;
+      }
+      sxmc::print_best_fit(std::cout, chain, sxmc::contour_intervals(chain, cl));
+      sxmc::print_correlations(std::cout, chain);
+      sxmc::print_best_fit(std::cout, chain, sxmc::contour_intervals(chain, cl));   // (the precision set above sticks, as in the reference)
+      return 0;
+    }
     const std::vector<sxmc::Interval> c = sxmc::contour_intervals(chain, cl), p = sxmc::projection_intervals(chain, cl);
     auto num = [](float x) {   // (JSON has no inf / nan: a fit that ran away prints as null)
       char b[40];

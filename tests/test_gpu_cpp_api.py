@@ -142,6 +142,15 @@ def test_cpp_bench_driver_from_a_fit_configuration(tmp_path):
             assert list(z.files) == ["bkg_a", "bkg", "sig", "e_scale_0", "r_shift_0", "e_res_0", "likelihood"]
             assert z["likelihood"].shape == z["sig"].shape and 100 < z["sig"].shape[0] <= 400
             assert np.all(np.isfinite(z["likelihood"]))
+            chain = np.stack([z[f] for f in z.files], axis=1).astype(np.float32)
+        # ... and beside it what sxmc.cpp:100-101 prints per experiment (LikelihoodSpace::print_best_fit +
+        # print_correlations): the C++ text equals the Python forms' on the saved chain, character for character
+        from sxmc_amd import ensemble
+        names = ["bkg_a", "bkg", "sig", "e_scale_0", "r_shift_0", "e_res_0"]
+        cl = float(np.float32(0.9))
+        want = ensemble.format_best_fit(names, ensemble.contour_intervals(chain, cl), chain[:, -1].min(), cl) + \
+            ensemble.format_correlations(names, ensemble.correlation_matrix(chain))
+        assert (tmp_path / "out" / ("lspace_%d.txt" % k)).read_text() == want
     assert outs[0]["rccl_nranks"] == 1 and outs[1]["ranks"] == 2
     assert outs[0]["median_upper_limit_source0"] == outs[1]["median_upper_limit_source0"]
     # a configuration the batched drivers cannot take is refused with the reason, not walked wrongly

@@ -122,3 +122,37 @@ def test_intervals_of_a_gpu_chain_three_ways(tmp_path):
     for p in m.pdfs:
         p.close()
     m.group.close()
+
+
+def test_best_fit_and_correlation_report(tmp_path):
+    """LikelihoodSpace::print_best_fit / print_correlations (likelihood.cpp:34-72, what sxmc.cpp:100-101 prints per
+    experiment): the C++ text equals the Python text character for character -- parameters of the best fit in NAME
+    order, the matrix' lower triangle zero as the reference leaves it, and the second best-fit block's NLL at the
+    precision of 3 that print_correlations leaves on the stream -- and the matrix equals the statement-by-statement loop."""
+    rng = np.random.default_rng(11)
+    n, names = 700, ["zeta_rate", "alpha", "mid_scale", "b"]
+    chain = rng.normal(size=(n, len(names) + 1)).astype(np.float32)
+    chain[:, 1] += np.float32(0.7) * chain[:, 0]
+    chain[:, 2] = np.float32(3.0) + np.float32(0.01) * chain[:, 2] - np.float32(0.005) * chain[:, 0]
+    chain[:, -1] = np.float32(-2.5e5) + np.float32(0.5) * (chain[:, :-1] ** 2).sum(axis=1)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "intervals_dump"])
+    path = os.path.join(str(tmp_path), "chain.f32")
+    chain.tofile(path)
+    cl = float(np.float32(0.9))
+    r = subprocess.run([DUMP, path, str(chain.shape[1]), repr(cl), "--report", ",".join(names)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    iv = ensemble.contour_intervals(chain, cl)
+    m = ensemble.correlation_matrix(chain)
+    want = ensemble.format_best_fit(names, iv, chain[:, -1].min(), cl) + ensemble.format_correlations(names, m) + \
+        ensemble.format_best_fit(names, iv, chain[:, -1].min(), cl, precision=3)
+    assert r.stdout == want, "\n" + r.stdout + "\n---\n" + want
+    lines = want.splitlines()
+    assert [l.split(":")[0].strip() for l in lines[1:5]] == sorted(names)          # std::map order
+    assert lines[5].startswith(" NLL: -2499") and lines[-1] == " NLL: -2.5e+05"
+    brute = np.asarray(ref.correlation_matrix(chain), np.float32)
+    assert np.array_equal(m, brute)
+    assert np.all(np.tril(m, -1) == 0) and np.all(np.diag(m) == 1)
+    assert abs(m[0, 1] - np.corrcoef(chain[:, 0], chain[:, 1])[0, 1]) < 1e-4
+    k = names.index("alpha")
+    assert lines[1] == " alpha: " + ref.interval_text(iv[k, 0], iv[k, 1], iv[k, 2])

@@ -386,10 +386,19 @@ def test_fit_samples_reloads_a_saved_chain_instead_of_walking(tmp_path):
         cfg = json.loads(io.strip_comments(EXAMPLE))
         cfg["fit"].update(samples="saved.npz", signal_name="shared", error_type=error_type)
         (tmp_path / "fit.json").write_text(json.dumps(cfg))
-        iv, limits, nm = io.run_config(str(tmp_path / "fit.json"))
+        import io as pyio
+        said = pyio.StringIO()
+        iv, limits, nm = io.run_config(str(tmp_path / "fit.json"), report=said)
         assert nm == names and iv.shape == (1, 4, 4) and limits == [float(iv[0, 1, 2])]
         r = subprocess.run([exe, "--config", str(tmp_path / "fit.json")], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
+        # best fit + correlation matrix as sxmc.cpp:100-101 prints them: the same text from both (the fitted mean of a
+        # projection interval agrees to 1e-6 only, so that block is compared for the contour estimator)
+        assert "-- Best fit --" in r.stderr and "-- Correlation matrix --" in r.stderr
+        if error_type == "contour":
+            assert r.stderr == said.getvalue(), "\n" + r.stderr + "---\n" + said.getvalue()
+        else:
+            assert r.stderr.split("-- Correlation matrix --")[1] == said.getvalue().split("-- Correlation matrix --")[1]
         rec = json.loads(r.stdout)
         assert rec["rows"] == 3000 and rec["error_type"] == error_type
         for p, n in enumerate(names[:-1]):
