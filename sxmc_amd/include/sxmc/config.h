@@ -671,18 +671,14 @@ struct FitConfig {
   size_t nfields = 0;                             //!< sample_fields.size()
   std::vector<Signal> signals;                    //!< in fit.signals order; nexpected and n_mc (BEFORE cuts) set
   std::vector<std::vector<float>> tables;         //!< tables[j]: signal j's samples, rows of nfields floats, cuts applied
-  std::map<unsigned, std::vector<float>> data;    //!< data sets: rows of nobservables + 1 floats (observables, dataset id)
+  /** data sets (config.cpp:260-296): per data set id one table PER LISTED FILE, rows of nobservables + 1 floats
+   *  (observables, dataset id) -- experiment i fits file i of every data set (sxmc.cpp:71-80), see experiment_data */
+  std::map<unsigned, std::vector<std::vector<float>>> data;
   std::string base_dir;
   size_t rows_total() const {
     size_t n = 0;
     for (const std::vector<float>& t : tables) n += nfields ? t.size() / nfields : 0;
     return n;
-  }
-  /** data events of every data set in dataset order, or empty when the configuration names none */
-  std::vector<float> all_data() const {
-    std::vector<float> out;
-    for (const auto& kv : data) out.insert(out.end(), kv.second.begin(), kv.second.end());
-    return out;
   }
 };
 
@@ -884,7 +880,8 @@ inline FitConfig parse_config(const std::string& text, const std::string& base_d
       const std::vector<float> s = read_dataset_to_samples(raw, fields, dataset, fc.sample_fields, cc);
       // GetSamples (pdfz.h:542-556): the observables, then the dataset id
       const size_t D = fc.observables.size();
-      std::vector<float>& out = fc.data[dataset];
+      fc.data[dataset].emplace_back();
+      std::vector<float>& out = fc.data[dataset].back();
       for (size_t r = 0; r < s.size() / fc.nfields; r++) {
         for (size_t k = 0; k < D; k++) out.push_back(s[r * fc.nfields + k]);
         out.push_back(s[r * fc.nfields + fc.nfields - 1]);
@@ -892,6 +889,22 @@ inline FitConfig parse_config(const std::string& text, const std::string& base_d
     }
   }
   return fc;
+}
+
+/** The data experiment i fits when the configuration lists data sets (sxmc.cpp:71-80): file i of EVERY data set, in
+ *  the order of the data set ids, appended (GetSamples).  false: no data sets configured -- the caller samples a fake
+ *  one.  A data set with fewer than i + 1 files is an error (the reference indexes past the end of its list). */
+inline bool experiment_data(const FitConfig& fc, unsigned i, std::vector<float>& rows) {
+  if (fc.data.empty()) return false;
+  rows.clear();
+  for (const auto& kv : fc.data) {
+    if (i >= kv.second.size()) {
+      throw ConfigError("data set " + std::to_string(kv.first) + " lists " + std::to_string(kv.second.size()) +
+                        " file(s): experiment " + std::to_string(i) + " has none to fit (one file per experiment)");
+    }
+    rows.insert(rows.end(), kv.second[i].begin(), kv.second[i].end());
+  }
+  return true;
 }
 
 /** FitConfig::FitConfig(filename). */

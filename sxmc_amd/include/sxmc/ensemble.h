@@ -427,6 +427,14 @@ inline std::function<void(unsigned, const Chain&)>& chain_sink() {
   return sink;
 }
 
+/** Set by a caller whose configuration lists data sets (sxmc.cpp:71-80): asked for experiment k's events (rows of
+ *  nobservables + 1 floats); true = `rows` holds them, false = the experiment samples a fake data set as usual.  May be
+ *  called from several host threads at once (one per chain in flight): it must only read. */
+inline std::function<bool(unsigned, std::vector<float>&)>& data_source() {
+  static std::function<bool(unsigned, std::vector<float>&)> source;
+  return source;
+}
+
 /** Set by a caller that wants what sxmc.cpp:100-101 prints for every experiment -- the text of print_best_fit followed
  *  by print_correlations -- handed over as (experiment index, text), one call at a time. */
 inline std::function<void(unsigned, const std::string&)>& report_sink() {
@@ -479,7 +487,10 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   // legacy stream or synchronises the device -- see MCMC::exclusive
   std::unique_lock<SetupLock> lock;
   if (exclusive) lock = std::unique_lock<SetupLock>(*exclusive);
-  std::vector<float> data = make_fake_dataset(rng, signals, systematics, observables, true);
+  std::vector<float> data;
+  if (!(data_source() && data_source()(k, data))) {
+    data = make_fake_dataset(rng, signals, systematics, observables, true);
+  }
   std::unique_ptr<MCMC> mcmc(new MCMC(sources, signals, systematics, observables, x, stream));
   mcmc->graph_steps = graph_steps;
   mcmc->exclusive = exclusive;

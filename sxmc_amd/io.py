@@ -240,17 +240,24 @@ def build_workload(fc):
     return w
 
 
-def load_data(fc, w):
-    """config.cpp:261-296: data sets clipped to the PDF boundaries (observables act as cuts)."""
+def load_data(fc, w, experiment=0):
+    """The data experiment i fits when the configuration lists data sets (config.cpp:261-296, sxmc.cpp:71-80): file i
+    of EVERY data set, in the order of the data set ids, clipped to the PDF boundaries (observables act as cuts).
+    None: no data sets configured (the caller samples a fake one)."""
+    if not fc.data:
+        return None
     cuts = [(o["field"], o["lower"], o["upper"]) for o in fc.observables] + \
            [(c["field"], c["lower"], c["upper"]) for c in fc.cuts]
     rows = []
     for dataset, files in sorted(fc.data.items()):
-        for f in files:
-            table, fields = read_table(os.path.join(fc.base_dir, f["filename"]))
-            s = read_dataset_to_samples(table, fields, dataset, fc.sample_fields, cuts)
-            rows.append(np.concatenate([s[:, :w.nobs], s[:, -1:]], axis=1))      # GetSamples: observables + dataset
-    return np.concatenate(rows, axis=0) if rows else None
+        if experiment >= len(files):        # (the reference indexes past the end of its list here)
+            raise ValueError("data set %d lists %d file(s): experiment %d has none to fit (one file per experiment)"
+                             % (dataset, len(files), experiment))
+        f = files[experiment]
+        table, fields = read_table(os.path.join(fc.base_dir, f["filename"]))
+        s = read_dataset_to_samples(table, fields, dataset, fc.sample_fields, cuts)
+        rows.append(np.concatenate([s[:, :w.nobs], s[:, -1:]], axis=1))      # GetSamples: observables + dataset
+    return np.concatenate(rows, axis=0)
 
 
 def write_chain(path, names, chain):
@@ -288,14 +295,12 @@ def run_config(path, out_dir=None, nexperiments=None, nsteps=None, report=None):
     m = MCMC(w, seed=fc.seed & 0xFFFFFFFF, fused=True, lut_output=False, consume=True)
     nexp = nexperiments or fc.nexperiments
     nsteps = nsteps or fc.nsteps
-    data = load_data(fc, w)
     allint, limits = [], []
     for i in range(nexp):
         rng = np.random.default_rng((fc.seed << 20) + i)
-        if data is None:
+        events = load_data(fc, w, i)                             # sxmc.cpp:71-80: file i of every configured data set
+        if events is None:
             events, _ = ensemble.make_fake_dataset(rng, w, m.pdfs, poisson=True)
-        else:
-            events = data
         m.reseed(((fc.seed << 20) + i) & 0xFFFFFFFF)
         chain, _ = m.walk(events, nsteps, fc.burnin_fraction, debug_mode=fc.debug_mode)
         if fc.error_type == "projection":                       # likelihood.cpp:104-137: the chosen estimator

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -137,6 +138,16 @@ static int run(int argc, char** argv) {
     if (!sxmc::same_systematics_everywhere(fc)) {
       throw std::runtime_error("the batched drivers (one launch for all signals) need every signal to list every "
                                "systematic of the fit, in the same order");
+    }
+    if (!fc.data.empty()) {
+      // configured data sets: experiment i fits file i of every data set instead of a fake one (sxmc.cpp:71-80)
+      auto shared = std::make_shared<sxmc::FitConfig>();
+      shared->data = fc.data;
+      for (unsigned i = 0; i < fc.nexperiments; i++) {   // (every experiment has its file: fail now, not mid-run)
+        std::vector<float> rows;
+        sxmc::experiment_data(*shared, i, rows);
+      }
+      sxmc::data_source() = [shared](unsigned k, std::vector<float>& rows) { return sxmc::experiment_data(*shared, k, rows); };
     }
     observables = fc.observables;
     systematics = fc.systematics;
@@ -337,6 +348,8 @@ static int run(int argc, char** argv) {
                       mg.setup_locks[i].held_seconds, mg.setup_locks[i].acquisitions);
         locks += b;
       }
+      std::string nev = "[";   // events each experiment fitted
+      for (size_t i = 0; i < mg.results.size(); i++) nev += (i ? ", " : "") + std::to_string(mg.results[i].nevents);
       for (size_t i = 0; i < G; i++) devs += (i ? ", " : "") + std::to_string(opt.devices[i]);
       for (size_t i = 0; i < mg.rccl_devices.size(); i++) rdevs += (i ? ", " : "") + std::to_string(mg.rccl_devices[i]);
       std::printf("{\"driver\": \"sxmc::ensemble_multi_gpu (C++)\", \"ranks\": %zu, \"devices\": %s], "
@@ -344,11 +357,13 @@ static int run(int argc, char** argv) {
                   "\"steps_each\": %u, \"chains_per_fill\": %u, \"sets\": %u, \"seconds\": %.4f, "
                   "\"replica_setup_seconds_max\": %.4f, \"experiments_per_sec\": %.4f, "
                   "\"experiments_per_sec_after_setup\": %.4f, \"steps_per_sec_inside\": %.1f, "
-                  "\"median_upper_limit_source0\": %.6g, \"gathered_floats\": %zu, \"setup_locks\": %s]}\n",
+                  "\"median_upper_limit_source0\": %.6g, \"gathered_floats\": %zu, \"nevents\": %s], "
+                  "\"data\": \"%s\", \"setup_locks\": %s]}\n",
                   G, devs.c_str(), opt.host_staging ? "host staging (rehearsal)" : "ncclAllGather (RCCL)",
                   mg.rccl_nranks, rdevs.c_str(), n, opt.esteps, opt.L, opt.S, sec, setup_max, n / sec, n / inside,
                   n * (double)opt.esteps / inside, mg.median_upper.empty() ? 0.0 : (double)mg.median_upper[0],
-                  mg.gathered.size(), locks.c_str());
+                  mg.gathered.size(), nev.c_str(), sxmc::data_source() ? "configured data sets" : "fake",
+                  locks.c_str());
       std::fflush(stdout);
     }
   }

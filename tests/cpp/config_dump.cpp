@@ -133,9 +133,13 @@ int main(int argc, char** argv) {
     std::printf("],\n \"data\": {");
     bool first = true;
     for (const auto& kv : fc.data) {
-      std::printf("%s\"%u\": ", first ? "" : ", ", kv.first);
+      std::printf("%s\"%u\": [", first ? "" : ", ", kv.first);
       first = false;
-      table_summary(kv.second, fc.observables.size() + 1);
+      for (size_t f = 0; f < kv.second.size(); f++) {   // one table per listed file (experiment f fits file f)
+        if (f) std::printf(", ");
+        table_summary(kv.second[f], fc.observables.size() + 1);
+      }
+      std::printf("]");
     }
     std::printf("},\n \"same_systematics_everywhere\": %s}\n", sxmc::same_systematics_everywhere(fc) ? "true" : "false");
     return 0;

@@ -153,6 +153,32 @@ def test_cpp_bench_driver_from_a_fit_configuration(tmp_path):
         assert (tmp_path / "out" / ("lspace_%d.txt" % k)).read_text() == want
     assert outs[0]["rccl_nranks"] == 1 and outs[1]["ranks"] == 2
     assert outs[0]["median_upper_limit_source0"] == outs[1]["median_upper_limit_source0"]
+    # configured data sets (sxmc.cpp:71-80): experiment i fits file i of every data set, clipped to the PDF boundaries
+    # and the cuts, instead of a fake data set; a data set with too few files is refused before anything runs
+    from sxmc_amd import io
+    kept = []
+    for i in range(3):
+        n = 700 + 150 * i
+        e = rng.normal(5.0, 2.5, n).astype(np.float32)
+        np.savez(tmp_path / ("data%d.npz" % i), e=e, e_true=e, r=(6.0 * rng.uniform(0, 1, n) ** (1 / 3)).astype(np.float32),
+                 valid=rng.integers(0, 5, n) > 0)
+    cfg = json.loads("\n".join(line.split("//")[0] for line in FIT.splitlines()))
+    cfg["data"] = {"0": [{"title": "d%d" % i, "filename": "data%d.npz" % i} for i in range(3)]}
+    (tmp_path / "withdata.json").write_text(json.dumps(cfg))
+    fc = io.load_config(str(tmp_path / "withdata.json"))
+    w = io.build_workload(fc)
+    kept = [io.load_data(fc, w, i).shape[0] for i in range(3)]
+    assert all(0 < k < 700 + 150 * i for i, k in enumerate(kept))
+    r = subprocess.run([exe, "--config", str(tmp_path / "withdata.json"), "--chains", "2", "--sets", "1", "--devices", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [json.loads(x) for x in r.stdout.strip().splitlines() if x.startswith("{")][-1]
+    assert last["data"] == "configured data sets" and last["nevents"] == kept
+    cfg["data"]["0"].pop()
+    (tmp_path / "short.json").write_text(json.dumps(cfg))
+    r = subprocess.run([exe, "--config", str(tmp_path / "short.json"), "--devices", "1"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 1 and "data set 0 lists 2 file(s): experiment 2 has none" in r.stderr
     # a configuration the batched drivers cannot take is refused with the reason, not walked wrongly
     bad = json.loads("\n".join(line.split("//")[0] for line in FIT.splitlines()))
     bad["signals"]["sig"]["systematics"] = ["e_scale"]

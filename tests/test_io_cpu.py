@@ -220,11 +220,16 @@ def test_cpp_load_config_matches_python_on_the_same_files(tmp_path, exe):
         assert rows < n_mc                                    # the cut removed something
     # data sets: clipped to the PDF boundaries, observables + dataset id
     w = io.build_workload(fc)
-    data = io.load_data(fc, w)
+    # (experiment i fits file i of every data set, sxmc.cpp:71-80: data set 0 lists two files, data set 1 one)
+    data = io.load_data(fc, w, 0)
+    assert [len(cpp["data"][k]) for k in ("0", "1")] == [2, 1]
     for ds in (0, 1):
         rows, total, xor = _fingerprint(data[data[:, -1] == ds])
-        t = cpp["data"][str(ds)]
+        t = cpp["data"][str(ds)][0]
         assert (t["rows"], t["sum"], t["xor"]) == (rows, total, xor)
+    assert np.all(np.diff(data[:, -1]) >= 0)                   # data set 0's rows, then data set 1's
+    with pytest.raises(ValueError, match="data set 1 lists 1 file"):
+        io.load_data(fc, w, 1)
     assert cpp["same_systematics_everywhere"] is False
 
 
