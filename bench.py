@@ -601,12 +601,12 @@ def cpp_host_record(args, nsteps=4000):
     C++".  The walk includes its set-up, both burn-in re-tunings and the jump-buffer flushes."""
     t0 = time.perf_counter()
     lines, failure = run_bench_cpp(["--scale", "1.0", "--steps", nsteps, "--graph-steps", args.graph_steps,
-                                    "--experiments", 8, "--exp-steps", 2000, "--chains", 4, "--sets", 2], 300)
+                                    "--experiments", 16, "--exp-steps", 2000, "--chains", 4, "--sets", 2], 300)
     if failure:
         return failure
     rec = lines[0]
     if len(lines) > 1:
-        rec["ensemble_lockstep"] = lines[1]     # 8 whole fake experiments as 2 lockstep sets of 4 chains
+        rec["ensemble_lockstep"] = lines[1]     # 16 whole fake experiments as 2 lockstep sets of 4 chains: two per lane
     rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
     rec["leg_seconds"] = time.perf_counter() - t0
     rec["note"] = "whole walk of %d steps including set-up, re-tuning and flushes; host = C++ only" % nsteps
@@ -621,7 +621,7 @@ def cpp_multi_gpu_record(args, ngpus, collective):
     run on the same cards as the ranks did and their blocks meet through host memory: RCCL refuses two ranks on one
     card, and the record says "host staging (rehearsal)"."""
     t0 = time.perf_counter()
-    nexp = 8 * ngpus if args.experiments < 0 else max(args.experiments, ngpus)
+    nexp = 16 * ngpus if args.experiments < 0 else max(args.experiments, ngpus)   # (two experiments per lane)
     devices = ",".join(str(d["device_index"]) for d in collective["devices"])
     extra = [] if collective["backend"] == "nccl" else ["--host-staging"]
     lines, failure = run_bench_cpp(["--scale", args.scale, "--no-walk", "--graph-steps", args.graph_steps,

@@ -60,6 +60,7 @@ const char* sxmc_version(void);
 
 int sxmc_device_count(int* count);
 int sxmc_set_device(int device);
+int sxmc_get_device(int* device); /* the calling thread's current device */
 /* name: at least 256 bytes. */
 int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes,
                      int* lds_bytes_per_cu, int* clock_khz);

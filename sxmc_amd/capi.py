@@ -49,6 +49,7 @@ _pi, _psz, _pd, _pvp = C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_
 SIGNATURES = {
     "sxmc_device_count": [_pi],
     "sxmc_set_device": [_i],
+    "sxmc_get_device": [C.POINTER(C.c_int)],
     "sxmc_device_info": [_i, C.c_char_p, _pi, _psz, _pi, _pi],
     "sxmc_set_tracing": [_i],
     "sxmc_device_synchronize": [],

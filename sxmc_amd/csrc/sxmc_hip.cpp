@@ -213,6 +213,8 @@ struct sxmc_hist {
   size_t read_bins_cap = 0;        // (grow-only: a new data set of about the same size re-uses the buffer)
   std::vector<void*> retired;      // outgrown device buffers, freed with the evaluator
   unsigned* d_cdf = nullptr;       // prefix sums of the histogram, for sxmc_hist_random_sample
+  float* d_sample = nullptr;       // ... and the rows it draws (grow-only: a fake experiment per walk draws about as many)
+  size_t cap_sample = 0;           // bytes
   bool has_points = false;
   size_t npoints = 0;
   float* pdf = nullptr;
@@ -1423,6 +1425,12 @@ int sxmc_set_device(int device) {
   return SXMC_OK;
 }
 
+int sxmc_get_device(int* device) {
+  SX_REQUIRE(device, "null argument");
+  SX_HIP(hipGetDevice(device));
+  return SXMC_OK;
+}
+
 int sxmc_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes, int* lds_bytes_per_cu,
                      int* clock_khz) {
   hipDeviceProp_t prop;
@@ -1752,6 +1760,7 @@ int sxmc_hist_destroy(sxmc_hist_t h) {
   if (h->d_read_bins) (void)hipFree(h->d_read_bins);
   for (void* p : h->retired) (void)hipFree(p);
   if (h->d_cdf) (void)hipFree(h->d_cdf);
+  if (h->d_sample) (void)hipFree(h->d_sample);
   free_sparse(h);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1938,12 +1947,21 @@ int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long 
   SX_HIP(hipMemcpy(&total, h->d_cdf + (h->total_nbins - 1), sizeof(unsigned), hipMemcpyDeviceToHost));
   SX_REQUIRE(total > 0, "cannot sample an empty histogram");
   const size_t row = (size_t)h->nobs + 1;
-  DevBuf out;
-  SX_HIP(out.alloc(sizeof(float) * nobserved * row + sizeof(unsigned)));   // + the count of points never accepted
-  unsigned* d_exhausted = reinterpret_cast<unsigned*>(out.as<float>() + nobserved * row);
+  // (the evaluator's own grow-only buffer: an allocation and a hipFree per draw would each wait for the device to
+  //  drain, i.e. for whatever other chains have queued)
+  const size_t need = sizeof(float) * nobserved * row + sizeof(unsigned);   // + the count of points never accepted
+  if (need > h->cap_sample) {
+    if (h->d_sample) SX_HIP(hipFree(h->d_sample));
+    h->d_sample = nullptr;
+    h->cap_sample = 0;
+    SX_HIP(hipMalloc((void**)&h->d_sample, need + need / 4));
+    h->cap_sample = need + need / 4;
+  }
+  float* const d_rows = h->d_sample;
+  unsigned* d_exhausted = reinterpret_cast<unsigned*>(d_rows + nobserved * row);
   SX_HIP(hipMemsetAsync(d_exhausted, 0, sizeof(unsigned), h->stream));
   SX_HIP(sx_random_sample(h->d_cdf, h->total_nbins, h->nobs, h->nbins.data(), h->lower.data(), h->upper.data(), lowers,
-                          uppers, seed, nobserved, (float)h->dataset, out.as<float>(), d_exhausted, h->stream));
+                          uppers, seed, nobserved, (float)h->dataset, d_rows, d_exhausted, h->stream));
   SX_HIP(hipStreamSynchronize(h->stream));
   unsigned exhausted = 0;
   SX_HIP(hipMemcpy(&exhausted, d_exhausted, sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -1953,7 +1971,7 @@ int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long 
                                     "would redraw for ever, pdfz.cpp:838-905): the cuts leave (almost) none of the "
                                     "histogram's content");
   }
-  SX_HIP(hipMemcpy(h_events, out.p, sizeof(float) * nobserved * row, hipMemcpyDeviceToHost));
+  SX_HIP(hipMemcpy(h_events, d_rows, sizeof(float) * nobserved * row, hipMemcpyDeviceToHost));
   return SXMC_OK;
 }
 

@@ -460,6 +460,13 @@ struct ExperimentResult {
   std::vector<Interval> intervals;  //!< one per parameter
   size_t accepted = 0;
   size_t nevents = 0;
+  /** where the experiment's host time went (seconds): its data (fake-data draw or configured files), the chain's
+   *  construction, the walk's set-up (buffers, SetEvalPoints, first evaluation), its steps, its tear-down (buffers
+   *  freed), the chain's destruction, the intervals.  What a short experiment spends outside `steps` is what an
+   *  ensemble of short experiments loses (bench_cpp prints the sums). */
+  struct Phases {
+    double data = 0, construct = 0, walk_setup = 0, steps = 0, walk_teardown = 0, destroy = 0, intervals = 0;
+  } phases;
 };
 
 /** The experiment loop of sxmc.cpp:59-145 over the given experiment indices (all of them on one GPU,
@@ -487,29 +494,43 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   // legacy stream or synchronises the device -- see MCMC::exclusive
   std::unique_lock<SetupLock> lock;
   if (exclusive) lock = std::unique_lock<SetupLock>(*exclusive);
+  typedef std::chrono::steady_clock PhaseClock;
+  auto since = [](PhaseClock::time_point t) { return std::chrono::duration<double>(PhaseClock::now() - t).count(); };
+  ExperimentResult r;
+  PhaseClock::time_point t = PhaseClock::now();
   std::vector<float> data;
   if (!(data_source() && data_source()(k, data))) {
     data = make_fake_dataset(rng, signals, systematics, observables, true);
   }
+  r.phases.data = since(t);
+  t = PhaseClock::now();
   std::unique_ptr<MCMC> mcmc(new MCMC(sources, signals, systematics, observables, x, stream));
   mcmc->graph_steps = graph_steps;
   mcmc->exclusive = exclusive;
   mcmc->lockstep = lockstep;
   mcmc->lockstep_index = lockstep_index;
   if (lockstep) mcmc->optimize = false;   // chains that share a fill pass share ONE launch shape: the default one
+  r.phases.construct = since(t);
   if (exclusive) lock.unlock();   // the walk takes it itself
+  t = PhaseClock::now();
   Chain chain = (*mcmc)(data, nsteps, burnin_fraction, false, sync_interval);
+  r.phases.walk_setup = chain.setup_seconds;
+  r.phases.steps = chain.steps_seconds;
+  r.phases.walk_teardown = since(t) - chain.setup_seconds - chain.steps_seconds;
+  t = PhaseClock::now();
   if (exclusive) lock.lock();
   mcmc.reset();
   if (exclusive) lock.unlock();
+  r.phases.destroy = since(t);
   if (chain_sink()) {
     static std::mutex sink_mutex;
     std::lock_guard<std::mutex> guard(sink_mutex);
     chain_sink()(k, chain);
   }
-  ExperimentResult r;
+  t = PhaseClock::now();
   r.index = k;
   r.intervals = extract_intervals(chain, cl, error_type);
+  r.phases.intervals = since(t);
   r.accepted = chain.accepted;
   r.nevents = data.size() / (observables.size() + 1);
   if (report_sink()) {
@@ -529,6 +550,7 @@ inline std::vector<ExperimentResult> ensemble(const std::vector<unsigned>& exper
                                               std::vector<Observable>& observables, unsigned nsteps,
                                               float burnin_fraction, float cl = 0.9f, unsigned sync_interval = 10000,
                                               unsigned graph_steps = 0, ErrorType error_type = ERROR_CONTOUR) {
+  PoolScope pool;   // the experiments' arrays recycle their blocks instead of allocating and freeing (device_array.h)
   std::vector<ExperimentResult> out;
   for (unsigned k : experiments) {
     out.push_back(run_experiment(k, base_seed, sources, signals, systematics, observables, nsteps, burnin_fraction,
@@ -551,6 +573,7 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
                                                          unsigned sync_interval = 10000, unsigned graph_steps = 0,
                                                          int device = -1, SetupLock* device_exclusive = nullptr,
                                                          ErrorType error_type = ERROR_CONTOUR) {
+  PoolScope pool;   // the experiments' arrays recycle their blocks instead of allocating and freeing (device_array.h)
   const size_t lanes = std::max<size_t>(1, std::min<size_t>(nconcurrent, experiments.size()));
   std::vector<ExperimentResult> out(experiments.size());
   std::vector<std::exception_ptr> errors(lanes);
@@ -612,6 +635,7 @@ inline std::vector<ExperimentResult> ensemble_lockstep(const std::vector<unsigne
                                                        unsigned graph_steps = 10, int device = -1,
                                                        SetupLock* device_exclusive = nullptr,
                                                        ErrorType error_type = ERROR_CONTOUR) {
+  PoolScope pool;   // the experiments' arrays recycle their blocks instead of allocating and freeing (device_array.h)
   const size_t L = std::max(2u, std::min(4u, chains_per_set)), S = std::max(1u, nsets), lanes = L * S;
   const size_t usable = experiments.size() / lanes * lanes;
   std::vector<ExperimentResult> out(experiments.size());
@@ -761,6 +785,7 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
                                            const std::vector<const std::vector<float>*>& tables, int nfields,
                                            std::vector<Systematic>& systematics, std::vector<Observable>& observables,
                                            unsigned nsteps, float burnin_fraction, const MultiGpuOptions& opt) {
+  PoolScope pool;   // (see ensemble(): blocks are pooled per device)
   typedef std::chrono::steady_clock Clock;
   const size_t G = devices.size();
   if (G == 0 || tables.size() != signals.size()) throw pdfz::Error("ensemble_multi_gpu: bad arguments");

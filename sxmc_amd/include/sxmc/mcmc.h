@@ -34,6 +34,9 @@ struct Chain {
   std::vector<std::string> names;  //!< parameter names, then "likelihood"
   std::vector<float> rows;         //!< row-major [nrows][names.size()]
   size_t accepted = 0;             //!< accepted proposals over the whole walk
+  double setup_seconds = 0;        //!< of the walk that made it: entry to the first step (buffers, SetEvalPoints, first
+                                   //!< evaluation, launch-shape trials), host clock
+  double steps_seconds = 0;        //!< ... and the steps themselves, re-tunings, flushes and graph recording included
   size_t nrows() const { return names.empty() ? 0 : rows.size() / names.size(); }
   float at(size_t row, size_t col) const { return rows[row * names.size() + col]; }
 };
@@ -321,6 +324,7 @@ class MCMC {
   /** MCMC::operator() (mcmc.cpp:143-387).  data: rows of nobservables+1 floats (last = dataset id). */
   Chain operator()(std::vector<float>& data, unsigned nsteps, float burnin_fraction,
                    const bool debug_mode = false, unsigned sync_interval = 10000) {
+    const std::chrono::steady_clock::time_point walk_t0 = std::chrono::steady_clock::now();
     std::unique_lock<SetupLock> excl;  // (first local: released last, after the arrays below are freed)
     if (exclusive) excl = std::unique_lock<SetupLock>(*exclusive);
     // array transfers of this walk are ordered on the chain's stream (a blocking copy through the legacy
@@ -517,6 +521,8 @@ class MCMC {
     };
 
     unsigned i = 0;
+    const std::chrono::steady_clock::time_point steps_t0 = std::chrono::steady_clock::now();
+    chain.setup_seconds = std::chrono::duration<double>(steps_t0 - walk_t0).count();
     while (i < nsteps) {
       // Re-tune the proposal from the burn-in samples (mcmc.cpp:274-311); the width becomes
       // scale_factor x the standard deviation of the parameter over the steps kept so far
@@ -681,6 +687,7 @@ class MCMC {
       i = f + 1;
     }
     if (strm) check(sxmc_stream_synchronize(strm));
+    chain.steps_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - steps_t0).count();
     if (lockstep) lockstep->leave(lockstep_index);
     // the evaluators borrowed this walk's arrays (lookup table, normalisations, parameter vectors): un-bind them
     // before they die, or the next evaluation of an evaluator would touch destroyed arrays

@@ -85,6 +85,25 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
 }  // namespace
 
 static int run(int argc, char** argv);
+// where the experiments' host time went, summed over the experiments (they overlap: lanes run side by side)
+static std::string phases_json(const std::vector<sxmc::ExperimentResult>& res) {
+  sxmc::ExperimentResult::Phases p;
+  for (const sxmc::ExperimentResult& r : res) {
+    p.data += r.phases.data;
+    p.construct += r.phases.construct;
+    p.walk_setup += r.phases.walk_setup;
+    p.steps += r.phases.steps;
+    p.walk_teardown += r.phases.walk_teardown;
+    p.destroy += r.phases.destroy;
+    p.intervals += r.phases.intervals;
+  }
+  char b[400];
+  std::snprintf(b, sizeof b, "{\"data\": %.4f, \"construct\": %.4f, \"walk_setup\": %.4f, \"steps\": %.4f, "
+                "\"walk_teardown\": %.4f, \"destroy\": %.4f, \"intervals\": %.4f}", p.data, p.construct, p.walk_setup,
+                p.steps, p.walk_teardown, p.destroy, p.intervals);
+  return b;
+}
+
 int main(int argc, char** argv) {
   try {
     return run(argc, argv);
@@ -297,10 +316,12 @@ static int run(int argc, char** argv) {
         std::printf("{\"driver\": \"sxmc::ensemble_lockstep (C++)\", \"experiments\": %zu, \"steps_each\": %u, "
                     "\"chains_per_fill\": %u, \"sets\": %u, \"seconds\": %.4f, \"experiments_per_sec\": %.4f, "
                     "\"steps_per_sec_inside\": %.1f, \"nevents_first\": %zu, "
+                    "\"phase_seconds_summed_over_experiments\": %s, "
                     "\"setup_lock\": {\"waited_seconds_summed_over_lanes\": %.4f, \"held_seconds\": %.4f, "
                     "\"acquisitions\": %llu, \"lanes\": %u}}\n",
                     res.size(), opt.esteps, opt.L, opt.S, sec, res.size() / sec, res.size() * (double)opt.esteps / sec,
-                    res.empty() ? (size_t)0 : res[0].nevents, lock.waited_seconds(), lock.held_seconds(), lock.count(),
+                    res.empty() ? (size_t)0 : res[0].nevents, phases_json(res).c_str(), lock.waited_seconds(),
+                    lock.held_seconds(), lock.count(),
                     opt.L * opt.S);
         std::fflush(stdout);
       }
@@ -358,12 +379,12 @@ static int run(int argc, char** argv) {
                   "\"replica_setup_seconds_max\": %.4f, \"experiments_per_sec\": %.4f, "
                   "\"experiments_per_sec_after_setup\": %.4f, \"steps_per_sec_inside\": %.1f, "
                   "\"median_upper_limit_source0\": %.6g, \"gathered_floats\": %zu, \"nevents\": %s], "
-                  "\"data\": \"%s\", \"setup_locks\": %s]}\n",
+                  "\"data\": \"%s\", \"phase_seconds_summed_over_experiments\": %s, \"setup_locks\": %s]}\n",
                   G, devs.c_str(), opt.host_staging ? "host staging (rehearsal)" : "ncclAllGather (RCCL)",
                   mg.rccl_nranks, rdevs.c_str(), n, opt.esteps, opt.L, opt.S, sec, setup_max, n / sec, n / inside,
                   n * (double)opt.esteps / inside, mg.median_upper.empty() ? 0.0 : (double)mg.median_upper[0],
                   mg.gathered.size(), nev.c_str(), sxmc::data_source() ? "configured data sets" : "fake",
-                  locks.c_str());
+                  phases_json(mg.results).c_str(), locks.c_str());
       std::fflush(stdout);
     }
   }
