@@ -321,6 +321,45 @@ TEST(DeviceArray, LazyMirrorSemantics) {
   EXPECT_EQ(0.0, z.readOnlyHostPtr()[1]);
 }
 
+// The block pool the ensemble runners hold (device_array.h): inside a PoolScope a released array's blocks come back for
+// the next array of the same size class -- zeroed on the host side like a fresh one, a never-written array still reads
+// as zeros on both sides -- and without a scope arrays allocate and free as before.
+TEST(DeviceArray, BlockPoolRecyclesBlocksInsideAScope) {
+  const int* first_dev = nullptr;
+  const int* first_host = nullptr;
+  {
+    sxmc::PoolScope scope;
+    EXPECT_TRUE(sxmc::BlockPool::instance().active());
+    {
+      hemi::Array<int> a(1000, true);
+      int* h = a.writeOnlyHostPtr();
+      for (int i = 0; i < 1000; i++) h[i] = i + 1;
+      first_host = h;
+      first_dev = a.readOnlyDevicePtr();
+      EXPECT_EQ(1000, a.readOnlyHostPtr()[999]);
+    }
+    {
+      hemi::Array<int> b(900, true);   // same size class (4096 bytes): the same blocks, and they read as zeros
+      EXPECT_TRUE(b.readOnlyDevicePtr() == first_dev);
+      EXPECT_TRUE(b.readOnlyHostPtr() == first_host);
+      EXPECT_EQ(0, b.readOnlyHostPtr()[899]);
+      b.ptr();                          // (device side valid, host stale: copied back on the next host read)
+      EXPECT_EQ(0, b.readOnlyHostPtr()[5]);
+      hemi::Array<int> c(5000, true);  // another class: other blocks
+      EXPECT_TRUE(c.readOnlyDevicePtr() != first_dev);
+      {
+        sxmc::PoolScope inner;         // scopes nest: the pool lives until the outermost ends
+      }
+      EXPECT_TRUE(sxmc::BlockPool::instance().active());
+    }
+  }
+  EXPECT_TRUE(!sxmc::BlockPool::instance().active());
+  hemi::Array<int> d(1000, true);      // no scope: a plain allocation, freed for real
+  d.writeOnlyHostPtr()[3] = 9;
+  d.readOnlyDevicePtr();
+  EXPECT_EQ(9, d.hostPtr()[3]);
+}
+
 // ------------------------------------------------------------------ NLL launch points + MCMC driver
 static unsigned lcg(unsigned& s) {
   s = s * 1664525u + 1013904223u;
@@ -630,7 +669,11 @@ TEST_F(SmallFit, ConcurrentExperimentsMatchSequential) {
       EXPECT_EQ(seq[i].intervals[p].upper, par[i].intervals[p].upper);
       EXPECT_EQ(seq[i].intervals[p].point_estimate, par[i].intervals[p].point_estimate);
     }
+    // every experiment says where its host time went; the pool the runners hold is gone when they return
+    EXPECT_TRUE(par[i].phases.steps > 0 && par[i].phases.data > 0 && par[i].phases.walk_setup > 0);
+    EXPECT_TRUE(par[i].phases.walk_teardown >= 0 && par[i].phases.intervals >= 0);
   }
+  EXPECT_TRUE(!sxmc::BlockPool::instance().active());
 }
 
 TEST_F(SmallFit, LockstepExperimentsMatchSequential) {
