@@ -326,8 +326,9 @@ class Leg:
         n = max(ROOFLINE_LAUNCHES, 0)
         self.fill_ms_total, self.nfill = self.fill_ms_region, self.nfill_region
         self.roofline_sample = "inside the timed region: the %d steps launched one by one" % self.nfill_region
+        self.region_chain = None
         if n > 0:
-            m.flush()
+            self.region_chain = m.flush()          # (rows kept, accepted) of the timed steps: what the line reports
             m.group.Profile(True, 2 * n + 8)
             if self.la is not None:
                 self.la.steps(2 * n, graph_passes=0)      # (one or two steps per pass: at least n passes)
@@ -764,7 +765,7 @@ def main():
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
     elapsed = leg.timed(args.steps)
 
-    chain, accepted = m.flush()
+    chain, accepted = leg.region_chain if leg.region_chain is not None else m.flush()
     if chain.shape[0] == 0:
         chain = np.zeros((1, w.nparameters + 1), np.float32)
     mine_iv = chain_intervals(chain, w.nparameters)[None]
