@@ -528,7 +528,10 @@ class Leg:
                              % (time_evals, len(which), w.nsignals, nchecked, w.nsamples_total, w.events.shape[0],
                                 time_evals, "" if frac == 1.0 else "; value scaled to the whole workload by sample count"),
                    "all_cores": {"value": frac / secn, "cores": ncores,
-                                 "note": "same oracle, pthreads over sample chunks with private histograms"}}
+                                 "note": "same oracle, pthreads over sample chunks with private histograms"
+                                         + ("" if ncores == (os.cpu_count() or 1) else
+                                            " (threads capped: their private histograms of %d bins are kept below 4 GB)"
+                                            % int(np.prod(w.nbins)))}}
         ok = par["bins_and_norms_bit_exact"] and exact_lut and rel <= 1e-6 and step_rel <= 2e-6
         par["ok"] = bool(ok)
         return par, cpu
