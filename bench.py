@@ -838,11 +838,12 @@ def main():
                 torch.cuda.synchronize()
                 t2 = time.perf_counter()
                 done = 0
+                ls_timing = {}
                 for lo in range(0, len(mine) - len(mine) % per_round, per_round):
                     batch = mine[lo:lo + per_round]
                     res = ensemble.run_experiments_in_lockstep(
                         w, [dist.experiment_seed(args.seed, k) for k in batch], args.exp_steps, sets,
-                        burnin_fraction=0.1, sync_interval=args.exp_steps, graph_steps=exp_graph)
+                        burnin_fraction=0.1, sync_interval=args.exp_steps, graph_steps=exp_graph, timing=ls_timing)
                     for i, r in enumerate(res):
                         local2[lo + i] = r[0]
                     done += len(batch)
@@ -854,6 +855,11 @@ def main():
                 lockstep = {"chains_per_fill": L, "sets_per_gpu": nsets, "count": ndone, "seconds": ls_elapsed,
                             "experiments_per_sec": ndone / ls_elapsed,
                             "steps_per_sec_inside": ndone * args.exp_steps / ls_elapsed,
+                            # the stepping alone (set-up of the experiments -- fake data, evaluation points, first
+                            # evaluation -- and their intervals left out): what an experiment of 1e5 steps consists of
+                            "stepping_seconds_rank0": ls_timing.get("stepping_seconds"),
+                            "steps_per_sec_while_stepping_rank0": (done * args.exp_steps / ls_timing["stepping_seconds"]
+                                                                   if ls_timing.get("stepping_seconds") else None),
                             "intervals_identical_to_separate_fills": same,
                             "note": "sxmc_multigroup_step_async: the chains of a set share ONE pass over the tables per "
                                     "step; sets on their own streams"}
@@ -883,7 +889,10 @@ def main():
             "gathered_shape": [int(x) for x in allint.shape],
             "note": "fake data set + MCMC walk with burn-in re-tuning + contour intervals per experiment; "
                     "at 1e5 steps per experiment (BASELINE config 3/4) that is %.4f experiments/s on this job"
-                    % (best["steps_per_sec_inside"] / 1e5),
+                    % (best["steps_per_sec_inside"] / 1e5)
+                    + ("" if not (best is lockstep and lockstep.get("steps_per_sec_while_stepping_rank0")) else
+                       " counting the set-up of these short experiments, %.4f per GPU by the stepping rate alone"
+                       % (lockstep["steps_per_sec_while_stepping_rank0"] / 1e5)),
         }
         for c in pool:
             capi.synchronize()

@@ -309,11 +309,15 @@ def run_experiment(workload, seed, nsteps, burnin_fraction=0.1, cl=0.9, sync_int
 
 
 def run_experiments_in_lockstep(workload, seeds, nsteps, sets, burnin_fraction=0.1, cl=0.9, sync_interval=10000,
-                                graph_steps=0):
+                                graph_steps=0, timing=None):
     """len(seeds) fake experiments at once on one GPU, the chains grouped into lockstep sets (mcmc.LockstepChains:
     the chains of a set share a stream and ONE fill pass per step; different sets run on different streams, so one
     set's step ends overlap another's fill).  Same schedule of re-tunings and flushes as a single walk; every
-    chain walks what it walks alone.  Returns a list of (intervals, chain, accepted) in the order of `seeds`."""
+    chain walks what it walks alone.  Returns a list of (intervals, chain, accepted) in the order of `seeds`.
+    timing (a dict, optional): "stepping_seconds" is increased by the wall time of the stepping alone -- from the last
+    chain's set-up (fake data, evaluation points, first evaluation) to the last flush, re-tunings and flushes
+    included -- which is what an experiment of BASELINE's 1e5 steps consists of."""
+    import time
     chains = [m for st in sets for m in st.chains]
     assert len(seeds) == len(chains)
     for st in sets:
@@ -323,6 +327,9 @@ def run_experiments_in_lockstep(workload, seeds, nsteps, sets, burnin_fraction=0
         m.reseed(seed & 0xFFFFFFFF)
         data, _ = make_fake_dataset(rng, workload, m.pdfs, poisson=True)
         m.walk_begin(data, nsteps, burnin_fraction, sync_interval=sync_interval)
+    if timing is not None:
+        capi.synchronize()
+    t0 = time.perf_counter()
     i = 0
     for f in chains[0].flush_schedule():            # the same schedule for every chain
         for m in chains:
@@ -336,6 +343,9 @@ def run_experiments_in_lockstep(workload, seeds, nsteps, sets, burnin_fraction=0
         for m in chains:
             m._flush_if_due(f)
         i = f + 1
+    if timing is not None:
+        capi.synchronize()
+        timing["stepping_seconds"] = timing.get("stepping_seconds", 0.0) + (time.perf_counter() - t0)
     out = []
     for m in chains:
         chain, accepted = m.walk_end()
