@@ -13,16 +13,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_bare_two_rank_bench_over_gloo():
+def test_bare_two_rank_bench_over_gloo(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["SXMC_DIST_BACKEND"] = "gloo"
+    env["SXMC_BENCH_FULL"] = str(tmp_path / "full.json")      # the full record (the stdout line is the compact one)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
                         "--prewarm", "20", "--scale", "0.02", "--events", "5000", "--experiments", "4", "--exp-steps", "300",
                         "--also", "cpp_multi_gpu"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    rec = json.loads(lines[0])
+    assert len(lines[0]) < 8192
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["rehearsal"] is True
+    assert line["parity"]["ok"] and line["roofline"]["launches_timed"] >= 100 and line["cpu_baseline"] is None
+    assert line["experiments"]["gathered_shape"] == [4, 15, 4] and line["also"]["cpp_multi_gpu"]["ranks"] == 2
+    rec = json.load(open(tmp_path / "full.json"))
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     c = rec["collective"]
     assert c["backend"] == "gloo" and c["world_size"] == 2 and c["rccl_nranks"] is None and c["launched_by"] == "bench.py"
