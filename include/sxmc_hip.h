@@ -165,10 +165,40 @@ int sxmc_hist_set_pdf_value_buffer(sxmc_hist_t h, float* d_output, int offset, i
 int sxmc_hist_set_normalization_buffer(sxmc_hist_t h, unsigned* d_norm, int offset);
 int sxmc_hist_set_parameter_buffer(sxmc_hist_t h, const double* d_params, int offset, int stride);
 
-/* EvalHist::EvalAsync / EvalFinished (pdfz.cpp:441-495): zero, fill, (evaluate) on the
- * evaluator's own stream; returns before completion. */
+/* EvalHist::EvalAsync / EvalFinished (pdfz.cpp:441-495): zero, fill, (evaluate); eval_async returns before
+ * completion, eval_finished when the evaluator's results are in its bound buffers.
+ * TRANSPARENT BATCHING.  The reference's callers evaluate their S signals as "EvalAsync on all, then EvalFinished on
+ * all" (mcmc.cpp:264-271, bench_sxmc.cpp:193-200).  Launched one by one that is S full-grid fills with S fixed
+ * costs; so sxmc_hist_eval_async DEFERS: the evaluator joins the calling host thread's batch, and the batch is
+ * launched as ONE group evaluation (what sxmc_group_eval_async does: one zero, ONE fill over all members' samples, one
+ * lookup) -- at once when the last evaluator of a batch seen before has arrived (so the device works while the caller
+ * goes on, as with the reference), otherwise at the first call that could tell the difference: sxmc_hist_eval_finished
+ * of a member, any copy, launch, synchronisation or stream query through this ABI, a change of a member's bindings,
+ * systematics or points, its destruction.  Results are identical (integer counters; the lookup is per evaluator).  An
+ * unchanged mcmc.cpp gets the batched fill this way; the explicit group API below remains for callers that want
+ * more (fused lookup + event sum, fused step end, HIP-graph replay).  A batch is per host thread: EvalFinished must
+ * come from the thread that called EvalAsync (SXMC_ERR_STATE otherwise).  While a HIP graph is being recorded on the
+ * calling thread, and after sxmc_set_deferred_eval(0) (or SXMC_DEFER_EVAL=0 in the environment), evaluations are
+ * launched as asked: each at once, on its evaluator's own stream. */
 int sxmc_hist_eval_async(sxmc_hist_t h, int do_eval_pdf);
 int sxmc_hist_eval_finished(sxmc_hist_t h);
+/* 0: sxmc_hist_eval_async launches at once on the evaluator's own stream (S separate launch sequences for S
+ * evaluators: the reference's literal behaviour; measurement / tests).  Default 1.  Process-wide. */
+int sxmc_set_deferred_eval(int enable);
+/* LAZY EvalFinished (default 1; SXMC_LAZY_FINISH=0 in the environment changes the default).  A batch of two or more
+ * deferred evaluations is launched on the legacy default stream -- where the reference's caller launches its NLL
+ * kernels (mcmc.cpp:314-348) and with which every blocking stream orders.  What the caller does next through this ABI
+ * on that stream or on a blocking stream (its kernels, blocking copies to the host, the next evaluation) is therefore
+ * ordered after the batch ON THE DEVICE, and sxmc_hist_eval_finished of such a batch does not stop the host: the wait
+ * is carried out by the first call that could tell the difference -- one that names a stream created non-blocking,
+ * or that synchronises or queries a stream or the device.  The host then runs ahead of the device as a caller of the
+ * group API does, instead of idling the device once per MCMC step.  NOT covered: device work the caller issues
+ * outside this ABI, on a non-blocking stream of its own, straight after EvalFinished -- such a caller sets 0, and
+ * EvalFinished blocks until the evaluation has finished, as in the reference. */
+int sxmc_set_lazy_finish(int enable);
+/* Process-wide counters of the batching above: group launches made for deferred evaluations, and the evaluations
+ * (evaluator x EvalAsync) they carried -- 1 and S per MCMC step of an unchanged mcmc.cpp.  For tests and logs. */
+int sxmc_deferred_eval_stats(unsigned long long* launches, unsigned long long* evaluations);
 
 /* Introspection used by CreateHistogram / GetSamples / tests (pdfz.cpp:498-594, pdfz.h:542-556). */
 int sxmc_hist_total_nbins(sxmc_hist_t h, int* total_nbins);
@@ -416,6 +446,18 @@ int sxmc_lookahead_begin(sxmc_stream_t s, int nparameters, const sxmc_rng_state*
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches);
 /* 0: sxmc_group_step_async always takes its three-launch route (measurement / tests).  Default 1. */
 int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);
+/* The step end of sxmc_group_step_async as ONE cooperative launch (default 1; SXMC_COOP_STEP_END=0 in the environment
+ * changes the default): where the event sum is at most 128 workgroups of 128 rows (up to 16 384 rows: BASELINE
+ * configs 2 and 3 with event classes), the look-ups + event sum (nll_event_chunks, nll_kernels.cpp:89-116), the step
+ * end (finish_nll_jump_pick_combo, :230-271) and the clearing for the next evaluation run in one kernel: the event
+ * sum's workgroups publish their partial sums and count themselves in, a finisher workgroup -- which has meanwhile
+ * done everything of the step end that does not need the sums -- waits for the count inside the kernel, and the
+ * other workgroups clear the histograms once all look-ups are done.  Same partial sums, same order: the chain is the
+ * one the separate launches walk, bit for bit.  2 launches per step instead of 3.  Every wait inside the kernel is
+ * bounded (~0.3 s): a workgroup that gives up counts a timeout, which sxmc_group_step_end_timeouts reports (0 in any
+ * healthy run; the results of a step that timed out are not valid). */
+int sxmc_group_set_cooperative_step_end(sxmc_group_t g, int enable);
+int sxmc_group_step_end_timeouts(sxmc_group_t g, unsigned* timeouts);
 /* Compiles (does not load or run) the fill kernel the library would specialise at run time for a program of
  * systematics -- see sxmc_group_set_runtime_kernels.  Needs no GPU: a build check, and the test hook of the
  * run-time compilation.  ops[i] = type | obs_slot << 4 | extra_slot << 8 | npars << 12 (npars 0 = one coefficient);

@@ -89,6 +89,9 @@ SIGNATURES = {
     "sxmc_hist_set_parameter_buffer": [_vp, _vp, _i, _i],
     "sxmc_hist_eval_async": [_vp, _i],
     "sxmc_hist_eval_finished": [_vp],
+    "sxmc_set_deferred_eval": [_i],
+    "sxmc_set_lazy_finish": [_i],
+    "sxmc_deferred_eval_stats": [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)],
     "sxmc_hist_total_nbins": [_vp, _pi],
     "sxmc_hist_bin_volume": [_vp, _pd],
     "sxmc_hist_nsamples": [_vp, _psz],
@@ -120,6 +123,8 @@ SIGNATURES = {
     "sxmc_group_step_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp,
                               _vp, _vp, _vp, _vp, _i],
     "sxmc_group_set_tail_kernel": [_vp, _i],
+    "sxmc_group_set_cooperative_step_end": [_vp, _i],
+    "sxmc_group_step_end_timeouts": [_vp, C.POINTER(C.c_uint)],
     "sxmc_rtc_compile_check": [_i, _i, _i, _i, _i, _vp, _i, _psz],
     "sxmc_rtc_compile_check_lockstep": [_i, _i, _i, _i, _vp, _i, _psz],
     "sxmc_group_last_step_launches": [_vp, _pi],

@@ -122,8 +122,19 @@ __device__ __forceinline__ void nll_total_device(size_t nparameters, size_t nsig
 
 // Sum of sums[0..n) over the workgroup; the total is returned to every thread.
 __device__ __forceinline__ double block_sum(size_t n, const double* sums, double* s_wave /*[17]*/) {
+  // (a thread's terms are added in index order, as before; sixteen loads are in flight at a time -- the reference's
+  //  launch shape hands 16 384 partial sums to 128 lanes, mcmc.cpp:37-45, and one load per addition made that 41 us)
   double t = 0.0;
-  for (size_t i = threadIdx.x; i < n; i += blockDim.x) t += sums[i];
+  size_t i = threadIdx.x;
+  const size_t bd = blockDim.x;
+  for (; i + 15 * bd < n; i += 16 * bd) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = sums[i + (size_t)k * bd];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += v[k];
+  }
+  for (; i < n; i += bd) t += sums[i];
   // a block size that is not a multiple of 64 leaves the last wave partly empty: what a shuffle reads from
   // a lane that does not exist is undefined, so those contributions are replaced by zero
   const int wave = threadIdx.x / kWave;
@@ -160,15 +171,19 @@ __device__ __forceinline__ double block_sum(size_t n, const double* sums, double
 constexpr int kStage = 256;
 
 // Returns (to every thread) whether the proposal was accepted.
-__device__ __forceinline__ bool finish_step_device(size_t npartial_sums, const double* sums, size_t nsignals,
-                                                   size_t nsources, const double* means, const double* sigmas,
-                                                   sxmc_rng_state* rng, double* nll_current,
-                                                   double* nll_proposed, double* v_current, double* v_proposed,
-                                                   int* accepted, int* counter, float* jump_buffer,
-                                                   int nparameters, const float* jump_width,
-                                                   const double* nexpected, const unsigned* n_mc,
-                                                   const short* source_id, const unsigned* norms,
-                                                   bool debug_mode) {
+// `wait`: called by every thread of the workgroup, once, after everything that does not need the partial sums has
+// been loaded and computed (phase A) and before the sums are read -- the cooperative step end (step_end_kernel) waits
+// there for the workgroups that are still summing, so that phase A runs under their look-ups.
+template <typename Wait>
+__device__ __forceinline__ bool finish_step_device_w(size_t npartial_sums, const double* sums, size_t nsignals,
+                                                     size_t nsources, const double* means, const double* sigmas,
+                                                     sxmc_rng_state* rng, double* nll_current,
+                                                     double* nll_proposed, double* v_current, double* v_proposed,
+                                                     int* accepted, int* counter, float* jump_buffer,
+                                                     int nparameters, const float* jump_width,
+                                                     const double* nexpected, const unsigned* n_mc,
+                                                     const short* source_id, const unsigned* norms,
+                                                     bool debug_mode, Wait&& wait) {
   __shared__ double s_wave[17];
   __shared__ double s_vprop[kStage], s_vcur[kStage], s_pen[kStage], s_z[kStage], s_term[kStage];
   __shared__ float s_jw[kStage];
@@ -178,6 +193,7 @@ __device__ __forceinline__ bool finish_step_device(size_t npartial_sums, const d
 
   const bool staged = nparameters <= kStage && nsignals <= (size_t)kStage;
   if (!staged) {
+    wait();
     double total_sum = block_sum(npartial_sums, sums, s_wave);
     if (threadIdx.x == 0) {
       nll_total_device(nparameters, nsignals, nsources, v_proposed, means, sigmas, &total_sum, nexpected, n_mc,
@@ -225,6 +241,7 @@ __device__ __forceinline__ bool finish_step_device(size_t npartial_sums, const d
   for (int j = threadIdx.x; j < (int)nsignals; j += blockDim.x) {
     s_term[j] = v_proposed[source_id[j]] * nexpected[j] * norms[j] / n_mc[j];  // :169-172
   }
+  wait();
   const double total_sum = block_sum(npartial_sums, sums, s_wave);  // barriers inside: LDS is visible after
 
   // ---- phase B
@@ -266,6 +283,20 @@ __device__ __forceinline__ bool finish_step_device(size_t npartial_sums, const d
   }
   if (threadIdx.x == 0) jump_buffer[row + nparameters] = (float)s_nllcur;
   return accept;
+}
+
+__device__ __forceinline__ bool finish_step_device(size_t npartial_sums, const double* sums, size_t nsignals,
+                                                   size_t nsources, const double* means, const double* sigmas,
+                                                   sxmc_rng_state* rng, double* nll_current,
+                                                   double* nll_proposed, double* v_current, double* v_proposed,
+                                                   int* accepted, int* counter, float* jump_buffer,
+                                                   int nparameters, const float* jump_width,
+                                                   const double* nexpected, const unsigned* n_mc,
+                                                   const short* source_id, const unsigned* norms,
+                                                   bool debug_mode) {
+  return finish_step_device_w(npartial_sums, sums, nsignals, nsources, means, sigmas, rng, nll_current, nll_proposed,
+                              v_current, v_proposed, accepted, counter, jump_buffer, nparameters, jump_width, nexpected,
+                              n_mc, source_id, norms, debug_mode, [] {});
 }
 
 // What the NEXT call of finish_step_device would propose if the step it decides were rejected -- i.e. from the

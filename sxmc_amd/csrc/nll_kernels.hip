@@ -67,12 +67,38 @@ __global__ void nll_event_chunks_kernel(const float* __restrict__ lut, const dou
   __syncthreads();
   const size_t offset = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // The reference's launch shape (64 x 256 lanes, mcmc.cpp:37-45) gives a lane a handful of events and the kernel is
+  // nothing but their loads' latency: the table values of an event are asked for sixteen signals at a time (indices
+  // past the last signal repeat it: no branches between the loads), and the NEXT event's first sixteen while this
+  // event's logarithm is taken.  The terms are added in signal order, the events in index order, as before.
+  constexpr int U = 16;
   double sum = 0;
+  float nxt[U];
+  auto request = [&](size_t i, size_t j0, float* v) {
+    const size_t ic = i < ne ? i : (ne ? ne - 1 : 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t j = j0 + (size_t)u < ns ? j0 + (size_t)u : ns - 1;
+      v[u] = lut[j * ne + ic];
+    }
+  };
+  if (ne == 0 || ns == 0) {
+    if (offset < stride) sums[offset] = 0.0;
+    return;
+  }
+  request(offset, 0, nxt);
   for (size_t i = offset; i < ne; i += stride) {
     double s = 0;
-    for (size_t j = 0; j < ns; j++) {
-      const float v = lut[j * ne + i];
-      s = s + s_coef[j] * (double)(!isnan(v) ? v : 0.0f);  // NaNs come from empty histograms
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = nxt[u];
+    for (size_t j0 = 0; j0 < ns; j0 += U) {
+      if (j0 > 0) request(i, j0, v);
+      if (j0 + U >= ns) request(i + stride, 0, nxt);   // (past the last event: a clamped, unused read)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (j0 + (size_t)u < ns) s = s + s_coef[j0 + u] * (double)(!isnan(v[u]) ? v[u] : 0.0f);  // NaN: empty histogram
+      }
     }
     if (s > 0) sum += log(s);
   }

@@ -247,6 +247,9 @@ __device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __rest
   const unsigned long long step = (unsigned long long)nblocks * blockDim.x;
   for (; i < npoints; i += step) {
     double s = 0.0;
+    // (the row's weight is asked for before the gathers, not after the logarithm: one memory round trip less on a
+    //  path that is nothing but round trips)
+    const unsigned wrow = weight ? to_global(weight)[i] : 1u;
     for (int j0 = 0; j0 < nsig; j0 += U) {
       if (!requested) load_read_bins(i, j0);
       requested = false;
@@ -266,7 +269,7 @@ __device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __rest
         }
       }
     }
-    if (s > 0) sum += weight ? (double)to_global(weight)[i] * log(s) : log(s);
+    if (s > 0) sum += weight ? (double)wrow * log(s) : log(s);
   }
 
 #pragma unroll
@@ -487,6 +490,108 @@ __global__ __launch_bounds__(256) void finish_zero_kernel(const SxSignalDesc* __
   const unsigned stride = zblocks * blockDim.x;
   for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
   if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
+}
+
+// THE STEP END IN ONE LAUNCH (cooperative).  eval_nll_kernel + finish_zero_kernel are two launches whose work is a chain
+// of memory round trips: at BASELINE config 3 they take 9.5 + 6.8 us plus two launch boundaries, 20 us of a 150 us step
+// (profiles/r03_c3_kernel_stats.csv), and more than the fill itself at config 2.  Earlier one-launch forms lost what
+// the boundary saved: the LAST workgroup to arrive ran the whole step end cold (15.7 against 14.7 us), and one
+// workgroup doing everything is far too slow beyond a few hundred look-ups.  Here the roles are fixed at launch:
+//   * workgroups 0 .. W-1 (the workers) do the look-ups and the event sum exactly as eval_nll_kernel does -- the same
+//     virtual blocks of 128 rows, the same partial sums, so the NLL and with it the chain stay bit-identical --,
+//     publish their partials (release) and count themselves in;
+//   * workgroup W (the finisher) meanwhile does everything of finish_nll_jump_pick_combo that does not need the sums
+//     (phase A of finish_step_device: all inputs loaded, the expected-rate and constraint terms, the next proposal's
+//     deviates) and then waits for the count to reach W; what is left after the last worker's arrival is one
+//     acquire, the reduction of W partials and phases B and C;
+//   * the workers, once all of them have arrived -- nothing reads the histograms any more --, clear the histograms for
+//     the next evaluation (what zero_kernel would do) while the finisher finishes; the finisher clears the
+//     normalisations, which it and the workers read.
+// Waiting inside a kernel needs the waited-for workgroups to be resident or to become resident: the grid is at most
+// 129 workgroups of 128 lanes with a few KB of LDS (the host takes this form only then), which the device holds many
+// times over beside any fill kernel; and every wait is BOUNDED -- a workgroup that does not see the count arrive within
+// ~0.3 s gives up, counts a timeout (sync[6], read by sxmc_group_step_end_timeouts) and goes on, so the grid always
+// drains.  The counters reset themselves: the last of the W + 1 workgroups to leave zeroes them.
+constexpr unsigned kEndSpinLimit = 200000u;
+
+__device__ __forceinline__ bool end_wait_for(unsigned* counter, unsigned target, unsigned* timeouts) {
+  // (one lane polls; ~1.5 us per poll with the sleep)
+  for (unsigned it = 0; it < kEndSpinLimit; it++) {
+    if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+__global__ __launch_bounds__(128) void step_end_kernel(const SxSignalDesc* __restrict__ lookup_descs,
+                                                       const SxSignalDesc* __restrict__ hist_descs, int nsig,
+                                                       unsigned long long npoints, const unsigned* __restrict__ weight,
+                                                       double* sums, unsigned* sync, unsigned nvb, unsigned zblocks,
+                                                       SxStepArgs a) {
+  extern __shared__ double sh[];
+  const unsigned W = gridDim.x - 1u;
+  unsigned* const arrive = sync + 4;
+  unsigned* const depart = sync + 5;
+  unsigned* const timeouts = sync + 6;
+  if (blockIdx.x == W) {
+    // ---- the finisher
+    sxdev::finish_step_device_w(nvb, sums, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                                a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                                a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
+                                a.debug_mode != 0, [&] {
+                                  if (threadIdx.x == 0) {
+                                    (void)end_wait_for(arrive, W, timeouts);
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                  }
+                                  __syncthreads();
+                                });
+    __syncthreads();
+    for (int j = threadIdx.x; j < nsig; j += blockDim.x) *hist_descs[j].norm = 0u;
+    if (threadIdx.x == 0) sync[0] = 0u;   // (the ticket of the other step-end forms: as finish_zero_kernel leaves it)
+  } else {
+    // ---- a worker: its virtual blocks of the event sum, as eval_nll_kernel's workgroups do them
+    for (unsigned vb = blockIdx.x; vb < nvb; vb += W) {
+      const double t = eval_nll_block_part(lookup_descs, nsig, npoints, weight, a.v_proposed, a.nexpected, a.n_mc,
+                                           a.source_id, a.norms, sh, vb, nvb);
+      if (threadIdx.x == 0 && !isnan(t)) sums[vb] = t;
+      __syncthreads();   // (the staging area is re-used by the next virtual block)
+    }
+    __shared__ int s_clear;
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the histograms may be cleared once EVERY worker has done its look-ups
+      s_clear = end_wait_for(arrive, W, timeouts) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_clear) {
+      const unsigned npieces = zblocks * (unsigned)nsig;
+      for (unsigned p = blockIdx.x; p < npieces; p += W) {
+        const SxSignalDesc& d = hist_descs[p / zblocks];
+        const unsigned chunk = p % zblocks;
+        unsigned* bins = d.bins;
+        const unsigned n = (unsigned)d.total_nbins;
+        const unsigned n4 = n >> 2;
+        uint4* b4 = reinterpret_cast<uint4*>(bins);
+        const unsigned stride = zblocks * blockDim.x;
+        for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
+      }
+    }
+  }
+  // ---- leaving: the last workgroup out resets the counters for the next launch (nobody reads them any more)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == W) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // LOCKSTEP SETS: the step ends of all chains of a set in two launches instead of two per chain.  The chains have
@@ -950,6 +1055,19 @@ hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(finish_zero_kernel, dim3(1 + (unsigned)zb * (unsigned)nsig), dim3(block), 0, s, d_descs, nsig,
                      (unsigned)zb, npartial, sums, ticket, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_step_end(const SxSignalDesc* lookup_descs, const SxSignalDesc* hist_descs, int nsig, int max_bins,
+                              unsigned long long npoints, const unsigned* weight, double* sums, unsigned* sync,
+                              int nvb, int workers, const SxStepArgs& a, hipStream_t s) {
+  const int block = 128;   // (the rows of a virtual block of the event sum: eval_nll_kernel's workgroup)
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
+  int zb = (max_bins / 4 + block - 1) / block;
+  if (zb < 1) zb = 1;
+  if (zb > 1024) zb = 1024;
+  hipLaunchKernelGGL(step_end_kernel, dim3((unsigned)workers + 1u), dim3(block), shmem, s, lookup_descs, hist_descs,
+                     nsig, npoints, weight, sums, sync, (unsigned)nvb, (unsigned)zb, a);
   return hipGetLastError();
 }
 

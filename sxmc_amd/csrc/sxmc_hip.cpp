@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +15,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rocprofiler-sdk-roctx/roctx.h>
@@ -249,6 +251,26 @@ struct sxmc_hist {
   bool bins_valid = true;          // false after a sparse evaluation: the dense histogram was not filled
   const sxmc_group* cleared_by = nullptr;  // the group whose finish_step cleared this histogram and nothing has
                                            // counted into it since (any group's fill resets it)
+  // sxmc_hist_eval_async defers (see "deferred evaluations" below)
+  std::shared_ptr<struct DeferredBatch> deferred;  // the host thread's batch of evaluations not launched yet it sits in
+  std::shared_ptr<struct BatchInFlight> inflight;  // the batched launch the last sxmc_hist_eval_async went into
+};
+
+// A host thread's evaluations asked for and not launched yet (sxmc_hist_eval_async).  Filled and launched by its
+// thread only; another thread may only take an evaluator OUT of it (sxmc_hist_destroy), under the mutex.
+struct DeferredBatch {
+  std::mutex m;
+  std::vector<sxmc_hist*> members;
+  std::atomic<size_t> n{0};                // members.size(), readable without the mutex
+  int do_eval_pdf = 0;
+  std::thread::id owner;
+};
+
+// One batched launch of deferred evaluations: the stream it went to, and whether some member's EvalFinished has
+// already waited for it (the siblings' EvalFinished then return at once: S - 1 runtime calls saved per step).
+struct BatchInFlight {
+  hipStream_t stream = nullptr;
+  std::atomic<bool> done{false};
 };
 
 namespace {
@@ -321,6 +343,8 @@ struct sxmc_group {
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
+  bool tuned = false;                              // a deferred batch's group: the launch-shape trials have run
+  int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default on)
   int last_step_launches = 0;                      // kernels the last sxmc_group_step_async launched
   unsigned long long plan_generation = 0;          // counts launch plans built (a multigroup re-validates on change)
   std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
@@ -1403,6 +1427,212 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse = false) {
   return SXMC_OK;
 }
 
+// ------------------------------------------------------------------------------ deferred evaluations
+// The reference's caller evaluates its S signals one by one: EvalAsync on every evaluator, then EvalFinished on every
+// evaluator (mcmc.cpp:264-271, bench_sxmc.cpp:193-200) -- S x (zero, fill, lookup) on S streams.  Launched as asked,
+// that is S full-grid fills with S fixed costs.  sxmc_hist_eval_async therefore DEFERS: the evaluator joins the calling
+// thread's batch, and the batch goes to the device as ONE group launch (zero, ONE fill over all members, lookup: what
+// sxmc_group_eval_async does) either when the last sibling of a batch seen before arrives -- so the device works while
+// the caller moves on to its EvalFinished calls, as with the reference -- or at the first call that could observe
+// the difference: sxmc_hist_eval_finished, any copy, launch, synchronisation or change of a member.  An unchanged
+// caller of the reference's sequence gets the batched fill; results are those of the separate launches bit for bit
+// (integer counters; the lookup is per evaluator either way).
+struct AutoGroup {
+  std::vector<sxmc_hist*> members;
+  sxmc_group* g = nullptr;
+};
+std::mutex g_auto_mutex;
+std::vector<AutoGroup> g_auto_groups;     // groups made for batches of two or more (a single evaluator has h->self)
+std::atomic<int> g_defer{-1};             // -1: ask the environment (SXMC_DEFER_EVAL=0 switches deferral off)
+thread_local std::shared_ptr<DeferredBatch> t_deferred;
+thread_local bool t_flushing = false;
+
+bool deferral_enabled() {
+  int v = g_defer.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv("SXMC_DEFER_EVAL");
+    v = (e && e[0] == '0') ? 0 : 1;
+    g_defer.store(v, std::memory_order_relaxed);
+  }
+  return v > 0;
+}
+
+std::atomic<unsigned long long> g_deferred_launches{0}, g_deferred_evaluations{0};
+
+// Where a batch is launched.  The reference's evaluators each launch on a stream of their own, and its caller's NLL
+// kernels go to the legacy default stream (HEMI_KERNEL_LAUNCH(..., 0, 0, ...), mcmc.cpp:314-348), which orders with
+// those streams implicitly.  A batch is ONE launch sequence, so there is nothing for separate streams to overlap, and
+// every hop between an evaluator's stream and the legacy stream costs the runtime a cross-queue dependency per step.
+// A batch of two or more therefore goes to the legacy default stream itself -- ordered with everything the reference's
+// streams would be ordered with, and with the caller's NLL kernels by plain queue order.  SXMC_DEFER_STREAM=own
+// launches on the first member's stream instead (measurement).
+hipStream_t batch_stream(const std::vector<sxmc_hist*>& m) {
+  static const bool own = [] {
+    const char* e = std::getenv("SXMC_DEFER_STREAM");
+    return e && std::string(e) == "own";
+  }();
+  return (m.size() >= 2 && !own) ? nullptr : m[0]->stream;
+}
+
+// EvalFinished's wait: hipStreamSynchronize.  (An MCMC step waits once per evaluation, mcmc.cpp:268-270, so polling
+// hipStreamQuery first was tried -- SXMC_FINISH_SPIN_US microseconds of it, default 0 -- and measured no faster at
+// BASELINE config 3, 4 450-4 480 against 4 530-4 570 steps/s: the runtime's own wait already spins.)
+hipError_t wait_for_stream(hipStream_t s) {
+  static const long spin_us = [] {
+    const char* e = std::getenv("SXMC_FINISH_SPIN_US");
+    return e ? std::atol(e) : 0L;
+  }();
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e == hipSuccess) return hipSuccess;
+      if (e != hipErrorNotReady) return e;
+      (void)hipGetLastError();
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+  }
+  return hipStreamSynchronize(s);
+}
+
+// Launches the calling thread's batch, if any.  Every entry point that could observe a deferred evaluation calls this
+// first (SX_FLUSH).
+int flush_deferred() {
+  if (!t_deferred || t_deferred->n.load(std::memory_order_relaxed) == 0 || t_flushing) return SXMC_OK;
+  std::vector<sxmc_hist*> m;
+  int do_eval_pdf = 0;
+  {
+    std::lock_guard<std::mutex> lock(t_deferred->m);
+    m.swap(t_deferred->members);
+    t_deferred->n.store(0, std::memory_order_relaxed);
+    do_eval_pdf = t_deferred->do_eval_pdf;
+    for (sxmc_hist* h : m) h->deferred.reset();
+  }
+  if (m.empty()) return SXMC_OK;
+  sxmc_group* g = nullptr;
+  if (m.size() == 1) {
+    if (!m[0]->self) {
+      int rc = sxmc_group_create(&m[0], 1, &m[0]->self);
+      if (rc) return rc;
+    }
+    g = m[0]->self;
+  } else {
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    for (AutoGroup& a : g_auto_groups)
+      if (a.members == m) g = a.g;
+    if (!g) {
+      int rc = sxmc_group_create(m.data(), (int)m.size(), &g);
+      if (rc) return rc;
+      g_auto_groups.push_back(AutoGroup{m, g});
+    }
+  }
+  auto fl = std::make_shared<BatchInFlight>();
+  fl->stream = batch_stream(m);
+  t_flushing = true;    // (the group calls below are themselves flush points)
+  int rc = SXMC_OK;
+  if (m.size() == 1 || m[0]->cfg_threads > 0 || m[0]->cfg_bpc > 0) {
+    g->cfg_threads = m[0]->cfg_threads;   // (a launch shape set by hand on the evaluators)
+    g->cfg_bpc = m[0]->cfg_bpc;
+  } else if (m.size() >= 2 && !g->tuned) {
+    // EvalHist's `optimize` (pdfz.cpp:622-727: trial launches at construction pick the launch shape) for the batch, at
+    // its first launch: a few trial fills choose the lane count per CU for this box.  Only a long pure stream has
+    // anything to choose (sxmc_group_optimize returns at once otherwise); the evaluation proper follows and zeroes
+    // what the trials counted.
+    g->tuned = true;
+    rc = sxmc_group_optimize(g, fl->stream, nullptr);
+  }
+  if (rc == SXMC_OK) rc = sxmc_group_eval_async(g, do_eval_pdf, fl->stream);
+  t_flushing = false;
+  for (sxmc_hist* h : m) h->inflight = rc == SXMC_OK ? fl : nullptr;
+  g_deferred_launches.fetch_add(1, std::memory_order_relaxed);
+  g_deferred_evaluations.fetch_add(m.size(), std::memory_order_relaxed);
+  return rc;
+}
+
+// Is the thread's batch complete -- a batch of two or more seen before, and no known batch goes on beyond it?
+bool deferred_batch_complete() {
+  std::lock_guard<std::mutex> own(t_deferred->m);           // (another thread may be taking a dying evaluator out)
+  const std::vector<sxmc_hist*>& m = t_deferred->members;
+  if (m.size() < 2) return false;
+  std::lock_guard<std::mutex> lock(g_auto_mutex);
+  bool exact = false;
+  for (const AutoGroup& a : g_auto_groups) {
+    if (a.members.size() < m.size() || !std::equal(m.begin(), m.end(), a.members.begin())) continue;
+    if (a.members.size() > m.size()) return false;
+    exact = true;
+  }
+  return exact;
+}
+
+// An evaluator dies: it leaves the batches, and the groups made for batches it was part of go with it.
+void forget_evaluator(sxmc_hist* h) {
+  std::vector<sxmc_group*> doomed;
+  {
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    for (size_t i = 0; i < g_auto_groups.size();) {
+      AutoGroup& a = g_auto_groups[i];
+      if (std::find(a.members.begin(), a.members.end(), h) != a.members.end()) {
+        doomed.push_back(a.g);
+        g_auto_groups.erase(g_auto_groups.begin() + (long)i);
+      } else {
+        i++;
+      }
+    }
+  }
+  for (sxmc_group* g : doomed) sxmc_group_destroy(g);
+}
+
+// LAZY EvalFinished.  A batch launched on the legacy default stream is ordered, on the device, before everything the
+// caller does next through this ABI on that stream or on any blocking stream -- its NLL kernels (mcmc.cpp:314-348),
+// blocking copies to the host, the next evaluation.  So sxmc_hist_eval_finished of such a batch does not stop the host:
+// it notes that the thread has an unwaited batch, and the wait happens at the first call that could tell -- one that
+// names a stream which does NOT order with the legacy stream (created non-blocking), or that synchronises.  The host
+// then runs ahead of the device like a caller of the group API does, instead of idling the device once per step while
+// it wakes up and launches the rest of the step (measured at BASELINE config 3: ~25 us of ~190).  What this cannot
+// cover is device work the caller issues OUTSIDE this ABI on a non-blocking stream of its own right after
+// EvalFinished; sxmc_set_lazy_finish(0) (SXMC_LAZY_FINISH=0) restores the blocking wait for such callers.
+std::atomic<int> g_lazy_finish{-1};
+thread_local bool t_unsettled = false;   // this thread returned from an EvalFinished without waiting
+bool lazy_finish_enabled() {
+  int v = g_lazy_finish.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv("SXMC_LAZY_FINISH");
+    v = (e && e[0] == '0') ? 0 : 1;
+    g_lazy_finish.store(v, std::memory_order_relaxed);
+  }
+  return v > 0;
+}
+int settle() {
+  if (!t_unsettled) return SXMC_OK;
+  t_unsettled = false;
+  SX_HIP(hipStreamSynchronize(nullptr));
+  return SXMC_OK;
+}
+// Before work is put on stream `s`: does `s` order with the legacy stream by itself?
+int settle_for(hipStream_t s) {
+  if (!t_unsettled || s == nullptr) return SXMC_OK;
+  unsigned flags = 0;
+  if (hipStreamGetFlags(s, &flags) == hipSuccess && !(flags & hipStreamNonBlocking)) return SXMC_OK;
+  (void)hipGetLastError();
+  return settle();
+}
+
+#define SX_ORDER(s)                                  \
+  do {                                               \
+    if (t_unsettled) {                               \
+      int _rc = settle_for((hipStream_t)(s));        \
+      if (_rc) return _rc;                           \
+    }                                                \
+  } while (0)
+
+#define SX_FLUSH()                                                          \
+  do {                                                                      \
+    if (t_deferred && t_deferred->n.load(std::memory_order_relaxed) != 0) { \
+      int _rc = flush_deferred();                                           \
+      if (_rc) return _rc;                                                  \
+    }                                                                       \
+  } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -1451,6 +1681,8 @@ int sxmc_set_tracing(int enable) {
 }
 
 int sxmc_device_synchronize(void) {
+  SX_FLUSH();
+  if (int rc_ = settle()) return rc_;
   SX_HIP(hipDeviceSynchronize());
   return SXMC_OK;
 }
@@ -1473,6 +1705,8 @@ int sxmc_malloc(void** d_ptr, size_t bytes) {
   return SXMC_OK;
 }
 int sxmc_free(void* d_ptr) {
+  SX_FLUSH();
+  if (int rc_ = settle()) return rc_;
   if (d_ptr) SX_HIP(hipFree(d_ptr));
   return SXMC_OK;
 }
@@ -1482,30 +1716,40 @@ int sxmc_host_alloc(void** h_ptr, size_t bytes) {
   return SXMC_OK;
 }
 int sxmc_host_free(void* h_ptr) {
+  SX_FLUSH();
+  if (int rc_ = settle()) return rc_;
   if (h_ptr) SX_HIP(hipHostFree(h_ptr));
   return SXMC_OK;
 }
 int sxmc_memcpy_h2d(void* d, const void* h, size_t n) {
+  SX_FLUSH();
   if (n) SX_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
   return SXMC_OK;
 }
 int sxmc_memcpy_d2h(void* h, const void* d, size_t n) {
+  SX_FLUSH();
   if (n) SX_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
   return SXMC_OK;
 }
 int sxmc_memcpy_d2d(void* d, const void* s, size_t n) {
+  SX_FLUSH();
   if (n) SX_HIP(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice));
   return SXMC_OK;
 }
 int sxmc_memcpy_h2d_async(void* d, const void* h, size_t n, sxmc_stream_t s) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (n) SX_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
   return SXMC_OK;
 }
 int sxmc_memcpy_d2h_async(void* h, const void* d, size_t n, sxmc_stream_t s) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (n) SX_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
   return SXMC_OK;
 }
 int sxmc_memset(void* d, int v, size_t n) {
+  SX_FLUSH();
   if (n) SX_HIP(hipMemset(d, v, n));
   return SXMC_OK;
 }
@@ -1525,14 +1769,20 @@ int sxmc_stream_create_nonblocking(sxmc_stream_t* s) {
   return SXMC_OK;
 }
 int sxmc_stream_destroy(sxmc_stream_t s) {
+  SX_FLUSH();
+  if (int rc_ = settle()) return rc_;
   if (s) SX_HIP(hipStreamDestroy((hipStream_t)s));
   return SXMC_OK;
 }
 int sxmc_stream_synchronize(sxmc_stream_t s) {
+  SX_FLUSH();
+  if (int rc_ = settle()) return rc_;
   SX_HIP(hipStreamSynchronize((hipStream_t)s));
   return SXMC_OK;
 }
 int sxmc_stream_query(sxmc_stream_t s, int* done) {
+  SX_FLUSH();
+  if (int rc_ = settle()) return rc_;
   SX_REQUIRE(done, "null argument");
   const hipError_t e = hipStreamQuery((hipStream_t)s);
   if (e == hipSuccess) {
@@ -1549,6 +1799,8 @@ int sxmc_stream_query(sxmc_stream_t s, int* done) {
 }
 
 int sxmc_graph_begin_capture(sxmc_stream_t s) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(s, "the legacy default stream cannot be captured: pass a created stream");
   SX_REQUIRE(!t_capturing, "a capture is already in progress on this thread");
   SX_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
@@ -1574,6 +1826,8 @@ int sxmc_graph_end_capture(sxmc_stream_t s, sxmc_graph_t* out) {
   return SXMC_OK;
 }
 int sxmc_graph_launch(sxmc_graph_t graph, sxmc_stream_t s, int times) {
+  SX_FLUSH();
+  SX_ORDER(s);
   TraceRange trace("sxmc: graph replay");
   SX_REQUIRE(graph, "null graph");
   SX_REQUIRE(times >= 0, "negative repeat count");
@@ -1597,6 +1851,8 @@ int sxmc_event_destroy(sxmc_event_t e) {
   return SXMC_OK;
 }
 int sxmc_event_record(sxmc_event_t e, sxmc_stream_t s) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_HIP(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
   return SXMC_OK;
 }
@@ -1754,7 +2010,17 @@ int sxmc_hist_create_shared(sxmc_hist_t base, sxmc_hist_t* out) {
 
 int sxmc_hist_destroy(sxmc_hist_t h) {
   if (!h) return SXMC_OK;
+  if (std::shared_ptr<DeferredBatch> b = h->deferred) {
+    // (an evaluation asked for and never waited for does not outlive its evaluator -- whichever thread asked)
+    std::lock_guard<std::mutex> lock(b->m);
+    b->members.erase(std::remove(b->members.begin(), b->members.end(), h), b->members.end());
+    b->n.store(b->members.size(), std::memory_order_relaxed);
+    h->deferred.reset();
+  }
+  (void)flush_deferred();
+  if (h->inflight && !h->inflight->done.load()) (void)hipStreamSynchronize(h->inflight->stream);
   (void)hipStreamSynchronize(h->stream);
+  forget_evaluator(h);
   if (h->self) sxmc_group_destroy(h->self);
   if (h->d_bins) (void)hipFree(h->d_bins);
   if (h->d_read_bins) (void)hipFree(h->d_read_bins);
@@ -1779,6 +2045,7 @@ int sxmc_hist_add_systematic(sxmc_hist_t h, int type, int obs, int extra_field, 
   SX_REQUIRE(npars >= 0 && npars <= SXMC_MAX_SYST_PARS, "Too many parameters for one systematic");
   SX_REQUIRE(npars == 0 || pars, "null parameter index list");
   SX_REQUIRE((int)h->systs.size() < SXMC_MAX_SYST, "Too many systematics on one evaluator");
+  if (h->deferred) SX_FLUSH();
   HostSyst s;
   s.type = type;
   s.obs = obs;
@@ -1797,6 +2064,7 @@ int sxmc_hist_add_systematic(sxmc_hist_t h, int type, int obs, int extra_field, 
 }
 
 int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints_floats) {
+  SX_FLUSH();
   TraceRange trace("sxmc: SetEvalPoints");
   SX_REQUIRE(h, "null evaluator");
   const size_t row = (size_t)h->nobs + 1;
@@ -1840,6 +2108,7 @@ int sxmc_hist_set_eval_points(sxmc_hist_t h, const float* points, size_t npoints
 int sxmc_hist_set_pdf_value_buffer(sxmc_hist_t h, float* d_output, int offset, int stride) {
   SX_REQUIRE(h, "null evaluator");
   if (h->pdf == d_output && h->pdf_off == offset && h->pdf_stride == stride) return SXMC_OK;
+  if (h->deferred) SX_FLUSH();   // (the evaluation asked for runs with the bindings it was asked with)
   h->pdf = d_output;
   h->pdf_off = offset;
   h->pdf_stride = stride;
@@ -1849,6 +2118,7 @@ int sxmc_hist_set_pdf_value_buffer(sxmc_hist_t h, float* d_output, int offset, i
 int sxmc_hist_set_normalization_buffer(sxmc_hist_t h, unsigned* d_norm, int offset) {
   SX_REQUIRE(h, "null evaluator");
   if (h->norm == d_norm && h->norm_off == offset) return SXMC_OK;
+  if (h->deferred) SX_FLUSH();
   h->norm = d_norm;
   h->norm_off = offset;
   h->version++;
@@ -1857,6 +2127,7 @@ int sxmc_hist_set_normalization_buffer(sxmc_hist_t h, unsigned* d_norm, int offs
 int sxmc_hist_set_parameter_buffer(sxmc_hist_t h, const double* d_params, int offset, int stride) {
   SX_REQUIRE(h, "null evaluator");
   if (h->params == d_params && h->par_off == offset && h->par_stride == stride) return SXMC_OK;
+  if (h->deferred) SX_FLUSH();
   h->params = d_params;
   h->par_off = offset;
   h->par_stride = stride;
@@ -1866,18 +2137,87 @@ int sxmc_hist_set_parameter_buffer(sxmc_hist_t h, const double* d_params, int of
 
 int sxmc_hist_eval_async(sxmc_hist_t h, int do_eval_pdf) {
   SX_REQUIRE(h, "null evaluator");
-  if (!h->self) {
-    int rc = sxmc_group_create(&h, 1, &h->self);
-    if (rc) return rc;
+  do_eval_pdf = do_eval_pdf ? 1 : 0;
+  if (t_capturing || !deferral_enabled()) {
+    // launched as asked, on the evaluator's own stream (a recording takes what is launched, when it is launched)
+    SX_FLUSH();
+    if (!h->self) {
+      int rc = sxmc_group_create(&h, 1, &h->self);
+      if (rc) return rc;
+    }
+    h->self->cfg_threads = h->cfg_threads;
+    h->self->cfg_bpc = h->cfg_bpc;
+    h->inflight.reset();
+    return sxmc_group_eval_async(h->self, do_eval_pdf, h->stream);
   }
-  h->self->cfg_threads = h->cfg_threads;
-  h->self->cfg_bpc = h->cfg_bpc;
-  return sxmc_group_eval_async(h->self, do_eval_pdf, h->stream);
+  // the checks an immediate launch would make: a caller that forgot a binding hears of it here, not at EvalFinished
+  if (!h->norm) return fail(SXMC_ERR_STATE, "evaluation before SetNormalizationBuffer");
+  if (!h->systs.empty() && !h->params) return fail(SXMC_ERR_STATE, "evaluation before SetParameterBuffer");
+  if (do_eval_pdf && h->has_points && !h->pdf) return fail(SXMC_ERR_STATE, "evaluation before SetPDFValueBuffer");
+  if (!t_deferred) {
+    t_deferred = std::make_shared<DeferredBatch>();
+    t_deferred->owner = std::this_thread::get_id();
+  }
+  if (h->deferred && h->deferred != t_deferred) {
+    return fail(SXMC_ERR_STATE, "EvalAsync of an evaluator whose previous EvalAsync, on another host thread, has not "
+                                "been followed by EvalFinished there");
+  }
+  // a second evaluation of the same evaluator, or another kind of evaluation, starts a new batch
+  if (h->deferred || (t_deferred->n.load(std::memory_order_relaxed) != 0 && t_deferred->do_eval_pdf != do_eval_pdf)) {
+    SX_FLUSH();
+  }
+  {
+    std::lock_guard<std::mutex> lock(t_deferred->m);
+    t_deferred->members.push_back(h);
+    t_deferred->n.store(t_deferred->members.size(), std::memory_order_relaxed);
+    t_deferred->do_eval_pdf = do_eval_pdf;
+    h->deferred = t_deferred;
+  }
+  h->inflight.reset();
+  if (deferred_batch_complete()) return flush_deferred();   // the last sibling: the device starts now
+  return SXMC_OK;
 }
 
 int sxmc_hist_eval_finished(sxmc_hist_t h) {
   SX_REQUIRE(h, "null evaluator");
+  if (h->deferred && h->deferred != t_deferred) {
+    return fail(SXMC_ERR_STATE, "EvalFinished on another host thread than the evaluator's EvalAsync");
+  }
+  SX_FLUSH();
+  if (std::shared_ptr<BatchInFlight> fl = h->inflight) {
+    // one wait per batch: the first sibling's EvalFinished waits, the others find it done
+    if (!fl->done.load(std::memory_order_acquire)) {
+      if (fl->stream == nullptr && lazy_finish_enabled() && !t_capturing) {
+        t_unsettled = true;      // (ordered on the device; the host waits when it could first tell: see settle_for)
+      } else {
+        SX_HIP(wait_for_stream(fl->stream));
+      }
+      fl->done.store(true, std::memory_order_release);
+    }
+    h->inflight.reset();
+    return SXMC_OK;
+  }
   SX_HIP(hipStreamSynchronize(h->stream));
+  return SXMC_OK;
+}
+
+int sxmc_set_deferred_eval(int enable) {
+  SX_FLUSH();
+  g_defer.store(enable ? 1 : 0, std::memory_order_relaxed);
+  return SXMC_OK;
+}
+
+int sxmc_set_lazy_finish(int enable) {
+  SX_FLUSH();
+  if (int rc = settle()) return rc;
+  g_lazy_finish.store(enable ? 1 : 0, std::memory_order_relaxed);
+  return SXMC_OK;
+}
+
+int sxmc_deferred_eval_stats(unsigned long long* launches, unsigned long long* evaluations) {
+  SX_REQUIRE(launches && evaluations, "null argument");
+  *launches = g_deferred_launches.load();
+  *evaluations = g_deferred_evaluations.load();
   return SXMC_OK;
 }
 
@@ -1902,6 +2242,7 @@ int sxmc_hist_npoints(sxmc_hist_t h, size_t* v) {
   return SXMC_OK;
 }
 int sxmc_hist_get_bins(sxmc_hist_t h, unsigned* out, size_t n) {
+  SX_FLUSH();
   SX_REQUIRE(h && out, "null argument");
   SX_REQUIRE(n == (size_t)h->total_nbins, "bins buffer size mismatch");
   if (!h->bins_valid) {
@@ -1919,6 +2260,7 @@ int sxmc_hist_get_read_bins(sxmc_hist_t h, int* out, size_t n) {
   return SXMC_OK;
 }
 int sxmc_hist_get_samples(sxmc_hist_t h, float* out, size_t n) {
+  SX_FLUSH();
   SX_REQUIRE(h && (out || n == 0), "null argument");
   SX_REQUIRE(n == h->nsamples * ((size_t)h->nobs + 1), "samples buffer size mismatch");
   if (!n) return SXMC_OK;
@@ -1934,6 +2276,7 @@ int sxmc_hist_get_samples(sxmc_hist_t h, float* out, size_t n) {
 }
 int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long seed, const float* lowers,
                             const float* uppers, float* h_events) {
+  SX_FLUSH();
   SX_REQUIRE(h && (h_events || nobserved == 0), "null argument");
   SX_REQUIRE(h->nobs <= 3, "Cannot EvalHist::CreateHistogram for dimensions greater than 3!");   // pdfz.cpp:499-501
   SX_REQUIRE((lowers == nullptr) == (uppers == nullptr), "give both cut arrays or neither");
@@ -1976,6 +2319,7 @@ int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long 
 }
 
 int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s) {
+  SX_FLUSH();
   SX_REQUIRE(h && s, "null argument");
   *s = h->stream;
   return SXMC_OK;
@@ -1985,6 +2329,7 @@ int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_p
   SX_REQUIRE(bin_threads == 0 || (bin_threads >= 64 && bin_threads <= 1024 && bin_threads % 64 == 0),
              "bin_threads must be 0 or a multiple of 64 up to 1024");
   SX_REQUIRE(bin_blocks_per_cu >= 0 && bin_blocks_per_cu <= 16, "bin_blocks_per_cu out of range");
+  if (h->deferred) SX_FLUSH();
   h->cfg_threads = bin_threads;
   h->cfg_bpc = bin_blocks_per_cu;
   return SXMC_OK;
@@ -2009,6 +2354,7 @@ int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* ou
 }
 
 int sxmc_group_destroy(sxmc_group_t g) {
+  SX_FLUSH();
   if (!g) return SXMC_OK;
   (void)hipDeviceSynchronize();
   for (LaunchClass& c : g->classes) free_class(c);
@@ -2035,6 +2381,8 @@ int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks
 }
 
 int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(g, "null group");
   SX_REQUIRE(!t_capturing, "not while recording a graph");
   if (chosen_threads) *chosen_threads = 0;
@@ -2189,6 +2537,8 @@ int sxmc_group_set_debug_mode(sxmc_group_t g, int mode) {
 }
 
 int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(g, "null group");
   int rc = group_refresh(g);
   if (rc) return rc;
@@ -2210,6 +2560,8 @@ int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s) {
 int sxmc_group_eval_nll_async(sxmc_group_t g, sxmc_stream_t s, const double* d_pars, const double* d_nexpected,
                               const unsigned* d_n_mc, const short* d_source_id, const unsigned* d_norms,
                               double* d_sums, int* npartial_out) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(g && d_pars && d_nexpected && d_n_mc && d_source_id && d_norms && d_sums && npartial_out,
              "null argument");
   int rc = group_refresh(g);
@@ -2253,6 +2605,8 @@ int sxmc_group_mcmc_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_
                                float* d_jump_buffer, int nparameters, size_t nsources, const float* d_jump_width,
                                const double* d_nexpected, const unsigned* d_n_mc, const short* d_source_id,
                                const unsigned* d_norms, int debug_mode) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(g && d_means && d_sigmas && d_rng && d_nll_current && d_nll_proposed && d_v_current && d_v_proposed &&
                  d_accepted && d_counter && d_jump_buffer && d_jump_width && d_nexpected && d_n_mc && d_source_id &&
                  d_norms,
@@ -2314,6 +2668,8 @@ int sxmc_group_finish_step_async(sxmc_group_t g, sxmc_stream_t s, size_t npartia
                                  int nparameters, size_t nsources, const float* d_jump_width,
                                  const double* d_nexpected, const unsigned* d_n_mc, const short* d_source_id,
                                  const unsigned* d_norms, int debug_mode) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(g && d_sums && d_means && d_sigmas && d_rng && d_nll_current && d_nll_proposed && d_v_current &&
                  d_v_proposed && d_accepted && d_counter && d_jump_buffer && d_jump_width && d_nexpected &&
                  d_n_mc && d_source_id && d_norms,
@@ -2371,6 +2727,19 @@ bool step_end_takes_tail(const sxmc_group* g, bool sparse, unsigned long long ne
 int step_sum_blocks(unsigned long long ne) {
   return (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + 127) / 128));
 }
+// Does the step end run as ONE cooperative launch (step_end_kernel: workgroups that wait for each other inside the
+// kernel)?  Only while the whole grid is small enough to be resident many times over -- at most 128 workers of 128
+// lanes: up to 16 384 rows, BASELINE configs 2 and 3 with event classes -- so that several chains' step ends, each
+// waiting for its own workgroups, always fit the device together.  Larger event sums keep the two-launch form.
+constexpr int kCoopMaxWorkers = 128;
+bool step_end_is_cooperative(const sxmc_group* g, unsigned long long ne) {
+  static const int env_default = [] {
+    const char* e = std::getenv("SXMC_COOP_STEP_END");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  const int on = g->cfg_coop < 0 ? env_default : g->cfg_coop;
+  return on != 0 && g->cfg_tail != 0 && step_sum_blocks(ne) <= kCoopMaxWorkers;
+}
 
 int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDesc* descs, unsigned long long ne,
                     const unsigned* weight, const SxStepArgs& a) {
@@ -2382,6 +2751,13 @@ int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDe
   // gains 0.6 us of 14.7.  Only the smallest problems take it.
   if (step_end_takes_tail(g, sparse, ne)) {
     SX_HIP(sx_launch_tail_step(descs, (int)g->members.size(), ne, weight, a, st));
+    g->last_step_launches += 1;
+  } else if (step_end_is_cooperative(g, ne)) {
+    // ONE launch: the event sum's workgroups + a finisher that waits for them inside the kernel (step_end_kernel)
+    const int nvb = step_sum_blocks(ne);
+    SX_HIP(sx_launch_step_end(descs, sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
+                              sparse ? g->max_bins_sparse : g->max_bins, ne, weight, g->d_step_sums, g->d_ticket, nvb, nvb,
+                              a, st));
     g->last_step_launches += 1;
   } else {
     g->last_step_launches += 2;
@@ -2409,6 +2785,8 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
                           double* d_v_proposed, int* d_accepted, int* d_counter, float* d_jump_buffer, int nparameters,
                           size_t nsources, const float* d_jump_width, const double* d_nexpected, const unsigned* d_n_mc,
                           const short* d_source_id, const unsigned* d_norms, int debug_mode) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(g && d_means && d_sigmas && d_rng && d_nll_current && d_nll_proposed && d_v_current && d_v_proposed &&
                  d_accepted && d_counter && d_jump_buffer && d_jump_width && d_nexpected && d_n_mc && d_source_id &&
                  d_norms,
@@ -2569,6 +2947,8 @@ int sxmc_multigroup_destroy(sxmc_multigroup_t mg) {
 }
 
 int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args) {
+  SX_FLUSH();
+  SX_ORDER(s);
   TraceRange trace("sxmc: lockstep step (one fill pass for the set's chains + their step ends)");
   SX_REQUIRE(mg && args, "null argument");
   hipStream_t st = (hipStream_t)s;
@@ -2700,6 +3080,8 @@ int sxmc_multigroup_set_joint_step_end(sxmc_multigroup_t mg, int enable) {
 // bound to a->d_v_proposed / a->d_norms), groups[1] the look-ahead vector (bound to d_v_lookahead / d_norms_lookahead).
 int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* a,
                                          double* d_v_lookahead, const unsigned* d_norms_lookahead, const int* d_cap) {
+  SX_FLUSH();
+  SX_ORDER(s);
   TraceRange trace("sxmc: look-ahead pass (two evaluations, one or two steps)");
   SX_REQUIRE(mg && a && d_v_lookahead && d_norms_lookahead, "null argument");
   SX_REQUIRE(mg->groups.size() == 2, "the look-ahead walk steps exactly two groups: the proposal's and the look-ahead's");
@@ -2836,6 +3218,8 @@ int sxmc_group_lookahead_supported(sxmc_group_t g, int* ok) {
 // were rejected (current vector + jump width x the deviates that step end will draw; generators untouched).
 int sxmc_lookahead_begin(sxmc_stream_t s, int nparameters, const sxmc_rng_state* d_rng, const float* d_jump_width,
                          const double* d_v_current, double* d_v_lookahead) {
+  SX_FLUSH();
+  SX_ORDER(s);
   SX_REQUIRE(d_rng && d_jump_width && d_v_current && d_v_lookahead && nparameters > 0, "null argument");
   SX_HIP(sx_launch_peek_next_proposal(nparameters, d_rng, d_jump_width, d_v_current, d_v_lookahead, (hipStream_t)s));
   return SXMC_OK;
@@ -2850,6 +3234,19 @@ int sxmc_group_last_step_launches(sxmc_group_t g, int* launches) {
 int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_tail = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_cooperative_step_end(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_coop = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_group_step_end_timeouts(sxmc_group_t g, unsigned* timeouts) {
+  SX_REQUIRE(g && timeouts, "null argument");
+  SX_FLUSH();
+  SX_HIP(hipMemcpy(timeouts, g->d_ticket + 6, sizeof(unsigned), hipMemcpyDeviceToHost));
   return SXMC_OK;
 }
 
@@ -2886,6 +3283,8 @@ int sxmc_rtc_compile_check_lockstep(int nobs, int nslot, int pre_width, int ncha
 }
 
 int sxmc_group_synchronize(sxmc_group_t g) {
+  SX_FLUSH();
+  if (int rc_ = settle()) return rc_;
   SX_REQUIRE(g, "null group");
   SX_HIP(hipStreamSynchronize(g->last_stream));
   return SXMC_OK;
@@ -2974,6 +3373,8 @@ static int check_launch(int grid, int block) {
 
 int sxmc_launch_init_device_rngs(int grid, int block, sxmc_stream_t s, int nthreads, unsigned long long seed,
                                  sxmc_rng_state* d_state) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (int rc = check_launch(grid, block)) return rc;
   SX_REQUIRE(d_state && (long long)grid * block >= nthreads, "init_device_rngs: grid*block < nthreads");
   SX_HIP(sx_nll_init_rngs(grid, block, (hipStream_t)s, nthreads, seed, d_state));
@@ -2983,6 +3384,8 @@ int sxmc_launch_init_device_rngs(int grid, int block, sxmc_stream_t s, int nthre
 int sxmc_launch_pick_new_vector(int grid, int block, sxmc_stream_t s, int nthreads, sxmc_rng_state* d_rng,
                                 const float* d_jump_width, const double* d_current_vector,
                                 double* d_proposed_vector) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (int rc = check_launch(grid, block)) return rc;
   SX_HIP(sx_nll_pick_new_vector(grid, block, (hipStream_t)s, nthreads, d_rng, d_jump_width, d_current_vector,
                                 d_proposed_vector));
@@ -2992,6 +3395,8 @@ int sxmc_launch_pick_new_vector(int grid, int block, sxmc_stream_t s, int nthrea
 int sxmc_launch_jump_decider(int grid, int block, sxmc_stream_t s, sxmc_rng_state* d_rng, double* d_nll_current,
                              const double* d_nll_proposed, double* d_v_current, const double* d_v_proposed,
                              unsigned nparameters, int* d_accepted, int* d_counter, float* d_jump_buffer) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (int rc = check_launch(grid, block)) return rc;
   SX_HIP(sx_nll_jump_decider(grid, block, (hipStream_t)s, d_rng, d_nll_current, d_nll_proposed, d_v_current,
                              d_v_proposed, nparameters, d_accepted, d_counter, d_jump_buffer));
@@ -3001,6 +3406,8 @@ int sxmc_launch_jump_decider(int grid, int block, sxmc_stream_t s, sxmc_rng_stat
 int sxmc_launch_nll_event_chunks(int grid, int block, sxmc_stream_t s, const float* d_lut, const double* d_pars,
                                  size_t ne, size_t ns, const double* d_nexpected, const unsigned* d_n_mc,
                                  const short* d_source_id, const unsigned* d_norms, double* d_sums) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (int rc = check_launch(grid, block)) return rc;
   SX_REQUIRE(ns <= 4096, "too many signals");
   SX_HIP(sx_nll_event_chunks(grid, block, (hipStream_t)s, d_lut, d_pars, ne, ns, d_nexpected, d_n_mc, d_source_id,
@@ -3010,6 +3417,8 @@ int sxmc_launch_nll_event_chunks(int grid, int block, sxmc_stream_t s, const flo
 
 int sxmc_launch_nll_event_reduce(int grid, int block, sxmc_stream_t s, size_t nthreads, const double* d_sums,
                                  double* d_total_sum) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (int rc = check_launch(grid, block)) return rc;
   SX_REQUIRE(grid == 1, "nll_event_reduce runs in one workgroup");
   SX_HIP(sx_nll_event_reduce(block, (hipStream_t)s, nthreads, d_sums, d_total_sum));
@@ -3020,6 +3429,8 @@ int sxmc_launch_nll_total(int grid, int block, sxmc_stream_t s, size_t nparamete
                           size_t nsignals, size_t nsources, const double* d_means, const double* d_sigmas,
                           const double* d_events_total, const double* d_nexpected, const unsigned* d_n_mc,
                           const short* d_source_id, const unsigned* d_norms, double* d_nll) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (int rc = check_launch(grid, block)) return rc;
   SX_HIP(sx_nll_total((hipStream_t)s, nparameters, d_pars, nsignals, nsources, d_means, d_sigmas, d_events_total,
                       d_nexpected, d_n_mc, d_source_id, d_norms, d_nll));
@@ -3034,6 +3445,8 @@ int sxmc_launch_finish_nll_jump_pick_combo(int grid, int block, sxmc_stream_t s,
                                            float* d_jump_buffer, int nparameters, const float* d_jump_width,
                                            const double* d_nexpected, const unsigned* d_n_mc,
                                            const short* d_source_id, const unsigned* d_norms, int debug_mode) {
+  SX_FLUSH();
+  SX_ORDER(s);
   if (int rc = check_launch(grid, block)) return rc;
   SX_REQUIRE(grid == 1, "finish_nll_jump_pick_combo runs in one workgroup");
   SX_HIP(sx_nll_finish_combo(block, (hipStream_t)s, npartial_sums, d_sums, nsignals, nsources, d_means, d_sigmas,
@@ -3045,6 +3458,7 @@ int sxmc_launch_finish_nll_jump_pick_combo(int grid, int block, sxmc_stream_t s,
 
 // test hook: d_out[k] = d_x[k]^i, formed as the polynomial systematics form it
 int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out) {
+  SX_FLUSH();
   SX_REQUIRE(d_x && d_out && n >= 0 && i >= 0 && i < 64, "bad arguments");
   SX_HIP(sx_launch_pow_int(d_x, n, i, d_out, nullptr));
   SX_HIP(hipDeviceSynchronize());
@@ -3053,6 +3467,7 @@ int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out) {
 
 // test hook: raw Philox output of state[0] (advances it by ndraws)
 int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws) {
+  SX_FLUSH();
   SX_HIP(sx_nll_philox_dump(nullptr, d_state, d_out, ndraws));
   SX_HIP(hipDeviceSynchronize());
   return SXMC_OK;

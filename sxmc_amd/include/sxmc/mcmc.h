@@ -504,6 +504,10 @@ class MCMC {
                                         &npartial));
       } else {
         if (reevaluate) {
+          // mcmc.cpp:264-271 as written.  (The evaluators launch on their own streams, which order with the legacy
+          // default stream -- where the reference launches its NLL kernels -- and with nothing else: a walk that was
+          // given its own stream waits for its step end before the evaluators read the new proposal.)
+          if (strm) check(sxmc_stream_synchronize(strm));
           for (pdfz::Eval* p : pdfs) p->EvalAsync();
           for (pdfz::Eval* p : pdfs) p->EvalFinished();
         }

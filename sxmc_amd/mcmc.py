@@ -8,7 +8,11 @@ forms are offered:
   * fused form       -- group.EvalNllAsync (zero, fill, lookup+event sum) ;
                         finish_nll_jump_pick_combo      (4 kernels, lut written, not re-read)
   * step form        -- group.McmcStepAsync: zero, fill, lookup + event sum + step end (3 kernels)
-Both produce the same numbers up to the order of the partial sums.
+  * drop-in form     -- fused="dropin": the reference's literal calls, mcmc.cpp:264-271 + 314-348 -- EvalAsync on
+                        every evaluator, EvalFinished on every evaluator, nll_event_chunks,
+                        finish_nll_jump_pick_combo -- with no group call at all; the library coalesces the S deferred
+                        evaluations into one batched launch (sxmc_hist_eval_async).  The reference form's chain.
+All produce the same numbers up to the order of the partial sums.
 """
 import numpy as np
 
@@ -45,6 +49,10 @@ class MCMC:
         self.w = w
         self.stream = stream
         self.fused = fused
+        if fused == "dropin" and stream is not None:
+            # the evaluators launch on their own (blocking) streams, which order with the legacy default stream only --
+            # where the reference launches its NLL kernels (HEMI_KERNEL_LAUNCH(..., 0, 0, ...), mcmc.cpp:314-348)
+            raise ValueError("the drop-in form launches its NLL kernels on the legacy default stream, like the reference")
         self.consume = bool(consume) and fused is True
         self.tail = True        # consume: one call per step (sxmc_group_step_async) instead of EvalNllAsync + FinishStepAsync
         self.nsources, self.nsignals = w.nsources, w.nsignals
@@ -168,7 +176,16 @@ class MCMC:
                                  self.nsources, self.jump_width, self.nexpected, self.n_mc, self.source_id,
                                  self.normalizations, debug_mode)
             return
-        if self.fused:
+        if self.fused == "dropin":
+            for p in self.pdfs:                  # mcmc.cpp:265-267
+                p.EvalAsync()
+            for p in self.pdfs:                  # mcmc.cpp:268-270
+                p.EvalFinished()
+            nll.nll_event_chunks(NLL_BLOCKS, NLL_BLOCK_SIZE, self.stream, self.lut, self.proposed_vector,
+                                 self.nevents, self.nsignals, self.nexpected, self.n_mc, self.source_id,
+                                 self.normalizations, self.event_partial_sums)
+            npartial = self.nnllthreads
+        elif self.fused:
             npartial = self.group.EvalNllAsync(self.stream, self.proposed_vector, self.nexpected, self.n_mc,
                                                self.source_id, self.normalizations, self.event_partial_sums)
         else:

@@ -170,6 +170,17 @@ class EvalGroup:
     def SetTailKernel(self, enable):
         capi.call("sxmc_group_set_tail_kernel", self._g, int(bool(enable)))
 
+    def SetCooperativeStepEnd(self, enable):
+        """The step end of StepAsync as ONE launch whose workgroups wait for each other (step_end_kernel) where the
+        event sum is small enough; off: look-ups + event sum, then step end + clearing (two launches)."""
+        capi.call("sxmc_group_set_cooperative_step_end", self._g, int(bool(enable)))
+
+    def StepEndTimeouts(self):
+        """Workgroups of the cooperative step end that gave up waiting (0 in a healthy run)."""
+        n = C.c_uint(0)
+        capi.call("sxmc_group_step_end_timeouts", self._g, C.byref(n))
+        return n.value
+
     def FinishStepAsync(self, stream, npartial_sums, sums, means, sigmas, rng, nll_current, nll_proposed, v_current,
                         v_proposed, accepted, counter, jump_buffer, nparameters, nsources, jump_width, nexpected,
                         n_mc, source_id, norms, debug_mode=False):

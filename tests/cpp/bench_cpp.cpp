@@ -4,10 +4,14 @@
 // sets on one GPU, or sharded over the GPUs of the node with sxmc::ensemble_multi_gpu (BASELINE config 4: a host
 // thread per GPU, ONE RCCL all-gather of the intervals).  One JSON line per leg on stdout.
 //
-//   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk]
+//   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk] [--reference-form | --sequential]
+//             [--burnin 0.1] [--sync-interval 10000]
 //             [--experiments 0] [--exp-steps 2000] [--chains 4] [--sets 2]
 //             [--devices G | --device-list 0,0] [--host-staging] [--config fit.json] [--output-dir d]
 //
+// --reference-form: the walk issues mcmc.cpp:264-271 + 314-348 as written (S x EvalAsync, S x EvalFinished,
+//   nll_event_chunks, finish_nll_jump_pick_combo; lookup table materialised, legacy default stream, no graph): what an
+//   unchanged mcmc.cpp gets from this library.  --sequential: the batched step without the look-ahead pass.
 // --devices G: the ensemble leg runs on devices 0..G-1 through ensemble_multi_gpu (needs --experiments).
 // --host-staging: the blocks meet through host memory instead of RCCL (rehearsal of G ranks on fewer cards).
 // --config: signals, observables, systematics, rates and sample tables come from a fit configuration
@@ -34,6 +38,10 @@ struct Options {
   double scale = 1.0;
   unsigned nsteps = 2000, graph_steps = 10;
   bool walk = true;
+  bool reference_form = false;   // the walk issues the reference's own call sequence (mcmc.cpp:264-271, 314-348)
+  bool sequential = false;       // ... or the batched step, one evaluation per step (no look-ahead)
+  float burnin = 0.1f;
+  unsigned sync_interval = 10000;
   unsigned nexp = 0, esteps = 2000, L = 4, S = 2;
   std::vector<int> devices;
   bool host_staging = false;
@@ -63,6 +71,10 @@ Options parse(int argc, char** argv) {
     else if (a == "--steps") o.nsteps = (unsigned)std::atoi(next());
     else if (a == "--graph-steps") o.graph_steps = (unsigned)std::atoi(next());
     else if (a == "--no-walk") o.walk = false;
+    else if (a == "--reference-form") o.reference_form = true;
+    else if (a == "--sequential") o.sequential = true;
+    else if (a == "--burnin") o.burnin = (float)std::atof(next());
+    else if (a == "--sync-interval") o.sync_interval = (unsigned)std::atoi(next());
     else if (a == "--experiments") o.nexp = (unsigned)std::atoi(next());
     else if (a == "--exp-steps") o.esteps = (unsigned)std::atoi(next());
     else if (a == "--chains") o.L = (unsigned)std::atoi(next());
@@ -272,28 +284,40 @@ static int run(int argc, char** argv) {
 
   if (opt.walk) {
     sxmc_stream_t strm = nullptr;
-    sxmc::check(sxmc_stream_create_nonblocking(&strm));
-    // SXMC_BENCH_LOOKAHEAD=0: one evaluation per step; default: the look-ahead walk (two evaluations per pass)
+    // the reference's sequence launches its NLL kernels on the legacy default stream (mcmc.cpp:314-348), which is what
+    // the evaluators' own streams order with; the batched forms walk on a stream of their own
+    if (!opt.reference_form) sxmc::check(sxmc_stream_create_nonblocking(&strm));
+    // SXMC_BENCH_LOOKAHEAD=0 / --sequential: one evaluation per step; default: the look-ahead walk (two per pass)
     const char* la_env = std::getenv("SXMC_BENCH_LOOKAHEAD");
-    const bool lookahead = !(la_env && la_env[0] == '0');
+    const bool lookahead = !(la_env && la_env[0] == '0') && !opt.sequential && !opt.reference_form;
     for (int pass = 0; pass < 2; pass++) {  // pass 0 warms up (clocks, launch plan); pass 1 is timed
       sxmc::MCMC mcmc(sources, signals, systematics, observables, 1234 + pass, strm);
-      mcmc.graph_steps = opt.graph_steps;
+      mcmc.graph_steps = opt.reference_form ? 0 : opt.graph_steps;
       mcmc.lookahead = lookahead;
+      mcmc.reference_form = opt.reference_form;
+      unsigned long long l0 = 0, e0 = 0, l1 = 0, e1 = 0;
+      sxmc::check(sxmc_deferred_eval_stats(&l0, &e0));
       const auto t0 = std::chrono::steady_clock::now();
-      sxmc::Chain chain = mcmc(data, pass == 0 ? std::min(opt.nsteps, 500u) : opt.nsteps, 0.1f, false, 10000);
+      sxmc::Chain chain = mcmc(data, pass == 0 ? std::min(opt.nsteps, 500u) : opt.nsteps, opt.burnin, false,
+                               opt.sync_interval);
       const double sec = seconds_since(t0);
+      sxmc::check(sxmc_deferred_eval_stats(&l1, &e1));
       if (pass == 1) {
-        std::printf("{\"driver\": \"sxmc::MCMC (C++)\", \"nsamples_total\": %zu, \"nsignals\": %zu, \"nevents\": %zu, "
+        std::printf("{\"driver\": \"%s\", \"nsamples_total\": %zu, \"nsignals\": %zu, \"nevents\": %zu, "
                     "\"steps\": %u, \"steps_per_graph\": %u, \"seconds\": %.4f, \"steps_per_sec\": %.1f, "
-                    "\"accepted\": %zu, \"rows_kept\": %zu, \"lookahead\": %s, \"passes\": %zu}\n",
-                    rows_total, signals.size(), data.size() / (observables.size() + 1), opt.nsteps, opt.graph_steps, sec,
-                    opt.nsteps / sec, chain.accepted, chain.nrows(), lookahead ? "true" : "false",
-                    mcmc.LookaheadPasses());
+                    "\"setup_seconds\": %.4f, \"stepping_seconds\": %.4f, \"steps_per_sec_stepping\": %.1f, "
+                    "\"burnin_fraction\": %.3f, \"sync_interval\": %u, "
+                    "\"accepted\": %zu, \"rows_kept\": %zu, \"lookahead\": %s, \"passes\": %zu, "
+                    "\"deferred_launches\": %llu, \"deferred_evaluations\": %llu}\n",
+                    opt.reference_form ? "sxmc::MCMC, the reference's call sequence (C++)" : "sxmc::MCMC (C++)",
+                    rows_total, signals.size(), data.size() / (observables.size() + 1), opt.nsteps, mcmc.graph_steps, sec,
+                    opt.nsteps / sec, chain.setup_seconds, chain.steps_seconds, opt.nsteps / chain.steps_seconds,
+                    (double)opt.burnin, opt.sync_interval, chain.accepted, chain.nrows(), lookahead ? "true" : "false",
+                    mcmc.LookaheadPasses(), l1 - l0, e1 - e0);
         std::fflush(stdout);
       }
     }
-    sxmc_stream_destroy(strm);
+    if (strm) sxmc_stream_destroy(strm);
   }
 
   // ---- ensemble leg: whole fake experiments (fake data drawn on the device, walk with burn-in re-tuning, contour

@@ -451,6 +451,37 @@ TEST_F(SmallFit, BatchedAndReferenceFormsWalkTheSameChain) {
   }
 }
 
+TEST_F(SmallFit, UnchangedCallSequenceIsBatchedBehindTheApi) {
+  // mcmc.cpp:264-271 as written -- EvalAsync on every evaluator, then EvalFinished on every evaluator -- with no
+  // group call: the library defers the S evaluations and launches them as ONE group evaluation.  The chain is the one
+  // S separate launch sequences walk (sxmc_set_deferred_eval(0)), bit for bit, and the counters show one launch
+  // sequence per step.
+  unsigned long long l0 = 0, e0 = 0, l1 = 0, e1 = 0, l2 = 0, e2 = 0;
+  sxmc::check(sxmc_deferred_eval_stats(&l0, &e0));
+  sxmc::MCMC a(sources, signals, systematics, observables, 5);
+  a.reference_form = true;
+  sxmc::Chain ca = a(data, 120, 0.1f, false, 50);
+  sxmc::check(sxmc_deferred_eval_stats(&l1, &e1));
+  sxmc::check(sxmc_set_deferred_eval(0));
+  sxmc::MCMC b(sources, signals, systematics, observables, 5);
+  b.reference_form = true;
+  sxmc::Chain cb = b(data, 120, 0.1f, false, 50);
+  sxmc::check(sxmc_deferred_eval_stats(&l2, &e2));
+  sxmc::check(sxmc_set_deferred_eval(1));
+  // 120 steps + the first evaluation of each of the S evaluators (mcmc.cpp:238-239: EvalAsync, EvalFinished one by one)
+  const size_t S = signals.size();
+  EXPECT_EQ((unsigned long long)(120 * S + S), e1 - e0);
+  EXPECT_EQ((unsigned long long)(120 + S), l1 - l0);
+  EXPECT_EQ(l1, l2);
+  EXPECT_EQ(e1, e2);
+  EXPECT_EQ(ca.nrows(), cb.nrows());
+  EXPECT_EQ(ca.accepted, cb.accepted);
+  EXPECT_TRUE(ca.accepted > 3 && ca.accepted < 120);
+  bool same = ca.rows.size() == cb.rows.size();
+  for (size_t k = 0; same && k < ca.rows.size(); k++) same = ca.rows[k] == cb.rows[k];
+  EXPECT_TRUE(same);
+}
+
 TEST_F(SmallFit, MetropolisWalkWithBurnIn) {
   sxmc::MCMC m(sources, signals, systematics, observables, 7);
   sxmc::Chain c = m(data, 600, 0.2f, false, 100);

@@ -1,0 +1,270 @@
+"""The unchanged caller.  mcmc.cpp:264-271 evaluates its S signals as "EvalAsync on all, then
+EvalFinished on all"; sxmc_hist_eval_async defers and the library launches the S evaluations as ONE group evaluation.
+Checked here: the results are those of the explicit group call and of S separate launches bit for bit (histograms,
+normalisations, lookup table, and the whole chain of a walk that uses nothing but the reference's calls), the
+batching really happens (launch counters), and every way a caller could look at a deferred evaluation sees it done."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sxmc_amd import capi, pdfz, workloads
+from sxmc_amd.capi import DeviceArray
+from sxmc_amd.mcmc import MCMC, make_systematic
+
+pytestmark = pytest.mark.gpu
+
+
+def stats():
+    a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+    capi.call("sxmc_deferred_eval_stats", C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+@pytest.fixture(autouse=True)
+def deferral_on():
+    capi.call("sxmc_set_deferred_eval", 1)
+    yield
+    capi.call("sxmc_set_deferred_eval", 1)
+
+
+def close(m):
+    capi.synchronize()
+    for p in m.pdfs:
+        p.close()
+    m.group.close()
+
+
+def walk(w, form, nsteps, seed=11):
+    m = MCMC(w, seed=seed, fused=form)
+    m.setup(sync_interval=nsteps + 1)
+    for _ in range(nsteps):
+        m.step()
+    rows, nacc = m.flush()
+    lut, norms = m.lut.get().copy(), m.normalizations.get().copy()
+    close(m)
+    return rows, nacc, lut, norms
+
+
+@pytest.mark.parametrize("make,scale,nevents", [(workloads.config1, 1.0, None), (workloads.config2, 0.02, 4000),
+                                                (workloads.config3, 0.004, 3000)])
+def test_unchanged_call_sequence_walks_the_group_paths_chain(make, scale, nevents):
+    w = make(scale) if nevents is None else make(scale, nevents=nevents)
+    nsteps = 60
+    want = walk(w, False, nsteps)                    # group.EvalAsync + nll_event_chunks + finish (same kernels)
+    l0, e0 = stats()
+    got = walk(w, "dropin", nsteps)                  # S x EvalAsync, S x EvalFinished, nll_event_chunks, finish
+    l1, e1 = stats()
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)) and got[1] == want[1]
+    assert np.array_equal(got[2].view(np.uint32), want[2].view(np.uint32)) and np.array_equal(got[3], want[3])
+    assert 0 < got[1] < nsteps                       # a chain that moves and also rejects
+    # every step's S evaluations went out as ONE launch sequence
+    assert e1 - e0 == w.nsignals * nsteps and l1 - l0 == nsteps
+    # ... and with deferral off (S separate launch sequences, the reference's literal behaviour) the same chain
+    capi.call("sxmc_set_deferred_eval", 0)
+    sep = walk(w, "dropin", nsteps)
+    assert stats() == (l1, e1)
+    assert np.array_equal(sep[0].view(np.uint32), want[0].view(np.uint32)) and sep[1] == want[1]
+
+
+def make_evaluators(w, nev=None):
+    events = w.events if nev is None else w.events[:nev]
+    ne = events.shape[0]
+    lut = DeviceArray.zeros(w.nsignals * ne, np.float32)
+    norms = DeviceArray.zeros(w.nsignals, np.uint32)
+    vec = w.parameter_means().astype(np.float64)
+    vec[w.nsources:] = [0.02, -0.004, 0.03][: w.nparameters - w.nsources]
+    pars = DeviceArray(vec)
+    pdfs = []
+    for j, s in enumerate(w.signals):
+        ev = pdfz.EvalHist(s.samples, s.nfields, w.nobs, w.lower, w.upper, w.nbins, dataset=s.dataset)
+        for d in w.systematics:
+            ev.AddSystematic(make_systematic(d))
+        ev.SetEvalPoints(events)
+        ev.SetPDFValueBuffer(lut, j * ne, 1)
+        ev.SetNormalizationBuffer(norms, j)
+        ev.SetParameterBuffer(pars, w.nsources)
+        pdfs.append(ev)
+    return pdfs, lut, norms, pars, vec, events
+
+
+def oracle_rows(w, vec, events):
+    geom = oracle.HistGeometry(w.lower, w.upper, w.nbins)
+    rows, norms, bins = [], [], []
+    for s in w.signals:
+        rb = oracle.set_eval_points(geom, events, s.dataset)
+        b, n = oracle.bin_samples(geom, s.samples, s.nfields, w.systematics, vec[w.nsources:])
+        row = np.zeros(events.shape[0], np.float32)
+        oracle.eval_pdf(rb, b, n, geom.bin_volume, out=row)
+        rows.append(row)
+        norms.append(n)
+        bins.append(b)
+    return np.concatenate(rows), np.array(norms, np.uint32), bins
+
+
+@pytest.mark.parametrize("observer", ["finished", "device_sync", "blocking_copy", "stream_sync", "one_finished"])
+def test_every_way_of_looking_sees_the_deferred_evaluations_done(observer):
+    w = workloads.config3(0.003, nevents=2000)
+    pdfs, lut, norms, pars, vec, events = make_evaluators(w)
+    want_lut, want_norms, want_bins = oracle_rows(w, vec, events)
+    l0, e0 = stats()
+    for p in pdfs:
+        p.EvalAsync()
+    assert stats() == (l0, e0)                     # a first batch is not known to be complete: nothing launched yet
+    if observer == "finished":
+        for p in pdfs:
+            p.EvalFinished()
+    elif observer == "device_sync":
+        capi.synchronize()
+    elif observer == "stream_sync":
+        st = C.c_void_p(0)
+        capi.call("sxmc_hist_get_stream", pdfs[3].handle, C.byref(st))
+        capi.call("sxmc_stream_synchronize", st)
+        capi.synchronize()
+    elif observer == "one_finished":
+        pdfs[-1].EvalFinished()                    # the batch is one launch: one member's wait is everybody's
+    got = lut.get()                                # ("blocking_copy": nothing but this read)
+    assert stats() == (l0 + 1, e0 + len(pdfs))
+    assert np.array_equal(got.view(np.uint32), want_lut.view(np.uint32))
+    assert np.array_equal(norms.get(), want_norms)
+    # the second round is a batch seen before: it goes to the device when its last sibling arrives
+    for p in pdfs[:-1]:
+        p.EvalAsync()
+    assert stats() == (l0 + 1, e0 + len(pdfs))
+    pdfs[-1].EvalAsync()
+    assert stats() == (l0 + 2, e0 + 2 * len(pdfs))
+    for p in pdfs:
+        p.EvalFinished()
+    assert np.array_equal(lut.get().view(np.uint32), want_lut.view(np.uint32))
+    # fill only (CreateHistogram's evaluation): another kind of evaluation is another batch; dense bins are there after
+    for p in pdfs:
+        p.EvalAsync(False)
+    for j, p in enumerate(pdfs):
+        assert np.array_equal(p.GetBins(), want_bins[j])
+    for p in pdfs:
+        p.close()
+
+
+def test_changes_and_destruction_while_deferred():
+    w = workloads.config3(0.003, nevents=1500)
+    pdfs, lut, norms, pars, vec, events = make_evaluators(w)
+    want_lut, want_norms, _ = oracle_rows(w, vec, events)
+    # a member re-bound after its EvalAsync: the evaluation asked for ran with the old binding
+    other = DeviceArray.zeros(w.nsignals, np.uint32)
+    for p in pdfs:
+        p.EvalAsync()
+    pdfs[2].SetNormalizationBuffer(other, 2)        # flushes first
+    capi.synchronize()
+    assert np.array_equal(norms.get(), want_norms) and other.get()[2] == 0
+    pdfs[2].SetNormalizationBuffer(norms, 2)
+    # the same evaluator asked twice: two evaluations, in order
+    l0, e0 = stats()
+    pdfs[0].EvalAsync()
+    pdfs[0].EvalAsync()
+    pdfs[0].EvalFinished()
+    assert stats() == (l0 + 2, e0 + 2)
+    # an evaluator destroyed while its evaluation is still deferred: the others' evaluations stand
+    norms.set(np.zeros(w.nsignals, np.uint32))
+    l0, e0 = stats()
+    for p in pdfs[::-1]:                            # (an order not seen before: nothing is launched yet)
+        p.EvalAsync()
+    assert stats() == (l0, e0)
+    pdfs[5].close()
+    for j, p in enumerate(pdfs):
+        if j != 5:
+            p.EvalFinished()
+    got = norms.get()
+    assert got[5] == 0 and np.array_equal(np.delete(got, 5), np.delete(want_norms, 5))
+    assert stats() == (l0 + 1, e0 + len(pdfs) - 1)
+    # an unbound evaluator is refused where it is asked, not at the flush
+    fresh = pdfz.EvalHist(w.signals[0].samples, w.signals[0].nfields, w.nobs, w.lower, w.upper, w.nbins)
+    with pytest.raises(capi.SxmcError):
+        fresh.EvalAsync()
+    fresh.close()
+    for j, p in enumerate(pdfs):
+        if j != 5:
+            p.close()
+
+
+def test_evaluators_on_two_host_threads_keep_their_own_batches():
+    import threading
+    w = workloads.config3(0.003, nevents=1000)
+    sets = [make_evaluators(w) for _ in range(2)]
+    want_lut, want_norms, _ = oracle_rows(w, sets[0][4], sets[0][5])
+    errors = []
+
+    def run(k):
+        try:
+            pdfs = sets[k][0]
+            for _ in range(5):
+                for p in pdfs:
+                    p.EvalAsync()
+                for p in pdfs:
+                    p.EvalFinished()
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for pdfs, lut, norms, *_ in sets:
+        assert np.array_equal(lut.get().view(np.uint32), want_lut.view(np.uint32))
+        assert np.array_equal(norms.get(), want_norms)
+    # EvalFinished from another thread than EvalAsync's is refused
+    sets[0][0][0].EvalAsync()
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(capi.load().sxmc_hist_eval_finished(sets[0][0][0].handle)))
+    t.start()
+    t.join()
+    assert seen == [capi.ERR_STATE]
+    sets[0][0][0].EvalFinished()
+    for pdfs, *_ in sets:
+        for p in pdfs:
+            p.close()
+
+
+@pytest.mark.parametrize("lazy", [1, 0])
+def test_lazy_finish_is_not_observable_through_the_abi(lazy):
+    """EvalFinished of a batch on the legacy stream does not stop the host (sxmc_set_lazy_finish); whatever the caller
+    does next through the ABI must still see the evaluation done -- also on a stream that does not order with the
+    legacy stream by itself."""
+    from sxmc_amd import nll
+    capi.call("sxmc_set_lazy_finish", lazy)
+    try:
+        w = workloads.config3(0.01, nevents=20000)
+        pdfs, lut, norms, pars, vec, events = make_evaluators(w)
+        ne = events.shape[0]
+        nexp = DeviceArray(np.array([s.nexpected for s in w.signals], np.float64))
+        n_mc = DeviceArray(np.array([s.n_mc for s in w.signals], np.uint32))
+        sid = DeviceArray(np.array([s.source_id for s in w.signals], np.int16))
+        full = DeviceArray(w.parameter_means().astype(np.float64))
+        sums_a, sums_b = DeviceArray.zeros(64 * 256, np.float64), DeviceArray.zeros(64 * 256, np.float64)
+        side = capi.new_stream(nonblocking=True)
+        rng = np.random.default_rng(7)
+        for it in range(12):
+            v = vec.copy()
+            v[w.nsources:] = rng.normal(0, [0.05, 0.01, 0.05])
+            pars.set(v)
+            for p in pdfs:
+                p.EvalAsync()
+            for p in pdfs:
+                p.EvalFinished()
+            # straight on: the reference's event sum over the lookup table, on a NON-BLOCKING stream
+            nll.nll_event_chunks(64, 256, side, lut, full, ne, w.nsignals, nexp, n_mc, sid, norms, sums_a)
+            capi.call("sxmc_stream_synchronize", side)
+            got = sums_a.get().copy()
+            capi.synchronize()
+            nll.nll_event_chunks(64, 256, None, lut, full, ne, w.nsignals, nexp, n_mc, sid, norms, sums_b)
+            capi.synchronize()
+            assert np.array_equal(got, sums_b.get()), it
+        want_lut, want_norms, _ = oracle_rows(w, v, events)
+        assert np.array_equal(lut.get().view(np.uint32), want_lut.view(np.uint32))
+        assert np.array_equal(norms.get(), want_norms)
+        for p in pdfs:
+            p.close()
+    finally:
+        capi.call("sxmc_set_lazy_finish", 1)

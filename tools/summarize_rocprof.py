@@ -4,6 +4,12 @@
   summarize_rocprof.py stats <dir> <out.csv>     kernel_stats.csv -> per-kernel calls / avg / share
   summarize_rocprof.py pmc <out.csv> <dir>...    counter_collection.csv (one dir per --pmc pass)
                                                  -> per-kernel mean counter values per launch
+  summarize_rocprof.py timeline <dir> <out.csv> [skip_fraction]
+                                                 kernel_trace.csv -> per kernel: calls, mean duration, mean IDLE GAP
+                                                 on the device before it starts (start minus the latest end of any
+                                                 earlier kernel, clamped at 0), and the mean period of the repeating
+                                                 sequence; the first skip_fraction (default 0.3) of the dispatches is
+                                                 left out (set-up, warm-up)
 Torch's data-generation kernels are dropped; kernel names are shortened to the function name.
 HBM bytes per launch of the fill kernel follow MI355X_MICROARCH.md (HBM section):
   FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced
@@ -75,8 +81,41 @@ def pmc(out, dirs):
     print(open(out).read())
 
 
+def timeline(d, out, skip=0.3):
+    rows = []
+    for r in csv.DictReader(open(find(d, "*kernel_trace.csv"))):
+        s = short(r["Kernel_Name"])
+        if s:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), s))
+    rows.sort()
+    rows = rows[int(len(rows) * skip):]
+    acc = collections.OrderedDict()
+    latest_end = None
+    for start, end, name in rows:
+        gap = max(0, start - latest_end) if latest_end is not None else 0
+        a = acc.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += (end - start) / 1e3
+        a[2] += gap / 1e3
+        latest_end = end if latest_end is None else max(latest_end, end)
+    span = (rows[-1][1] - rows[0][0]) / 1e3 if rows else 0.0
+    busy = sum(a[1] for a in acc.values())
+    with open(out, "w") as f:
+        f.write("kernel,calls,avg_us,avg_idle_gap_before_us\n")
+        for k, a in acc.items():
+            f.write("%s,%d,%.2f,%.2f\n" % (k, a[0], a[1] / a[0], a[2] / a[0]))
+        f.write("# window %.1f us, kernels busy %.1f us (%.1f %%), idle %.1f us\n"
+                % (span, busy, 100.0 * busy / max(span, 1e-9), span - busy))
+        most = max((a[0] for a in acc.values()), default=0)
+        if most:
+            f.write("# period of the most frequent kernel: %.2f us\n" % (span / most))
+    print(open(out).read())
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 0.3)
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3:])
