@@ -446,8 +446,8 @@ int sxmc_lookahead_begin(sxmc_stream_t s, int nparameters, const sxmc_rng_state*
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches);
 /* 0: sxmc_group_step_async always takes its three-launch route (measurement / tests).  Default 1. */
 int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);
-/* The step end of sxmc_group_step_async as ONE cooperative launch (default 1; SXMC_COOP_STEP_END=0 in the environment
- * changes the default): where the event sum is at most 128 workgroups of 128 rows (up to 16 384 rows: BASELINE
+/* The step end of sxmc_group_step_async as ONE cooperative launch (default 0: measured no faster than the two launches
+ * it replaces -- DESIGN.md section 4; SXMC_COOP_STEP_END=1 in the environment changes the default): where the event sum is at most 128 workgroups of 128 rows (up to 16 384 rows: BASELINE
  * configs 2 and 3 with event classes), the look-ups + event sum (nll_event_chunks, nll_kernels.cpp:89-116), the step
  * end (finish_nll_jump_pick_combo, :230-271) and the clearing for the next evaluation run in one kernel: the event
  * sum's workgroups publish their partial sums and count themselves in, a finisher workgroup -- which has meanwhile

@@ -344,7 +344,7 @@ struct sxmc_group {
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
   bool tuned = false;                              // a deferred batch's group: the launch-shape trials have run
-  int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default on)
+  int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default off)
   int last_step_launches = 0;                      // kernels the last sxmc_group_step_async launched
   unsigned long long plan_generation = 0;          // counts launch plans built (a multigroup re-validates on change)
   std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
@@ -2728,14 +2728,18 @@ int step_sum_blocks(unsigned long long ne) {
   return (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + 127) / 128));
 }
 // Does the step end run as ONE cooperative launch (step_end_kernel: workgroups that wait for each other inside the
-// kernel)?  Only while the whole grid is small enough to be resident many times over -- at most 128 workers of 128
-// lanes: up to 16 384 rows, BASELINE configs 2 and 3 with event classes -- so that several chains' step ends, each
-// waiting for its own workgroups, always fit the device together.  Larger event sums keep the two-launch form.
+// kernel)?  Only on request (sxmc_group_set_cooperative_step_end / SXMC_COOP_STEP_END=1): MEASURED, it does not pay --
+// inside a replayed graph the gap between eval_nll_kernel and finish_zero_kernel is 0-1.3 us, not the ~2.2 us a launch
+// was thought to cost, and the hand-off inside one kernel (release, counter, poll, acquire) costs what a kernel boundary
+// costs: BASELINE config 3 17.8 us as one kernel against 9.5 + 6.6 us as two, config 2 11.3 against 6.1 + 5.2
+// (profiles/r04_step_end_ab_*).  And only while the whole grid is small enough to be resident many times over -- at
+// most 128 workers of 128 lanes: up to 16 384 rows, BASELINE configs 2 and 3 with event classes -- so that several
+// chains' step ends, each waiting for its own workgroups, always fit the device together.
 constexpr int kCoopMaxWorkers = 128;
 bool step_end_is_cooperative(const sxmc_group* g, unsigned long long ne) {
   static const int env_default = [] {
     const char* e = std::getenv("SXMC_COOP_STEP_END");
-    return (e && e[0] == '0') ? 0 : 1;
+    return (e && e[0] == '1') ? 1 : 0;
   }();
   const int on = g->cfg_coop < 0 ? env_default : g->cfg_coop;
   return on != 0 && g->cfg_tail != 0 && step_sum_blocks(ne) <= kCoopMaxWorkers;

@@ -82,6 +82,7 @@ def test_lookahead_walk_still_partitions_like_the_sequential_step():
     cooperatively -- same blocks, so the two walks must still be one chain."""
     w = workloads.config3(0.004, nevents=20000)
     m = MCMC(w, seed=9, lut_output=False, consume=True, stream=capi.new_stream())
+    m.group.SetCooperativeStepEnd(True)
     want = m.walk(w.events, 150, 0.1, sync_interval=50, graph_steps=5)
     assert m.group.LastStepLaunches() == 2
     close(m)
