@@ -58,6 +58,7 @@ def test_several_chains_step_ends_in_flight_together():
     chains = [base] + [MCMC(w, seed=31 + k, lut_output=False, consume=True, stream=capi.new_stream(), share_with=base)
                        for k in range(1, 4)]
     for m in chains:
+        m.group.SetCooperativeStepEnd(True)
         m.walk_begin(w.events, 200, 0.1, sync_interval=50)
     # advance the four walks in turn, a run of steps at a time, so that their kernels are queued side by side
     schedules = [m.flush_schedule() for m in chains]
