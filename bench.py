@@ -204,7 +204,8 @@ def chain_intervals(chain, nparameters):
     return out
 
 
-FORMS = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True}
+FORMS = {"step": "step", "fused": True, "graph": True, "reference": False, "pdfz": True, "dropin": "dropin"}
+K40_SAMPLES_PER_SEC = 2.99546e9     # /root/reference/README.md:322, `bench_sxmc pdfz` on an Nvidia Tesla K40 (the table's best)
 
 
 class Leg:
@@ -245,8 +246,8 @@ class Leg:
             self.host_signals = []
         self.host_tables = {j: tensors[j].cpu().numpy() for j in self.host_signals}
         self.m = MCMC(w, seed=exp_seed & 0xFFFFFFFF, fused=FORMS[form], samples_on_device=tensors,
-                      stream=capi.new_stream() if form == "graph" else None, lut_output=lut_output,
-                      consume=not lut_output)
+                      stream=capi.new_stream() if form == "graph" else None, lut_output=lut_output or form == "dropin",
+                      consume=not lut_output and form != "dropin")
         del tensors
         torch.cuda.empty_cache()
         threads, bpc = (int(x) for x in args.launch.split(","))
@@ -270,6 +271,10 @@ class Leg:
         # (the jump buffer holds every step between two flushes: the longest run here, the post-timed sample included)
         m.setup(sync_interval=max(steps, warmup + 1, min(args.prewarm, 100) + 1, 2 * ROOFLINE_LAUNCHES + 8, 1))
         m.group.SetDebugMode(args.debug_mode)
+        if self.form == "pdfz":
+            # bench_sxmc evaluates at params = 0 (bench_sxmc.cpp:66, 166): the evaluators stay bound to the proposal
+            # vector, which is put back to the means (the systematics' are 0) and never stepped
+            m.proposed_vector.set(self.w.parameter_means().astype(np.float64))
         # EvalHist::Optimize's role (pdfz.cpp:622-727): a few trial launches pick the lane count per CU for this box
         if not args.no_autotune and args.launch == "0,0":
             self.tuned_threads = m.group.Optimize(m.stream)
@@ -292,11 +297,18 @@ class Leg:
         self.run_steps(warmup)
         m.flush()
 
-    def one_step(self):
+    def one_step(self, through_group=False):
         m = self.m
-        if self.form == "pdfz":      # EvalAsync on all, EvalFinished on all (bench_sxmc.cpp:193-200)
+        if self.form == "pdfz" and through_group:
+            # the same launches through the explicit group call: what the roofline sample profiles (the fill's events
+            # hang on m.group; the evaluations the library batches behind the per-evaluator calls run the same plan)
             m.group.EvalAsync(True, None)
             m.group.EvalFinished()
+        elif self.form == "pdfz":    # EvalAsync on all, EvalFinished on all (bench_sxmc.cpp:90-96, 193-200): the
+            for p in m.pdfs:         # evaluators' OWN calls -- the library defers them and launches one batch
+                p.EvalAsync()
+            for p in m.pdfs:
+                p.EvalFinished()
         else:
             m.step()
 
@@ -362,7 +374,7 @@ class Leg:
                 self.la.steps(2 * n, graph_passes=0)      # (one or two steps per pass: at least n passes)
             else:
                 for _ in range(n):
-                    self.one_step()
+                    self.one_step(through_group=True)
             torch.cuda.synchronize()
             post_ms, post_n = m.group.ProfileRead()
             m.group.Profile(False, 0)
@@ -636,21 +648,105 @@ def run_bench_cpp(argv, timeout):
     return lines, None
 
 
-def cpp_host_record(args, nsteps=4000):
+def cpp_host_records(args, want, lut_materialized_value=None, nsteps=4000):
     """BASELINE config 3 at full size walked entirely by the C++ host layer (tests/cpp/bench_cpp: sxmc::build_pdfz +
-    sxmc::MCMC over the C ABI, graph-replayed steps, no Python in that process): the north star's "host code stays
-    C++".  The walk includes its set-up, both burn-in re-tunings and the jump-buffer flushes."""
+    sxmc::MCMC over the C ABI, no Python in that process): the north star's "host code stays C++".  ONE child process
+    builds the tables once and walks, as asked for in `want`:
+      cpp_host     -- the look-ahead walk, 4 000 steps incl. set-up, both burn-in re-tunings and the flushes, then 16
+                      whole fake experiments as 2 lockstep sets of 4 chains;
+      c3_dropin    -- mcmc.cpp:264-271 + 314-348 AS WRITTEN (S x EvalAsync, S x EvalFinished, nll_event_chunks,
+                      finish_nll_jump_pick_combo; lookup table materialised; legacy default stream; no graph, no group
+                      call): what an unchanged caller gets, the library batching the S evaluations behind the API;
+      c3_1e5_walk  -- BASELINE config 3 as written: 1e5 steps, burn-in fraction 0.1 (re-tuning at 1e4 and 2e4 steps),
+                      sync_interval 10 000 (mcmc.cpp:261-378), one evaluation per step and as the look-ahead walk;
+                      BASELINE.md section 4's bar: 60 % of the HBM roofline = 1e5 steps in 34 s.
+    Returns {name: record}; a bench_cpp that fails gives every wanted name a {"failed": ...} record."""
     t0 = time.perf_counter()
-    lines, failure = run_bench_cpp(["--scale", "1.0", "--steps", nsteps, "--graph-steps", args.graph_steps,
-                                    "--experiments", 16, "--exp-steps", 2000, "--chains", 4, "--sets", 2], 300)
+    walks = []
+    if "cpp_host" in want:
+        walks.append("lookahead=%d" % nsteps)
+    if "c3_dropin" in want:
+        walks.append("reference=3000")
+    if "c3_1e5_walk" in want:
+        walks += ["sequential=100000", "lookahead=100000"]
+    argv = ["--scale", "1.0", "--graph-steps", args.graph_steps, "--walks", ",".join(walks), "--burnin", "0.1",
+            "--sync-interval", "10000"]
+    if "cpp_host" in want:
+        argv += ["--experiments", 16, "--exp-steps", 2000, "--chains", 4, "--sets", 2]
+    lines, failure = run_bench_cpp(argv, 420)
     if failure:
-        return failure
-    rec = lines[0]
-    if len(lines) > 1:
-        rec["ensemble_lockstep"] = lines[1]     # 16 whole fake experiments as 2 lockstep sets of 4 chains: two per lane
-    rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
+        return {name: dict(failure) for name in want}
+    by_walk = {}
+    for ln in lines:
+        if "walk" in ln:
+            by_walk[(ln["walk"], ln["steps"])] = ln
+    out = {}
+    if "cpp_host" in want:
+        rec = dict(by_walk[("lookahead", nsteps)])
+        ens = [ln for ln in lines if "ensemble_lockstep" in ln.get("driver", "")]
+        if ens:
+            rec["ensemble_lockstep"] = ens[0]     # 16 whole fake experiments as 2 lockstep sets of 4 chains: two per lane
+        rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
+        rec["note"] = "whole walk of %d steps including set-up, re-tuning and flushes; host = C++ only" % nsteps
+        out["cpp_host"] = rec
+    if "c3_dropin" in want:
+        rec = dict(by_walk[("reference", 3000)])
+        rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
+        rec["launches_per_step"] = 5     # zero, fill (all signals), eval_pdf, nll_event_chunks, finish_nll_jump_pick_combo
+        rec["deferred_evaluations_per_launch"] = rec["deferred_evaluations"] / max(rec["deferred_launches"], 1)
+        if lut_materialized_value:
+            rec["ratio_to_lut_materialized"] = rec["value"] / lut_materialized_value
+        rec["note"] = ("the reference's own call sequence (mcmc.cpp:264-271, 314-348), unchanged: whole walk of 3000 steps "
+                       "incl. set-up and re-tunings; the S = 12 EvalAsync calls of a step leave the library as ONE launch "
+                       "sequence (sxmc_hist_eval_async defers), EvalFinished waits lazily (sxmc_set_lazy_finish)")
+        out["c3_dropin"] = rec
+    if "c3_1e5_walk" in want:
+        seq, la = by_walk[("sequential", 100000)], by_walk[("lookahead", 100000)]
+        budget = 34.0     # BASELINE.md section 4: >= 60 % of the HBM roofline <=> 1e5 steps in <= 34 s
+        out["c3_1e5_walk"] = {
+            "value": seq["steps_per_sec"], "unit": "evals/s", "nsteps": 100000, "seconds": seq["seconds"],
+            "steps_per_sec": seq["steps_per_sec"], "accepted": seq["accepted"], "rows_kept": seq["rows_kept"],
+            "budget_seconds": budget, "within_budget": bool(seq["seconds"] <= budget),
+            "sequential": dict(seq, within_budget=bool(seq["seconds"] <= budget)),
+            "lookahead_walk": dict(la, within_budget=bool(la["seconds"] <= budget)),
+            "note": "BASELINE config 3 as written: sxmc::MCMC (C++ host) walks 1e5 steps, burn-in fraction 0.1 (widths "
+                    "re-tuned from the chain at 1e4 and 2e4 steps, rows before 2e4 dropped), sync_interval 10 000 "
+                    "(mcmc.cpp:261-378); `seconds` includes the walk's set-up; top level = one evaluation per step"}
+    share = (time.perf_counter() - t0) / max(len(out), 1)
+    for rec in out.values():
+        rec["leg_seconds"] = share
+    return out
+
+
+def pdfz_record(args, torch, dev, name, exp_seed):
+    """The reference's own benchmark loops (bench/bench_sxmc.cpp): `pdfz` = ONE evaluator of 1e7 N(0,1) samples, 1-D,
+    1000 bins on [-3, 3), one shift systematic at p = 0, 1e5 evaluation points; 1 warm-up + 100 x (EvalAsync,
+    EvalFinished) (:34-102) -- and `pdfz_group` = 29 evaluators of 1e3 ... 3e6 samples, per repetition EvalAsync on all,
+    then EvalFinished on all (:105-225).  The evaluators' own calls, nothing else: what the timed loop of bench_sxmc
+    does.  samples/s as it prints them, beside README.md:317-322's table (best entry: 2.995e9 on a Tesla K40)."""
+    t0 = time.perf_counter()
+    leg = Leg(args, torch, dev, name, "pdfz", False, 7 if name == "bench_pdfz" else 8, exp_seed, scale=1.0,
+              keep_host="all", overrides={"prewarm": 1})
+    leg.setup(100, 1)
+    elapsed = leg.timed(100, collective=False)
+    rf = leg.roofline()
+    par, cpu = leg.parity(time_evals=1)
+    n = int(leg.w.nsamples_total)
+    rec = {"value": 100 / elapsed, "unit": "evals/s", "steps": 100, "warmup": 1, "ms_per_step": 1e3 * elapsed / 100,
+           "samples_per_sec": n * 100 / elapsed, "vs_published": n * 100 / elapsed / K40_SAMPLES_PER_SEC,
+           "published": {"samples_per_sec": K40_SAMPLES_PER_SEC, "device": "Nvidia Tesla K40",
+                         "source": "reference README.md:317-322 (bench_sxmc pdfz)"},
+           "fill_kernel_us": 1e3 * rf["avg_launch_ms"], "frac": rf["frac"], "config": leg.config(), "roofline": rf,
+           "parity": par, "cpu_baseline": cpu,
+           "note": "timed loop = the evaluators' own EvalAsync / EvalFinished calls (the library batches them); the "
+                   "histogram's one observable is only shifted, so the table is kept sorted by it and a 256-sample granule "
+                   "whose end values fall into one bin is counted without reading its samples: the fill streams 12 bytes "
+                   "per granule (`frac` is on those bytes; the kernel is launch-bound)"}
+    leg.close()
     rec["leg_seconds"] = time.perf_counter() - t0
-    rec["note"] = "whole walk of %d steps including set-up, re-tuning and flushes; host = C++ only" % nsteps
+    if par is not None and not par["ok"]:
+        print(json.dumps({name: rec}), file=sys.stderr)
+        raise SystemExit("PARITY FAILURE (%s): GPU result differs from the CPU oracle" % name)
     return rec
 
 
@@ -736,7 +832,7 @@ def parse_args(argv=None):
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
                     help="sub-records measured after the headline: comma list of c3_lookahead, c3_lut_materialized, c2, c5, "
-                         "c2_float_columns, cpp_host, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
+                         "c2_float_columns, bench_pdfz, bench_pdfz_group, cpp_host, c3_dropin, c3_1e5_walk, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
                          "GPU, cpp_multi_gpu (sxmc::ensemble_multi_gpu over the same cards) at N > 1; none = skip")
     ap.add_argument("--also-steps", type=int, default=200, help="timed steps of each sub-record (C5: a quarter)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
@@ -1012,7 +1108,7 @@ def main():
         full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and not args.debug_mode
         also = "none"
         if full_c3 and want_cpu and args.form == "graph" and world == 1:
-            also = "c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,cpp_host"
+            also = "c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,bench_pdfz,bench_pdfz_group,cpp_host,c3_dropin,c3_1e5_walk"
         elif full_c3 and args.form == "graph" and world > 1:
             also = "cpp_multi_gpu"        # the C++ one-process runner over the same N cards
     if world > 1:
@@ -1028,7 +1124,9 @@ def main():
         if world == 1:
             leg.close()
         recs = {}
-        for name in [x.strip() for x in also.split(",") if x.strip()]:
+        names = [x.strip() for x in also.split(",") if x.strip()]
+        cpp_names = [n for n in names if n in ("cpp_host", "c3_dropin", "c3_1e5_walk")]
+        for name in names:
             if name == "c3_lookahead":            # the same walk taken one or two steps per pass (two evaluations per pass)
                 recs[name] = also_record(args, torch, dev, "c3", "graph", False, 3 * args.also_steps, 20, exp_seed, "all",
                                          lookahead=True)
@@ -1042,13 +1140,17 @@ def main():
             elif name == "c5":
                 recs[name] = also_record(args, torch, dev, "c5", "graph", False, max(10, args.also_steps // 4), 10,
                                          exp_seed, "ends")
-            elif name == "cpp_host":
-                recs[name] = cpp_host_record(args)
+            elif name in ("bench_pdfz", "bench_pdfz_group"):
+                recs[name] = pdfz_record(args, torch, dev, name, exp_seed)
+            elif name in cpp_names:
+                if name == cpp_names[0]:      # ONE bench_cpp process for all of them (the tables are built once)
+                    lm = recs.get("c3_lut_materialized") or {}
+                    recs.update(cpp_host_records(args, cpp_names, lut_materialized_value=lm.get("value")))
             elif name == "cpp_multi_gpu":
                 recs[name] = cpp_multi_gpu_record(args, world, collective)
             else:
                 raise SystemExit("unknown --also entry %r" % name)
-            if isinstance(recs[name], dict) and "failed" in recs[name]:
+            if isinstance(recs.get(name), dict) and "failed" in recs[name]:
                 failed_leg = name
         result["also"] = recs
 

@@ -5,7 +5,7 @@
 // thread per GPU, ONE RCCL all-gather of the intervals).  One JSON line per leg on stdout.
 //
 //   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk] [--reference-form | --sequential]
-//             [--burnin 0.1] [--sync-interval 10000]
+//             [--burnin 0.1] [--sync-interval 10000] [--walks lookahead=100000,sequential=100000,reference=3000]
 //             [--experiments 0] [--exp-steps 2000] [--chains 4] [--sets 2]
 //             [--devices G | --device-list 0,0] [--host-staging] [--config fit.json] [--output-dir d]
 //
@@ -40,6 +40,9 @@ struct Options {
   bool walk = true;
   bool reference_form = false;   // the walk issues the reference's own call sequence (mcmc.cpp:264-271, 314-348)
   bool sequential = false;       // ... or the batched step, one evaluation per step (no look-ahead)
+  // --walks name=steps,...: several timed walks in ONE process over the same tables (names: lookahead, sequential,
+  // reference), each preceded by a short warm-up walk of its own form
+  std::vector<std::pair<std::string, unsigned>> walks;
   float burnin = 0.1f;
   unsigned sync_interval = 10000;
   unsigned nexp = 0, esteps = 2000, L = 4, S = 2;
@@ -71,6 +74,18 @@ Options parse(int argc, char** argv) {
     else if (a == "--steps") o.nsteps = (unsigned)std::atoi(next());
     else if (a == "--graph-steps") o.graph_steps = (unsigned)std::atoi(next());
     else if (a == "--no-walk") o.walk = false;
+    else if (a == "--walks") {
+      std::string v = next();
+      size_t pos = 0;
+      while (pos < v.size()) {
+        const size_t comma = v.find(',', pos), end = comma == std::string::npos ? v.size() : comma;
+        const std::string item = v.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos) throw std::runtime_error("--walks wants name=steps[,name=steps...]");
+        o.walks.emplace_back(item.substr(0, eq), (unsigned)std::atoi(item.c_str() + eq + 1));
+        pos = end + 1;
+      }
+    }
     else if (a == "--reference-form") o.reference_form = true;
     else if (a == "--sequential") o.sequential = true;
     else if (a == "--burnin") o.burnin = (float)std::atof(next());
@@ -283,41 +298,50 @@ static int run(int argc, char** argv) {
   }
 
   if (opt.walk) {
-    sxmc_stream_t strm = nullptr;
-    // the reference's sequence launches its NLL kernels on the legacy default stream (mcmc.cpp:314-348), which is what
-    // the evaluators' own streams order with; the batched forms walk on a stream of their own
-    if (!opt.reference_form) sxmc::check(sxmc_stream_create_nonblocking(&strm));
-    // SXMC_BENCH_LOOKAHEAD=0 / --sequential: one evaluation per step; default: the look-ahead walk (two per pass)
+    std::vector<std::pair<std::string, unsigned>> walks = opt.walks;
     const char* la_env = std::getenv("SXMC_BENCH_LOOKAHEAD");
-    const bool lookahead = !(la_env && la_env[0] == '0') && !opt.sequential && !opt.reference_form;
-    for (int pass = 0; pass < 2; pass++) {  // pass 0 warms up (clocks, launch plan); pass 1 is timed
-      sxmc::MCMC mcmc(sources, signals, systematics, observables, 1234 + pass, strm);
-      mcmc.graph_steps = opt.reference_form ? 0 : opt.graph_steps;
-      mcmc.lookahead = lookahead;
-      mcmc.reference_form = opt.reference_form;
-      unsigned long long l0 = 0, e0 = 0, l1 = 0, e1 = 0;
-      sxmc::check(sxmc_deferred_eval_stats(&l0, &e0));
-      const auto t0 = std::chrono::steady_clock::now();
-      sxmc::Chain chain = mcmc(data, pass == 0 ? std::min(opt.nsteps, 500u) : opt.nsteps, opt.burnin, false,
-                               opt.sync_interval);
-      const double sec = seconds_since(t0);
-      sxmc::check(sxmc_deferred_eval_stats(&l1, &e1));
-      if (pass == 1) {
-        std::printf("{\"driver\": \"%s\", \"nsamples_total\": %zu, \"nsignals\": %zu, \"nevents\": %zu, "
-                    "\"steps\": %u, \"steps_per_graph\": %u, \"seconds\": %.4f, \"steps_per_sec\": %.1f, "
-                    "\"setup_seconds\": %.4f, \"stepping_seconds\": %.4f, \"steps_per_sec_stepping\": %.1f, "
-                    "\"burnin_fraction\": %.3f, \"sync_interval\": %u, "
-                    "\"accepted\": %zu, \"rows_kept\": %zu, \"lookahead\": %s, \"passes\": %zu, "
-                    "\"deferred_launches\": %llu, \"deferred_evaluations\": %llu}\n",
-                    opt.reference_form ? "sxmc::MCMC, the reference's call sequence (C++)" : "sxmc::MCMC (C++)",
-                    rows_total, signals.size(), data.size() / (observables.size() + 1), opt.nsteps, mcmc.graph_steps, sec,
-                    opt.nsteps / sec, chain.setup_seconds, chain.steps_seconds, opt.nsteps / chain.steps_seconds,
-                    (double)opt.burnin, opt.sync_interval, chain.accepted, chain.nrows(), lookahead ? "true" : "false",
-                    mcmc.LookaheadPasses(), l1 - l0, e1 - e0);
-        std::fflush(stdout);
-      }
+    if (walks.empty()) {
+      // SXMC_BENCH_LOOKAHEAD=0 / --sequential: one evaluation per step; default: the look-ahead walk (two per pass)
+      const bool la = !(la_env && la_env[0] == '0') && !opt.sequential && !opt.reference_form;
+      walks.emplace_back(opt.reference_form ? "reference" : la ? "lookahead" : "sequential", opt.nsteps);
     }
-    if (strm) sxmc_stream_destroy(strm);
+    for (const auto& wk : walks) {
+      const bool reference_form = wk.first == "reference", lookahead = wk.first == "lookahead";
+      if (!reference_form && !lookahead && wk.first != "sequential") throw std::runtime_error("unknown walk " + wk.first);
+      const unsigned nsteps = wk.second;
+      // the reference's sequence launches its NLL kernels on the legacy default stream (mcmc.cpp:314-348), which is
+      // what the evaluators' own streams order with; the batched forms walk on a stream of their own
+      sxmc_stream_t strm = nullptr;
+      if (!reference_form) sxmc::check(sxmc_stream_create_nonblocking(&strm));
+      for (int pass = 0; pass < 2; pass++) {  // pass 0 warms up (clocks, launch plan); pass 1 is timed
+        sxmc::MCMC mcmc(sources, signals, systematics, observables, 1234 + pass, strm);
+        mcmc.graph_steps = reference_form ? 0 : opt.graph_steps;
+        mcmc.lookahead = lookahead;
+        mcmc.reference_form = reference_form;
+        unsigned long long l0 = 0, e0 = 0, l1 = 0, e1 = 0;
+        sxmc::check(sxmc_deferred_eval_stats(&l0, &e0));
+        const auto t0 = std::chrono::steady_clock::now();
+        sxmc::Chain chain = mcmc(data, pass == 0 ? std::min(nsteps, 500u) : nsteps, opt.burnin, false, opt.sync_interval);
+        const double sec = seconds_since(t0);
+        sxmc::check(sxmc_deferred_eval_stats(&l1, &e1));
+        if (pass == 1) {
+          std::printf("{\"driver\": \"%s\", \"walk\": \"%s\", \"nsamples_total\": %zu, \"nsignals\": %zu, "
+                      "\"nevents\": %zu, "
+                      "\"steps\": %u, \"steps_per_graph\": %u, \"seconds\": %.4f, \"steps_per_sec\": %.1f, "
+                      "\"setup_seconds\": %.4f, \"stepping_seconds\": %.4f, \"steps_per_sec_stepping\": %.1f, "
+                      "\"burnin_fraction\": %.3f, \"sync_interval\": %u, "
+                      "\"accepted\": %zu, \"rows_kept\": %zu, \"lookahead\": %s, \"passes\": %zu, "
+                      "\"deferred_launches\": %llu, \"deferred_evaluations\": %llu}\n",
+                      reference_form ? "sxmc::MCMC, the reference's call sequence (C++)" : "sxmc::MCMC (C++)",
+                      wk.first.c_str(), rows_total, signals.size(), data.size() / (observables.size() + 1), nsteps,
+                      mcmc.graph_steps, sec, nsteps / sec, chain.setup_seconds, chain.steps_seconds,
+                      nsteps / chain.steps_seconds, (double)opt.burnin, opt.sync_interval, chain.accepted, chain.nrows(),
+                      lookahead ? "true" : "false", mcmc.LookaheadPasses(), l1 - l0, e1 - e0);
+          std::fflush(stdout);
+        }
+      }
+      if (strm) sxmc_stream_destroy(strm);
+    }
   }
 
   // ---- ensemble leg: whole fake experiments (fake data drawn on the device, walk with burn-in re-tuning, contour
