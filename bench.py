@@ -1039,6 +1039,8 @@ def main():
             "steps_per_sec_inside": best["steps_per_sec_inside"],
             "median_upper_limit_source0": dist.median(allint[:, 0, 2]),
             "gathered_shape": [int(x) for x in allint.shape],
+            # every experiment's block arrived from its rank (the blocks are padded with NaN rows, which must not remain)
+            "gather_complete": bool(not np.isnan(allint).any()),
             "note": "fake data set + MCMC walk with burn-in re-tuning + contour intervals per experiment; "
                     "at 1e5 steps per experiment (BASELINE config 3/4) that is %.4f experiments/s on this job"
                     % (best["steps_per_sec_inside"] / 1e5)
@@ -1158,8 +1160,10 @@ def main():
         emit(result, json_out)
     if world == 1:
         dist.shutdown()
-    # (at N > 1 the failed leg is the extra C++ runner: its record says so, the job's own measurement stands)
-    if failed_leg and world == 1:
+    # a failed leg fails the job at every N -- AFTER the line is out: the ranks' own measurement stands in it, and the
+    # exit code says that something beside it did not run (at N > 1 that is the C++ one-process runner over the same
+    # cards: hiding its first failure on a real node would be worse than a red run)
+    if failed_leg:
         raise SystemExit("bench.py: the %s leg FAILED (its record says how): %s"
                          % (failed_leg, result["also"][failed_leg].get("failed")))
 

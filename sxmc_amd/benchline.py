@@ -109,7 +109,7 @@ def compact_experiments(ex):
     if not isinstance(ex, dict):
         return None
     out = _pick(ex, ("count", "steps_each", "form", "experiments_per_sec", "steps_per_sec_inside",
-                     "median_upper_limit_source0"))
+                     "median_upper_limit_source0", "gather_complete"))
     if ex.get("gathered_shape") is not None:
         out["gathered_shape"] = ex["gathered_shape"]
     ls = ex.get("lockstep")

@@ -95,23 +95,54 @@ class RcclComm:
     the 128-byte id handed round over the torch.distributed process group that already exists, sxmc_comm_init_rank
     everywhere) -- the same entry points the C++ runner uses.  `query()` asks the communicator itself."""
 
-    def __init__(self):
+    def __init__(self, init_timeout=None):
+        """Collective over the existing process group: EVERY rank must call it, and every rank leaves it the same way.
+        Rank 0 ALWAYS broadcasts -- the id, or None and the reason when it could not make one (so the others are never
+        left waiting in a broadcast that will not come: ADVICE r3); a missing id raises the same error on every rank,
+        before any rank enters ncclCommInitRank, which is itself a collective.  That call runs under a time limit
+        (`init_timeout` seconds, SXMC_RCCL_INIT_TIMEOUT, default 120): a rank still inside it when the limit passes
+        cannot be rescued -- its peers may have failed -- so the process says so and exits non-zero, which ends the job
+        (spawn_ranks and torch.distributed.run both end the other ranks) instead of hanging it."""
         import ctypes as C
+        import threading
 
         import torch.distributed as dist
 
         from . import capi
         rank, _, world = env_world()
-        box = [None]
+        box = [None, None]
         if rank == 0:
-            buf = C.create_string_buffer(128)
-            capi.call("sxmc_comm_unique_id", buf, 128)
-            box[0] = buf.raw
+            try:
+                buf = C.create_string_buffer(128)
+                capi.call("sxmc_comm_unique_id", buf, 128)
+                box = [buf.raw, None]
+            except Exception as exc:      # noqa: BLE001 (the other ranks must hear of it, whatever it is)
+                box = [None, "%s: %s" % (type(exc).__name__, exc)]
         dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise capi.SxmcError(capi.ERR_HIP, "rank 0 could not make an RCCL id: %s" % box[1])
+        if init_timeout is None:
+            init_timeout = float(os.environ.get("SXMC_RCCL_INIT_TIMEOUT", "120"))
         h = C.c_void_p(0)
-        rc = capi.load().sxmc_comm_init_rank(box[0], 128, world, rank, C.byref(h))
-        if rc != capi.OK:
-            raise capi.SxmcError(rc, capi.load().sxmc_comm_last_error().decode())
+        lib = capi.load()
+        device = C.c_int(-1)
+        lib.sxmc_get_device(C.byref(device))
+        result = {}
+
+        def join_communicator():          # (a new host thread starts on device 0: bind it to this rank's card first)
+            lib.sxmc_set_device(device.value)
+            result["rc"] = lib.sxmc_comm_init_rank(box[0], 128, world, rank, C.byref(h))
+
+        t = threading.Thread(target=join_communicator, daemon=True)
+        t.start()
+        t.join(init_timeout)
+        if t.is_alive():
+            import sys
+            print("sxmc_amd.dist: rank %d is still inside ncclCommInitRank after %.0f s (a peer failed or never "
+                  "arrived); ending the job" % (rank, init_timeout), file=sys.stderr, flush=True)
+            os._exit(70)
+        if result.get("rc") != capi.OK:
+            raise capi.SxmcError(result.get("rc", capi.ERR_HIP), lib.sxmc_comm_last_error().decode())
         self.h = h
 
     def query(self):
@@ -171,7 +202,10 @@ def collective_record(device_index, device_info):
     if backend == "nccl":
         # librccl through the C ABI, beside torch's own communicator.  Should it fail on some rank (it has never been
         # run on more than one card: no multi-GPU box was available to the builder), every rank learns of it and the
-        # job goes on with torch.distributed's all_gather alone -- and says so in the line -- instead of stopping
+        # job goes on with torch.distributed's all_gather alone -- and says so in the line -- instead of stopping.
+        # Every rank takes the same sequence of collectives whatever fails where: RcclComm's broadcast (rank 0 always
+        # sends), ncclCommInitRank only if an id arrived (under a time limit: a rank stuck in it ends the job), then
+        # the MIN all-reduce below.
         try:
             comm = RcclComm()
             _, nranks, comm_device = comm.query()

@@ -740,6 +740,14 @@ struct MultiGpuOptions {
    *  default. */
   enum Exchange { RCCL, HOST_STAGING } exchange = RCCL;
   double exchange_timeout_seconds = 120.0;   //!< a collective still pending after this long is aborted (fail fast)
+  /** Which lock serialises set-up (allocation, uploads, launch plans, module loads), graph recording and tear-down of
+   *  the device threads.  PROCESS_WIDE (default): ONE lock for all cards -- a thread never allocates or synchronises a
+   *  device while another thread records a graph, on whichever card.  PER_DEVICE: one lock per card, chains on
+   *  different cards never wait for each other (graph capture is thread-local, allocation and device-wide
+   *  synchronisation are per device -- by the runtime's documentation).  No run on more than one card is on record
+   *  yet, so the conservative lock is the default; the per-device one is for measuring on a real node
+   *  (bench_cpp --per-device-locks), and becomes the default once such a run has shown it sound. */
+  enum Locking { PROCESS_WIDE, PER_DEVICE } locking = PROCESS_WIDE;
   ErrorType error_type = ERROR_CONTOUR;      //!< fit.error_type: contour or projection intervals
   /** Called by every device thread (argument: its rank) when its experiments are done, before the rendezvous.
    *  May throw: the tests inject a failing rank with it. */
@@ -778,7 +786,8 @@ struct MultiGpuEnsemble {
  *  experiment that threw, an allocation -- NO rank enters the all-gather and the first error is rethrown.  A rank
  *  whose collective does not complete (a peer lost after the rendezvous, exchange_timeout_seconds, an asynchronous
  *  RCCL error) aborts its communicator (ncclCommAbort) instead of waiting: the call returns an error, never hangs.
- *  Locking: set-up, graph recording and tear-down take the lock of THEIR device only (SetupLock, one per card). */
+ *  Locking: set-up, graph recording and tear-down are serialised by ONE lock for the process (MultiGpuOptions::locking;
+ *  PER_DEVICE: the lock of their own card only). */
 inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsigned nexperiments,
                                            unsigned long long base_seed, std::vector<Source>& sources,
                                            const std::vector<Signal>& signals,
@@ -814,8 +823,10 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
   }
   std::vector<float> rank0((size_t)G * block, std::numeric_limits<float>::quiet_NaN());
   std::vector<std::exception_ptr> errors(G);
-  std::map<int, SetupLock> locks;   // one per card (ranks rehearsed on one card share it)
-  for (int d : devices) (void)locks[d];
+  // one lock for the process, or one per card (ranks rehearsed on one card share theirs); key -1 = the process's
+  std::map<int, SetupLock> locks;
+  const bool per_device = opt.locking == MultiGpuOptions::PER_DEVICE;
+  for (int d : devices) (void)locks[per_device ? d : -1];
   Rendezvous meet(G);
   std::atomic<bool> give_up{false};   // a rank abandoned the exchange: the others stop waiting for it
   std::vector<std::thread> threads;
@@ -824,7 +835,7 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
       std::vector<Signal> mine;
       float *d_send = nullptr, *d_recv = nullptr;
       sxmc_stream_t strm = nullptr;
-      SetupLock& exclusive = locks.find(devices[r])->second;   // (every key exists; find does not modify the map)
+      SetupLock& exclusive = locks.find(per_device ? devices[r] : -1)->second;   // (find does not modify the map)
       std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());
       bool ok = true;
       const Clock::time_point t0 = Clock::now();

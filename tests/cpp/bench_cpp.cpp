@@ -7,7 +7,7 @@
 //   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk] [--reference-form | --sequential]
 //             [--burnin 0.1] [--sync-interval 10000] [--walks lookahead=100000,sequential=100000,reference=3000]
 //             [--experiments 0] [--exp-steps 2000] [--chains 4] [--sets 2]
-//             [--devices G | --device-list 0,0] [--host-staging] [--config fit.json] [--output-dir d]
+//             [--devices G | --device-list 0,0] [--host-staging] [--per-device-locks] [--config fit.json] [--output-dir d]
 //
 // --reference-form: the walk issues mcmc.cpp:264-271 + 314-348 as written (S x EvalAsync, S x EvalFinished,
 //   nll_event_chunks, finish_nll_jump_pick_combo; lookup table materialised, legacy default stream, no graph): what an
@@ -48,6 +48,7 @@ struct Options {
   unsigned nexp = 0, esteps = 2000, L = 4, S = 2;
   std::vector<int> devices;
   bool host_staging = false;
+  bool per_device_locks = false;   // ensemble_multi_gpu: one set-up lock per card instead of one for the process
   std::string config;
   std::string output_dir;   // every experiment's chain as <output_dir>/<prefix>_<k>.npz (sxmc.cpp:130-141)
 };
@@ -99,6 +100,7 @@ Options parse(int argc, char** argv) {
       for (int d = 0; d < g; d++) o.devices.push_back(d);
     } else if (a == "--device-list") o.devices = parse_list(next());
     else if (a == "--host-staging") o.host_staging = true;
+    else if (a == "--per-device-locks") o.per_device_locks = true;
     else if (a == "--config") o.config = next();
     else if (a == "--output-dir") o.output_dir = next();
     else throw std::runtime_error("unknown argument " + a);
@@ -396,6 +398,7 @@ static int run(int argc, char** argv) {
     mo.nconcurrent = std::max(1u, opt.L * opt.S);
     mo.error_type = error_type;
     if (opt.host_staging) mo.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
+    if (opt.per_device_locks) mo.locking = sxmc::MultiGpuOptions::PER_DEVICE;
     const size_t G = opt.devices.size();
     for (int pass = 0; pass < 2; pass++) {   // pass 0: one round per device (kernel compilation, clocks)
       const unsigned n = pass == 0 ? (unsigned)std::min<size_t>(opt.nexp, G * std::max(1u, opt.L * opt.S)) : opt.nexp;
@@ -427,12 +430,14 @@ static int run(int argc, char** argv) {
                   "\"replica_setup_seconds_max\": %.4f, \"experiments_per_sec\": %.4f, "
                   "\"experiments_per_sec_after_setup\": %.4f, \"steps_per_sec_inside\": %.1f, "
                   "\"median_upper_limit_source0\": %.6g, \"gathered_floats\": %zu, \"nevents\": %s], "
-                  "\"data\": \"%s\", \"phase_seconds_summed_over_experiments\": %s, \"setup_locks\": %s]}\n",
+                  "\"data\": \"%s\", \"phase_seconds_summed_over_experiments\": %s, \"locking\": \"%s\", "
+                  "\"setup_locks\": %s]}\n",
                   G, devs.c_str(), opt.host_staging ? "host staging (rehearsal)" : "ncclAllGather (RCCL)",
                   mg.rccl_nranks, rdevs.c_str(), n, opt.esteps, opt.L, opt.S, sec, setup_max, n / sec, n / inside,
                   n * (double)opt.esteps / inside, mg.median_upper.empty() ? 0.0 : (double)mg.median_upper[0],
                   mg.gathered.size(), nev.c_str(), sxmc::data_source() ? "configured data sets" : "fake",
-                  phases_json(mg.results).c_str(), locks.c_str());
+                  phases_json(mg.results).c_str(), opt.per_device_locks ? "one lock per card" : "one lock for the process",
+                  locks.c_str());
       std::fflush(stdout);
     }
   }

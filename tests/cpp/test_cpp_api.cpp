@@ -768,8 +768,12 @@ TEST_F(SmallFit, MultiGpuRunnerWithTwoLogicalRanksOnOneCard) {
   // G = 2 device threads, both on card 0, through everything but the RCCL call (RCCL refuses two ranks on one card;
   // MultiGpuOptions::HOST_STAGING stands in for the all-gather): sharding k mod G, a replica of the evaluators per
   // thread, the rendezvous, the order of the results, the medians.  Three ranks as well (uneven shares, padded blocks).
-  for (int G : {2, 3}) {
-    const unsigned N = 7;
+  // ... and EIGHT (the node's shape, BASELINE config 4: every rank with two or three experiments), with one lock for the
+  // process (the default) and with one per card.
+  for (int G : {2, 3, 8, -8}) {
+    const bool per_device = G < 0;
+    G = G < 0 ? -G : G;
+    const unsigned N = G == 8 ? 19 : 7;
     std::vector<unsigned> ks;
     for (unsigned k = 0; k < N; k++) ks.push_back(k);
     std::vector<sxmc::ExperimentResult> seq =
@@ -782,10 +786,12 @@ TEST_F(SmallFit, MultiGpuRunnerWithTwoLogicalRanksOnOneCard) {
     opt.lockstep_chains = 2;
     opt.lockstep_sets = 1;
     opt.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
+    if (per_device) opt.locking = sxmc::MultiGpuOptions::PER_DEVICE;
     sxmc::MultiGpuEnsemble mg = sxmc::ensemble_multi_gpu(std::vector<int>((size_t)G, 0), N, 21, sources, signals, tabs, 4,
                                                          systematics, observables, 300, 0.2f, opt);
     EXPECT_EQ(0, mg.rccl_nranks);
     EXPECT_EQ((size_t)1, mg.setup_locks.size());   // one card, one lock, shared by the ranks
+    EXPECT_EQ(per_device ? 0 : -1, mg.setup_locks[0].device);   // (-1: the process's lock)
     EXPECT_TRUE(mg.setup_locks[0].acquisitions > 0 && mg.setup_locks[0].held_seconds > 0);
     EXPECT_EQ((size_t)G, mg.rank_seconds.size());
     for (unsigned k = 0; k < N; k++) {
@@ -815,17 +821,18 @@ TEST_F(SmallFit, MultiGpuRunnerFailsFastWhenOneRankFails) {
   for (const std::vector<float>& t : tables) tabs.push_back(&t);
   int ndev = 0;
   ASSERT_EQ(SXMC_OK, sxmc_device_count(&ndev));
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass < 3; pass++) {   // (pass 2: eight logical ranks on card 0, a rank in the middle fails)
     sxmc::MultiGpuOptions opt;
     opt.sync_interval = 100;
     opt.graph_steps = 8;
     opt.lockstep_chains = 0;
     opt.nconcurrent = 2;
-    opt.exchange = pass == 0 ? sxmc::MultiGpuOptions::HOST_STAGING : sxmc::MultiGpuOptions::RCCL;
+    opt.exchange = pass == 1 ? sxmc::MultiGpuOptions::RCCL : sxmc::MultiGpuOptions::HOST_STAGING;
     std::vector<int> devices;
     if (pass == 0) devices = {0, 0};
+    else if (pass == 2) devices.assign(8, 0);
     else for (int d = 0; d < ndev && d < 8; d++) devices.push_back(d);
-    const size_t bad = devices.size() - 1;
+    const size_t bad = pass == 2 ? 5 : devices.size() - 1;
     opt.before_exchange = [bad](size_t r) {
       if (r == bad) throw pdfz::Error("injected failure");
     };
@@ -833,7 +840,8 @@ TEST_F(SmallFit, MultiGpuRunnerFailsFastWhenOneRankFails) {
     bool threw = false;
     std::string msg;
     try {
-      sxmc::ensemble_multi_gpu(devices, 4, 21, sources, signals, tabs, 4, systematics, observables, 200, 0.2f, opt);
+      sxmc::ensemble_multi_gpu(devices, pass == 2 ? 10 : 4, 21, sources, signals, tabs, 4, systematics, observables, 200,
+                               0.2f, opt);
     } catch (const pdfz::Error& e) {
       threw = true;
       msg = e.msg;
