@@ -342,6 +342,7 @@ struct sxmc_group {
   int cfg_order = 1, cfg_seen_order = -1;          // ... with the rows of a bucket ordered by a monotonically written observable
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
+  std::string plan_note;                           // why a launch of the plan took a slower general path (for launch_info)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
   bool tuned = false;                              // a deferred batch's group: the launch-shape trials have run
   int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default off)
@@ -745,6 +746,7 @@ int group_rebuild(sxmc_group* g) {
   g->max_bins = 0;
   g->max_points = 0;
   g->same_points = n > 0;
+  g->plan_note.clear();
 
   int threads = g->cfg_threads > 0 ? g->cfg_threads : 512;
   if (threads < 64 || threads > 1024 || threads % 64) threads = 512;
@@ -884,6 +886,11 @@ int group_rebuild(sxmc_group* g) {
       }
       runs_mode = !lds_hist && narrow && h->has_points && h->d_table &&
                   have_kernel(cd.nobs, cd.nslot, prew, 1, prog2, sp, &rtc_sparse);
+      if (!lds_hist && !narrow && h->has_points && h->d_table) {
+        // (a regression on very large histograms must be visible: sxmc_group_launch_info prints this)
+        g->plan_note = "histogram with a bin count or stride of 2^23 or more: the sparse counting over runs (one signed "
+                       "24-bit multiply-add per index) does not apply, the general sparse path runs instead";
+      }
       if (runs_mode) {
         rc2 = build_bucket_tables(h, bs);
         if (rc2) return rc2;
@@ -2520,6 +2527,7 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
     text += line;
   }
   if (!g->rtc_note.empty()) text += "runtime specialisation failed: " + g->rtc_note.substr(0, 300) + "\n";
+  if (!g->plan_note.empty()) text += "note: " + g->plan_note + "\n";
   std::snprintf(out, n, "%s", text.c_str());
   return SXMC_OK;
 }

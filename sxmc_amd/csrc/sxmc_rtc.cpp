@@ -95,6 +95,7 @@ std::string spec_key(const SxRtcSpec& k) {
 
 // Compiles the specialisation to a gfx950 code object.  Needs no device.
 bool compile(const SxRtcSpec& k, std::vector<char>& code, std::string& err) {
+  code.clear();
   const std::string src = kernel_source(k), types = join(kRtcTypesSrc), fill = join(kRtcFillSrc);
   const char* headers[] = {types.c_str(), fill.c_str()};
   const char* names[] = {"sxmc_device_types.h", "fill_kernels.inc.h"};
@@ -129,6 +130,7 @@ bool compile(const SxRtcSpec& k, std::vector<char>& code, std::string& err) {
   }
   (void)hiprtcDestroyProgram(&prog);
   if (r != HIPRTC_SUCCESS) {
+    code.clear();   // (the caller caches `code` per specialisation: a half-filled image must not be loaded on the next device)
     err = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(r);
     return false;
   }

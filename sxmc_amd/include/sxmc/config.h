@@ -297,9 +297,12 @@ struct NpyView {
   bool fortran = false;
   const unsigned char* data = nullptr;
   size_t nbytes = 0;
-  size_t count() const {
+  size_t count() const {   // (saturates instead of wrapping: a hostile shape must not look small)
     size_t n = 1;
-    for (size_t s : shape) n *= s;
+    for (size_t s : shape) {
+      if (s != 0 && n > ((size_t)-1) / s) return (size_t)-1;
+      n *= s;
+    }
     return n;
   }
 };
@@ -488,6 +491,7 @@ inline void read_table(const std::string& path, std::vector<float>& matrix, std:
       throw ConfigError(path + ": " + std::to_string(v.shape[1]) + " columns but " + std::to_string(npy_fields.size()) +
                         " field names (\"fields\": [...] in the signal's configuration)");
     }
+    if (v.count() > v.nbytes) throw ConfigError(path + ": the header's shape does not fit the file (truncated data)");
     matrix.resize(v.count());
     detail::npy_to_float(v, matrix.data(), 1, path);
     fields = npy_fields;
@@ -505,6 +509,13 @@ inline void read_table(const std::string& path, std::vector<float>& matrix, std:
     }
     if (k == 0) {
       nrows = v.shape[0];
+      // (the header's shape is checked against the member's bytes BEFORE anything is sized by it: a corrupt header must
+      //  end in a ConfigError, not in a bad_alloc or a multi-GB allocation)
+      if (nrows > m.size) throw ConfigError("field '" + name + "' of " + path + ": " + std::to_string(nrows) +
+                                            " rows do not fit the member's " + std::to_string(m.size) + " bytes");
+      if (members.size() != 0 && nrows > ((size_t)-1) / sizeof(float) / members.size()) {
+        throw ConfigError(path + ": rows x fields overflows");
+      }
       matrix.assign(nrows * members.size(), 0.0f);
     } else if (v.shape[0] != nrows) {
       throw ConfigError("fields of " + path + " differ in length");
@@ -521,7 +532,8 @@ inline void read_table(const std::string& path, std::vector<float>& matrix, std:
 inline std::vector<float> read_dataset_to_samples(const std::vector<float>& dataset,
                                                   const std::vector<std::string>& dataset_fields, unsigned dataset_id,
                                                   const std::vector<std::string>& sample_fields,
-                                                  const std::vector<Observable>& cuts) {
+                                                  const std::vector<Observable>& cuts,
+                                                  size_t required = (size_t)-1) {
   const size_t nf = dataset_fields.size(), ns = sample_fields.size();
   if (ns == 0 || nf == 0) return {};
   std::vector<char> has_cut(nf, 0);
@@ -533,10 +545,14 @@ inline std::vector<float> read_dataset_to_samples(const std::vector<float>& data
         lo[i] = c.lower;
         hi[i] = c.upper;
       }
+  // `required`: how many of the leading sample fields the data set must carry (default: all -- the MC tables).  Real
+  // data has no Monte Carlo truth branch; the reference maps such a field past the row (signal.cpp:72-77) and never
+  // looks at it again (GetSamples keeps the observables only), so for data sets -- required = the observables -- a
+  // missing non-observable field becomes a column of zeros instead of an error.
   std::vector<size_t> map;
   for (size_t i = 0; i + 1 < ns; i++) {
     const size_t idx = std::find(dataset_fields.begin(), dataset_fields.end(), sample_fields[i]) - dataset_fields.begin();
-    if (idx >= nf) {   // (the reference reads past the row here)
+    if (idx >= nf && i < required) {   // (the reference reads past the row here)
       throw ConfigError("sample field '" + sample_fields[i] + "' is not a field of the data set");
     }
     map.push_back(idx);
@@ -551,7 +567,7 @@ inline std::vector<float> read_dataset_to_samples(const std::vector<float>& data
       if (has_cut[j] && ((double)row[j] < lo[j] || (double)row[j] > hi[j])) valid = false;
     }
     if (!valid) continue;
-    for (size_t j = 0; j + 1 < ns; j++) out.push_back(row[map[j]]);
+    for (size_t j = 0; j + 1 < ns; j++) out.push_back(map[j] < nf ? row[map[j]] : 0.0f);
     out.push_back((float)dataset_id);
   }
   return out;
@@ -877,7 +893,7 @@ inline FitConfig parse_config(const std::string& text, const std::string& base_d
       std::vector<std::string> fields, npy_fields;
       for (const json::Value& fv : row["fields"].items) npy_fields.push_back(fv.asString("fields[]"));
       read_table(detail::join_path(base_dir, row["filename"].asString("filename")), raw, fields, npy_fields);
-      const std::vector<float> s = read_dataset_to_samples(raw, fields, dataset, fc.sample_fields, cc);
+      const std::vector<float> s = read_dataset_to_samples(raw, fields, dataset, fc.sample_fields, cc, fc.observables.size());
       // GetSamples (pdfz.h:542-556): the observables, then the dataset id
       const size_t D = fc.observables.size();
       fc.data[dataset].emplace_back();

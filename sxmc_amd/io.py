@@ -73,24 +73,34 @@ def write_table(path, matrix, fields):
     np.savez(path, **{f: np.asarray(matrix)[:, i] for i, f in enumerate(fields)})
 
 
-def read_dataset_to_samples(dataset, dataset_fields, dataset_id, sample_fields, cuts):
+def read_dataset_to_samples(dataset, dataset_fields, dataset_id, sample_fields, cuts, required=None):
     """signal.cpp:50-109.  dataset: [n, len(dataset_fields)]; sample_fields ends with "DATASET";
     cuts: list of (field, lower, upper) -- an event is dropped when a cut field is < lower or > upper
-    (bounds inclusive).  Returns float32 [nkept, len(sample_fields)]."""
+    (bounds inclusive); when several cuts name one field the LAST one counts, as in the reference's lookup table
+    (signal.cpp:57-69 overwrites the field's bounds cut by cut).
+    required: how many of the leading sample fields must exist in the data set (default: all of them, the MC tables).
+    A data set of real events carries no Monte Carlo truth branch: the reference maps such a field past the row
+    (signal.cpp:72-77) and never looks at it again -- GetSamples keeps the observables only -- so for data sets
+    (required = number of observables) a missing non-observable field is filled with 0 instead of being refused.
+    Returns float32 [nkept, len(sample_fields)]."""
     dataset = np.asarray(dataset, np.float32)
     keep = np.ones(dataset.shape[0], bool)
+    last = {}
     for field, lower, upper in cuts:
-        for j, name in enumerate(dataset_fields):
-            if name == field:
-                col = dataset[:, j]
-                keep &= ~((col < np.float64(lower)) | (col > np.float64(upper)))
-    idx = []
-    for f in sample_fields[:-1]:
-        if f not in dataset_fields:
+        last[field] = (lower, upper)
+    for j, name in enumerate(dataset_fields):
+        if name in last:
+            lower, upper = last[name]
+            col = dataset[:, j]
+            keep &= ~((col < np.float64(lower)) | (col > np.float64(upper)))
+    required = len(sample_fields) - 1 if required is None else required
+    out = np.zeros((int(keep.sum()), len(sample_fields)), np.float32)
+    kept = dataset[keep]
+    for k, f in enumerate(sample_fields[:-1]):
+        if f in dataset_fields:
+            out[:, k] = kept[:, dataset_fields.index(f)]
+        elif k < required:
             raise KeyError("sample field %r not in data set fields %r" % (f, dataset_fields))
-        idx.append(dataset_fields.index(f))
-    out = np.empty((int(keep.sum()), len(sample_fields)), np.float32)
-    out[:, :-1] = dataset[keep][:, idx]
     out[:, -1] = dataset_id
     return out
 
@@ -255,7 +265,7 @@ def load_data(fc, w, experiment=0):
                              % (dataset, len(files), experiment))
         f = files[experiment]
         table, fields = read_table(os.path.join(fc.base_dir, f["filename"]))
-        s = read_dataset_to_samples(table, fields, dataset, fc.sample_fields, cuts)
+        s = read_dataset_to_samples(table, fields, dataset, fc.sample_fields, cuts, required=len(fc.observables))
         rows.append(np.concatenate([s[:, :w.nobs], s[:, -1:]], axis=1))      # GetSamples: observables + dataset
     return np.concatenate(rows, axis=0)
 

@@ -161,6 +161,7 @@ def test_strides_beyond_24_bits_take_the_general_path():
     m.setup(sync_interval=8)
     info = m.group.LaunchInfo()
     assert "hist=global" in info and "+runs" not in info, info
+    assert "note:" in info and "2^23" in info, info      # (and the plan says why it fell back: ADVICE r3)
     proposal = m.proposed_vector.get()
     m.step(debug_mode=True)
     rows, nacc = m.flush()
@@ -175,7 +176,7 @@ def test_strides_beyond_24_bits_take_the_general_path():
                             workloads.C3_SIGMAS, ev, "strides below 2^23")
     m2 = MCMC(w2, seed=4, fused=True)
     m2.setup(sync_interval=8)
-    assert "+runs" in m2.group.LaunchInfo(), m2.group.LaunchInfo()
+    assert "+runs" in m2.group.LaunchInfo() and "note:" not in m2.group.LaunchInfo(), m2.group.LaunchInfo()
     proposal = m2.proposed_vector.get()
     m2.step(debug_mode=True)
     m2.flush()

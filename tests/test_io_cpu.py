@@ -67,6 +67,25 @@ def test_cuts_are_inclusive_and_columns_are_packed():
     assert out.tolist() == [[6.0, 5.5, 3.0], [7.0, 6.5, 3.0], [1.0, 1.5, 3.0]]
 
 
+def test_last_cut_on_a_field_wins_and_data_sets_need_no_truth_field():
+    data = np.array([[6.0, 9.0, 5.5], [7.0, 10.0, 6.5], [8.0, 10.5, 7.5], [9.0, -0.1, 8.5], [1.0, 0.0, 1.5]], np.float32)
+    fields = ["energy", "radius", "mc_energy"]
+    # two cuts on one field: signal.cpp:57-69 overwrites the field's bounds cut by cut -- only the LAST one is applied
+    # (the first alone would keep nothing)
+    out = io.read_dataset_to_samples(data, fields, 3, ["energy", "mc_energy", "DATASET"],
+                                     [("radius", 100.0, 200.0), ("radius", 0.0, 10.0)])
+    assert out.tolist() == [[6.0, 5.5, 3.0], [7.0, 6.5, 3.0], [1.0, 1.5, 3.0]]
+    # real data carries no Monte Carlo truth branch: as a data set (required = the observables) the field is zeros ...
+    real = data[:, :2]
+    out = io.read_dataset_to_samples(real, fields[:2], 0, ["energy", "mc_energy", "DATASET"], [], required=1)
+    assert out[:, 0].tolist() == [6.0, 7.0, 8.0, 9.0, 1.0] and not out[:, 1].any() and not out[:, 2].any()
+    # ... but an observable must be there, and an MC table must carry every field
+    with pytest.raises(KeyError):
+        io.read_dataset_to_samples(real[:, 1:], ["radius"], 0, ["energy", "mc_energy", "DATASET"], [], required=1)
+    with pytest.raises(KeyError):
+        io.read_dataset_to_samples(real, fields[:2], 0, ["energy", "mc_energy", "DATASET"], [])
+
+
 def test_tables_and_chains_roundtrip(tmp_path):
     m = np.arange(12, dtype=np.float32).reshape(4, 3)
     io.write_table(tmp_path / "t.npz", m, ["a", "b", "c"])
@@ -152,6 +171,11 @@ def _write_keyed_files(tmp_path):
         # the archive's field order differs from the sample-field order; dtypes: double, float, int, bool
         np.savez(tmp_path / name, valid=rng.integers(0, 3, n), r=rng.uniform(-0.5, 6.5, n).astype(np.float32),
                  e_true=e_true, junk=rng.integers(0, 2, n).astype(bool), e=(e_true + rng.normal(0, 0.4, n)))
+    # d1.npz again as REAL data would come: no Monte Carlo truth branch (e_true), which a resolution_scale systematic
+    # of the fit names -- a data set needs the observables only (signal.cpp:72-77 + GetSamples)
+    with np.load(tmp_path / "d1.npz") as f:
+        kept = {k: f[k] for k in f.files if k != "e_true"}
+    np.savez(tmp_path / "d1.npz", **kept)
     (tmp_path / "fit.json").write_text(KEYED)
     return str(tmp_path / "fit.json")
 
