@@ -446,16 +446,18 @@ int sxmc_lookahead_begin(sxmc_stream_t s, int nparameters, const sxmc_rng_state*
 int sxmc_group_last_step_launches(sxmc_group_t g, int* launches);
 /* 0: sxmc_group_step_async always takes its three-launch route (measurement / tests).  Default 1. */
 int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);
-/* The step end of sxmc_group_step_async as ONE cooperative launch (default 0: measured no faster than the two launches
- * it replaces -- DESIGN.md section 4; SXMC_COOP_STEP_END=1 in the environment changes the default): where the event sum is at most 128 workgroups of 128 rows (up to 16 384 rows: BASELINE
+/* The step end of sxmc_group_step_async as ONE cooperative launch (default 1; SXMC_COOP_STEP_END=0 in the environment
+ * changes the default): where the event sum is at most 128 workgroups of 128 rows (up to 16 384 rows: BASELINE
  * configs 2 and 3 with event classes), the look-ups + event sum (nll_event_chunks, nll_kernels.cpp:89-116), the step
- * end (finish_nll_jump_pick_combo, :230-271) and the clearing for the next evaluation run in one kernel: the event
- * sum's workgroups publish their partial sums and count themselves in, a finisher workgroup -- which has meanwhile
- * done everything of the step end that does not need the sums -- waits for the count inside the kernel, and the
- * other workgroups clear the histograms once all look-ups are done.  Same partial sums, same order: the chain is the
- * one the separate launches walk, bit for bit.  2 launches per step instead of 3.  Every wait inside the kernel is
- * bounded (~0.3 s): a workgroup that gives up counts a timeout, which sxmc_group_step_end_timeouts reports (0 in any
- * healthy run; the results of a step that timed out are not valid). */
+ * end (finish_nll_jump_pick_combo, :230-271) and the clearing for the next evaluation run in one kernel: every
+ * workgroup of the event sum hands its partial sum to a finisher workgroup through a slot of its own (one device-scope
+ * store; no fences, no counters); the finisher -- which has meanwhile done everything of the step end that does not
+ * need the sums -- polls the slots, finishes the step and empties them, which tells the other workgroups that every
+ * look-up is done and the histograms may be cleared.  Same partial sums, same order: the chain is the one the
+ * separate launches walk, bit for bit.  2 launches per step instead of 3: 14.2 us against 9.5 + 6.8 at BASELINE
+ * config 3, 9.3 against 6.1 + 5.3 at config 2 (+10 % evaluations per second).  Every wait inside the kernel is bounded
+ * (~0.3 s): a lane that gives up counts a timeout, which sxmc_group_step_end_timeouts reports (0 in any healthy run;
+ * the results of a step that timed out are not valid). */
 int sxmc_group_set_cooperative_step_end(sxmc_group_t g, int enable);
 int sxmc_group_step_end_timeouts(sxmc_group_t g, unsigned* timeouts);
 /* Compiles (does not load or run) the fill kernel the library would specialise at run time for a program of

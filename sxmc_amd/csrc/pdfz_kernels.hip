@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <vector>
+
 #include "nll_device.h"
 
 #include "fill_kernels.inc.h"
@@ -493,104 +495,114 @@ __global__ __launch_bounds__(256) void finish_zero_kernel(const SxSignalDesc* __
 }
 
 // THE STEP END IN ONE LAUNCH (cooperative).  eval_nll_kernel + finish_zero_kernel are two launches whose work is a chain
-// of memory round trips: at BASELINE config 3 they take 9.5 + 6.8 us plus two launch boundaries, 20 us of a 150 us step
+// of memory round trips: at BASELINE config 3 they take 9.5 + 6.6 us, 18-20 us of a 150 us step with their boundaries
 // (profiles/r03_c3_kernel_stats.csv), and more than the fill itself at config 2.  Earlier one-launch forms lost what
-// the boundary saved: the LAST workgroup to arrive ran the whole step end cold (15.7 against 14.7 us), and one
-// workgroup doing everything is far too slow beyond a few hundred look-ups.  Here the roles are fixed at launch:
-//   * workgroups 0 .. W-1 (the workers) do the look-ups and the event sum exactly as eval_nll_kernel does -- the same
-//     virtual blocks of 128 rows, the same partial sums, so the NLL and with it the chain stay bit-identical --,
-//     publish their partials (release) and count themselves in;
+// the boundary saved: the LAST workgroup to arrive ran the whole step end cold (round 2: 15.7 against 14.7 us); one
+// workgroup doing everything is far too slow beyond a few hundred look-ups; and a first cooperative form of this
+// round -- partials published with a release fence and an arrival COUNTER, the finisher acquiring -- cost 17.8 us
+// against 16.2 (profiles/r04_step_end_ab_*): a fence is an L2 write-back, the counter another round trip, the acquire
+// an L2 invalidate, and a kernel boundary inside a replayed graph is only 0-1.3 us.  This form has no fences and no
+// counters.  The roles are fixed at launch:
+//   * workgroups 0 .. W-1 (the workers: W = the virtual blocks of the event sum, at most 128) do the look-ups and the
+//     event sum exactly as eval_nll_kernel's workgroups do -- the same blocks of 128 rows, the same partial sums, so
+//     the NLL and with it the chain stay bit-identical -- and hand their partial over with ONE device-scope atomic
+//     store into their own 64-bit slot (the partial IS the message: nothing else of the worker's needs to be visible);
 //   * workgroup W (the finisher) meanwhile does everything of finish_nll_jump_pick_combo that does not need the sums
-//     (phase A of finish_step_device: all inputs loaded, the expected-rate and constraint terms, the next proposal's
-//     deviates) and then waits for the count to reach W; what is left after the last worker's arrival is one
-//     acquire, the reduction of W partials and phases B and C;
-//   * the workers, once all of them have arrived -- nothing reads the histograms any more --, clear the histograms for
-//     the next evaluation (what zero_kernel would do) while the finisher finishes; the finisher clears the
-//     normalisations, which it and the workers read.
+//     (phase A of finish_step_device: every input loaded, the expected-rate and constraint terms, the next proposal's
+//     deviates); then lane i polls slot i until it holds a value (device-scope atomic loads), the values go to LDS,
+//     and what is left after the last worker's partial lands is a barrier, the reduction and phases B and C;
+//   * once the finisher holds ALL partials -- every look-up is done, nothing reads the histograms any more -- it
+//     empties the slots again, which is also the workers' signal: each polls its own slot until it is empty, then
+//     clears its share of the histograms for the next evaluation (what zero_kernel would do) while the finisher
+//     finishes; the finisher clears the normalisations, which it and the workers read.
+// A slot holds the partial's bit pattern, or kSlotEmpty, or kSlotNaN for "my partial came out NaN" -- then the value
+// of the last step whose partial did not is used, which is what eval_nll_kernel's unwritten array element amounts to
+// (nll_kernels.cpp:113-115 does not store a NaN partial); both markers are NaN patterns no stored partial can have.
 // Waiting inside a kernel needs the waited-for workgroups to be resident or to become resident: the grid is at most
 // 129 workgroups of 128 lanes with a few KB of LDS (the host takes this form only then), which the device holds many
-// times over beside any fill kernel; and every wait is BOUNDED -- a workgroup that does not see the count arrive within
-// ~0.3 s gives up, counts a timeout (sync[6], read by sxmc_group_step_end_timeouts) and goes on, so the grid always
-// drains.  The counters reset themselves: the last of the W + 1 workgroups to leave zeroes them.
+// times over beside any fill kernel; the workers wait only for the finisher and the finisher only for the workers,
+// all of one launch; and every wait is BOUNDED -- a lane that does not see its slot change within ~0.3 s gives up,
+// counts a timeout (sync[6], read by sxmc_group_step_end_timeouts) and goes on, so the grid always drains.
 constexpr unsigned kEndSpinLimit = 200000u;
-
-__device__ __forceinline__ bool end_wait_for(unsigned* counter, unsigned target, unsigned* timeouts) {
-  // (one lane polls; ~1.5 us per poll with the sleep)
-  for (unsigned it = 0; it < kEndSpinLimit; it++) {
-    if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-    __builtin_amdgcn_s_sleep(2);
-  }
-  __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return false;
-}
+constexpr unsigned long long kSlotEmpty = 0x7FF8DEADBEEF0001ull, kSlotNaN = 0x7FF8DEADBEEF0002ull;
 
 __global__ __launch_bounds__(128) void step_end_kernel(const SxSignalDesc* __restrict__ lookup_descs,
                                                        const SxSignalDesc* __restrict__ hist_descs, int nsig,
                                                        unsigned long long npoints, const unsigned* __restrict__ weight,
-                                                       double* sums, unsigned* sync, unsigned nvb, unsigned zblocks,
-                                                       SxStepArgs a) {
+                                                       unsigned long long* slots, double* last_good, unsigned* sync,
+                                                       unsigned nvb, unsigned zblocks, SxStepArgs a) {
   extern __shared__ double sh[];
-  const unsigned W = gridDim.x - 1u;
-  unsigned* const arrive = sync + 4;
-  unsigned* const depart = sync + 5;
+  const unsigned W = gridDim.x - 1u;   // == nvb
   unsigned* const timeouts = sync + 6;
   if (blockIdx.x == W) {
     // ---- the finisher
-    sxdev::finish_step_device_w(nvb, sums, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+    __shared__ double s_part[128];
+    sxdev::finish_step_device_w(nvb, s_part, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
                                 a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
                                 a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
                                 a.debug_mode != 0, [&] {
-                                  if (threadIdx.x == 0) {
-                                    (void)end_wait_for(arrive, W, timeouts);
-                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                  const unsigned i = threadIdx.x;
+                                  if (i < nvb) {
+                                    unsigned long long v = kSlotEmpty;
+                                    unsigned it = 0;
+                                    for (; it < kEndSpinLimit; it++) {
+                                      v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                      if (v != kSlotEmpty) break;
+                                      __builtin_amdgcn_s_sleep(1);
+                                    }
+                                    double t;
+                                    if (v == kSlotEmpty) {   // gave up: flagged, the step is not valid
+                                      __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                      t = 0.0;
+                                    } else if (v == kSlotNaN) {
+                                      t = last_good[i];
+                                    } else {
+                                      t = __longlong_as_double((long long)v);
+                                      last_good[i] = t;
+                                    }
+                                    s_part[i] = t;
                                   }
                                   __syncthreads();
+                                  // every partial is in: the look-ups are over.  Empty the slots -- for the next launch,
+                                  // and as the workers' signal that the histograms may be cleared.
+                                  if (i < nvb) __hip_atomic_store(slots + i, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 });
     __syncthreads();
     for (int j = threadIdx.x; j < nsig; j += blockDim.x) *hist_descs[j].norm = 0u;
     if (threadIdx.x == 0) sync[0] = 0u;   // (the ticket of the other step-end forms: as finish_zero_kernel leaves it)
-  } else {
-    // ---- a worker: its virtual blocks of the event sum, as eval_nll_kernel's workgroups do them
-    for (unsigned vb = blockIdx.x; vb < nvb; vb += W) {
-      const double t = eval_nll_block_part(lookup_descs, nsig, npoints, weight, a.v_proposed, a.nexpected, a.n_mc,
-                                           a.source_id, a.norms, sh, vb, nvb);
-      if (threadIdx.x == 0 && !isnan(t)) sums[vb] = t;
-      __syncthreads();   // (the staging area is re-used by the next virtual block)
-    }
-    __shared__ int s_clear;
-    if (threadIdx.x == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // the histograms may be cleared once EVERY worker has done its look-ups
-      s_clear = end_wait_for(arrive, W, timeouts) ? 1 : 0;
-    }
-    __syncthreads();
-    if (s_clear) {
-      const unsigned npieces = zblocks * (unsigned)nsig;
-      for (unsigned p = blockIdx.x; p < npieces; p += W) {
-        const SxSignalDesc& d = hist_descs[p / zblocks];
-        const unsigned chunk = p % zblocks;
-        unsigned* bins = d.bins;
-        const unsigned n = (unsigned)d.total_nbins;
-        const unsigned n4 = n >> 2;
-        uint4* b4 = reinterpret_cast<uint4*>(bins);
-        const unsigned stride = zblocks * blockDim.x;
-        for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
-      }
-    }
+    return;
   }
-  // ---- leaving: the last workgroup out resets the counters for the next launch (nobody reads them any more)
-  __syncthreads();
+  // ---- a worker: its virtual block of the event sum, as eval_nll_kernel's workgroup does it
+  const unsigned vb = blockIdx.x;
+  const double t = eval_nll_block_part(lookup_descs, nsig, npoints, weight, a.v_proposed, a.nexpected, a.n_mc,
+                                       a.source_id, a.norms, sh, vb, nvb);
+  __shared__ int s_clear;
   if (threadIdx.x == 0) {
-    const unsigned before = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (before == W) {
-      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slots + vb, isnan(t) ? kSlotNaN : (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the store has landed before this lane starts reading the slot)
+    // the histograms may be cleared once the finisher has every worker's partial: it then empties the slots
+    unsigned it = 0;
+    for (; it < kEndSpinLimit; it++) {
+      if (__hip_atomic_load(slots + vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotEmpty) break;
+      __builtin_amdgcn_s_sleep(1);
     }
+    if (it == kEndSpinLimit) __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_clear = it < kEndSpinLimit ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_clear) return;
+  const unsigned npieces = zblocks * (unsigned)nsig;
+  for (unsigned p = blockIdx.x; p < npieces; p += W) {
+    const SxSignalDesc& d = hist_descs[p / zblocks];
+    const unsigned chunk = p % zblocks;
+    unsigned* bins = d.bins;
+    const unsigned n = (unsigned)d.total_nbins;
+    const unsigned n4 = n >> 2;
+    uint4* b4 = reinterpret_cast<uint4*>(bins);
+    const unsigned stride = zblocks * blockDim.x;
+    for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
   }
 }
 
@@ -1059,16 +1071,24 @@ hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_
 }
 
 hipError_t sx_launch_step_end(const SxSignalDesc* lookup_descs, const SxSignalDesc* hist_descs, int nsig, int max_bins,
-                              unsigned long long npoints, const unsigned* weight, double* sums, unsigned* sync,
-                              int nvb, int workers, const SxStepArgs& a, hipStream_t s) {
+                              unsigned long long npoints, const unsigned* weight, unsigned long long* slots,
+                              double* last_good, unsigned* sync, int nvb, const SxStepArgs& a, hipStream_t s) {
   const int block = 128;   // (the rows of a virtual block of the event sum: eval_nll_kernel's workgroup)
   const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
   int zb = (max_bins / 4 + block - 1) / block;
   if (zb < 1) zb = 1;
   if (zb > 1024) zb = 1024;
-  hipLaunchKernelGGL(step_end_kernel, dim3((unsigned)workers + 1u), dim3(block), shmem, s, lookup_descs, hist_descs,
-                     nsig, npoints, weight, sums, sync, (unsigned)nvb, (unsigned)zb, a);
+  hipLaunchKernelGGL(step_end_kernel, dim3((unsigned)nvb + 1u), dim3(block), shmem, s, lookup_descs, hist_descs, nsig,
+                     npoints, weight, slots, last_good, sync, (unsigned)nvb, (unsigned)zb, a);
   return hipGetLastError();
+}
+
+// the cooperative step end's slots start out empty
+hipError_t sx_step_end_slots_init(unsigned long long* slots, double* last_good, int n) {
+  std::vector<unsigned long long> h((size_t)n, kSlotEmpty);
+  hipError_t e = hipMemcpy(slots, h.data(), sizeof(unsigned long long) * (size_t)n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(last_good, 0, sizeof(double) * (size_t)n);
+  return e;
 }
 
 hipError_t sx_launch_chain_ends(const SxChainEnds& e, int nchains, int nsig, int max_bins, int block, hipStream_t s) {

@@ -97,8 +97,9 @@ hipError_t sx_rtc_launch(void* fn, int grid, int threads, size_t lds_bytes, cons
 
 hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, unsigned* ticket, hipStream_t s);
 hipError_t sx_launch_step_end(const SxSignalDesc* lookup_descs, const SxSignalDesc* hist_descs, int nsig, int max_bins,
-                              unsigned long long npoints, const unsigned* weight, double* sums, unsigned* sync,
-                              int nvb, int workers, const SxStepArgs& a, hipStream_t s);
+                              unsigned long long npoints, const unsigned* weight, unsigned long long* slots,
+                              double* last_good, unsigned* sync, int nvb, const SxStepArgs& a, hipStream_t s);
+hipError_t sx_step_end_slots_init(unsigned long long* slots, double* last_good, int n);
 hipError_t sx_launch_chain_ends(const SxChainEnds& e, int nchains, int nsig, int max_bins, int block, hipStream_t s);
 hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,
                                  const double* sums, unsigned* ticket, const SxStepArgs& a, int block, hipStream_t s);

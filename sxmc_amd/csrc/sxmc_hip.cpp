@@ -345,7 +345,7 @@ struct sxmc_group {
   std::string plan_note;                           // why a launch of the plan took a slower general path (for launch_info)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
   bool tuned = false;                              // a deferred batch's group: the launch-shape trials have run
-  int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default off)
+  int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default on)
   int last_step_launches = 0;                      // kernels the last sxmc_group_step_async launched
   unsigned long long plan_generation = 0;          // counts launch plans built (a multigroup re-validates on change)
   std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
@@ -376,6 +376,8 @@ struct sxmc_group {
   unsigned long long capture_epoch = 0;  // last recording this group launched in
   unsigned* d_ticket = nullptr;  // arrival counter of the fused step end, zeroed by the zero kernel
   double* d_step_sums = nullptr; // 1024 partial sums of the fused step
+  unsigned long long* d_coop_slots = nullptr;  // cooperative step end: one hand-over slot per worker (step_end_kernel)
+  double* d_coop_last = nullptr;               // ... and the last partial of each that was not NaN
   // profiling of the fill kernel
   bool prof = false;
   std::vector<hipEvent_t> ev0, ev1;
@@ -2351,8 +2353,15 @@ int sxmc_group_create(const sxmc_hist_t* members, int nmembers, sxmc_group_t* ou
   hipError_t e = hipMalloc((void**)&g->d_ticket, 256);
   if (e == hipSuccess) e = hipMemset(g->d_ticket, 0, 256);
   if (e == hipSuccess) e = hipMalloc((void**)&g->d_step_sums, 1024 * sizeof(double));
+  // (the cooperative step end's hand-over slots, 128 workers at most: see step_end_is_cooperative)
+  if (e == hipSuccess) e = hipMalloc((void**)&g->d_coop_slots, sizeof(unsigned long long) * 128);
+  if (e == hipSuccess) e = hipMalloc((void**)&g->d_coop_last, sizeof(double) * 128);
+  if (e == hipSuccess) e = sx_step_end_slots_init(g->d_coop_slots, g->d_coop_last, 128);
   if (e != hipSuccess) {
     if (g->d_ticket) (void)hipFree(g->d_ticket);
+    if (g->d_step_sums) (void)hipFree(g->d_step_sums);
+    if (g->d_coop_slots) (void)hipFree(g->d_coop_slots);
+    if (g->d_coop_last) (void)hipFree(g->d_coop_last);
     delete g;
     return fail(SXMC_ERR_HIP, std::string("group allocation: ") + hipGetErrorString(e));
   }
@@ -2369,6 +2378,8 @@ int sxmc_group_destroy(sxmc_group_t g) {
   if (g->d_descs_sparse) (void)hipFree(g->d_descs_sparse);
   if (g->d_ticket) (void)hipFree(g->d_ticket);
   if (g->d_step_sums) (void)hipFree(g->d_step_sums);
+  if (g->d_coop_slots) (void)hipFree(g->d_coop_slots);
+  if (g->d_coop_last) (void)hipFree(g->d_coop_last);
   free_event_classes(g->ec[0]);
   free_event_classes(g->ec[1]);
   for (hipEvent_t e : g->ev0) (void)hipEventDestroy(e);
@@ -2736,18 +2747,18 @@ int step_sum_blocks(unsigned long long ne) {
   return (int)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (ne + 127) / 128));
 }
 // Does the step end run as ONE cooperative launch (step_end_kernel: workgroups that wait for each other inside the
-// kernel)?  Only on request (sxmc_group_set_cooperative_step_end / SXMC_COOP_STEP_END=1): MEASURED, it does not pay --
-// inside a replayed graph the gap between eval_nll_kernel and finish_zero_kernel is 0-1.3 us, not the ~2.2 us a launch
-// was thought to cost, and the hand-off inside one kernel (release, counter, poll, acquire) costs what a kernel boundary
-// costs: BASELINE config 3 17.8 us as one kernel against 9.5 + 6.6 us as two, config 2 11.3 against 6.1 + 5.2
-// (profiles/r04_step_end_ab_*).  And only while the whole grid is small enough to be resident many times over -- at
-// most 128 workers of 128 lanes: up to 16 384 rows, BASELINE configs 2 and 3 with event classes -- so that several
-// chains' step ends, each waiting for its own workgroups, always fit the device together.
+// kernel)?  By default (sxmc_group_set_cooperative_step_end / SXMC_COOP_STEP_END=0 switch it off), where the whole grid
+// is small enough to be resident many times over -- at most 128 workers of 128 lanes: up to 16 384 rows, BASELINE
+// configs 2 and 3 with event classes -- so that several chains' step ends, each waiting for its own workgroups, always
+// fit the device together.  Measured (profiles/r04_step_end_ab_*): with the partials handed over through per-worker
+// slots (no fences, no counters) one kernel of 14.2 us replaces 9.5 + 6.8 us at BASELINE config 3 (+1.4 % evaluations
+// per second) and 9.3 replaces 6.1 + 5.3 us at config 2 (+10 %); the first form -- release fence, arrival counter,
+// acquire -- was SLOWER than the two launches (17.8 us): inside a replayed graph a kernel boundary costs 0-1.3 us.
 constexpr int kCoopMaxWorkers = 128;
 bool step_end_is_cooperative(const sxmc_group* g, unsigned long long ne) {
   static const int env_default = [] {
     const char* e = std::getenv("SXMC_COOP_STEP_END");
-    return (e && e[0] == '1') ? 1 : 0;
+    return (e && e[0] == '0') ? 0 : 1;
   }();
   const int on = g->cfg_coop < 0 ? env_default : g->cfg_coop;
   return on != 0 && g->cfg_tail != 0 && step_sum_blocks(ne) <= kCoopMaxWorkers;
@@ -2768,8 +2779,8 @@ int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDe
     // ONE launch: the event sum's workgroups + a finisher that waits for them inside the kernel (step_end_kernel)
     const int nvb = step_sum_blocks(ne);
     SX_HIP(sx_launch_step_end(descs, sparse ? g->d_descs_sparse : g->d_descs, (int)g->members.size(),
-                              sparse ? g->max_bins_sparse : g->max_bins, ne, weight, g->d_step_sums, g->d_ticket, nvb, nvb,
-                              a, st));
+                              sparse ? g->max_bins_sparse : g->max_bins, ne, weight, g->d_coop_slots, g->d_coop_last,
+                              g->d_ticket, nvb, a, st));
     g->last_step_launches += 1;
   } else {
     g->last_step_launches += 2;
