@@ -606,6 +606,117 @@ __global__ __launch_bounds__(128) void step_end_kernel(const SxSignalDesc* __res
   }
 }
 
+// The look-ahead pass's step end as ONE cooperative launch: eval_nll2_kernel + finish2_zero_kernel with the hand-over
+// of step_end_kernel.  Workers 0 .. nvb-1 sum candidate A's virtual blocks, nvb .. 2 nvb-1 candidate B's (each exactly
+// as eval_nll2_kernel's workgroups do: same blocks, same partial sums -- the walk stays the sequential chain bit for
+// bit); slot w belongs to worker w.  The finisher (workgroup 2 nvb) does phase A of the step's
+// finish_nll_jump_pick_combo while they work, then lane w polls slot w (2 nvb <= 128 lanes); once it holds every
+// partial of BOTH candidates it empties the slots -- the workers' signal to clear both candidates' histograms -- and
+// goes on as finish2_zero_kernel's workgroup 0: the step from A, if that rejected the following step from B, the
+// next look-ahead vector, the normalisations cleared.
+__global__ __launch_bounds__(128) void step_end2_kernel(const SxSignalDesc* __restrict__ lookup_a,
+                                                        const SxSignalDesc* __restrict__ lookup_b,
+                                                        const SxSignalDesc* __restrict__ hist_a,
+                                                        const SxSignalDesc* __restrict__ hist_b, int nsig,
+                                                        unsigned long long npoints, const unsigned* __restrict__ weight_a,
+                                                        const unsigned* __restrict__ weight_b, unsigned long long* slots,
+                                                        double* last_good, unsigned* sync, unsigned nvb, unsigned zblocks,
+                                                        const unsigned* norms_b, double* v_b, const int* cap, SxStepArgs a) {
+  extern __shared__ double sh[];
+  const unsigned W = gridDim.x - 1u;   // == 2 * nvb
+  unsigned* const timeouts = sync + 6;
+  if (blockIdx.x == W) {
+    // ---- the finisher
+    __shared__ double s_part[128];     // [0, nvb): candidate A's partial sums, [nvb, 2 nvb): candidate B's
+    __shared__ int s_before;
+    if (threadIdx.x == 0) s_before = a.counter[0];
+    __syncthreads();
+    const int limit = cap ? cap[0] : 0x7FFFFFFF;
+    auto collect = [&] {
+      const unsigned i = threadIdx.x;
+      if (i < W) {
+        unsigned long long v = kSlotEmpty;
+        for (unsigned it = 0; it < kEndSpinLimit; it++) {
+          v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v != kSlotEmpty) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        double t;
+        if (v == kSlotEmpty) {
+          __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t = 0.0;
+        } else if (v == kSlotNaN) {
+          t = last_good[i];
+        } else {
+          t = __longlong_as_double((long long)v);
+          last_good[i] = t;
+        }
+        s_part[i] = t;
+      }
+      __syncthreads();
+      if (i < W) __hip_atomic_store(slots + i, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (s_before < limit) {      // (a pass launched after the walk reached its stop decides nothing)
+      const bool accepted = sxdev::finish_step_device_w(
+          nvb, s_part, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current, a.nll_proposed, a.v_current,
+          a.v_proposed, a.accepted, a.counter, a.jump_buffer, a.nparameters, a.jump_width, a.nexpected, a.n_mc,
+          a.source_id, a.norms, a.debug_mode != 0, collect);
+      __syncthreads();
+      if (!accepted && s_before + 1 < limit) {
+        sxdev::finish_step_device(nvb, s_part + nvb, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                                  a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                                  a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, norms_b,
+                                  a.debug_mode != 0);
+        __syncthreads();
+      }
+      sxdev::peek_next_proposal_device(a.nparameters, a.rng, a.jump_width, a.v_current, v_b);
+    } else {
+      collect();                 // (the workers still hand over and wait for their signal)
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nsig; j += blockDim.x) {
+      *hist_a[j].norm = 0u;
+      *hist_b[j].norm = 0u;
+    }
+    return;
+  }
+  // ---- a worker
+  const bool second = blockIdx.x >= nvb;
+  const unsigned vb = second ? blockIdx.x - nvb : blockIdx.x;
+  const double t = eval_nll_block_part(second ? lookup_b : lookup_a, nsig, npoints, second ? weight_b : weight_a,
+                                       second ? v_b : a.v_proposed, a.nexpected, a.n_mc, a.source_id,
+                                       second ? norms_b : a.norms, sh, vb, nvb);
+  __shared__ int s_clear;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(slots + blockIdx.x, isnan(t) ? kSlotNaN : (unsigned long long)__double_as_longlong(t),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned it = 0;
+    for (; it < kEndSpinLimit; it++) {
+      if (__hip_atomic_load(slots + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotEmpty) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (it == kEndSpinLimit) __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_clear = it < kEndSpinLimit ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_clear) return;
+  const unsigned npieces = 2u * zblocks * (unsigned)nsig;
+  for (unsigned p = blockIdx.x; p < npieces; p += W) {
+    const unsigned which = p / (zblocks * (unsigned)nsig);
+    const unsigned q = p - which * zblocks * (unsigned)nsig;
+    const SxSignalDesc& d = (which ? hist_b : hist_a)[q / zblocks];
+    const unsigned chunk = q % zblocks;
+    unsigned* bins = d.bins;
+    const unsigned n = (unsigned)d.total_nbins;
+    const unsigned n4 = n >> 2;
+    uint4* b4 = reinterpret_cast<uint4*>(bins);
+    const unsigned stride = zblocks * blockDim.x;
+    for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
+  }
+}
+
 // LOCKSTEP SETS: the step ends of all chains of a set in two launches instead of two per chain.  The chains have
 // their own events (event classes, weights), parameter vectors, generators and jump buffers, so nothing is shared
 // but the launch: chain = blockIdx.y, and inside a chain every workgroup does exactly what it does in
@@ -1080,6 +1191,22 @@ hipError_t sx_launch_step_end(const SxSignalDesc* lookup_descs, const SxSignalDe
   if (zb > 1024) zb = 1024;
   hipLaunchKernelGGL(step_end_kernel, dim3((unsigned)nvb + 1u), dim3(block), shmem, s, lookup_descs, hist_descs, nsig,
                      npoints, weight, slots, last_good, sync, (unsigned)nvb, (unsigned)zb, a);
+  return hipGetLastError();
+}
+
+hipError_t sx_launch_step_end2(const SxSignalDesc* lookup_a, const SxSignalDesc* lookup_b, const SxSignalDesc* hist_a,
+                               const SxSignalDesc* hist_b, int nsig, int max_bins, unsigned long long npoints,
+                               const unsigned* weight_a, const unsigned* weight_b, unsigned long long* slots,
+                               double* last_good, unsigned* sync, int nvb, const unsigned* norms_b, double* v_b,
+                               const int* cap, const SxStepArgs& a, hipStream_t s) {
+  const int block = 128;
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);  // whole chunks
+  int zb = (max_bins / 4 + block - 1) / block;
+  if (zb < 1) zb = 1;
+  if (zb > 1024) zb = 1024;
+  hipLaunchKernelGGL(step_end2_kernel, dim3(2u * (unsigned)nvb + 1u), dim3(block), shmem, s, lookup_a, lookup_b, hist_a,
+                     hist_b, nsig, npoints, weight_a, weight_b, slots, last_good, sync, (unsigned)nvb, (unsigned)zb,
+                     norms_b, v_b, cap, a);
   return hipGetLastError();
 }
 

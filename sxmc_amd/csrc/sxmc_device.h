@@ -99,6 +99,11 @@ hipError_t sx_launch_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, u
 hipError_t sx_launch_step_end(const SxSignalDesc* lookup_descs, const SxSignalDesc* hist_descs, int nsig, int max_bins,
                               unsigned long long npoints, const unsigned* weight, unsigned long long* slots,
                               double* last_good, unsigned* sync, int nvb, const SxStepArgs& a, hipStream_t s);
+hipError_t sx_launch_step_end2(const SxSignalDesc* lookup_a, const SxSignalDesc* lookup_b, const SxSignalDesc* hist_a,
+                               const SxSignalDesc* hist_b, int nsig, int max_bins, unsigned long long npoints,
+                               const unsigned* weight_a, const unsigned* weight_b, unsigned long long* slots,
+                               double* last_good, unsigned* sync, int nvb, const unsigned* norms_b, double* v_b,
+                               const int* cap, const SxStepArgs& a, hipStream_t s);
 hipError_t sx_step_end_slots_init(unsigned long long* slots, double* last_good, int n);
 hipError_t sx_launch_chain_ends(const SxChainEnds& e, int nchains, int nsig, int max_bins, int block, hipStream_t s);
 hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,

@@ -3172,9 +3172,6 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
   // each candidate's event sum is cut exactly like the sequential step's (group_step_tail): the same blocks of 128
   // rows, the same cap, so the partial sums and their reduction round identically
   const int half = step_sum_blocks(ne);
-  SX_HIP(sx_launch_eval_nll2(ea.d_descs, eb.d_descs, (int)ga->members.size(), ne, ea.d_weight, eb.d_weight,
-                             a->d_v_proposed, d_v_lookahead, a->d_nexpected, a->d_n_mc, a->d_source_id, a->d_norms,
-                             d_norms_lookahead, ga->d_step_sums, gb->d_step_sums, half, block, st));
   SxStepArgs k;
   k.nsignals = ga->members.size();
   k.nsources = a->nsources;
@@ -3195,12 +3192,24 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
   k.n_mc = a->d_n_mc;
   k.source_id = a->d_source_id;
   k.norms = a->d_norms;
-  SX_HIP(sx_launch_finish2_zero(ga->d_descs, gb->d_descs, (int)ga->members.size(), std::max(ga->max_bins, gb->max_bins),
-                                (size_t)half, ga->d_step_sums, gb->d_step_sums, d_norms_lookahead, d_v_lookahead, d_cap, k,
-                                128, st));
+  // the pass's step end: ONE cooperative launch where both candidates' event sums fit 128 lanes of a finisher
+  // (step_end2_kernel; the same switch as the sequential step's), else lookup + event sums, then step end + clearing
+  const bool coop = 2 * half <= kCoopMaxWorkers && step_end_is_cooperative(ga, ne);
+  if (coop) {
+    SX_HIP(sx_launch_step_end2(ea.d_descs, eb.d_descs, ga->d_descs, gb->d_descs, (int)ga->members.size(),
+                               std::max(ga->max_bins, gb->max_bins), ne, ea.d_weight, eb.d_weight, ga->d_coop_slots,
+                               ga->d_coop_last, ga->d_ticket, half, d_norms_lookahead, d_v_lookahead, d_cap, k, st));
+  } else {
+    SX_HIP(sx_launch_eval_nll2(ea.d_descs, eb.d_descs, (int)ga->members.size(), ne, ea.d_weight, eb.d_weight,
+                               a->d_v_proposed, d_v_lookahead, a->d_nexpected, a->d_n_mc, a->d_source_id, a->d_norms,
+                               d_norms_lookahead, ga->d_step_sums, gb->d_step_sums, half, block, st));
+    SX_HIP(sx_launch_finish2_zero(ga->d_descs, gb->d_descs, (int)ga->members.size(), std::max(ga->max_bins, gb->max_bins),
+                                  (size_t)half, ga->d_step_sums, gb->d_step_sums, d_norms_lookahead, d_v_lookahead, d_cap, k,
+                                  128, st));
+  }
   for (size_t c = 0; c < 2; c++) {
     sxmc_group* g = mg->groups[c];
-    g->last_step_launches += (int)ga->classes.size() + 2;
+    g->last_step_launches += (int)ga->classes.size() + (coop ? 1 : 2);
     g->prezeroed = 1;
     for (sxmc_hist* h : g->members) {
       h->bins_valid = false;

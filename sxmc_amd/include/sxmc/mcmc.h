@@ -688,6 +688,16 @@ class MCMC {
       chain.accepted += (size_t)naccepted;
       jump_counter.writeOnlyHostPtr()[0] = 0;
       accept_counter.writeOnlyHostPtr()[0] = 0;
+      if (batched) {
+        // the cooperative step end waits inside its kernel, with a bound: a wait that ran into it left the steps of
+        // this run invalid -- never seen on a healthy device, and not to be passed on silently if it ever happens
+        unsigned timeouts = 0;
+        check(sxmc_group_step_end_timeouts(group, &timeouts));
+        if (timeouts) {
+          throw pdfz::Error("MCMC: " + std::to_string(timeouts) + " workgroup(s) of the cooperative step end gave up "
+                            "waiting (sxmc_group_step_end_timeouts): the chain is not valid");
+        }
+      }
       i = f + 1;
     }
     if (strm) check(sxmc_stream_synchronize(strm));

@@ -352,6 +352,12 @@ class MCMC:
         self.jump_counter.set(np.zeros(1, np.int32))
         self.accept_counter.set(np.zeros(1, np.int32))
         self._since_flush = 0
+        if self.consume:
+            # (the cooperative step end waits inside its kernel, with a bound; a wait that ran into it invalidates the run)
+            timeouts = self.group.StepEndTimeouts()
+            if timeouts:
+                raise RuntimeError("%d workgroup(s) of the cooperative step end gave up waiting: the chain is not valid"
+                                   % timeouts)
         return rows.copy(), nacc
 
     def run(self, nsteps, debug_mode=False):

@@ -146,7 +146,7 @@ def test_strides_beyond_24_bits_take_the_general_path():
     nb, lower, upper = [100, 2900, 2900], [0.0, 0.0, -1.0], [10.0, 6.0, 1.0]
     signals = []
     for j in range(2):
-        n = 300_001
+        n = 3_000_001          # (enough rows per bucket of c -- 2 900 of them -- for the table to be bucketed at all)
         e_true = rng.normal(4.0 + j, 1.5, n)
         tab = np.stack([e_true + rng.normal(0, 0.3, n), 6.0 * rng.uniform(size=n) ** (1 / 3), rng.uniform(-1, 1, n),
                         e_true, np.zeros(n)], axis=1).astype(np.float32)
@@ -161,7 +161,7 @@ def test_strides_beyond_24_bits_take_the_general_path():
     m.setup(sync_interval=8)
     info = m.group.LaunchInfo()
     assert "hist=global" in info and "+runs" not in info, info
-    assert "note:" in info and "2^23" in info, info      # (and the plan says why it fell back: ADVICE r3)
+    assert "table=bucketed" in info and "note:" in info and "2^23" in info, info   # (the plan says why it fell back)
     proposal = m.proposed_vector.get()
     m.step(debug_mode=True)
     rows, nacc = m.flush()
