@@ -761,12 +761,23 @@ def cpp_multi_gpu_record(args, ngpus, collective):
     nexp = 16 * ngpus if args.experiments < 0 else max(args.experiments, ngpus)   # (two experiments per lane)
     devices = ",".join(str(d["device_index"]) for d in collective["devices"])
     extra = [] if collective["backend"] == "nccl" else ["--host-staging"]
-    lines, failure = run_bench_cpp(["--scale", args.scale, "--no-walk", "--graph-steps", args.graph_steps,
-                                    "--experiments", nexp, "--exp-steps", args.exp_steps, "--chains", 4, "--sets", 2,
-                                    "--device-list", devices] + extra, 300)
+    argv = ["--scale", args.scale, "--no-walk", "--graph-steps", args.graph_steps, "--experiments", nexp,
+            "--exp-steps", args.exp_steps, "--chains", 4, "--sets", 2, "--device-list", devices] + extra
+    # Measured with one set-up lock PER CARD (graph recording stays exclusive for the process: MultiGpuOptions::
+    # PER_DEVICE) -- with ONE lock for the process, the library's default until a run on more than one card is on
+    # record, the cards' set-ups take turns and the runner's rate says more about the lock than about the cards.  Should
+    # the relaxed mode fail on a real node, the leg is repeated with the process-wide lock and the record carries both.
+    lines, failure = run_bench_cpp(argv + ["--per-device-locks"], 300)
+    relaxed_failure = None
     if failure:
+        relaxed_failure = failure
+        lines, failure = run_bench_cpp(argv, 300)
+    if failure:
+        failure["per_device_locks"] = relaxed_failure
         return failure
     rec = lines[-1]
+    if relaxed_failure:
+        rec["per_device_locks_failed"] = relaxed_failure
     rec["leg_seconds"] = time.perf_counter() - t0
     return rec
 

@@ -459,7 +459,9 @@ int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);
  * (~0.3 s): a lane that gives up counts a timeout, which sxmc_group_step_end_timeouts reports (0 in any healthy run;
  * the results of a step that timed out are not valid). */
 int sxmc_group_set_cooperative_step_end(sxmc_group_t g, int enable);
-int sxmc_group_step_end_timeouts(sxmc_group_t g, unsigned* timeouts);
+/* s: the stream the count is read through (the chain's own; NULL = a blocking copy through the legacy stream, which
+ * must not happen while another host thread records a graph). */
+int sxmc_group_step_end_timeouts(sxmc_group_t g, sxmc_stream_t s, unsigned* timeouts);
 /* Compiles (does not load or run) the fill kernel the library would specialise at run time for a program of
  * systematics -- see sxmc_group_set_runtime_kernels.  Needs no GPU: a build check, and the test hook of the
  * run-time compilation.  ops[i] = type | obs_slot << 4 | extra_slot << 8 | npars << 12 (npars 0 = one coefficient);

@@ -148,10 +148,12 @@ def compact_also(rec):
               "rows_kept", "lookahead", "samples_per_sec", "vs_published", "experiments_per_sec",
               "experiments_per_sec_after_setup", "steps_per_sec_inside", "ranks", "rccl_nranks", "exchange",
               "chain_identical_to_group_path", "ratio_to_lut_materialized", "launches_per_step", "budget_seconds",
-              "within_budget", "nsteps"):
+              "within_budget", "nsteps", "locking"):
         if k in rec and not isinstance(rec[k], (dict, list)):
             v = rec[k]
             out[k] = (v if len(v) <= 48 else v[:45] + "...") if isinstance(v, str) else _num(v)
+    if rec.get("per_device_locks_failed"):
+        out["per_device_locks_failed"] = str(rec["per_device_locks_failed"].get("failed"))[:100]
     rf = rec.get("roofline")
     if isinstance(rf, dict):
         out["whole_step_frac"] = _num(rf.get("whole_step_frac"))

@@ -3275,10 +3275,17 @@ int sxmc_group_set_cooperative_step_end(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
-int sxmc_group_step_end_timeouts(sxmc_group_t g, unsigned* timeouts) {
+int sxmc_group_step_end_timeouts(sxmc_group_t g, sxmc_stream_t s, unsigned* timeouts) {
   SX_REQUIRE(g && timeouts, "null argument");
   SX_FLUSH();
-  SX_HIP(hipMemcpy(timeouts, g->d_ticket + 6, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (s) {
+    // on the chain's own stream: a copy through the legacy stream is what the runtime refuses while ANOTHER host
+    // thread records a graph on a blocking stream (see sxmc_graph_begin_capture)
+    SX_HIP(hipMemcpyAsync(timeouts, g->d_ticket + 6, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)s));
+    SX_HIP(hipStreamSynchronize((hipStream_t)s));
+  } else {
+    SX_HIP(hipMemcpy(timeouts, g->d_ticket + 6, sizeof(unsigned), hipMemcpyDeviceToHost));
+  }
   return SXMC_OK;
 }
 

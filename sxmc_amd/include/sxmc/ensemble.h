@@ -741,13 +741,20 @@ struct MultiGpuOptions {
   enum Exchange { RCCL, HOST_STAGING } exchange = RCCL;
   double exchange_timeout_seconds = 120.0;   //!< a collective still pending after this long is aborted (fail fast)
   /** Which lock serialises set-up (allocation, uploads, launch plans, module loads), graph recording and tear-down of
-   *  the device threads.  PROCESS_WIDE (default): ONE lock for all cards -- a thread never allocates or synchronises a
-   *  device while another thread records a graph, on whichever card.  PER_DEVICE: one lock per card, chains on
-   *  different cards never wait for each other (graph capture is thread-local, allocation and device-wide
-   *  synchronisation are per device -- by the runtime's documentation).  No run on more than one card is on record
-   *  yet, so the conservative lock is the default; the per-device one is for measuring on a real node
-   *  (bench_cpp --per-device-locks), and becomes the default once such a run has shown it sound. */
-  enum Locking { PROCESS_WIDE, PER_DEVICE } locking = PROCESS_WIDE;
+   *  the device threads.
+   *  PROCESS_WIDE (default): ONE lock for all cards -- a thread never allocates or synchronises a device while another
+   *  thread records a graph or sets up, on whichever card.  No run on more than one card is on record yet, so the
+   *  conservative lock is the default.
+   *  PER_DEVICE: one lock per card for set-up and tear-down -- the cards' set-ups run side by side -- while GRAPH
+   *  RECORDING stays exclusive for the whole process (RecordingGate: whoever records waits for every set-up section in
+   *  the process to end, and new ones wait for the recording): only the paths that never record graphs are relaxed.
+   *  With 16 experiments per card at 77 ms of set-up each, one lock for 8 cards serialises ~10 s of set-up against
+   *  ~3.5 s of walking per card; this mode is what a real node is measured with (bench_cpp --per-device-locks, which
+   *  bench.py's multi-GPU leg tries first).
+   *  PER_RANK (tests): a lock per rank even when ranks share a card -- set-up on one host thread beside stepping and
+   *  set-up of another on the SAME device, recording still exclusive: the concurrency PER_DEVICE allows between cards,
+   *  exercised on a box with one. */
+  enum Locking { PROCESS_WIDE, PER_DEVICE, PER_RANK } locking = PROCESS_WIDE;
   ErrorType error_type = ERROR_CONTOUR;      //!< fit.error_type: contour or projection intervals
   /** Called by every device thread (argument: its rank) when its experiments are done, before the rendezvous.
    *  May throw: the tests inject a failing rank with it. */
@@ -825,8 +832,15 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
   std::vector<std::exception_ptr> errors(G);
   // one lock for the process, or one per card (ranks rehearsed on one card share theirs); key -1 = the process's
   std::map<int, SetupLock> locks;
-  const bool per_device = opt.locking == MultiGpuOptions::PER_DEVICE;
-  for (int d : devices) (void)locks[per_device ? d : -1];
+  RecordingGate gate;   // recording anywhere excludes set-up everywhere (shared by the locks below; see MultiGpuOptions)
+  auto lock_key = [&](size_t r) {
+    return opt.locking == MultiGpuOptions::PER_DEVICE ? devices[r]
+           : opt.locking == MultiGpuOptions::PER_RANK ? 1000 + (int)r : -1;
+  };
+  for (size_t r = 0; r < G; r++) {
+    locks.emplace(std::piecewise_construct, std::forward_as_tuple(lock_key(r)),
+                  std::forward_as_tuple(opt.locking == MultiGpuOptions::PROCESS_WIDE ? nullptr : &gate));
+  }
   Rendezvous meet(G);
   std::atomic<bool> give_up{false};   // a rank abandoned the exchange: the others stop waiting for it
   std::vector<std::thread> threads;
@@ -835,7 +849,7 @@ inline MultiGpuEnsemble ensemble_multi_gpu(const std::vector<int>& devices, unsi
       std::vector<Signal> mine;
       float *d_send = nullptr, *d_recv = nullptr;
       sxmc_stream_t strm = nullptr;
-      SetupLock& exclusive = locks.find(per_device ? devices[r] : -1)->second;   // (find does not modify the map)
+      SetupLock& exclusive = locks.find(lock_key(r))->second;   // (find does not modify the map)
       std::vector<float> send(block, std::numeric_limits<float>::quiet_NaN());
       bool ok = true;
       const Clock::time_point t0 = Clock::now();

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -47,11 +48,22 @@ struct Chain {
  *  users spent waiting for it and holding it: with G devices x lanes host threads that is the Amdahl term of an
  *  ensemble, and a run reports it instead of guessing (bench_cpp: "setup_lock").  One per device: chains on
  *  different devices never contend. */
+/** Shared by the SetupLocks of several cards (ensemble_multi_gpu with one lock per card): GRAPH RECORDING anywhere in the
+ *  process excludes set-up -- allocation, uploads, launch plans, module loads, device-wide synchronisation --
+ *  everywhere in the process, while the set-ups of different cards run side by side.  Holding a SetupLock holds the gate
+ *  shared; begin_recording() trades that for the exclusive side until end_recording(). */
+struct RecordingGate {
+  std::shared_timed_mutex m;
+};
+
 class SetupLock {
  public:
+  SetupLock() = default;
+  explicit SetupLock(RecordingGate* gate_) : gate(gate_) {}
   void lock() {
     const auto t0 = std::chrono::steady_clock::now();
     m.lock();
+    if (gate) gate->m.lock_shared();
     since = std::chrono::steady_clock::now();
     waited_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(since - t0).count(),
                         std::memory_order_relaxed);
@@ -61,7 +73,20 @@ class SetupLock {
     held_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(
                           std::chrono::steady_clock::now() - since).count(),
                       std::memory_order_relaxed);
+    if (gate) gate->m.unlock_shared();
     m.unlock();
+  }
+  /** The holder is about to record a HIP graph: nobody in the process may be inside a set-up section meanwhile (the
+   *  other holders of the gate finish theirs first; new ones wait).  Only the holder of this lock calls these. */
+  void begin_recording() {
+    if (!gate) return;
+    gate->m.unlock_shared();
+    gate->m.lock();
+  }
+  void end_recording() {
+    if (!gate) return;
+    gate->m.unlock();
+    gate->m.lock_shared();
   }
   double waited_seconds() const { return 1e-9 * (double)waited_ns.load(); }   //!< summed over all the threads that asked
   double held_seconds() const { return 1e-9 * (double)held_ns.load(); }
@@ -69,8 +94,22 @@ class SetupLock {
 
  private:
   std::mutex m;
+  RecordingGate* gate = nullptr;
   std::chrono::steady_clock::time_point since;   // (written and read by the holder only)
   std::atomic<unsigned long long> waited_ns{0}, held_ns{0}, acquisitions{0};
+};
+
+/** begin_recording / end_recording of a held SetupLock (may be null or not held: nothing to do then), scope-bound. */
+struct RecordingScope {
+  SetupLock* lock;
+  explicit RecordingScope(SetupLock* l, bool held) : lock(held ? l : nullptr) {
+    if (lock) lock->begin_recording();
+  }
+  ~RecordingScope() {
+    if (lock) lock->end_recording();
+  }
+  RecordingScope(const RecordingScope&) = delete;
+  RecordingScope& operator=(const RecordingScope&) = delete;
 };
 
 /** Chains advanced TOGETHER (sxmc_multigroup_step_async): one fill pass over the shared sample tables per step for
@@ -146,6 +185,7 @@ class LockstepSet {
         // recording does not tolerate another thread's allocations: under the process's set-up mutex
         std::unique_lock<SetupLock> excl;
         if (exclusive) excl = std::unique_lock<SetupLock>(*exclusive);
+        RecordingScope recording(exclusive, exclusive != nullptr);
         if (graph) sxmc_graph_destroy(graph);
         graph = nullptr;
         int rc = sxmc_graph_begin_capture(stream);
@@ -547,6 +587,7 @@ class MCMC {
       resolve();
       if (!ahead && gsteps > 0 && i > 0 && n >= gsteps) {
         if (!graph) {  // record gsteps steps once; the launch plan is current after the eager step 0
+          RecordingScope recording(exclusive, excl.owns_lock());
           check(sxmc_graph_begin_capture(strm));
           try {
             for (unsigned k = 0; k < gsteps; k++) one_step();
@@ -644,6 +685,7 @@ class MCMC {
               one_pass();   // (plans in place before recording)
               ahead_planned = true;
               k--;
+              RecordingScope recording(exclusive, excl.owns_lock());
               check(sxmc_graph_begin_capture(strm));
               try {
                 for (unsigned q = 0; q < gsteps; q++) one_pass();
@@ -692,7 +734,7 @@ class MCMC {
         // the cooperative step end waits inside its kernel, with a bound: a wait that ran into it left the steps of
         // this run invalid -- never seen on a healthy device, and not to be passed on silently if it ever happens
         unsigned timeouts = 0;
-        check(sxmc_group_step_end_timeouts(group, &timeouts));
+        check(sxmc_group_step_end_timeouts(group, strm, &timeouts));
         if (timeouts) {
           throw pdfz::Error("MCMC: " + std::to_string(timeouts) + " workgroup(s) of the cooperative step end gave up "
                             "waiting (sxmc_group_step_end_timeouts): the chain is not valid");

@@ -354,7 +354,7 @@ class MCMC:
         self._since_flush = 0
         if self.consume:
             # (the cooperative step end waits inside its kernel, with a bound; a wait that ran into it invalidates the run)
-            timeouts = self.group.StepEndTimeouts()
+            timeouts = self.group.StepEndTimeouts(self.stream)
             if timeouts:
                 raise RuntimeError("%d workgroup(s) of the cooperative step end gave up waiting: the chain is not valid"
                                    % timeouts)

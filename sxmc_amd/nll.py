@@ -175,10 +175,10 @@ class EvalGroup:
         event sum is small enough; off: look-ups + event sum, then step end + clearing (two launches)."""
         capi.call("sxmc_group_set_cooperative_step_end", self._g, int(bool(enable)))
 
-    def StepEndTimeouts(self):
-        """Workgroups of the cooperative step end that gave up waiting (0 in a healthy run)."""
+    def StepEndTimeouts(self, stream=None):
+        """Workgroups of the cooperative step end that gave up waiting (0 in a healthy run), read through `stream`."""
         n = C.c_uint(0)
-        capi.call("sxmc_group_step_end_timeouts", self._g, C.byref(n))
+        capi.call("sxmc_group_step_end_timeouts", self._g, ptr(stream), C.byref(n))
         return n.value
 
     def FinishStepAsync(self, stream, npartial_sums, sums, means, sigmas, rng, nll_current, nll_proposed, v_current,

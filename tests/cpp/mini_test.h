@@ -57,6 +57,9 @@ inline int run_all(const char* filter) {
     } catch (const std::exception& e) {
       failed++;
       std::printf("[ FAIL ] %s\n    exception: %s\n", full.c_str(), e.what());
+#ifdef MINI_TEST_EXTRA_CATCH
+    MINI_TEST_EXTRA_CATCH   // (a test file's own exception types, e.g. one that carries `.msg`)
+#endif
     } catch (...) {
       failed++;
       std::printf("[ FAIL ] %s\n    unknown exception\n", full.c_str());

@@ -9,6 +9,12 @@
 #include <sxmc/pdfz.h>
 
 #include "../../sxmc_amd/include/sxmc/ensemble.h"
+// (pdfz::Error is the reference's exception type: a plain struct with `msg`, not a std::exception)
+#define MINI_TEST_EXTRA_CATCH                                                              \
+  }                                                                                        \
+  catch (const pdfz::Error& e) {                                                           \
+    failed++;                                                                              \
+    std::printf("[ FAIL ] %s\n    pdfz::Error: %s\n", full.c_str(), e.msg.c_str());
 #include "mini_test.h"
 
 using std::isnan;
@@ -770,9 +776,12 @@ TEST_F(SmallFit, MultiGpuRunnerWithTwoLogicalRanksOnOneCard) {
   // thread, the rendezvous, the order of the results, the medians.  Three ranks as well (uneven shares, padded blocks).
   // ... and EIGHT (the node's shape, BASELINE config 4: every rank with two or three experiments), with one lock for the
   // process (the default) and with one per card.
-  for (int G : {2, 3, 8, -8}) {
-    const bool per_device = G < 0;
-    G = G < 0 ? -G : G;
+  // -8: one lock per card (one card here: one lock); -108: one lock PER RANK -- eight host threads setting up, stepping
+  // and tearing down side by side on the same device, only graph recording exclusive (what PER_DEVICE allows between
+  // cards, exercised on one).
+  for (int G : {2, 3, 8, -8, -108}) {
+    const bool per_device = G == -8, per_rank = G == -108;
+    G = G < 0 ? 8 : G;
     const unsigned N = G == 8 ? 19 : 7;
     std::vector<unsigned> ks;
     for (unsigned k = 0; k < N; k++) ks.push_back(k);
@@ -787,11 +796,12 @@ TEST_F(SmallFit, MultiGpuRunnerWithTwoLogicalRanksOnOneCard) {
     opt.lockstep_sets = 1;
     opt.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
     if (per_device) opt.locking = sxmc::MultiGpuOptions::PER_DEVICE;
+    if (per_rank) opt.locking = sxmc::MultiGpuOptions::PER_RANK;
     sxmc::MultiGpuEnsemble mg = sxmc::ensemble_multi_gpu(std::vector<int>((size_t)G, 0), N, 21, sources, signals, tabs, 4,
                                                          systematics, observables, 300, 0.2f, opt);
     EXPECT_EQ(0, mg.rccl_nranks);
-    EXPECT_EQ((size_t)1, mg.setup_locks.size());   // one card, one lock, shared by the ranks
-    EXPECT_EQ(per_device ? 0 : -1, mg.setup_locks[0].device);   // (-1: the process's lock)
+    EXPECT_EQ(per_rank ? (size_t)G : (size_t)1, mg.setup_locks.size());   // one card: one lock shared by the ranks
+    if (!per_rank) EXPECT_EQ(per_device ? 0 : -1, mg.setup_locks[0].device);   // (-1: the process's lock)
     EXPECT_TRUE(mg.setup_locks[0].acquisitions > 0 && mg.setup_locks[0].held_seconds > 0);
     EXPECT_EQ((size_t)G, mg.rank_seconds.size());
     for (unsigned k = 0; k < N; k++) {
