@@ -1475,12 +1475,17 @@ std::atomic<unsigned long long> g_deferred_launches{0}, g_deferred_evaluations{0
 // A batch of two or more therefore goes to the legacy default stream itself -- ordered with everything the reference's
 // streams would be ordered with, and with the caller's NLL kernels by plain queue order.  SXMC_DEFER_STREAM=own
 // launches on the first member's stream instead (measurement).
+// (While ANY host thread of the process records a graph the runtime refuses work on the legacy stream -- "operation
+// would make the legacy stream depend on a capturing blocking stream" -- so a batch that falls into such a moment goes
+// to the first member's stream and is waited for there: slower, never wrong.)
+std::atomic<int> g_captures_in_progress{0};
 hipStream_t batch_stream(const std::vector<sxmc_hist*>& m) {
   static const bool own = [] {
     const char* e = std::getenv("SXMC_DEFER_STREAM");
     return e && std::string(e) == "own";
   }();
-  return (m.size() >= 2 && !own) ? nullptr : m[0]->stream;
+  const bool legacy_ok = g_captures_in_progress.load(std::memory_order_acquire) == 0;
+  return (m.size() >= 2 && !own && legacy_ok) ? nullptr : m[0]->stream;
 }
 
 // EvalFinished's wait: hipStreamSynchronize.  (An MCMC step waits once per evaluation, mcmc.cpp:268-270, so polling
@@ -1813,6 +1818,7 @@ int sxmc_graph_begin_capture(sxmc_stream_t s) {
   SX_REQUIRE(s, "the legacy default stream cannot be captured: pass a created stream");
   SX_REQUIRE(!t_capturing, "a capture is already in progress on this thread");
   SX_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+  g_captures_in_progress.fetch_add(1, std::memory_order_acq_rel);
   t_capturing = true;
   t_capture_epoch++;
   t_capture_groups.clear();
@@ -1822,6 +1828,7 @@ int sxmc_graph_end_capture(sxmc_stream_t s, sxmc_graph_t* out) {
   SX_REQUIRE(s && out, "null argument");
   SX_REQUIRE(t_capturing, "no capture in progress on this thread");
   t_capturing = false;
+  g_captures_in_progress.fetch_sub(1, std::memory_order_acq_rel);
   for (sxmc_group* g : t_capture_groups) g->prezeroed = 0;  // nothing recorded has run yet
   t_capture_groups.clear();
   hipGraph_t graph = nullptr;
