@@ -313,11 +313,13 @@ class Leg:
             m.step()
 
     # form "graph": the fused sequence replayed from a HIP graph of --graph-steps recorded steps.  Replayed
-    # launches carry no events, so the last steps of every run are launched one by one with HIP events
-    # around the fill kernel: the roofline figures come from those, inside the same timed region.
-    def eager_share(self, n):          # about a tenth of the steps, and whatever does not fill a whole graph
+    # launches carry no events: the roofline figures come from steps launched one by one AFTER the timed region.
+    def eager_share(self, n):          # whatever does not fill a whole graph
+        # (round 3 also launched a tenth of the timed steps one by one, with events around the fill, for the roofline
+        #  figures; those now come from launches made AFTER the timed region, and the timed region is the walk as a
+        #  driver walks it -- graph replays: at --steps 20 half of the 3 ms timed were the slower eager launches)
         gs = self.graph_state["steps_per_graph"]
-        return n if gs <= 0 or n < 2 * gs else n - ((n - n // 10) // gs) * gs
+        return n if gs <= 0 else n % gs
 
     def run_steps(self, n):
         from sxmc_amd import capi
