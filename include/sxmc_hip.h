@@ -459,6 +459,19 @@ int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable);
  * (~0.3 s): a lane that gives up counts a timeout, which sxmc_group_step_end_timeouts reports (0 in any healthy run;
  * the results of a step that timed out are not valid). */
 int sxmc_group_set_cooperative_step_end(sxmc_group_t g, int enable);
+/* THE WHOLE STEP IN ONE LAUNCH (default 0: built, bit-identical and MEASURED SLOWER than the fill followed by the
+ * cooperative step end -- 6 640-6 970 against 6 870-7 260 evaluations/s at BASELINE config 3, DESIGN.md section 4;
+ * SXMC_FUSED_STEP=1 in the environment changes the default).  Where the step
+ * end is cooperative (above), the plan is a single fill launch with a built-in kernel that has the form (the ordered
+ * programs -- BASELINE config 3 --, the empty program over a pre-binned column -- config 2) and at most 256
+ * parameters and signals, sxmc_group_step_async launches the fill's workgroups AND the step end's finisher and workers
+ * as one grid: the roles start on CUs the fill's first workgroups have left, wait for the fill's workgroups to count
+ * themselves done (each after its flush has landed), acquire, and go on as the cooperative step end.  Waits go from
+ * later blocks to earlier ones (which the dispatcher has started before them) except the finisher's for its workers;
+ * all are bounded and counted like the step end's.  Same arithmetic, same partial sums: the chain is the same bit for
+ * bit.  1 launch per step.  A step whose fill is being timed (sxmc_group_profile) is launched unfused, so that the
+ * fill's own duration stays measurable. */
+int sxmc_group_set_fused_step(sxmc_group_t g, int enable);
 /* s: the stream the count is read through (the chain's own; NULL = a blocking copy through the legacy stream, which
  * must not happen while another host thread records a graph). */
 int sxmc_group_step_end_timeouts(sxmc_group_t g, sxmc_stream_t s, unsigned* timeouts);

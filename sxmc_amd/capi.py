@@ -124,6 +124,7 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _i],
     "sxmc_group_set_tail_kernel": [_vp, _i],
     "sxmc_group_set_cooperative_step_end": [_vp, _i],
+    "sxmc_group_set_fused_step": [_vp, _i],
     "sxmc_group_step_end_timeouts": [_vp, _vp, C.POINTER(C.c_uint)],
     "sxmc_rtc_compile_check": [_i, _i, _i, _i, _i, _vp, _i, _psz],
     "sxmc_rtc_compile_check_lockstep": [_i, _i, _i, _i, _vp, _i, _psz],

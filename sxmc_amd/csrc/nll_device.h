@@ -121,12 +121,17 @@ __device__ __forceinline__ void nll_total_device(size_t nparameters, size_t nsig
 }
 
 // Sum of sums[0..n) over the workgroup; the total is returned to every thread.
+// BD > 0: the workgroup's LOGICAL size -- the first BD lanes of a larger launch do the work of a workgroup of BD (the
+// others have left): the fused step kernel runs its step-end roles in workgroups of the fill's size (see
+// fill_step_kernel in pdfz_kernels.hip), and the partition of every sum must be the one a launch of BD lanes has.
+template <int BD = 0>
 __device__ __forceinline__ double block_sum(size_t n, const double* sums, double* s_wave /*[17]*/) {
+  const unsigned bdim = BD > 0 ? (unsigned)BD : blockDim.x;
   // (a thread's terms are added in index order, as before; sixteen loads are in flight at a time -- the reference's
   //  launch shape hands 16 384 partial sums to 128 lanes, mcmc.cpp:37-45, and one load per addition made that 41 us)
   double t = 0.0;
   size_t i = threadIdx.x;
-  const size_t bd = blockDim.x;
+  const size_t bd = bdim;
   for (; i + 15 * bd < n; i += 16 * bd) {
     double v[16];
 #pragma unroll
@@ -139,13 +144,13 @@ __device__ __forceinline__ double block_sum(size_t n, const double* sums, double
   // a lane that does not exist is undefined, so those contributions are replaced by zero
   const int wave = threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
-  const int live = min(kWave, (int)blockDim.x - wave * kWave);
+  const int live = min(kWave, (int)bdim - wave * kWave);
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) {
     const double o = __shfl_down(t, off, kWave);
     t += (lane + off < live) ? o : 0.0;
   }
-  const int nwaves = (blockDim.x + kWave - 1) / kWave;
+  const int nwaves = ((int)bdim + kWave - 1) / kWave;
   if ((threadIdx.x & (kWave - 1)) == 0) s_wave[wave] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -174,7 +179,7 @@ constexpr int kStage = 256;
 // `wait`: called by every thread of the workgroup, once, after everything that does not need the partial sums has
 // been loaded and computed (phase A) and before the sums are read -- the cooperative step end (step_end_kernel) waits
 // there for the workgroups that are still summing, so that phase A runs under their look-ups.
-template <typename Wait>
+template <int BD = 0, typename Wait>
 __device__ __forceinline__ bool finish_step_device_w(size_t npartial_sums, const double* sums, size_t nsignals,
                                                      size_t nsources, const double* means, const double* sigmas,
                                                      sxmc_rng_state* rng, double* nll_current,
@@ -191,10 +196,11 @@ __device__ __forceinline__ bool finish_step_device_w(size_t npartial_sums, const
   __shared__ int s_accept, s_count;
   __shared__ double s_nllcur, s_u;
 
+  const unsigned bdim = BD > 0 ? (unsigned)BD : blockDim.x;
   const bool staged = nparameters <= kStage && nsignals <= (size_t)kStage;
-  if (!staged) {
+  if (!staged) {   // (never with BD > 0: the host offers the fused kernel only for vectors that are staged)
     wait();
-    double total_sum = block_sum(npartial_sums, sums, s_wave);
+    double total_sum = block_sum<BD>(npartial_sums, sums, s_wave);
     if (threadIdx.x == 0) {
       nll_total_device(nparameters, nsignals, nsources, v_proposed, means, sigmas, &total_sum, nexpected, n_mc,
                        source_id, norms, nll_proposed);
@@ -215,7 +221,7 @@ __device__ __forceinline__ bool finish_step_device_w(size_t npartial_sums, const
     nc = nll_current[0];
     count = counter[0];
   }
-  for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
+  for (int i = threadIdx.x; i < nparameters; i += (int)bdim) {
     const double p = v_proposed[i], mean = means[i], sigma = sigmas[i];
     const float jw = jump_width[i];
     s_vprop[i] = p;
@@ -238,11 +244,11 @@ __device__ __forceinline__ bool finish_step_device_w(size_t npartial_sums, const
       rng[i].offset = st.offset;
     }
   }
-  for (int j = threadIdx.x; j < (int)nsignals; j += blockDim.x) {
+  for (int j = threadIdx.x; j < (int)nsignals; j += (int)bdim) {
     s_term[j] = v_proposed[source_id[j]] * nexpected[j] * norms[j] / n_mc[j];  // :169-172
   }
   wait();
-  const double total_sum = block_sum(npartial_sums, sums, s_wave);  // barriers inside: LDS is visible after
+  const double total_sum = block_sum<BD>(npartial_sums, sums, s_wave);  // barriers inside: LDS is visible after
 
   // ---- phase B
   if (threadIdx.x == 0) {
@@ -275,7 +281,7 @@ __device__ __forceinline__ bool finish_step_device_w(size_t npartial_sums, const
   // ---- phase C
   const bool accept = s_accept != 0;
   const size_t row = (size_t)s_count * (size_t)(nparameters + 1);
-  for (int i = threadIdx.x; i < nparameters; i += blockDim.x) {
+  for (int i = threadIdx.x; i < nparameters; i += (int)bdim) {
     const double cur = accept ? s_vprop[i] : s_vcur[i];
     if (accept) v_current[i] = cur;
     jump_buffer[row + i] = (float)cur;
@@ -294,7 +300,7 @@ __device__ __forceinline__ bool finish_step_device(size_t npartial_sums, const d
                                                    const double* nexpected, const unsigned* n_mc,
                                                    const short* source_id, const unsigned* norms,
                                                    bool debug_mode) {
-  return finish_step_device_w(npartial_sums, sums, nsignals, nsources, means, sigmas, rng, nll_current, nll_proposed,
+  return finish_step_device_w<0>(npartial_sums, sums, nsignals, nsources, means, sigmas, rng, nll_current, nll_proposed,
                               v_current, v_proposed, accepted, counter, jump_buffer, nparameters, jump_width, nexpected,
                               n_mc, source_id, norms, debug_mode, [] {});
 }

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstring>
 #include <vector>
 
 #include "nll_device.h"
@@ -201,6 +202,11 @@ struct EvalMember {
 // (valid in thread 0).  A row is an event -- or, with `weight`, a class of events that fall into the same
 // bin of every member (the descriptors then point at the class tables and carry no lookup-table output):
 // its log term counts weight[row] times.
+// `ready`: called by every thread, once, after the loads that do not depend on the evaluation (the rows' event-bin
+// tables, the first row's weight: set by SetEvalPoints) have been ISSUED and before anything the fill writes is read
+// (histograms, normalisations): the fused step kernel waits there for the fill's workgroups, with those loads in
+// flight under the wait.
+template <int BD = 0, typename Ready>   // (BD > 0: the workgroup's logical size, see block_sum in nll_device.h)
 __device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __restrict__ descs, int nsig,
                                                       unsigned long long npoints, const unsigned* __restrict__ weight,
                                                       const double* __restrict__ pars,
@@ -208,16 +214,17 @@ __device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __rest
                                                       const unsigned* __restrict__ n_mc,
                                                       const short* __restrict__ source_id,
                                                       const unsigned* __restrict__ norms, double* sh,
-                                                      unsigned block_index, unsigned nblocks) {
+                                                      unsigned block_index, unsigned nblocks, Ready&& ready) {
   double* s_wave = sh;  // [16] wave sums, then nsig EvalMember records
   EvalMember* s_mem = reinterpret_cast<EvalMember*>(sh + 16);
+  const unsigned bdim = BD > 0 ? (unsigned)BD : blockDim.x;
 
   // The events' bin indices of the first members are requested before anything else: their addresses
   // need only the descriptors (uniform, scalar loads), so the loads fly while the per-member factors
   // below are fetched and staged.
   constexpr int U = 16;
   int rb[U];
-  unsigned long long i = (unsigned long long)block_index * blockDim.x + threadIdx.x;
+  unsigned long long i = (unsigned long long)block_index * bdim + threadIdx.x;
   // (clamped indices, no branches: all U table addresses are fetched together, then all U loads issued)
   auto load_read_bins = [&](unsigned long long ev, int j0) {
     const unsigned long long evc = ev < npoints ? ev : npoints - 1;
@@ -229,10 +236,15 @@ __device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __rest
 #pragma unroll
     for (int u = 0; u < U; u++) rb[u] = (j0 + u < nsig && ev < npoints) ? rb[u] : -2;
   };
-  if (npoints == 0 || nsig <= 0) return 0.0;   // uniform: nothing to look up
+  if (npoints == 0 || nsig <= 0) {   // uniform: nothing to look up
+    ready();
+    return 0.0;
+  }
   load_read_bins(i, 0);
+  unsigned wfirst = weight ? to_global(weight)[i < npoints ? i : npoints - 1] : 1u;
+  ready();
 
-  for (int j = threadIdx.x; j < nsig; j += blockDim.x) {
+  for (int j = threadIdx.x; j < nsig; j += (int)bdim) {
     const SxSignalDesc& d = descs[j];
     s_mem[j].read_bins = d.read_bins;
     s_mem[j].bins = d.bins;
@@ -246,12 +258,12 @@ __device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __rest
 
   double sum = 0.0;
   bool requested = true;
-  const unsigned long long step = (unsigned long long)nblocks * blockDim.x;
+  const unsigned long long step = (unsigned long long)nblocks * bdim;
   for (; i < npoints; i += step) {
     double s = 0.0;
     // (the row's weight is asked for before the gathers, not after the logarithm: one memory round trip less on a
     //  path that is nothing but round trips)
-    const unsigned wrow = weight ? to_global(weight)[i] : 1u;
+    const unsigned wrow = requested ? wfirst : (weight ? to_global(weight)[i] : 1u);
     for (int j0 = 0; j0 < nsig; j0 += U) {
       if (!requested) load_read_bins(i, j0);
       requested = false;
@@ -281,9 +293,22 @@ __device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __rest
   __syncthreads();
   double t = 0.0;
   if (threadIdx.x == 0) {
-    for (int w = 0; w < (int)(blockDim.x / kWave); w++) t += s_wave[w];
+    for (int w = 0; w < (int)(bdim / kWave); w++) t += s_wave[w];
   }
   return t;
+}
+
+template <int BD = 0>
+__device__ __forceinline__ double eval_nll_block_part(const SxSignalDesc* __restrict__ descs, int nsig,
+                                                      unsigned long long npoints, const unsigned* __restrict__ weight,
+                                                      const double* __restrict__ pars,
+                                                      const double* __restrict__ nexpected,
+                                                      const unsigned* __restrict__ n_mc,
+                                                      const short* __restrict__ source_id,
+                                                      const unsigned* __restrict__ norms, double* sh,
+                                                      unsigned block_index, unsigned nblocks) {
+  return eval_nll_block_part<BD>(descs, nsig, npoints, weight, pars, nexpected, n_mc, source_id, norms, sh, block_index,
+                                 nblocks, [] {});
 }
 
 __device__ __forceinline__ double eval_nll_block(const SxSignalDesc* __restrict__ descs, int nsig,
@@ -526,56 +551,65 @@ __global__ __launch_bounds__(256) void finish_zero_kernel(const SxSignalDesc* __
 constexpr unsigned kEndSpinLimit = 200000u;
 constexpr unsigned long long kSlotEmpty = 0x7FF8DEADBEEF0001ull, kSlotNaN = 0x7FF8DEADBEEF0002ull;
 
-__global__ __launch_bounds__(128) void step_end_kernel(const SxSignalDesc* __restrict__ lookup_descs,
-                                                       const SxSignalDesc* __restrict__ hist_descs, int nsig,
-                                                       unsigned long long npoints, const unsigned* __restrict__ weight,
-                                                       unsigned long long* slots, double* last_good, unsigned* sync,
-                                                       unsigned nvb, unsigned zblocks, SxStepArgs a) {
-  extern __shared__ double sh[];
-  const unsigned W = gridDim.x - 1u;   // == nvb
+// The roles of the cooperative step end.  `role` < W: worker `role`; `role` == W: the finisher.  BD > 0: the logical
+// workgroup size when the roles run inside a launch of larger workgroups (fill_step_kernel); lanes >= BD have left.
+// `ready`: called by every thread of the workgroup, once, before anything the fill writes is read (see
+// eval_nll_block_part): nothing for step_end_kernel, whose launch follows the fill's; the wait for the fill's workgroups
+// in fill_step_kernel.
+template <int BD, typename Ready>
+__device__ __forceinline__ void step_end_role(unsigned role, unsigned W, const SxSignalDesc* __restrict__ lookup_descs,
+                                              const SxSignalDesc* __restrict__ hist_descs, int nsig,
+                                              unsigned long long npoints, const unsigned* __restrict__ weight,
+                                              unsigned long long* slots, double* last_good, unsigned* sync,
+                                              unsigned nvb, unsigned zblocks, const SxStepArgs& a, double* sh,
+                                              Ready&& ready) {
+  const unsigned bdim = BD > 0 ? (unsigned)BD : blockDim.x;
   unsigned* const timeouts = sync + 6;
-  if (blockIdx.x == W) {
-    // ---- the finisher
+  if (role == W) {
+    // ---- the finisher (its phase A reads the normalisations: after the fill)
+    ready();
     __shared__ double s_part[128];
-    sxdev::finish_step_device_w(nvb, s_part, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
-                                a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
-                                a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
-                                a.debug_mode != 0, [&] {
-                                  const unsigned i = threadIdx.x;
-                                  if (i < nvb) {
-                                    unsigned long long v = kSlotEmpty;
-                                    unsigned it = 0;
-                                    for (; it < kEndSpinLimit; it++) {
-                                      v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                      if (v != kSlotEmpty) break;
-                                      __builtin_amdgcn_s_sleep(1);
-                                    }
-                                    double t;
-                                    if (v == kSlotEmpty) {   // gave up: flagged, the step is not valid
-                                      __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                      t = 0.0;
-                                    } else if (v == kSlotNaN) {
-                                      t = last_good[i];
-                                    } else {
-                                      t = __longlong_as_double((long long)v);
-                                      last_good[i] = t;
-                                    }
-                                    s_part[i] = t;
-                                  }
-                                  __syncthreads();
-                                  // every partial is in: the look-ups are over.  Empty the slots -- for the next launch,
-                                  // and as the workers' signal that the histograms may be cleared.
-                                  if (i < nvb) __hip_atomic_store(slots + i, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                });
+    sxdev::finish_step_device_w<BD>(nvb, s_part, a.nsignals, a.nsources, a.means, a.sigmas, a.rng, a.nll_current,
+                                    a.nll_proposed, a.v_current, a.v_proposed, a.accepted, a.counter, a.jump_buffer,
+                                    a.nparameters, a.jump_width, a.nexpected, a.n_mc, a.source_id, a.norms,
+                                    a.debug_mode != 0, [&] {
+                                      const unsigned i = threadIdx.x;
+                                      if (i < nvb) {
+                                        unsigned long long v = kSlotEmpty;
+                                        unsigned it = 0;
+                                        for (; it < kEndSpinLimit; it++) {
+                                          v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                          if (v != kSlotEmpty) break;
+                                          __builtin_amdgcn_s_sleep(1);
+                                        }
+                                        double t;
+                                        if (v == kSlotEmpty) {   // gave up: flagged, the step is not valid
+                                          __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                          t = 0.0;
+                                        } else if (v == kSlotNaN) {
+                                          t = last_good[i];
+                                        } else {
+                                          t = __longlong_as_double((long long)v);
+                                          last_good[i] = t;
+                                        }
+                                        s_part[i] = t;
+                                      }
+                                      __syncthreads();
+                                      // every partial is in: the look-ups are over.  Empty the slots -- for the next
+                                      // launch, and as the workers' signal that the histograms may be cleared.
+                                      if (i < nvb) {
+                                        __hip_atomic_store(slots + i, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                      }
+                                    });
     __syncthreads();
-    for (int j = threadIdx.x; j < nsig; j += blockDim.x) *hist_descs[j].norm = 0u;
+    for (int j = threadIdx.x; j < nsig; j += (int)bdim) *hist_descs[j].norm = 0u;
     if (threadIdx.x == 0) sync[0] = 0u;   // (the ticket of the other step-end forms: as finish_zero_kernel leaves it)
     return;
   }
   // ---- a worker: its virtual block of the event sum, as eval_nll_kernel's workgroup does it
-  const unsigned vb = blockIdx.x;
-  const double t = eval_nll_block_part(lookup_descs, nsig, npoints, weight, a.v_proposed, a.nexpected, a.n_mc,
-                                       a.source_id, a.norms, sh, vb, nvb);
+  const unsigned vb = role;
+  const double t = eval_nll_block_part<BD>(lookup_descs, nsig, npoints, weight, a.v_proposed, a.nexpected, a.n_mc,
+                                           a.source_id, a.norms, sh, vb, nvb, ready);
   __shared__ int s_clear;
   if (threadIdx.x == 0) {
     __hip_atomic_store(slots + vb, isnan(t) ? kSlotNaN : (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED,
@@ -593,17 +627,121 @@ __global__ __launch_bounds__(128) void step_end_kernel(const SxSignalDesc* __res
   __syncthreads();
   if (!s_clear) return;
   const unsigned npieces = zblocks * (unsigned)nsig;
-  for (unsigned p = blockIdx.x; p < npieces; p += W) {
+  for (unsigned p = role; p < npieces; p += W) {
     const SxSignalDesc& d = hist_descs[p / zblocks];
     const unsigned chunk = p % zblocks;
     unsigned* bins = d.bins;
     const unsigned n = (unsigned)d.total_nbins;
     const unsigned n4 = n >> 2;
     uint4* b4 = reinterpret_cast<uint4*>(bins);
-    const unsigned stride = zblocks * blockDim.x;
-    for (unsigned i = chunk * blockDim.x + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+    const unsigned stride = zblocks * bdim;
+    for (unsigned i = chunk * bdim + threadIdx.x; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
     if (chunk == 0 && threadIdx.x < (n & 3u)) bins[(n4 << 2) + threadIdx.x] = 0u;
   }
+}
+
+__global__ __launch_bounds__(128) void step_end_kernel(const SxSignalDesc* __restrict__ lookup_descs,
+                                                       const SxSignalDesc* __restrict__ hist_descs, int nsig,
+                                                       unsigned long long npoints, const unsigned* __restrict__ weight,
+                                                       unsigned long long* slots, double* last_good, unsigned* sync,
+                                                       unsigned nvb, unsigned zblocks, SxStepArgs a) {
+  extern __shared__ double sh[];
+  step_end_role<0>(blockIdx.x, gridDim.x - 1u, lookup_descs, hist_descs, nsig, npoints, weight, slots, last_good, sync,
+                   nvb, zblocks, a, sh, [] {});
+}
+
+// THE WHOLE STEP IN ONE LAUNCH: fill_step_kernel = a fill kernel + the roles above as extra workgroups of the SAME launch.
+// What is left between the fill and the cooperative step end as two launches is the second kernel's ramp (~2.5 us), the
+// gap before it (~1.3 us) and its first loads (descriptors, event-bin tables, weights, staged factors: two memory round
+// trips) -- all of which can sit under the fill's tail, whose workgroups finish over ~8 us.  Blocks
+// 0 .. nfill-1 are the fill's workgroups, unchanged, each counting itself done (after its flush has landed: every lane
+// waits for its own atomics, then one device-scope increment); block nfill is the finisher, blocks nfill+1 .. the
+// workers.  A role workgroup starts on a CU as soon as a fill workgroup has left it (they all carry the fill's LDS
+// allotment, one workgroup per CU), does what does not depend on the histograms, waits for the count to reach nfill,
+// acquires, and goes on as step_end_role.  Who waits for whom: the roles for fill workgroups and the workers for the
+// finisher -- all EARLIER blocks of the same launch, which the dispatcher has started before them; the fill
+// workgroups wait for nobody; only the finisher (one workgroup per launch) waits for later blocks.  So the launch
+// makes progress whatever else shares the device, and every wait is bounded as in step_end_kernel.
+// The roles run with the fill's workgroup size; lanes >= 128 leave at once and the rest behave as a workgroup of 128
+// (BD = 128 throughout: the same virtual blocks, partial sums and reduction tree as step_end_kernel -- bit-identical).
+struct SxTailArgs {   // a kernel argument, by value (pointers that arrive as arguments are uniform and known to be global)
+  const SxSignalDesc* lookup_descs;
+  const SxSignalDesc* hist_descs;
+  int nsig;
+  unsigned nvb, zblocks, pad;
+  unsigned long long npoints;
+  const unsigned* weight;
+  unsigned long long* slots;
+  double* last_good;
+  unsigned* sync;
+  SxStepArgs a;
+};
+
+template <typename Fill>
+__device__ __forceinline__ void fill_step_body(unsigned nfill, const SxTailArgs& t, unsigned dbg, Fill&& fill) {
+  if (blockIdx.x < nfill) {
+    fill();
+    // this workgroup's flush has landed before it counts itself done: every lane waits for the acknowledgement of its
+    // own device-scope atomics (they are performed at the memory side: acknowledged = performed), then one lane adds
+    // to the count at the same scope.  (No release fence: on gfx950 that is a write-back of the XCD's whole L2, which
+    // every workgroup would pay at the tail of the launch, and nothing but those atomics has to be published.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(t.sync + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (threadIdx.x >= 128u) return;   // (whole waves: the roles are workgroups of 128)
+  if (dbg & 8u) return;              // measurement hook (RESULTS ARE WRONG): the fill's part of the launch alone
+  SX_WG_STAMP(0);                    // (measurement build: a role's entry, its sight of the fill's end, its exit)
+  extern __shared__ double sh_tail[];
+  const unsigned role_index = blockIdx.x - nfill;            // 0: the finisher, 1 ..: workers
+  const unsigned W = t.nvb;
+  const unsigned role = role_index == 0 ? W : role_index - 1u;
+  // The wait for the fill.  No acquire fence after it: what the roles read of the fill's -- counters and normalisations,
+  // all written by device-scope atomics at the memory side -- is read here for the first time since the launch began
+  // (the launch itself started with the caches invalidated, and the fill's workgroups read none of it), so no stale
+  // copy can sit in this CU's L1 or this XCD's L2; and an agent-scope acquire on gfx950 invalidates the XCD's WHOLE L2,
+  // once per role workgroup, under the other roles' look-ups (measured: the roles took 28 us instead of 14).
+  auto fill_done = [&] {
+    if (threadIdx.x == 0) {
+      unsigned* done = t.sync + 7;
+      unsigned it = 0;
+      for (; it < kEndSpinLimit; it++) {
+        if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nfill) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (it == kEndSpinLimit) __hip_atomic_fetch_add(t.sync + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    SX_WG_STAMP(1);
+    __syncthreads();
+  };
+  step_end_role<128>(role, W, t.lookup_descs, t.hist_descs, t.nsig, t.npoints, t.weight, t.slots, t.last_good, t.sync,
+                     t.nvb, t.zblocks, t.a, sh_tail, fill_done);
+  // the finisher is the last to need the count of this launch: it zeroes it for the next one
+  if (role == W && threadIdx.x == 0) {
+    __hip_atomic_store(t.sync + 7, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SX_WG_STAMP(2);
+}
+
+template <int NOBS, int NSLOT, typename PROG>
+__global__ __launch_bounds__(1024) void fill_ordered_step_kernel(const SxSignalDesc* __restrict__ descs,
+                                                                 const SxSegment* __restrict__ segs,
+                                                                 const unsigned* __restrict__ blk_off, unsigned layout,
+                                                                 unsigned dbg, unsigned nfill, SxTailArgs tail) {
+  fill_step_body(nfill, tail, dbg, [&] {
+    SxChainDescs one;
+    one.d[0] = one.d[1] = one.d[2] = one.d[3] = descs;
+    fill_ordered_body<NOBS, NSLOT, PROG, 1, true>(one, segs, blk_off, layout, dbg);
+  });
+}
+
+template <int NOBS, int NSLOT, typename PROG, int PREW>
+__global__ __launch_bounds__(1024) void fill_step_kernel(const SxSignalDesc* __restrict__ descs,
+                                                         const SxSegment* __restrict__ segs,
+                                                         const unsigned* __restrict__ blk_off, unsigned hist_words,
+                                                         unsigned dbg, unsigned nfill, SxTailArgs tail) {
+  fill_step_body(nfill, tail, dbg, [&] { fill_body<NOBS, NSLOT, true, PROG, PREW>(descs, segs, blk_off, hist_words, dbg); });
 }
 
 // The look-ahead pass's step end as ONE cooperative launch: eval_nll2_kernel + finish2_zero_kernel with the hand-over
@@ -841,18 +979,39 @@ void launch_fill(const SxLaunchShape& sh, K k, dim3 grid, dim3 block, size_t lds
   }
 }
 
+// Which built-in fills also exist fused with the step end (fill_step_kernel / fill_ordered_step_kernel): the ordered
+// programs, and the LDS-histogram kernels of the EMPTY program over a pre-binned column (BASELINE config 2).
+template <bool LDS_HIST, typename PROG, int PREW>
+constexpr bool has_step_form() {
+  return LDS_HIST && PROG::n == 0 && (PREW == 1 || PREW == 2);
+}
+
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW = 0>
 hipError_t launch_fill_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                          const unsigned* blk_off, hipStream_t s) {
+  // LDS: 4 header words + hist_words + 64 trash words
+  // LDS-histogram launches: hist_words bins + 64 trash words; others: room for the sparse coarse filter
+  const unsigned hist_words = (unsigned)(sh.lds_bytes / 4 - 4 - (LDS_HIST ? 64 : 0));
+  if constexpr (has_step_form<LDS_HIST, PROG, PREW>()) {
+    if (sh.tail) {   // the whole step in this launch: the fill's workgroups + finisher + workers
+      auto ks = fill_step_kernel<NOBS, NSLOT, PROG, PREW>;
+      if (sh.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ks),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(ks, dim3(sh.grid + sh.tail_blocks), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off,
+                         hist_words, (unsigned)sh.debug_mode, (unsigned)sh.grid, *static_cast<const SxTailArgs*>(sh.tail));
+      return hipGetLastError();
+    }
+  }
+  if (sh.tail) return hipErrorInvalidValue;   // (the host asks sx_fill_has_step_form first)
   auto k = fill_kernel<NOBS, NSLOT, LDS_HIST, PROG, PREW>;
   if (sh.lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  // LDS: 4 header words + hist_words + 64 trash words
-  // LDS-histogram launches: hist_words bins + 64 trash words; others: room for the sparse coarse filter
-  const unsigned hist_words = (unsigned)(sh.lds_bytes / 4 - 4 - (LDS_HIST ? 64 : 0));
   launch_fill(sh, k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, hist_words,
               (unsigned)sh.debug_mode);
   return hipGetLastError();
@@ -952,6 +1111,17 @@ constexpr int kNumStatic = (int)(sizeof(kStaticPrograms) / sizeof(kStaticProgram
 template <int NOBS, int NSLOT, typename PROG>
 hipError_t launch_fill_ordered_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                                  const unsigned* blk_off, hipStream_t s) {
+  if (sh.tail) {   // the whole step in this launch: the fill's workgroups + finisher + workers
+    auto ks = fill_ordered_step_kernel<NOBS, NSLOT, PROG>;
+    if (sh.lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ks),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(ks, dim3(sh.grid + sh.tail_blocks), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off,
+                       sh.lds_layout, (unsigned)sh.debug_mode, (unsigned)sh.grid, *static_cast<const SxTailArgs*>(sh.tail));
+    return hipGetLastError();
+  }
   auto k = fill_ordered_kernel<NOBS, NSLOT, PROG>;
   if (sh.lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -999,6 +1169,40 @@ bool sx_fill_static_supports(int prog, int lds_hist, int prebin) {
   if (prebin == kPreGranule) return e.fn_gran[lds_hist ? 0 : 1] != nullptr;
   if (prebin) return (lds_hist ? e.fn_pre[0] : e.fn_g_pre[0]) != nullptr;
   return (lds_hist ? e.fn : e.fn_g) != nullptr;
+}
+
+// Does the launch described by `sh` also exist fused with the step end (see fill_step_kernel)?
+bool sx_fill_has_step_form(const SxLaunchShape& sh) {
+  if (sh.rtc_fill || !sh.lds_hist || sh.grid <= 0) return false;
+  if (sh.pre_width == kPreOrdered) return sh.static_prog >= 0 && sh.static_prog < kNumOrdered;
+  if (sh.pre_width == 1 || sh.pre_width == 2) {
+    return sh.static_prog >= 0 && sh.static_prog < kNumStatic && kStaticPrograms[sh.static_prog].nops == 0 &&
+           kStaticPrograms[sh.static_prog].fn_pre[sh.pre_width - 1] != nullptr;
+  }
+  return false;
+}
+size_t sx_tail_args_bytes() { return sizeof(SxTailArgs); }
+// Fills the host image of a group's SxTailArgs (the device struct is private to this file).
+void sx_tail_args_fill(void* image, const SxSignalDesc* lookup_descs, const SxSignalDesc* hist_descs, int nsig,
+                       int max_bins, unsigned long long npoints, const unsigned* weight, unsigned long long* slots,
+                       double* last_good, unsigned* sync, int nvb, const SxStepArgs& a) {
+  SxTailArgs t;
+  std::memset(&t, 0, sizeof t);   // (padding too: the host compares images bytewise to see whether to upload again)
+  int zb = (max_bins / 4 + 127) / 128;
+  if (zb < 1) zb = 1;
+  if (zb > 1024) zb = 1024;
+  t.lookup_descs = lookup_descs;
+  t.hist_descs = hist_descs;
+  t.nsig = nsig;
+  t.nvb = (unsigned)nvb;
+  t.zblocks = (unsigned)zb;
+  t.npoints = npoints;
+  t.weight = weight;
+  t.slots = slots;
+  t.last_good = last_good;
+  t.sync = sync;
+  std::memcpy(&t.a, &a, sizeof a);
+  std::memcpy(image, &t, sizeof t);
 }
 
 bool sx_fill_static_supports_sparse_runs(int prog) {

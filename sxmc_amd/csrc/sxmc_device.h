@@ -74,7 +74,16 @@ struct SxLaunchShape {
   // also time the packets between them: +2.5-3 us per launch, a fifth of BASELINE config 2's fill.)
   void* ev_start = nullptr;
   void* ev_stop = nullptr;
+  // the whole step in this launch (fill_step_kernel): HOST image of the step end's arguments (sx_tail_args_fill; passed
+  // to the kernel by value) and the extra workgroups (finisher + workers) appended to the grid; null: the fill alone
+  const void* tail = nullptr;
+  int tail_blocks = 0;
 };
+bool sx_fill_has_step_form(const SxLaunchShape& sh);
+size_t sx_tail_args_bytes();
+void sx_tail_args_fill(void* image, const SxSignalDesc* lookup_descs, const SxSignalDesc* hist_descs, int nsig,
+                       int max_bins, unsigned long long npoints, const unsigned* weight, unsigned long long* slots,
+                       double* last_good, unsigned* sync, int nvb, const struct SxStepArgs& a);
 
 // A fill kernel specialised at run time (sxmc_rtc.cpp): the template arguments of fill_body / fill_sparse_body.
 struct SxRtcSpec {

@@ -376,6 +376,8 @@ struct sxmc_group {
   unsigned long long capture_epoch = 0;  // last recording this group launched in
   unsigned* d_ticket = nullptr;  // arrival counter of the fused step end, zeroed by the zero kernel
   double* d_step_sums = nullptr; // 1024 partial sums of the fused step
+  std::vector<char> h_tail;          // fused step (fill_step_kernel): the step end's arguments, passed to the kernel by value
+  int cfg_fused = -1;                // the whole step in ONE launch where the fill has that form (-1: SXMC_FUSED_STEP, default OFF: measured slower)
   unsigned long long* d_coop_slots = nullptr;  // cooperative step end: one hand-over slot per worker (step_end_kernel)
   double* d_coop_last = nullptr;               // ... and the last partial of each that was not NaN
   // profiling of the fill kernel
@@ -2771,6 +2773,34 @@ bool step_end_is_cooperative(const sxmc_group* g, unsigned long long ne) {
   return on != 0 && g->cfg_tail != 0 && step_sum_blocks(ne) <= kCoopMaxWorkers;
 }
 
+// Does a step of this group run as ONE launch (fill_step_kernel)?  Only on request (sxmc_group_set_fused_step /
+// SXMC_FUSED_STEP=1): built, bit-identical, and MEASURED SLOWER than the fill followed by the cooperative step end --
+// config 3: 6 640-6 970 against 6 870-7 260 evals/s, config 2: 43.5 k against 51.5 k (profiles/r04_step_forms_ab_*).
+// In-kernel stamps (profiles/r04_fused_step_study.log) say why: the roles are resident 10-15 us before the fill ends
+// and see its end 2.0-2.3 us after the last fill workgroup has left, but then need 12.2 us for what the separate
+// step_end_kernel does in 14.2 us INCLUDING its launch -- waiting for the fill's flush to be acknowledged and the
+// count to travel costs what the kernel boundary costs (0.9 us gap + ~2.5 us ramp), and the look-ups are no faster
+// for their tables having been fetched early.  Where offered: the step end is cooperative anyway, the plan is one
+// fill launch that has the fused form (the built-in ordered programs: BASELINE config 3; the empty program over a
+// pre-binned column: config 2), the vectors are short enough for the finisher's staged form, and the fill's LDS leaves
+// room for the roles' own.
+bool step_is_fused(const sxmc_group* g, bool sparse, unsigned long long ne, int nparameters) {
+  static const int env_default = [] {
+    const char* e = std::getenv("SXMC_FUSED_STEP");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  const int on = g->cfg_fused < 0 ? env_default : g->cfg_fused;
+  if (!on || sparse || g->classes.size() != 1 || (g->debug_mode & ~8)) return false;   // (8: the fused launch without its roles)
+  if (step_end_takes_tail(g, sparse, ne) || !step_end_is_cooperative(g, ne)) return false;
+  if (nparameters > 256 || g->members.size() > 256) return false;
+  const LaunchClass& c = g->classes[0];
+  if (!sx_fill_has_step_form(c.shape) || c.shape.threads < 128) return false;
+  DeviceProps props;
+  if (get_props(props)) return false;
+  const size_t staging = 16 * sizeof(double) + ((g->members.size() + 15) / 16 * 16) * 48;   // eval_nll_block_part's
+  return c.shape.lds_bytes >= staging && c.shape.lds_bytes + 16 * 1024 <= (size_t)props.lds_per_cu;
+}
+
 int group_step_tail(sxmc_group* g, hipStream_t st, bool sparse, const SxSignalDesc* descs, unsigned long long ne,
                     const unsigned* weight, const SxStepArgs& a) {
   TraceRange trace("sxmc: step end (lookup + event sum, finish_nll_jump_pick_combo + clearing)");
@@ -2843,9 +2873,6 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
     weight = ec.d_weight;
   }
   const bool zero_launched = g->prezeroed != (sparse ? 2 : 1);   // (group_fill decides the same way, plus bookkeeping)
-  rc = group_fill(g, st, sparse);
-  if (rc) return rc;
-  g->last_step_launches = (int)g->classes.size() + (zero_launched ? 1 : 0);
   SxStepArgs a;
   a.nsignals = g->members.size();
   a.nsources = nsources;
@@ -2866,6 +2893,35 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
   a.n_mc = d_n_mc;
   a.source_id = d_source_id;
   a.norms = d_norms;
+  // THE WHOLE STEP IN ONE LAUNCH where the fill has that form (fill_step_kernel: the fill's workgroups, then a finisher
+  // and the event sum's workers as later blocks of the same grid) -- not for a launch whose fill is being timed
+  // (sxmc_group_profile: the fill alone is what the roofline figures are about, so profiled steps stay two launches)
+  const bool profiled = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size();
+  const bool fused = !profiled && step_is_fused(g, sparse, ne, nparameters);
+  if (fused) {
+    LaunchClass& c = g->classes[0];
+    const int nvb = step_sum_blocks(ne);
+    g->h_tail.resize(sx_tail_args_bytes());   // (passed to the kernel by value: frozen at capture like every argument)
+    sx_tail_args_fill(g->h_tail.data(), descs, g->d_descs, (int)g->members.size(), g->max_bins, ne, weight,
+                      g->d_coop_slots, g->d_coop_last, g->d_ticket, nvb, a);
+    c.shape.tail = g->h_tail.data();
+    c.shape.tail_blocks = nvb + 1;
+  }
+  rc = group_fill(g, st, sparse);
+  if (fused) {
+    g->classes[0].shape.tail = nullptr;
+    g->classes[0].shape.tail_blocks = 0;
+  }
+  if (rc) return rc;
+  g->last_step_launches = (int)g->classes.size() + (zero_launched ? 1 : 0);
+  if (fused) {
+    g->prezeroed = 1;
+    for (sxmc_hist* h : g->members) {
+      h->bins_valid = false;
+      h->cleared_by = g;
+    }
+    return SXMC_OK;
+  }
   return group_step_tail(g, st, sparse, descs, ne, weight, a);
 }
 
@@ -3279,6 +3335,12 @@ int sxmc_group_set_tail_kernel(sxmc_group_t g, int enable) {
 int sxmc_group_set_cooperative_step_end(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_coop = enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_fused_step(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_fused = enable ? 1 : 0;
   return SXMC_OK;
 }
 

@@ -175,6 +175,11 @@ class EvalGroup:
         event sum is small enough; off: look-ups + event sum, then step end + clearing (two launches)."""
         capi.call("sxmc_group_set_cooperative_step_end", self._g, int(bool(enable)))
 
+    def SetFusedStep(self, enable):
+        """The whole step as ONE launch (fill_step_kernel: the fill's workgroups + the step end's roles in one grid)
+        where the plan allows it; off: the fill, then the step end."""
+        capi.call("sxmc_group_set_fused_step", self._g, int(bool(enable)))
+
     def StepEndTimeouts(self, stream=None):
         """Workgroups of the cooperative step end that gave up waiting (0 in a healthy run), read through `stream`."""
         n = C.c_uint(0)

@@ -21,9 +21,12 @@ def close(m):
     m.group.close()
 
 
-def walk(w, coop, nsteps, graph_steps=0, lut_output=False, seed=5, burnin=0.1):
+def walk(w, coop, nsteps, graph_steps=0, lut_output=False, seed=5, burnin=0.1, fused=False, force_ordering=False):
     m = MCMC(w, seed=seed, lut_output=lut_output, consume=True, stream=capi.new_stream())
     m.group.SetCooperativeStepEnd(coop)
+    m.group.SetFusedStep(fused)
+    if force_ordering:
+        m.group.SetOrdering(True, force=True)     # (a table this small would not be ordered by default)
     chain, acc = m.walk(w.events, nsteps, burnin, sync_interval=50, graph_steps=graph_steps)
     launches, timeouts = m.group.LastStepLaunches(), m.group.StepEndTimeouts()
     close(m)
@@ -59,6 +62,7 @@ def test_several_chains_step_ends_in_flight_together():
                        for k in range(1, 4)]
     for m in chains:
         m.group.SetCooperativeStepEnd(True)
+        m.group.SetFusedStep(False)
         m.walk_begin(w.events, 200, 0.1, sync_interval=50)
     # advance the four walks in turn, a run of steps at a time, so that their kernels are queued side by side
     schedules = [m.flush_schedule() for m in chains]
@@ -84,6 +88,7 @@ def test_lookahead_walk_still_partitions_like_the_sequential_step():
     w = workloads.config3(0.004, nevents=20000)
     m = MCMC(w, seed=9, lut_output=False, consume=True, stream=capi.new_stream())
     m.group.SetCooperativeStepEnd(True)
+    m.group.SetFusedStep(False)
     want = m.walk(w.events, 150, 0.1, sync_interval=50, graph_steps=5)
     assert m.group.LastStepLaunches() == 2
     close(m)
@@ -92,3 +97,52 @@ def test_lookahead_walk_still_partitions_like_the_sequential_step():
     assert m.lookahead_passes > 0
     close(m)
     assert got[1] == want[1] and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("make,scale,nevents,plan", [(workloads.config3, 0.004, 3000, "table=ordered"),
+                                                     (workloads.config3, 0.02, 40000, "table=ordered"),
+                                                     (workloads.config2, 0.02, 5000, "table=prebinned")])
+def test_whole_step_in_one_launch_walks_the_same_chain(make, scale, nevents, plan):
+    """fill_step_kernel: the fill's workgroups and the step end's finisher + workers as ONE grid (the roles wait for the
+    fill's workgroups to count themselves done).  Same arithmetic and partial sums as the separate launches: the chain
+    must be theirs bit for bit, eager and graph-replayed; 1 launch per step; no timeouts."""
+    w = make(scale, nevents=nevents)
+    ordered = "ordered" in plan
+    want = walk(w, False, 150, fused=False, force_ordering=ordered)
+    assert want[2] == 3
+    for graph_steps in (0, 6):
+        got = walk(w, True, 150, graph_steps, fused=True, force_ordering=ordered)
+        assert got[2] == 1, got[2]
+        assert got[3] == 0
+        assert got[1] == want[1] and 0 < got[1] < 150
+        assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+
+
+def test_fused_steps_of_several_chains_share_the_device():
+    """Four chains on four streams, each step ONE launch whose later blocks wait for its earlier ones: the launches of
+    different chains interleave on the device and must all drain; every chain walks what it walks alone."""
+    w = workloads.config3(0.004, nevents=3000)
+    alone = [walk(w, True, 160, graph_steps=8, seed=41 + k, fused=False, force_ordering=True) for k in range(4)]
+    base = MCMC(w, seed=41, lut_output=False, consume=True, stream=capi.new_stream())
+    chains = [base] + [MCMC(w, seed=41 + k, lut_output=False, consume=True, stream=capi.new_stream(), share_with=base)
+                       for k in range(1, 4)]
+    for m in chains:
+        m.group.SetOrdering(True, force=True)
+        m.group.SetFusedStep(True)
+        m.walk_begin(w.events, 160, 0.1, sync_interval=40)
+    schedules = chains[0].flush_schedule()
+    done = [0] * 4
+    for f in schedules:
+        for k, m in enumerate(chains):
+            m._retune_if_due(done[k])
+            m.steps(f - done[k] + 1, 8, False)
+        for k, m in enumerate(chains):
+            m._flush_if_due(f)
+            done[k] = f + 1
+    for k, m in enumerate(chains):
+        rows, acc = m.walk_end()
+        assert "ordered" in m.group.LaunchInfo() and m.group.LastStepLaunches() == 1
+        assert m.group.StepEndTimeouts() == 0
+        assert acc == alone[k][1] and np.array_equal(rows.view(np.uint32), alone[k][0].view(np.uint32))
+    for m in chains[::-1]:
+        close(m)
