@@ -291,6 +291,29 @@ int sxmc_group_set_bucketing(sxmc_group_t g, int enable);
  * keeps the unordered bucketed table.  enable = 2: wherever it applies (tests).  Histograms beyond LDS capacity: the
  * sparse counting over runs and the dense evaluation have ordered forms too (run-time compiled). */
 int sxmc_group_set_ordering(sxmc_group_t g, int enable);
+/* Codes (default on; needs an ordered table with its histogram in LDS, 2 to 4 streamed fields and only one-coefficient
+ * systematics on them).  shift / scale / cos-theta scale / resolution scale with one coefficient are affine maps of
+ * the sample's fields (pdfz.cpp:316-330), so for the evaluation's parameters the bin coordinate of a written
+ * observable is ONE affine function of the fields, which the reference evaluates in double, operation by operation,
+ * to within a few units in the last place of it.  The ordered copy therefore keeps each streamed field a second time
+ * as a 16-bit code inside a window (value = base + (code + 1/2) step, off by at most step / 2: checked when the
+ * table is laid out), two fields to a word, and the fill streams THOSE: it composes the program into
+ * single-precision coefficients over the codes per evaluation, together with an error bound that covers the half
+ * step, its own single-precision arithmetic and the reference's double roundings, and bins every sample whose bin
+ * coordinate lies further than that bound from the nearest bin edge straight from its codes -- that bin IS the
+ * reference's.  The few samples in 10^4 that lie closer go into a queue in LDS and are binned at the end of the
+ * stream from their float values with the reference's arithmetic, as are rows outside the windows and the granules
+ * that straddle an edge of the ordered observable.  Parameters that are not finite, or so large that the bound
+ * reaches an eighth of a bin, switch the codes off for that evaluation (the float columns are streamed).  BASELINE
+ * config 3 streams 4 bytes per sample instead of 8.  Histograms, norms and NLL stay bit-identical (parity tests:
+ * on / off, the CPU restatement, samples within ulps of the transformed edges, rows outside the windows, queues
+ * that overflow).  enable = 0: stream the float columns; 1: use the codes where they apply; -1: the library's
+ * default (on unless the environment says SXMC_CODES=0). */
+int sxmc_group_set_codes(sxmc_group_t g, int enable);
+/* What the codes of the group's current plan amount to: members whose fill streams codes, rows they hold, rows marked
+ * "ask the exact columns" (outside a window) and rows marked "never counted" (not finite, or granule padding). */
+int sxmc_group_codes_info(sxmc_group_t g, int* members, unsigned long long* rows, unsigned long long* exact_rows,
+                          unsigned long long* never_rows);
 /* Run-time kernels (default on).  The fill is fastest as straight-line code with the program of systematics
  * (apply_systematic, pdfz.cpp:306-331: which systematic writes which column, in which order, with how many
  * polynomial coefficients) fixed at compile time.  The library carries such kernels for a handful of programs;

@@ -112,6 +112,8 @@ SIGNATURES = {
     "sxmc_group_set_prebinning": [_vp, _i],
     "sxmc_group_set_bucketing": [_vp, _i],
     "sxmc_group_set_ordering": [_vp, _i],
+    "sxmc_group_set_codes": [_vp, _i],
+    "sxmc_group_codes_info": [_vp, _pi, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)],
     "sxmc_group_set_runtime_kernels": [_vp, _i],
     "sxmc_group_launch_info": [_vp, C.c_char_p, _sz],
     "sxmc_group_set_lut_output": [_vp, _i],

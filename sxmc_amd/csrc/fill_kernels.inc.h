@@ -688,6 +688,85 @@ __device__ __forceinline__ void run_static_part(double (&f)[NSLOT][SXMC_VEC], co
     if constexpr (((int)((OPS >> 4) & 15u) == ORD) == WANT) apply_static<NSLOT, OPS>(f, c + sx_prog_cstart<OPS...>((int)I));
   }(), ...);
 }
+// CODES (fill_ordered_body).  shift, scale, cos-theta scale and resolution scale with ONE coefficient are affine maps
+// of the sample's fields (pdfz.cpp:316-330), and so is their composition: after the program, observable k is
+//     x_k = sum_m A[k][m] * field_m + C[k]                       (in real arithmetic)
+// with A and C functions of the evaluation's parameters alone.  The reference evaluates that in double, operation
+// by operation; its result differs from the real-arithmetic value by a few units in the last place of the largest
+// intermediate.  So a sample whose real-arithmetic bin coordinate (x_k - lo_k) * scale_k lies further from every
+// integer than (what is not known about the field values) + (those roundings) lands in the same bin either way --
+// and the fill may work that bin out from ANY approximation of the fields that comes with an error bound.  The
+// bucketed copy therefore holds each streamed field a second time as a 16-bit code (layout_kernels.hip:
+// code = floor((x - qbase) / qstep), so x = qbase + (code + 1/2) * qstep +- qstep / 2): 2 bytes per field and sample
+// instead of 4.  Per evaluation every wave composes the program into A and C (AffineForm below, in double), folds
+// window, binning and scale into single-precision coefficients
+//     u_k = sum_m alpha[k][m] * code_m + gamma[k]
+// and an error bound eps[k] that covers the half code step, the single-precision evaluation of u and the double
+// roundings of the reference's own arithmetic (bounded through `mag`, a bound on every intermediate's magnitude).
+// A sample with eps <= frac(u_k) <= 1 - eps in every observable is binned from its codes: floor(u_k) IS the
+// reference's index (or outside the domain when it is not in [0, nbins)).  Any other sample -- about 2 eps of them,
+// a few in 10^4 -- is "ambiguous": its row number goes into a queue in LDS, and at the end of the stream the
+// workgroup reads those rows' float values and bins them with the reference's arithmetic (exact_one).  Coefficients
+// that are not finite, or so large that eps reaches 1/8, switch the codes off for that evaluation: the float
+// columns are streamed as before.  Counts are integers; every sample is binned either by the reference's arithmetic
+// or by an argument about it: bit-identical histograms (tests/test_gpu_codes.py: against the float stream and the
+// CPU restatement, samples placed within ulps of the transformed edges, windows that exclude samples, queues that
+// overflow).
+template <int NQ>
+struct AffineForm {
+  double a[NQ];   // coefficients of the NQ streamed fields
+  double c;       // constant
+  double mag;     // >= |value| of the slot at any point of the program, for any field values inside the windows
+};
+
+template <int NQ, unsigned OPC>
+__device__ __forceinline__ void apply_affine(AffineForm<NQ> (&f)[NQ], const double* coef) {
+  constexpr int type = (int)(OPC & 15u), K = (int)((OPC >> 4) & 15u), E = (int)((OPC >> 8) & 15u);
+  static_assert(sx_op_npars(OPC) == 1 && K < NQ, "not an affine systematic");
+  const double p = 0.0 + coef[0] * 1.0;
+  const double ap = __builtin_fabs(p);
+  if constexpr (type == SXMC_SYST_SHIFT) {
+    f[K].c = f[K].c + p;
+    f[K].mag = f[K].mag + ap;
+  }
+  if constexpr (type == SXMC_SYST_SCALE) {
+    const double s = 1 + p;
+#pragma unroll
+    for (int m = 0; m < NQ; m++) f[K].a[m] = f[K].a[m] * s;
+    f[K].c = f[K].c * s;
+    f[K].mag = f[K].mag * (1 + ap);
+  }
+  if constexpr (type == SXMC_SYST_CTSCALE) {
+    const double s = 1 + p;
+#pragma unroll
+    for (int m = 0; m < NQ; m++) f[K].a[m] = f[K].a[m] * s;
+    f[K].c = 1 + (f[K].c - 1) * s;
+    f[K].mag = 1 + (f[K].mag + 1) * (1 + ap);
+  }
+  if constexpr (type == SXMC_SYST_RESOLUTION_SCALE) {
+    static_assert(E < NQ, "slot out of range");
+#pragma unroll
+    for (int m = 0; m < NQ; m++) f[K].a[m] = f[K].a[m] + p * (f[K].a[m] - f[E].a[m]);
+    f[K].c = f[K].c + p * (f[K].c - f[E].c);
+    f[K].mag = f[K].mag + ap * (f[K].mag + f[E].mag);
+  }
+}
+// the systematics of the program that do NOT write slot ORD, composed
+template <int NQ, int ORD, unsigned... OPS, unsigned long... I>
+__device__ __forceinline__ void run_affine(AffineForm<NQ> (&f)[NQ], const double* c, StaticProg<OPS...>, ISeq<I...>) {
+  ([&] {
+    if constexpr ((int)((OPS >> 4) & 15u) != ORD) apply_affine<NQ, OPS>(f, c + sx_prog_cstart<OPS...>((int)I));
+  }(), ...);
+}
+// can the part of the program that does not write slot ORD be composed that way?
+template <int ORD, unsigned... OPS>
+constexpr bool prog_is_affine(StaticProg<OPS...>) {
+  return (true && ... && ((int)((OPS >> 4) & 15u) == ORD || sx_op_npars(OPS) == 1));
+}
+__device__ __forceinline__ float uniform_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
 // SPARSE COUNTING OVER A BUCKETED TABLE, WALKED IN RUNS.  Histograms beyond LDS capacity, evaluated for lookup
 // (BASELINE config 5).  The table is bucketed (layout_kernels.hip) and laid out so that every WAVE walks its own
 // run of consecutive granules of the sorted order: a wave stays inside one bucket -- one tuple of bin indices of
@@ -1156,22 +1235,30 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   constexpr int ORD = NSLOT - 1;       // the ordered observable's column
   constexpr int NSTREAM = NSLOT - 1;   // columns every granule streams
   constexpr int NG = NOBS > 0 ? NOBS : 1, NS = NSTREAM > 0 ? NSTREAM : 1, NC = PROG::ncoef > 0 ? PROG::ncoef : 1;
+  // CODES (see AffineForm above): the streamed slots as 16-bit codes, two to a word
+  constexpr bool kCodes = LDS_HIST && NOBS >= 1 && NSTREAM >= 2 && NSTREAM <= SXMC_MAX_QSLOTS && prog_is_affine<ORD>(PROG{});
+  constexpr int NQ = kCodes ? NSTREAM : 1, QW = (NQ + 1) / 2;
+  constexpr int kDepth = 2;            // units of codes a lane keeps in flight (half the bytes per unit: twice the units)
   typedef typename MakeISeq<PROG::n>::type Seq;
   extern __shared__ unsigned lds[];
   const unsigned tid = threadIdx.x;
   const unsigned nthreads = blockDim.x;
   const unsigned lane = tid & (kWave - 1);
   // LDS: words 0..3 the chains' in-domain counters, then per chain R replicas of the histogram, rstride words
-  // apart (then 64 spare words).  `layout` = rstride | log2(R) << 24.  Inside a granule only the observables
-  // binned per sample vary, so a wave's 64 updates go to a handful of bins, strided by the other observables'
-  // strides: few banks, many lanes per word.  Two remedies: the word of bin b is b with its low six bits XORed
-  // by the next six (bins a multiple of 64 apart land in different banks), and lane l updates replica l mod R
-  // (rstride = 16 mod 64: the replicas of one bin sit in different banks too).  The flush adds the replicas up.
+  // apart, then 64 spare words, then the queue of ambiguous rows (codes): 4 header words + 2 words per entry.
+  // `layout` = rstride | log2(R) << 24 | log2(queue entries) << 28 (0: no queue).  Inside a granule only the
+  // observables binned per sample vary, so a wave's 64 updates go to a handful of bins, strided by the other
+  // observables' strides: few banks, many lanes per word.  Two remedies: the word of bin b is b with its low six
+  // bits XORed by the next six (bins a multiple of 64 apart land in different banks), and lane l updates replica
+  // l mod R (rstride = 16 mod 64: the replicas of one bin sit in different banks too).  The flush adds the replicas up.
   unsigned* s_norm = lds;
   unsigned* hist = lds + 4;
-  const unsigned rstride = layout & 0xFFFFFFu, rlog = layout >> 24, R = 1u << rlog;
+  const unsigned rstride = layout & 0xFFFFFFu, rlog = (layout >> 24) & 15u, R = 1u << rlog;
   const unsigned cstride = rstride << rlog;            // one chain's replicas
   const unsigned myrep = (lane & (R - 1u)) * rstride;
+  const unsigned qlog = layout >> 28, qcap = qlog ? 1u << qlog : 0u;
+  unsigned* qhead = lds + 4 + (LDS_HIST ? NCHAIN * cstride : 0u) + 64;
+  unsigned* qent = qhead + 4;
 
   bool lds_clean = false;
   SX_WG_STAMP(0);
@@ -1205,6 +1292,17 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     const unsigned long long vfirst = v0 + tid;
     const unsigned long long vwave = v0 + (tid - lane);   // the wave's first unit: a granule boundary
 
+    // the table of codes, when the launch has one (dbg & 8: measurement / test hook, stream the floats regardless)
+    bool use_q = false;
+    gptr<const vuint4g> qcol[QW];
+    if constexpr (kCodes) {
+      use_q = d.qcol != nullptr && !(dbg & 8u);
+#pragma unroll
+      for (int w = 0; w < QW; w++) {
+        qcol[w] = to_global(reinterpret_cast<const vuint4g*>(d.qcol + (unsigned long long)w * d.col_pitch));
+      }
+    }
+
     vfloat4 raw[NS];
     unsigned rawpre;
     auto load = [&](unsigned long long v) {
@@ -1216,13 +1314,55 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       rawpre = precol[v >> 6];
       __builtin_amdgcn_sched_barrier(0);
     };
-    load(vfirst < v1 ? vfirst : vlast);
+    // two buffers of kDepth units each: one is worked on while the other's loads are in flight
+    vuint4g rq[2][kDepth][QW];
+    unsigned rp[2][kDepth];
+    const unsigned long long niter = (v1 - v0 + step - 1) / step;
+    // (32-bit unit numbers: the host offers codes only for tables below 2^22 granules, so a unit's byte offset fits
+    // 32 bits and the loads take the form base in scalar registers + 32-bit offset: one add per load instead of a
+    // 64-bit multiply-add, compare and select)
+    const unsigned vfirst32 = (unsigned)vfirst, step32 = (unsigned)step, vlast32 = (unsigned)vlast;
+    auto issue = [&](int buf, unsigned long long it_first) {
+#pragma unroll
+      for (int i = 0; i < kDepth; i++) {
+        unsigned v = vfirst32 + ((unsigned)it_first + (unsigned)i) * step32;
+        v = v < vlast32 ? v : vlast32;
+        if ((dbg & 2u) && it_first != 0ull) v = vlast32;
+#pragma unroll
+        for (int w = 0; w < QW; w++) {
+          rq[buf][i][w] = __builtin_nontemporal_load(
+              (gptr<const vuint4g>)((gptr<const char>)qcol[w] + (unsigned long long)(v * 16u)));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        rp[buf][i] = *(gptr<const unsigned>)((gptr<const char>)precol + (unsigned long long)((v >> 6) * 4u));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // (the wait for a buffer's loads goes HERE -- all that is outstanding at this point is that buffer -- and the
+    // other buffer's loads are issued right after it)
+    auto arrive = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < kDepth; i++) {
+#pragma unroll
+        for (int w = 0; w < QW; w++) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) asm volatile("" : "+v"(rq[buf][i][w][e]));
+        }
+        asm volatile("" : "+v"(rp[buf][i]));
+      }
+    };
+    if (use_q) {
+      if constexpr (kCodes) issue(0, 0ull);
+    } else {
+      load(vfirst < v1 ? vfirst : vlast);
+    }
 
     if (!lds_clean) {
       if (LDS_HIST) {
         for (unsigned b = tid; b < NCHAIN * cstride; b += nthreads) hist[b] = 0u;
       }
       if (tid < 4) s_norm[tid] = 0u;
+      if (kCodes && qcap != 0u && tid == 0) qhead[0] = 0u;
       __syncthreads();
     }
 
@@ -1259,145 +1399,406 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     }
     asm volatile("" : "+v"(ostv));
 
-    unsigned long long v = vfirst;
-    const unsigned long long niter = (v1 - v0 + step - 1) / step;
-    for (unsigned long long it = 0; it < niter; ++it, v += step) {
-      const int j = (int)(it & 63ull);
-      if (j == 0) {
-        // ---- codes of this wave's next 64 granules, one per lane
-        const unsigned long long vg = vwave + (it + lane) * step;
-        const bool live = vg < v1;
-        const vfloat2 e = edges[(live ? vg : vlast) >> 6];
-#pragma unroll
-        for (int c = 0; c < NCHAIN; c++) {
-          double x0 = (double)e.x, x1 = (double)e.y;
-          run_ordered_scalar<ORD>(x0, craw[c], PROG{}, Seq{});
-          run_ordered_scalar<ORD>(x1, craw[c], PROG{}, Seq{});
-          const bool nan = wild[c] || !(x0 == x0) || !(x1 == x1);
-          const int i0 = (int)((x0 - olo) * osc), i1 = (int)((x1 - olo) * osc);
-          const int e0 = !(x0 >= olo) ? -1 : (!(x0 < ohi) ? 0x7FFFFFFF : i0);
-          const int e1 = !(x1 >= olo) ? -1 : (!(x1 < ohi) ? 0x7FFFFFFF : i1);
-          unsigned code = (nan || e0 != e1) ? kOrdMixed
-                          : ((e0 < 0 || e0 == 0x7FFFFFFF) ? kOrdSkip
-                                                         : (unsigned)(LDS_HIST ? __mul24(e0, ost) : e0 * ost));
-          codes[c] = live ? code : kOrdSkip;
-        }
-      }
-      unsigned code[NCHAIN];
-      bool anymixed = false;
+    // ---- codes of the wave's next 64 granules in the ordered observable, one per lane (every 64 steps)
+    auto granule_codes = [&](unsigned long long it) {
+      const unsigned long long vg = vwave + (it + lane) * step;
+      const bool live = vg < v1;
+      const vfloat2 e = edges[(live ? vg : vlast) >> 6];
 #pragma unroll
       for (int c = 0; c < NCHAIN; c++) {
-        code[c] = (unsigned)__builtin_amdgcn_readlane((int)codes[c], j);
-        anymixed = anymixed || code[c] == kOrdMixed;
+        double x0 = (double)e.x, x1 = (double)e.y;
+        run_ordered_scalar<ORD>(x0, craw[c], PROG{}, Seq{});
+        run_ordered_scalar<ORD>(x1, craw[c], PROG{}, Seq{});
+        const bool nan = wild[c] || !(x0 == x0) || !(x1 == x1);
+        const int i0 = (int)((x0 - olo) * osc), i1 = (int)((x1 - olo) * osc);
+        const int e0 = !(x0 >= olo) ? -1 : (!(x0 < ohi) ? 0x7FFFFFFF : i0);
+        const int e1 = !(x1 >= olo) ? -1 : (!(x1 < ohi) ? 0x7FFFFFFF : i1);
+        unsigned code = (nan || e0 != e1) ? kOrdMixed
+                        : ((e0 < 0 || e0 == 0x7FFFFFFF) ? kOrdSkip
+                                                       : (unsigned)(LDS_HIST ? __mul24(e0, ost) : e0 * ost));
+        codes[c] = live ? code : kOrdSkip;
       }
+    };
 
-      double f0[NS][SXMC_VEC];
+    // ---- one granule of one chain with the reference's arithmetic on the float columns.  f0: the streamed slots
+    // widened; rawo: the ordered observable's unit (read only when `mixed`).  pdfz.cpp:388-398.
+    // ALL: every in-domain sample counts in vcnt (the float stream); otherwise only those whose index is out of range
+    // -- over codes the norm is the sum of the LDS histogram plus exactly those.
+    auto exact_granule = [&](auto ALL, int c, bool mixed, const double (&f0)[NS][SXMC_VEC], const vfloat4& rawo,
+                             unsigned off, unsigned codec) {
+      constexpr bool kCountAll = decltype(ALL)::value != 0;
+      double f[NSLOT][SXMC_VEC];
 #pragma unroll
       for (int k = 0; k < NSTREAM; k++) {
-        f0[k][0] = (double)raw[k].x;
-        f0[k][1] = (double)raw[k].y;
-        f0[k][2] = (double)raw[k].z;
-        f0[k][3] = (double)raw[k].w;
-      }
-      const unsigned prebits = (unsigned)uniform_i((int)rawpre);
 #pragma unroll
-      for (int k = 0; k < NSTREAM; k++) {
+        for (int q = 0; q < SXMC_VEC; q++) f[k][q] = f0[k][q];
+      }
+      f[ORD][0] = f[ORD][1] = f[ORD][2] = f[ORD][3] = 0.0;
+      run_static_part<NSLOT, ORD, false>(f, craw[c], PROG{}, Seq{});
+      // The per-sample part, written for the vector unit's instruction count (what bounds several chains in
+      // one pass): the domain tests are compares into scalar mask registers, combined and counted (popcount)
+      // on the scalar unit; the histogram update runs under that mask.
+      auto samples = [&](auto MIXED) {
+        constexpr bool kMixed = decltype(MIXED)::value != 0;
+        int base = (int)(off + (kMixed ? 0u : codec));
+        asm volatile("" : "+v"(base));   // (in a vector register: idx * stride + base is then one multiply-add)
+        const unsigned cbase = (unsigned)c * cstride + myrep;
 #pragma unroll
-        for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f0[k][q]));
+        for (int q = 0; q < SXMC_VEC; q++) {
+          bool ind = true;
+          int bin = base;
+#pragma unroll
+          for (int k = 0; k < NOBS; k++) {
+            const double x = f[k][q];
+            ind = ind & (x >= lo[k]) & (x < hi[k]);      // (NaN fails)
+            const int idx = (int)((x - lo[k]) * sc[k]);
+            bin = LDS_HIST ? mad24(idx, stv[k], bin) : idx * stv[k] + bin;
+          }
+          if constexpr (kMixed) {
+            const double x = f[ORD][q];
+            ind = ind & (x >= olo) & (x < ohi);
+            const int idx = (int)((x - olo) * osc);
+            bin = LDS_HIST ? mad24(idx, ostv, bin) : idx * ostv + bin;
+          }
+          if constexpr (kCountAll) {
+            vcnt[c] += ind ? 1u : 0u;                    // (an add-with-carry straight from the compare mask;
+                                                         //  a ballot + s_bcnt1 costs a v_cndmask and a v_cmp instead)
+          } else {
+            vcnt[c] += (ind && !((unsigned)bin < B)) ? 1u : 0u;
+          }
+          // in domain but index out of range (the reference's one-past-the-end case) still counts in the norm
+          if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
+            if constexpr (LDS_HIST) {
+              __hip_atomic_fetch_add(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              __hip_atomic_fetch_add(&gbins0[(unsigned)bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+      };
+      if (mixed) {   // (the wait for the extra column sits in here, off the common path)
+        f[ORD][0] = (double)rawo.x;
+        f[ORD][1] = (double)rawo.y;
+        f[ORD][2] = (double)rawo.z;
+        f[ORD][3] = (double)rawo.w;
+        run_static_part<NSLOT, ORD, true>(f, craw[c], PROG{}, Seq{});
+        samples(IntC<1>{});
+      } else {
+        samples(IntC<0>{});
       }
-      // a mixed granule: this once the ordered observable's column is needed too
-      vfloat4 rawo = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (anymixed) {
-        rawo = __builtin_nontemporal_load(&col[ORD][v < v1 ? v : vlast]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      const unsigned long long vl = v + step;
-      load((vl < v1 && !(dbg & 2u)) ? vl : vlast);
-      if (dbg & 1u) {
+    };
+
+    if (!use_q) {
+      // ================================================================ the float columns, one unit in flight
+      unsigned long long v = vfirst;
+      for (unsigned long long it = 0; it < niter; ++it, v += step) {
+        const int j = (int)(it & 63ull);
+        if (j == 0) granule_codes(it);
+        unsigned code[NCHAIN];
+        bool anymixed = false;
+#pragma unroll
+        for (int c = 0; c < NCHAIN; c++) {
+          code[c] = (unsigned)__builtin_amdgcn_readlane((int)codes[c], j);
+          anymixed = anymixed || code[c] == kOrdMixed;
+        }
+
+        double f0[NS][SXMC_VEC];
+#pragma unroll
+        for (int k = 0; k < NSTREAM; k++) {
+          f0[k][0] = (double)raw[k].x;
+          f0[k][1] = (double)raw[k].y;
+          f0[k][2] = (double)raw[k].z;
+          f0[k][3] = (double)raw[k].w;
+        }
+        const unsigned prebits = (unsigned)uniform_i((int)rawpre);
 #pragma unroll
         for (int k = 0; k < NSTREAM; k++) {
 #pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) sink += (f0[k][q] == 12345.678) ? 1u : 0u;
+          for (int q = 0; q < SXMC_VEC; q++) asm volatile("" : "+v"(f0[k][q]));
         }
-        sink += (prebits == 12345u) ? 1u : 0u;
-        continue;
-      }
-      const unsigned off = LDS_HIST ? prebits & 0xFFFFFFu : prebits, nvalid = (prebits >> 24) + 1u;
+        // a mixed granule: this once the ordered observable's column is needed too
+        vfloat4 rawo = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (anymixed) {
+          rawo = __builtin_nontemporal_load(&col[ORD][v < v1 ? v : vlast]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned long long vl = v + step;
+        load((vl < v1 && !(dbg & 2u)) ? vl : vlast);
+        if (dbg & 1u) {
+#pragma unroll
+          for (int k = 0; k < NSTREAM; k++) {
+#pragma unroll
+            for (int q = 0; q < SXMC_VEC; q++) sink += (f0[k][q] == 12345.678) ? 1u : 0u;
+          }
+          sink += (prebits == 12345u) ? 1u : 0u;
+          continue;
+        }
+        const unsigned off = LDS_HIST ? prebits & 0xFFFFFFu : prebits, nvalid = (prebits >> 24) + 1u;
 
 #pragma unroll
-      for (int c = 0; c < NCHAIN; c++) {
-        if (code[c] == kOrdSkip) continue;          // (wave-uniform) outside the ordered observable's domain
-        const bool mixed = code[c] == kOrdMixed;
-        if constexpr (NOBS == 0) {
-          if (!mixed) {
-            // nothing varies inside the granule: all its rows go to one bin
-            const unsigned bin = off + code[c];
-            ncnt[c] += nvalid;
-            if (lane == 0) {
-              if (bin < B && !(dbg & 4u)) {
-                __hip_atomic_fetch_add(&hist[(unsigned)c * cstride + lds_slot(bin)], nvalid, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int c = 0; c < NCHAIN; c++) {
+          if (code[c] == kOrdSkip) continue;          // (wave-uniform) outside the ordered observable's domain
+          const bool mixed = code[c] == kOrdMixed;
+          if constexpr (NOBS == 0) {
+            if (!mixed) {
+              // nothing varies inside the granule: all its rows go to one bin
+              const unsigned bin = off + code[c];
+              ncnt[c] += nvalid;
+              if (lane == 0) {
+                if (bin < B && !(dbg & 4u)) {
+                  __hip_atomic_fetch_add(&hist[(unsigned)c * cstride + lds_slot(bin)], nvalid, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
               }
+              continue;
             }
-            continue;
           }
+          exact_granule(IntC<1>{}, c, mixed, f0, rawo, off, code[c]);
         }
+      }
+    } else if constexpr (kCodes) {
+      // ================================================================ the codes, kDepth units in flight
+      // ---- the program composed, per chain, into single-precision coefficients over the codes (AffineForm)
+      float af[NCHAIN][NG][NQ], gf[NCHAIN][NG], ef[NCHAIN][NG], omf[NCHAIN][NG];
+      unsigned nbk[NG];
+      bool cok[NCHAIN];
+#pragma unroll
+      for (int k = 0; k < NOBS; k++) nbk[k] = (unsigned)d.nbins[k];
+#pragma unroll
+      for (int c = 0; c < NCHAIN; c++) {
+        AffineForm<NQ> form[NQ];
+#pragma unroll
+        for (int m = 0; m < NQ; m++) {
+#pragma unroll
+          for (int n = 0; n < NQ; n++) form[m].a[n] = (m == n) ? 1.0 : 0.0;
+          form[m].c = 0.0;
+          const double wlo = d.qbase[m], whi = d.qbase[m] + 65534.0 * d.qstep[m];
+          form[m].mag = __builtin_fmax(__builtin_fabs(wlo), __builtin_fabs(whi));
+        }
+        run_affine<NQ, ORD>(form, craw[c], PROG{}, Seq{});
+        bool ok = !wild[c];
+#pragma unroll
+        for (int k = 0; k < NOBS; k++) {
+          double sum_abs = 0.0, g = form[k].c - lo[k];
+#pragma unroll
+          for (int m = 0; m < NQ; m++) {
+            const double alpha = form[k].a[m] * d.qstep[m] * sc[k];
+            sum_abs = sum_abs + __builtin_fabs(alpha);
+            g = g + form[k].a[m] * (d.qbase[m] + 0.5 * d.qstep[m]);
+            af[c][k][m] = uniform_f((float)alpha);
+          }
+          g = g * sc[k];
+          // half a code step per field (+ the slack of the table's own check) | the single-precision evaluation of
+          // u: coefficients rounded to 24 bits times codes below 2^16, NQ + 1 roundings of partial sums no larger
+          // than mu | the reference's double arithmetic: <= 8 operations' roundings, each amplified no more than
+          // `mag` grows (2^-53 each; 2^-44 leaves a factor 64 for the composition's own roundings)
+          const double mu = sum_abs * 65536.0 + __builtin_fabs(g) + (double)nbk[k];
+          const double eps = 0.5 * sum_abs * (1.0 + 0x1p-19) + mu * 0x1p-21 +
+                             (form[k].mag + __builtin_fabs(lo[k])) * sc[k] * 0x1p-44;
+          ok = ok && (eps < 0.125);                      // (NaN fails)
+          gf[c][k] = uniform_f((float)g);
+          const float e32 = (float)(eps * 1.01);         // (covers the rounding of this conversion and of 1 - e32)
+          ef[c][k] = uniform_f(e32);
+          omf[c][k] = uniform_f(1.0f - e32);
+        }
+        cok[c] = uniform_i(ok ? 1 : 0) != 0;
+      }
+
+      // ---- one row with the reference's arithmetic on its float values (an ambiguous sample)
+      auto exact_one = [&](int c, unsigned row, unsigned offcode) {
         double f[NSLOT][SXMC_VEC];
 #pragma unroll
         for (int k = 0; k < NSTREAM; k++) {
-#pragma unroll
-          for (int q = 0; q < SXMC_VEC; q++) f[k][q] = f0[k][q];
+          const double x = (double)((gptr<const float>)col[k])[row];
+          f[k][0] = f[k][1] = f[k][2] = f[k][3] = x;
         }
         f[ORD][0] = f[ORD][1] = f[ORD][2] = f[ORD][3] = 0.0;
         run_static_part<NSLOT, ORD, false>(f, craw[c], PROG{}, Seq{});
-        // The per-sample part, written for the vector unit's instruction count (what bounds several chains in
-        // one pass): the domain tests are compares into scalar mask registers, combined and counted (popcount)
-        // on the scalar unit; the histogram update runs under that mask.  pdfz.cpp:388-398.
-        auto samples = [&](auto MIXED) {
-          constexpr bool kMixed = decltype(MIXED)::value != 0;
-          int base = (int)(off + (kMixed ? 0u : code[c]));
-          asm volatile("" : "+v"(base));   // (in a vector register: idx * stride + base is then one multiply-add)
-          const unsigned cbase = (unsigned)c * cstride + myrep;
+        bool ind = true;
+        int bin = (int)offcode;
+#pragma unroll
+        for (int k = 0; k < NOBS; k++) {
+          const double x = f[k][0];
+          ind = ind & (x >= lo[k]) & (x < hi[k]);
+          const int idx = (int)((x - lo[k]) * sc[k]);
+          bin = mad24(idx, stv[k], bin);
+        }
+        vcnt[c] += (ind && !((unsigned)bin < B)) ? 1u : 0u;   // (the others are counted with the histogram)
+        if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
+          __hip_atomic_fetch_add(&hist[(unsigned)c * cstride + myrep + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+
+      // ---- one granule of one chain from its codes.  Written for the vector unit's instruction count, which is
+      // what bounds this path: no in-domain counter (the norm is the histogram's sum), no range check of the flat
+      // index (the caller sends granules whose offset could push it past the end down the exact path), the rows
+      // marked "ask the exact columns" / "never counted" found with one test per lane.
+      const unsigned spare = (unsigned)NCHAIN * cstride + lane;   // (one of the 64 spare words behind the histograms)
+      auto coarse_granule = [&](int c, const vuint4g (&w)[QW], unsigned vunit, unsigned offcode) {
+        int base = (int)offcode;
+        asm volatile("" : "+v"(base));
+        const unsigned cbase = (unsigned)c * cstride + myrep;
+        unsigned rare = 0u;                              // bit q: the lane's q-th sample goes to the exact path
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          float cv[NQ];
+#pragma unroll
+          for (int m = 0; m < NQ; m++) {
+            const unsigned word = w[m >> 1][q];
+            cv[m] = (float)((m & 1) ? (word & 0xFFFFu) : (word >> 16));
+          }
+          bool amb = false, ind = true;
+          int bin = base;
+#pragma unroll
+          for (int k = 0; k < NOBS; k++) {
+            float u = gf[c][k];
+#pragma unroll
+            for (int m = 0; m < NQ; m++) u = __builtin_fmaf(af[c][k][m], cv[m], u);
+            const float fr = __builtin_amdgcn_fractf(u);            // u - floor(u), in [0, 1)
+            amb = amb | !((fr >= ef[c][k]) & (fr <= omf[c][k]));   // (NaN: ambiguous)
+            const int idx = (int)__builtin_floorf(u);
+            ind = ind & ((unsigned)idx < nbk[k]);
+            bin = mad24(idx, stv[k], bin);
+          }
+          // (no predication: a sample that is not counted adds to the lane's spare word instead, so the four samples
+          // of the lane are four independent instruction chains the vector unit can interleave -- with 3 or 4 waves
+          // per SIMD it is their latency, not their number, that this path waits for)
+          const unsigned word = (ind && !amb && !(dbg & 4u)) ? cbase + lds_slot((unsigned)bin) : spare;
+          __hip_atomic_fetch_add(&hist[word], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          rare |= amb ? (1u << q) : 0u;
+        }
+        // rows with a special code in the high half of word 0 (their arithmetic above meant nothing: if it counted
+        // them, that is taken back here)
+        const unsigned wmax = max(max(w[0][0], w[0][1]), max(w[0][2], w[0][3]));
+        const bool special = wmax >= ((unsigned)SXMC_QCODE_EXACT << 16);
+        if (__builtin_amdgcn_ballot_w64(rare != 0u || special) != 0ull) {   // (a few steps in a hundred)
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) {
-            bool ind = true;
-            int bin = base;
+            const bool sp = w[0][q] >= ((unsigned)SXMC_QCODE_EXACT << 16);
+            if (sp && !((rare >> q) & 1u)) {
+              // counted from codes that were no codes: recompute that bin and take the count back
+              float cv[NQ];
 #pragma unroll
-            for (int k = 0; k < NOBS; k++) {
-              const double x = f[k][q];
-              ind = ind & (x >= lo[k]) & (x < hi[k]);      // (NaN fails)
-              const int idx = (int)((x - lo[k]) * sc[k]);
-              bin = LDS_HIST ? mad24(idx, stv[k], bin) : idx * stv[k] + bin;
-            }
-            if constexpr (kMixed) {
-              const double x = f[ORD][q];
-              ind = ind & (x >= olo) & (x < ohi);
-              const int idx = (int)((x - olo) * osc);
-              bin = LDS_HIST ? mad24(idx, ostv, bin) : idx * ostv + bin;
-            }
-            vcnt[c] += ind ? 1u : 0u;                      // (an add-with-carry straight from the compare mask;
-                                                           //  a ballot + s_bcnt1 costs a v_cndmask and a v_cmp instead)
-            // in domain but index out of range (the reference's one-past-the-end case) still counts in the norm
-            if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
-              if constexpr (LDS_HIST) {
-                __hip_atomic_fetch_add(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
+              for (int m = 0; m < NQ; m++) {
+                const unsigned word = w[m >> 1][q];
+                cv[m] = (float)((m & 1) ? (word & 0xFFFFu) : (word >> 16));
+              }
+              bool ind = true;
+              int bin = base;
+#pragma unroll
+              for (int k = 0; k < NOBS; k++) {
+                float u = gf[c][k];
+#pragma unroll
+                for (int m = 0; m < NQ; m++) u = __builtin_fmaf(af[c][k][m], cv[m], u);
+                const int idx = (int)__builtin_floorf(u);
+                ind = ind & ((unsigned)idx < nbk[k]);
+                bin = mad24(idx, stv[k], bin);
+              }
+              if (ind && !(dbg & 4u)) {
+                __hip_atomic_fetch_sub(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-              } else {
-                __hip_atomic_fetch_add(&gbins0[(unsigned)bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
             }
+            if (!(((rare >> q) & 1u) || sp)) continue;
+            if (w[0][q] >= ((unsigned)SXMC_QCODE_NEVER << 16)) continue;   // not finite: never counted
+            const unsigned row = vunit * SXMC_VEC + (unsigned)q;
+            unsigned slot = qcap;
+            if (qcap != 0u) {
+              slot = __hip_atomic_fetch_add(&qhead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (slot < qcap) {
+              qent[2u * slot] = row;
+              qent[2u * slot + 1u] = NCHAIN > 1 ? (offcode | ((unsigned)c << 28)) : offcode;
+            } else {
+              exact_one(c, row, offcode);                // (queue full, or none: here and now)
+            }
           }
-        };
-        if (mixed) {   // (the wait for the extra column sits in here, off the common path)
-          f[ORD][0] = (double)rawo.x;
-          f[ORD][1] = (double)rawo.y;
-          f[ORD][2] = (double)rawo.z;
-          f[ORD][3] = (double)rawo.w;
-          run_static_part<NSLOT, ORD, true>(f, craw[c], PROG{}, Seq{});
-          samples(IntC<1>{});
-        } else {
-          samples(IntC<0>{});
         }
+      };
+
+      // largest value the per-sample part can add to a granule's offset: a granule whose offset + span stays below
+      // the histogram's size needs no range check per sample
+      unsigned span = 0u;
+#pragma unroll
+      for (int k = 0; k < NOBS; k++) span += (nbk[k] - 1u) * (unsigned)st[k];
+
+      auto process_unit = [&](unsigned long long it, const vuint4g (&w)[QW], unsigned pre) {
+        const unsigned v = vfirst32 + (unsigned)it * step32;
+        const int j = (int)(it & 63ull);
+        if (j == 0) granule_codes(it);
+        unsigned code[NCHAIN];
+#pragma unroll
+        for (int c = 0; c < NCHAIN; c++) code[c] = (unsigned)__builtin_amdgcn_readlane((int)codes[c], j);
+        const unsigned prebits = (unsigned)uniform_i((int)pre);
+        if (dbg & 1u) {
+#pragma unroll
+          for (int q = 0; q < QW; q++) sink += (w[q][0] == 12345u) ? 1u : 0u;
+          sink += (prebits == 12345u) ? 1u : 0u;
+          return;
+        }
+        const unsigned off = prebits & 0xFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < NCHAIN; c++) {
+          if (code[c] == kOrdSkip) continue;          // (wave-uniform) outside the ordered observable's domain
+          const bool mixed = code[c] == kOrdMixed;
+          if (mixed || !cok[c] || !(off + code[c] + span < B)) {
+            // a granule that straddles an edge of the ordered observable, a chain whose coefficients rule the codes
+            // out, an offset from which the flat index could leave the histogram: this once the float columns
+            // are read (loads and waits sit in here, off the common path)
+            const unsigned vc = v < vlast32 ? v : vlast32;
+            vfloat4 rawf[NS], rawo = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < NSTREAM; k++) rawf[k] = __builtin_nontemporal_load(&col[k][vc]);
+            if (mixed) rawo = __builtin_nontemporal_load(&col[ORD][vc]);
+            double f0[NS][SXMC_VEC];
+#pragma unroll
+            for (int k = 0; k < NSTREAM; k++) {
+              f0[k][0] = (double)rawf[k].x;
+              f0[k][1] = (double)rawf[k].y;
+              f0[k][2] = (double)rawf[k].z;
+              f0[k][3] = (double)rawf[k].w;
+            }
+            exact_granule(IntC<0>{}, c, mixed, f0, rawo, off, code[c]);
+          } else {
+            coarse_granule(c, w, v, off + code[c]);
+          }
+        }
+      };
+
+      for (unsigned long long it0 = 0; it0 < niter; it0 += 2 * kDepth) {
+        arrive(0);
+        issue(1, it0 + kDepth);
+#pragma unroll
+        for (int i = 0; i < kDepth; i++) {
+          if (it0 + (unsigned long long)i < niter) process_unit(it0 + (unsigned long long)i, rq[0][i], rp[0][i]);
+        }
+        arrive(1);
+        issue(0, it0 + 2 * kDepth);
+#pragma unroll
+        for (int i = 0; i < kDepth; i++) {
+          if (it0 + (unsigned long long)(kDepth + i) < niter) {
+            process_unit(it0 + (unsigned long long)(kDepth + i), rq[1][i], rp[1][i]);
+          }
+        }
+      }
+
+      // ---- the ambiguous rows, all lanes at once
+      if (qcap != 0u) {
+        __syncthreads();
+        const unsigned pushed = qhead[0];
+        const unsigned nq = pushed < qcap ? pushed : qcap;
+        for (unsigned i = tid; i < nq; i += nthreads) {
+          const unsigned row = qent[2u * i], w1 = qent[2u * i + 1u];
+          const unsigned cc = NCHAIN > 1 ? w1 >> 28 : 0u, oc = NCHAIN > 1 ? (w1 & 0x0FFFFFFFu) : w1;
+#pragma unroll
+          for (int c = 0; c < NCHAIN; c++) {
+            if (cc == (unsigned)c) exact_one(c, row, oc);
+          }
+        }
+        __syncthreads();
+        if (tid == 0) qhead[0] = 0u;
       }
     }
 
@@ -1428,12 +1829,22 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       // words are cleared only if the workgroup has another segment to count.
       const bool more = si + 1u < seg_end;
       const unsigned wend = (B + 63u) & ~63u;
+      unsigned total = 0u;
 #pragma unroll 4
       for (unsigned w = tid; LDS_HIST && w < wend; w += nthreads) {
         unsigned n = 0u;
         for (unsigned r = 0; r < R; r++) n += hist[(unsigned)c * cstride + r * rstride + w];
+        total += n;
         // (a word of the last block whose bin would be >= B was never written)
         if (n != 0u) __hip_atomic_fetch_add(&gbins[lds_slot(w)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (use_q) {   // (codes: the in-domain count is the histogram's sum + what vcnt holds; workgroup-uniform)
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kWave);
+        if (lane == 0 && total != 0u) {
+          __hip_atomic_fetch_add(&s_norm[c], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
       }
       if (LDS_HIST && more) {
         __syncthreads();

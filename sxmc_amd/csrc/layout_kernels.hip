@@ -16,6 +16,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstring>
+
 #pragma clang fp contract(off)
 
 namespace {
@@ -108,6 +110,84 @@ __global__ __launch_bounds__(256) void bucket_gather_kernel(const float* __restr
           live ? cols[(unsigned long long)gc.col[c] * pitch + row] : __int_as_float(0x7fc00000);
     }
   }
+}
+
+// CODES (fill_ordered_body in fill_kernels.inc.h).  The streamed columns of a bucketed copy once more, each value as a
+// 16-bit code inside a window [base, base + 65534 step]: code = floor((x - base) / step), so that
+// |x - (base + (code + 1/2) step)| <= step / 2 -- CHECKED here in double, with the slack the fill's error bound
+// grants (2^-20 relative); a value that fails the check, or lies outside the window, marks its row "ask the exact
+// columns" (high half of word 0 = 0xFFFE), a value that is not finite marks it "never counted" (0xFFFF: NaN and
+// +-inf stay outside every domain under systematics with finite coefficients; the granules' padding rows are NaN).
+struct CodePlan {
+  int nslots;
+  double base[SXMC_MAX_QSLOTS], step[SXMC_MAX_QSLOTS];
+};
+
+__device__ __forceinline__ unsigned ordered_bits(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+
+// finite minimum and maximum of every column, as order-preserving bit patterns (mm[2c], mm[2c + 1]; pre-set to
+// 0xFFFFFFFF / 0 by the host)
+__global__ __launch_bounds__(256) void column_minmax_kernel(const float* __restrict__ cols, unsigned long long pitch,
+                                                            int ncols, unsigned long long n, unsigned* __restrict__ mm) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (int c = 0; c < ncols; c++) {
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+      const float x = cols[(unsigned long long)c * pitch + i];
+      if (fabsf(x) < __builtin_inff()) {
+        const unsigned b = ordered_bits(x);
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+      if (lo != 0xFFFFFFFFu) atomicMin(&mm[2 * c], lo);
+      if (hi != 0u) atomicMax(&mm[2 * c + 1], hi);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void column_codes_kernel(const float* __restrict__ cols, unsigned long long pitch,
+                                                           CodePlan plan, unsigned long long n,
+                                                           unsigned* __restrict__ qcol, unsigned* __restrict__ tally) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned nexact = 0u, nnever = 0u;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    unsigned code[SXMC_MAX_QSLOTS] = {0u, 0u, 0u, 0u};
+    bool never = false, exact = false;
+    for (int m = 0; m < plan.nslots; m++) {
+      const double x = (double)cols[(unsigned long long)m * pitch + i];
+      if (!(fabs(x) < __builtin_inf())) {
+        never = true;
+        continue;
+      }
+      const double t = (x - plan.base[m]) / plan.step[m];
+      if (!(t >= 0.0 && t < (double)(SXMC_QCODE_MAX + 1u))) {
+        exact = true;
+        continue;
+      }
+      const unsigned q = (unsigned)t;
+      const double centre = plan.base[m] + ((double)q + 0.5) * plan.step[m];
+      if (!(fabs(x - centre) <= 0.5 * plan.step[m] * (1.0 + 0x1p-20))) exact = true;
+      code[m] = q;
+    }
+    if (never) code[0] = SXMC_QCODE_NEVER; else if (exact) code[0] = SXMC_QCODE_EXACT;
+    nexact += (!never && exact) ? 1u : 0u;
+    nnever += never ? 1u : 0u;
+    for (int w = 0; w < (plan.nslots + 1) / 2; w++) {
+      qcol[(unsigned long long)w * pitch + i] = (code[2 * w] << 16) | (2 * w + 1 < plan.nslots ? code[2 * w + 1] : 0u);
+    }
+  }
+  if (nexact) atomicAdd(&tally[0], nexact);
+  if (nnever) atomicAdd(&tally[1], nnever);
 }
 
 // EvalHist::RandomSample (pdfz.cpp:817-922) without leaving the device: a bin is drawn with probability
@@ -228,6 +308,68 @@ hipError_t sx_bucket_gather(const float* cols, unsigned long long pitch, int nco
   hipLaunchKernelGGL(bucket_gather_kernel, dim3(grid), dim3(256), 0, s, cols, pitch, gc, sorted_rows, d_src, d_valid,
                      ngranules, out, out_pitch);
   return hipGetLastError();
+}
+
+// finite minimum / maximum of `ncols` columns of `n` rows: out[2c], out[2c + 1] (min > max: no finite value)
+hipError_t sx_column_minmax(const float* cols, unsigned long long pitch, int ncols, unsigned long long n, float* out,
+                            hipStream_t s) {
+  if (ncols <= 0 || ncols > SXMC_MAX_NFIELDS) return hipErrorInvalidValue;
+  unsigned h[2 * SXMC_MAX_NFIELDS];
+  for (int c = 0; c < ncols; c++) {
+    h[2 * c] = 0xFFFFFFFFu;
+    h[2 * c + 1] = 0u;
+  }
+  unsigned* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, sizeof(unsigned) * 2 * ncols);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(d, h, sizeof(unsigned) * 2 * ncols, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && n) {
+    hipLaunchKernelGGL(column_minmax_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, cols, pitch, ncols, n, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(unsigned) * 2 * ncols, hipMemcpyDeviceToHost, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(d);
+  if (e != hipSuccess) return e;
+  if (e2 != hipSuccess) return e2;
+  for (int c = 0; c < 2 * ncols; c++) {
+    const bool none = h[2 * (c / 2)] == 0xFFFFFFFFu && h[2 * (c / 2) + 1] == 0u;
+    const unsigned b = h[c], u = (b >> 31) ? (b & 0x7FFFFFFFu) : ~b;
+    float x;
+    std::memcpy(&x, &u, 4);
+    out[c] = none ? ((c & 1) ? -1.0f : 1.0f) : x;
+  }
+  return hipSuccess;
+}
+
+// the table of codes of `nslots` columns (CodePlan above); tally[0]: rows marked "ask the exact columns", tally[1]:
+// rows marked "never counted"
+hipError_t sx_column_codes(const float* cols, unsigned long long pitch, int nslots, const double* base, const double* step,
+                           unsigned long long n, unsigned* qcol, unsigned long long* tally, hipStream_t s) {
+  if (nslots < 1 || nslots > SXMC_MAX_QSLOTS) return hipErrorInvalidValue;
+  CodePlan plan{};
+  plan.nslots = nslots;
+  for (int m = 0; m < nslots; m++) {
+    plan.base[m] = base[m];
+    plan.step[m] = step[m];
+  }
+  unsigned* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, sizeof(unsigned) * 2);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d, 0, sizeof(unsigned) * 2, s);
+  if (e == hipSuccess && n) {
+    hipLaunchKernelGGL(column_codes_kernel, dim3(grid_for(n, 16384)), dim3(256), 0, s, cols, pitch, plan, n, qcol, d);
+    e = hipGetLastError();
+  }
+  unsigned h[2] = {0u, 0u};
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(d);
+  if (tally) {
+    tally[0] = h[0];
+    tally[1] = h[1];
+  }
+  return e != hipSuccess ? e : e2;
 }
 
 // inclusive prefix sum of the histogram (counts fit 32 bits: the reference's norm is a uint32 too)

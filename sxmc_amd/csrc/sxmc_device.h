@@ -159,6 +159,11 @@ hipError_t sx_bucket_first(const unsigned* sorted_keys, unsigned long long n, un
 hipError_t sx_bucket_gather(const float* cols, unsigned long long pitch, int ncols, const int* col_list,
                             const unsigned* sorted_rows, const unsigned* d_src, const unsigned* d_valid,
                             unsigned long long ngranules, float* out, unsigned long long out_pitch, hipStream_t s);
+// 16-bit codes of the streamed columns of a bucketed copy (fill_ordered_body's CODES)
+hipError_t sx_column_minmax(const float* cols, unsigned long long pitch, int ncols, unsigned long long n, float* out,
+                            hipStream_t s);
+hipError_t sx_column_codes(const float* cols, unsigned long long pitch, int nslots, const double* base, const double* step,
+                           unsigned long long n, unsigned* qcol, unsigned long long* tally, hipStream_t s);
 hipError_t sx_hist_cdf(const unsigned* d_bins, unsigned* d_cdf, int nbins_total, hipStream_t s);
 hipError_t sx_random_sample(const unsigned* d_cdf, int nbins_total, int nobs, const int* nbins, const double* lower,
                             const double* upper, const float* cut_lo, const float* cut_hi, unsigned long long seed,

@@ -19,6 +19,10 @@
 #define SXMC_SPARSE_EMPTY 0xFFu   /* directory flag: the bucket holds no event bin */
 #define SXMC_SPARSE_SLOW 0xFEu    /* directory flag: look every sample up in the global table (see the kernel) */
 #define SXMC_SPARSE_SMAX_LOG2 9  /* largest per-wave table: 512 entries */
+#define SXMC_MAX_QSLOTS 4        /* streamed slots a table of 16-bit codes can stand in for (fill_ordered_body) */
+#define SXMC_QCODE_MAX 65533u    /* largest code of a value inside its window */
+#define SXMC_QCODE_EXACT 0xFFFEu /* "outside the window: ask the exact columns" */
+#define SXMC_QCODE_NEVER 0xFFFFu /* "not finite: never counted" */
 
 // One systematic, addressed by SLOT (position among the columns a launch loads), not by field.
 // Restates SystematicDescriptor (pdfz.cpp:48-54) with the parameter indices inlined.
@@ -90,6 +94,14 @@ struct SxSignalDesc {
   int pdf_stride;
   int pad0;
   double bin_volume;
+  // --- CODES (fill_ordered_body): the streamed slots of the bucketed copy once more, each value as a 16-bit code
+  //     code = floor((x - qbase) / qstep), two slots per 32-bit word (slot 2w in the high half of word w, slot 2w + 1
+  //     in the low half), word column w at qcol + w * col_pitch.  Code 0xFFFE in the high half of word 0: some slot
+  //     of the row lies outside its window (the exact columns decide); 0xFFFF there: some slot is not finite (the row
+  //     can never be counted).  Null: the launch streams the float columns.
+  const unsigned* qcol;
+  double qbase[SXMC_MAX_QSLOTS];
+  double qstep[SXMC_MAX_QSLOTS];
 };
 
 // One piece of fill work: units v0 + tid, + step, ... < v1 of member `sig` (a unit = SXMC_VEC samples).

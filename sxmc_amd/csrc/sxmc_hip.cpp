@@ -174,6 +174,12 @@ struct SampleStore {
     float* d_gedge = nullptr;       // [ngranules] pairs {first, last} value of the sort's ordered observable
     size_t ngranules = 0;           // physical granules (with the runs' padding)
     size_t nkept = 0;               // samples in the copy
+    // CODES (fill_ordered_body): the streamed fields once more as 16-bit codes, two per word; built on demand
+    unsigned* d_qcol = nullptr;     // [(nq + 1) / 2][pitch]
+    int nq = 0;                     // fields coded (the streamed ones: all but the ordered observable's)
+    bool codes_tried = false;
+    double qbase[SXMC_MAX_QSLOTS] = {0}, qstep[SXMC_MAX_QSLOTS] = {0};
+    unsigned long long q_exact_rows = 0, q_never_rows = 0;   // rows marked "ask the exact columns" / "never counted"
   };
   std::vector<std::unique_ptr<BucketSort>> sorts;
   std::vector<std::unique_ptr<Bucketed>> bucketed;
@@ -195,6 +201,7 @@ struct SampleStore {
       if (b->d_gpre) (void)hipFree(b->d_gpre);
       if (b->d_gkp) (void)hipFree(b->d_gkp);
       if (b->d_gedge) (void)hipFree(b->d_gedge);
+      if (b->d_qcol) (void)hipFree(b->d_qcol);
     }
     for (auto& b : sorts)
       if (b->d_rows) (void)hipFree(b->d_rows);
@@ -289,6 +296,7 @@ struct LaunchClass {
   bool light = false; // a pure stream: runs best with few waves per CU (see group_rebuild)
   bool runs_mode = false;  // bucketed tables laid out in per-wave runs; the sparse flavour runs fill_sparse_kernel
   int teams = 1;           // teams of workgroups per member over a bucketed table (sxplan::interleaved_segments)
+  bool codes = false;      // ordered tables: the streamed columns go as 16-bit codes (fill_ordered_body's CODES)
 };
 
 void free_class(LaunchClass& c) {
@@ -341,6 +349,7 @@ struct sxmc_group {
   bool order_blocked = false;                      // a plan with ordered tables beyond LDS could not be laid out in runs
   int cfg_order = 1, cfg_seen_order = -1;          // ... with the rows of a bucket ordered by a monotonically written observable
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
+  int cfg_codes = -1, cfg_seen_codes = -2;         // ordered tables streamed as 16-bit codes (-1: SXMC_CODES, default on)
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
   std::string plan_note;                           // why a launch of the plan took a slower general path (for launch_info)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
@@ -666,6 +675,99 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
   b->complete = true;
   *out = b;
   return SXMC_OK;
+}
+
+// CODES (fill_ordered_body): the streamed fields of a bucketed copy with an ordered observable once more, as 16-bit
+// codes inside a window per field, two fields to a word.  `cd`: the member as its fill sees it -- slots 0 .. nobs-1 are
+// observables (their domains centre the windows), the others fields only read.  The window of an observable is its
+// finite range in the table cut to the domain widened by its own width on either side (a value further out needs a
+// scale or shift of the order of the whole domain to come back in: its row is marked "ask the exact columns"
+// instead); the window of a field that is only read is its finite range, cut to three such widths around the
+// observables' windows when they overlap at all.  Built once per copy; left out (d_qcol stays null) when more than
+// 2 % of the rows would ask the exact columns: such a table gains nothing.
+bool codes_enabled(const sxmc_group* g) {
+  if (g->cfg_codes >= 0) return g->cfg_codes != 0;
+  static const bool on = [] {
+    const char* e = std::getenv("SXMC_CODES");
+    return !e || std::atoi(e) != 0;
+  }();
+  return on;
+}
+
+int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSignalDesc& cd) {
+  SampleStore& st = *h->store;
+  std::lock_guard<std::mutex> lock(st.pre_mutex);
+  SampleStore::Bucketed* b = const_cast<SampleStore::Bucketed*>(bkc);
+  if (b->codes_tried) return SXMC_OK;
+  b->codes_tried = true;
+  const int nq = (int)b->fields.size() - 1;
+  if (nq < 2 || nq > SXMC_MAX_QSLOTS || b->ngranules == 0 || !b->sort || b->sort->ordered < 0) return SXMC_OK;
+  const unsigned long long n = (unsigned long long)b->ngranules * 256ull;
+  float mm[2 * SXMC_MAX_NFIELDS];
+  SX_HIP(sx_column_minmax(b->d_cols, b->pitch, nq, n, mm, nullptr));
+  double ulo = 0, uhi = -1;   // union of the observables' windows
+  for (int m = 0; m < nq; m++) {
+    double wlo = mm[2 * m], whi = mm[2 * m + 1];
+    const bool none = !(wlo <= whi);
+    if (m < cd.nobs) {
+      const double lo = cd.lower[m], hi = cd.upper[m], w = hi - lo;
+      wlo = none ? lo - w : std::max(wlo, lo - w);
+      whi = none ? hi + w : std::min(whi, hi + w);
+      if (!(wlo < whi)) {   // (no finite value near the domain)
+        wlo = lo - w;
+        whi = hi + w;
+      }
+      if (uhi < ulo) {
+        ulo = wlo;
+        uhi = whi;
+      } else {
+        ulo = std::min(ulo, wlo);
+        uhi = std::max(uhi, whi);
+      }
+    } else if (none) {
+      wlo = 0;
+      whi = 1;
+    } else if (ulo <= uhi) {
+      const double w = uhi - ulo, clo = std::max(wlo, ulo - 3 * w), chi = std::min(whi, uhi + 3 * w);
+      if (clo < chi) {
+        wlo = clo;
+        whi = chi;
+      }
+    }
+    double step = (whi - wlo) / 65532.0;   // (the largest value lands in code 65532 of 0 .. 65533)
+    if (!(step > 0) || !std::isfinite(step)) step = std::max(std::fabs(wlo), 1.0) * 0x1p-20;
+    b->qbase[m] = wlo;
+    b->qstep[m] = step;
+  }
+  SX_HIP(hipMalloc((void**)&b->d_qcol, sizeof(unsigned) * b->pitch * (size_t)((nq + 1) / 2)));
+  unsigned long long tally[2] = {0, 0};
+  hipError_t e = sx_column_codes(b->d_cols, b->pitch, nq, b->qbase, b->qstep, n, b->d_qcol, tally, nullptr);
+  if (e != hipSuccess || (double)tally[0] > 0.02 * (double)std::max<size_t>(b->nkept, 1)) {
+    (void)hipFree(b->d_qcol);
+    b->d_qcol = nullptr;
+    if (e != hipSuccess) return fail(SXMC_ERR_HIP, std::string("codes of a bucketed table: ") + hipGetErrorString(e));
+    return SXMC_OK;
+  }
+  b->nq = nq;
+  b->q_exact_rows = tally[0];
+  b->q_never_rows = tally[1];
+  return SXMC_OK;
+}
+
+// LDS of fill_ordered_body's queue of ambiguous rows: 4 header words + 2 words per entry
+size_t ordered_queue_bytes(unsigned qlog) { return qlog ? (4 + ((size_t)2 << qlog)) * 4 : 0; }
+// the largest queue (<= 2048 entries, >= 64) that fits `room` bytes, as log2(entries); 0: none
+unsigned ordered_queue_log(size_t room) {
+  unsigned qlog = 11;
+  // (test hook, read whenever a plan is built: SXMC_CODES_QUEUE_LOG = 6 .. 11 caps the queue, 0 = no queue at all --
+  // every ambiguous row is then decided where it is met; the results do not depend on it)
+  if (const char* e = std::getenv("SXMC_CODES_QUEUE_LOG")) {
+    const int v = std::atoi(e);
+    if (v <= 0) return 0;
+    qlog = (unsigned)std::min(std::max(v, 6), 11);
+  }
+  while (qlog >= 6 && ordered_queue_bytes(qlog) > room) qlog--;
+  return qlog >= 6 ? qlog : 0;
 }
 
 // The evaluator's event bins grouped by the buckets of a sort (fill_sparse_kernel): per bucket key an
@@ -1144,6 +1246,23 @@ int group_rebuild(sxmc_group* g) {
         d.pre = bk->d_gpre;
         d.edges = bk->d_gedge;
         g->member_bucket[(size_t)idx] = bk;
+        // CODES: ordered table, histogram in LDS, 2 to 4 streamed fields, every systematic on them affine (one
+        // coefficient) -- the conditions fill_ordered_body's kCodes states at compile time
+        bool affine = ordered && c.shape.lds_hist && c.shape.nobs >= 1 && c.shape.nslot - 1 >= 2 &&
+                      c.shape.nslot - 1 <= SXMC_MAX_QSLOTS && !c.runs_mode && codes_enabled(g);
+        for (unsigned w : c.prog) affine = affine && ((int)((w >> 4) & 15u) == c.shape.nslot - 1 || ((w >> 12) & 15u) == 0u);
+        if (affine) {
+          rc = get_bucket_codes(h, bk, d);
+          if (rc) return rc;
+          if (bk->d_qcol) {
+            d.qcol = bk->d_qcol;
+            for (int m = 0; m < bk->nq; m++) {
+              d.qbase[m] = bk->qbase[m];
+              d.qstep[m] = bk->qstep[m];
+            }
+            c.codes = true;
+          }
+        }
       }
       d.vec_start = prefix;
       prefix += d.nvec;
@@ -1172,6 +1291,11 @@ int group_rebuild(sxmc_group* g) {
       while (rlog < 2 && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) <= share) rlog++;
       c.shape.lds_layout = ordered_rstride(cls_max_bins) | (rlog << 24);
       c.shape.lds_bytes = ordered_lds_bytes(cls_max_bins, 1, rlog);
+      if (c.codes) {   // the queue of ambiguous rows, in what the replicas leave of the workgroup's share
+        const unsigned qlog = share > c.shape.lds_bytes ? ordered_queue_log(share - c.shape.lds_bytes) : 0;
+        c.shape.lds_layout |= qlog << 28;
+        c.shape.lds_bytes += ordered_queue_bytes(qlog);
+      }
     }
     unsigned long long grid = (unsigned long long)props.cus * bpc;
     const unsigned long long want = (c.total_vec + threads - 1) / threads;  // >= 1 unit per lane
@@ -1260,6 +1384,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_bucket = g->cfg_bucket;
   g->cfg_seen_order = g->cfg_order;
   g->cfg_seen_rtc = g->cfg_rtc;
+  g->cfg_seen_codes = g->cfg_codes;
   g->plan_generation++;
   g->built = true;
   return SXMC_OK;
@@ -1296,7 +1421,7 @@ int group_refresh(sxmc_group* g) {
                g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_teams != g->cfg_teams ||
                g->cfg_seen_prebin != g->cfg_prebin ||
                g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc ||
-               g->cfg_seen_order != g->cfg_order;
+               g->cfg_seen_order != g->cfg_order || g->cfg_seen_codes != g->cfg_codes;
   bool points = false;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
@@ -2523,6 +2648,33 @@ int sxmc_group_set_ordering(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_codes(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_codes = enable < 0 ? -1 : enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_group_codes_info(sxmc_group_t g, int* members, unsigned long long* rows, unsigned long long* exact_rows,
+                          unsigned long long* never_rows) {
+  SX_REQUIRE(g && members && rows && exact_rows && never_rows, "null argument");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  *members = 0;
+  *rows = *exact_rows = *never_rows = 0;
+  for (const LaunchClass& c : g->classes) {
+    if (!c.codes) continue;
+    for (int idx : c.member_idx) {
+      const SampleStore::Bucketed* bk = g->member_bucket[(size_t)idx];
+      if (!bk || !bk->d_qcol) continue;
+      *members += 1;
+      *rows += (unsigned long long)bk->ngranules * 256ull;
+      *exact_rows += bk->q_exact_rows;
+      *never_rows += bk->q_never_rows;
+    }
+  }
+  return SXMC_OK;
+}
+
 int sxmc_group_set_runtime_kernels(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_rtc = enable ? 1 : 0;
@@ -2541,7 +2693,7 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
     std::snprintf(line, sizeof line,
                   "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d teams=%d\n",
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
-                  c.shape.pre_width == 5 ? "ordered" : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
+                  c.shape.pre_width == 5 ? (c.codes ? "ordered+codes" : "ordered") : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
                   c.shape.grid, c.partition, c.teams);
     text += line;
@@ -2989,6 +3141,11 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
       while (rlog < 2 && (4 + (C * rstride << (rlog + 1)) + 64) * 4 <= (size_t)props.lds_per_cu) rlog++;
       lds = (4 + (C * rstride << rlog) + 64) * 4;
       hist_words = rstride | ((size_t)rlog << 24);
+      if (c0.codes) {   // the queue of ambiguous rows (fill_ordered_body's CODES), shared by the chains
+        const unsigned qlog = (size_t)props.lds_per_cu > lds ? ordered_queue_log((size_t)props.lds_per_cu - lds) : 0;
+        lds += ordered_queue_bytes(qlog);
+        hist_words |= (size_t)qlog << 28;
+      }
     }
     if (lds > (size_t)props.lds_per_cu) {
       mg->why_not = "the chains' histograms do not fit LDS together";
@@ -3439,12 +3596,14 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
     const SxSignalDesc& d = g->h_descs[i];
     // columns the fill streams: float slots minus the observables covered by the pre-binned column
     int pre_w = 0, pre_dims = 0;
+    bool codes = false;
     for (const LaunchClass& c : g->classes) {
       for (int idx : c.member_idx) {
         if (idx == (int)i && c.shape.pre_width) {
           pre_w = c.shape.pre_width;
           for (int k = 0; k < d.nobs; k++) pre_dims += (c.pre_mask >> k) & 1u;
         }
+        if (idx == (int)i) codes = c.codes;
       }
     }
     if (const SampleStore::Bucketed* bk = i < g->member_bucket.size() ? g->member_bucket[i] : nullptr) {
@@ -3452,9 +3611,12 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
       // + one word per granule
       // (ordered: that observable's column is needed only in the granules that straddle a bin edge -- which ones
       // depends on the parameters; not counted -- and each granule has two end values besides its word)
+      // (codes: the streamed fields at 16 bits each, two to a word; the float values of the ambiguous rows -- a few
+      // in 10^4, which ones depends on the parameters -- are not counted either)
       const bool ord = bk->sort && bk->sort->ordered >= 0;
-      fr += (double)bk->nkept * 4.0 * (double)(bk->fields.size() - (ord ? 1 : 0)) +
-            ((ord ? 8.0 : 0.0) + (bk->runs > 1 ? 8.0 : 4.0)) * (double)bk->ngranules;
+      const double row_bytes = (codes && bk->d_qcol) ? 4.0 * (double)((bk->nq + 1) / 2)
+                                                     : 4.0 * (double)(bk->fields.size() - (ord ? 1 : 0));
+      fr += (double)bk->nkept * row_bytes + ((ord ? 8.0 : 0.0) + (bk->runs > 1 ? 8.0 : 4.0)) * (double)bk->ngranules;
     } else {
       fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
     }

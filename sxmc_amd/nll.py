@@ -107,6 +107,18 @@ class EvalGroup:
         has enough granules per bin edge to pay; force: wherever it applies)."""
         capi.call("sxmc_group_set_ordering", self._g, 2 if (enable and force) else int(bool(enable)))
 
+    def SetCodes(self, enable):
+        """Stream an ordered table's fields as 16-bit codes with an exact recheck of the samples near a bin edge
+        (default on where it applies; None: the library's default).  See include/sxmc_hip.h."""
+        capi.call("sxmc_group_set_codes", self._g, -1 if enable is None else int(bool(enable)))
+
+    def CodesInfo(self):
+        """(members streaming codes, rows, rows that always ask the exact columns, rows never counted)."""
+        m = C.c_int(0)
+        r, e, n = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        capi.call("sxmc_group_codes_info", self._g, C.byref(m), C.byref(r), C.byref(e), C.byref(n))
+        return m.value, r.value, e.value, n.value
+
     def SetRuntimeKernels(self, enable):
         """Specialise the fill kernel through hiprtc for programs of systematics that are not built in (default on)."""
         capi.call("sxmc_group_set_runtime_kernels", self._g, int(bool(enable)))
