@@ -1238,7 +1238,8 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   // CODES (see AffineForm above): the streamed slots as 16-bit codes, two to a word
   constexpr bool kCodes = LDS_HIST && NOBS >= 1 && NSTREAM >= 2 && NSTREAM <= SXMC_MAX_QSLOTS && prog_is_affine<ORD>(PROG{});
   constexpr int NQ = kCodes ? NSTREAM : 1, QW = (NQ + 1) / 2;
-  constexpr int kDepth = 2;            // units of codes a lane keeps in flight (half the bytes per unit: twice the units)
+  constexpr int kRing = 4;             // units of codes a lane holds: one being worked on, the others in flight
+  static_assert(64 % kRing == 0, "a block of 64 units is a whole number of rounds of the ring");
   typedef typename MakeISeq<PROG::n>::type Seq;
   extern __shared__ unsigned lds[];
   const unsigned tid = threadIdx.x;
@@ -1253,12 +1254,21 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   // l mod R (rstride = 16 mod 64: the replicas of one bin sit in different banks too).  The flush adds the replicas up.
   unsigned* s_norm = lds;
   unsigned* hist = lds + 4;
-  const unsigned rstride = layout & 0xFFFFFFu, rlog = (layout >> 24) & 15u, R = 1u << rlog;
+  // (bit 27: the host laid the LDS out for the codes' padded form of the histogram -- see `outer` below)
+  const unsigned rstride = layout & 0xFFFFFFu, rlog = (layout >> 24) & 7u, R = 1u << rlog;
+  const bool outer_layout = ((layout >> 27) & 1u) != 0u;
   const unsigned cstride = rstride << rlog;            // one chain's replicas
   const unsigned myrep = (lane & (R - 1u)) * rstride;
-  const unsigned qlog = layout >> 28, qcap = qlog ? 1u << qlog : 0u;
-  unsigned* qhead = lds + 4 + (LDS_HIST ? NCHAIN * cstride : 0u) + 64;
-  unsigned* qent = qhead + 4;
+  // the queues of the codes path: every WAVE owns a slice of (1 << qlog) / waves entries of two words behind the spare
+  // words -- first the ambiguous rows {row, granule's bin offset | chain << 28}, then, in the last eighth, whole
+  // granules left to the float columns {wave's first unit | chain << 28, the ordered observable's code}.  Filled and
+  // emptied by its wave alone: no atomics, no barriers.
+  const unsigned qlog = layout >> 28;
+  const unsigned qwave = qlog ? (1u << qlog) / (nthreads / kWave) : 0u;      // entries per wave
+  const unsigned gq_min = (unsigned)(kRing * NCHAIN) + 1u;                    // (a round of the ring must fit)
+  const unsigned gq_cap = qwave / 8u > gq_min ? qwave / 8u : gq_min, rq_cap = qwave > gq_cap ? qwave - gq_cap : 0u;
+  unsigned* qrows = lds + 4 + (LDS_HIST ? NCHAIN * cstride : 0u) + 64 + 4 + (tid / kWave) * (2u * qwave);
+  unsigned* qgran = qrows + 2u * rq_cap;
 
   bool lds_clean = false;
   SX_WG_STAMP(0);
@@ -1292,11 +1302,12 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     const unsigned long long vfirst = v0 + tid;
     const unsigned long long vwave = v0 + (tid - lane);   // the wave's first unit: a granule boundary
 
-    // the table of codes, when the launch has one (dbg & 8: measurement / test hook, stream the floats regardless)
-    bool use_q = false;
+    // the table of codes, when the launch has one (dbg & 8: measurement / test hook, stream the floats regardless);
+    // every wave needs room for at least 16 queue entries
+    bool want_q = false;
     gptr<const vuint4g> qcol[QW];
     if constexpr (kCodes) {
-      use_q = d.qcol != nullptr && !(dbg & 8u);
+      want_q = d.qcol != nullptr && !(dbg & 8u) && rq_cap >= 8u;
 #pragma unroll
       for (int w = 0; w < QW; w++) {
         qcol[w] = to_global(reinterpret_cast<const vuint4g*>(d.qcol + (unsigned long long)w * d.col_pitch));
@@ -1314,55 +1325,19 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       rawpre = precol[v >> 6];
       __builtin_amdgcn_sched_barrier(0);
     };
-    // two buffers of kDepth units each: one is worked on while the other's loads are in flight
-    vuint4g rq[2][kDepth][QW];
-    unsigned rp[2][kDepth];
     const unsigned long long niter = (v1 - v0 + step - 1) / step;
-    // (32-bit unit numbers: the host offers codes only for tables below 2^22 granules, so a unit's byte offset fits
-    // 32 bits and the loads take the form base in scalar registers + 32-bit offset: one add per load instead of a
-    // 64-bit multiply-add, compare and select)
+    // a ring of kRing units of codes: one is worked on while the loads of the others are in flight.  (32-bit unit
+    // numbers: the host offers codes only for tables below 2^22 granules, so a unit's byte offset fits 32 bits and
+    // the loads take the form base in scalar registers + 32-bit offset.)
+    vuint4g rq[kRing][QW];
     const unsigned vfirst32 = (unsigned)vfirst, step32 = (unsigned)step, vlast32 = (unsigned)vlast;
-    auto issue = [&](int buf, unsigned long long it_first) {
-#pragma unroll
-      for (int i = 0; i < kDepth; i++) {
-        unsigned v = vfirst32 + ((unsigned)it_first + (unsigned)i) * step32;
-        v = v < vlast32 ? v : vlast32;
-        if ((dbg & 2u) && it_first != 0ull) v = vlast32;
-#pragma unroll
-        for (int w = 0; w < QW; w++) {
-          rq[buf][i][w] = __builtin_nontemporal_load(
-              (gptr<const vuint4g>)((gptr<const char>)qcol[w] + (unsigned long long)(v * 16u)));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        rp[buf][i] = *(gptr<const unsigned>)((gptr<const char>)precol + (unsigned long long)((v >> 6) * 4u));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    // (the wait for a buffer's loads goes HERE -- all that is outstanding at this point is that buffer -- and the
-    // other buffer's loads are issued right after it)
-    auto arrive = [&](int buf) {
-#pragma unroll
-      for (int i = 0; i < kDepth; i++) {
-#pragma unroll
-        for (int w = 0; w < QW; w++) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) asm volatile("" : "+v"(rq[buf][i][w][e]));
-        }
-        asm volatile("" : "+v"(rp[buf][i]));
-      }
-    };
-    if (use_q) {
-      if constexpr (kCodes) issue(0, 0ull);
-    } else {
-      load(vfirst < v1 ? vfirst : vlast);
-    }
+    if (!want_q) load(vfirst < v1 ? vfirst : vlast);
 
     if (!lds_clean) {
       if (LDS_HIST) {
         for (unsigned b = tid; b < NCHAIN * cstride; b += nthreads) hist[b] = 0u;
       }
       if (tid < 4) s_norm[tid] = 0u;
-      if (kCodes && qcap != 0u && tid == 0) qhead[0] = 0u;
       __syncthreads();
     }
 
@@ -1422,6 +1397,19 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
 
     // ---- one granule of one chain with the reference's arithmetic on the float columns.  f0: the streamed slots
     // widened; rawo: the ordered observable's unit (read only when `mixed`).  pdfz.cpp:388-398.
+    // CODES, PADDED FORM of the LDS histogram (`outer`): one observable binned per sample and that one the histogram's
+    // outermost dimension (stride S, S * nbins = B).  Bin b = idx * S + r then lives in word (idx + 1) * S' + r of a
+    // replica, S' = S or S + 1, whichever is odd: lanes that differ in idx hit different banks without a swizzle, and
+    // the rows idx = -1 and idx = nbins are guard rows -- a sample that is outside the domain or ambiguous is sent
+    // there by clamping its index instead of being predicated away.  Per sample the address is then ONE multiply-add.
+    bool outer = false;
+    unsigned oS = 1u, oSp = 1u;
+    float oinvS = 1.0f;
+    auto codes_word = [&](unsigned bin) -> unsigned {     // (off the hot path: the exact arithmetic's bins)
+      if (!outer) return lds_slot(bin);
+      const unsigned q = (unsigned)(((float)bin + 0.5f) * oinvS);   // bin / S: exact while S * (nbins + 1) < 2^22
+      return bin + oSp + (oSp - oS) * q;
+    };
     // ALL: every in-domain sample counts in vcnt (the float stream); otherwise only those whose index is out of range
     // -- over codes the norm is the sum of the LDS histogram plus exactly those.
     auto exact_granule = [&](auto ALL, int c, bool mixed, const double (&f0)[NS][SXMC_VEC], const vfloat4& rawo,
@@ -1469,8 +1457,8 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
           // in domain but index out of range (the reference's one-past-the-end case) still counts in the norm
           if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
             if constexpr (LDS_HIST) {
-              __hip_atomic_fetch_add(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+              const unsigned wd = kCountAll ? lds_slot((unsigned)bin) : codes_word((unsigned)bin);
+              __hip_atomic_fetch_add(&hist[cbase + wd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
               __hip_atomic_fetch_add(&gbins0[(unsigned)bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1488,6 +1476,64 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
         samples(IntC<0>{});
       }
     };
+
+    // ---- codes: the program composed, per chain, into single-precision coefficients over the codes (AffineForm);
+    // a chain whose parameters rule that out sends the whole evaluation back to the float columns
+    float af[NCHAIN][NG][NQ], gf[NCHAIN][NG], ef[NCHAIN][NG], omf[NCHAIN][NG];
+    unsigned nbk[NG];
+    bool use_q = want_q;
+    if constexpr (kCodes) {
+      if (want_q) {
+#pragma unroll
+        for (int k = 0; k < NOBS; k++) nbk[k] = (unsigned)d.nbins[k];
+#pragma unroll
+        for (int c = 0; c < NCHAIN; c++) {
+          AffineForm<NQ> form[NQ];
+#pragma unroll
+          for (int m = 0; m < NQ; m++) {
+#pragma unroll
+            for (int n = 0; n < NQ; n++) form[m].a[n] = (m == n) ? 1.0 : 0.0;
+            form[m].c = 0.0;
+            const double wlo = d.qbase[m], whi = d.qbase[m] + 65534.0 * d.qstep[m];
+            form[m].mag = __builtin_fmax(__builtin_fabs(wlo), __builtin_fabs(whi));
+          }
+          run_affine<NQ, ORD>(form, craw[c], PROG{}, Seq{});
+          bool ok = !wild[c];
+#pragma unroll
+          for (int k = 0; k < NOBS; k++) {
+            double sum_abs = 0.0, g = form[k].c - lo[k];
+#pragma unroll
+            for (int m = 0; m < NQ; m++) {
+              const double alpha = form[k].a[m] * d.qstep[m] * sc[k];
+              sum_abs = sum_abs + __builtin_fabs(alpha);
+              g = g + form[k].a[m] * (d.qbase[m] + 0.5 * d.qstep[m]);
+              af[c][k][m] = uniform_f((float)alpha);
+            }
+            g = g * sc[k];
+            // half a code step per field (+ the slack of the table's own check) | the single-precision evaluation
+            // of u: coefficients rounded to 24 bits times codes below 2^16, NQ + 1 roundings of partial sums no
+            // larger than mu | the reference's double arithmetic: <= 8 systematics' roundings, each amplified no more
+            // than `mag` grows (2^-53 each; 2^-44 leaves a factor 64 for the composition's own roundings)
+            const double mu = sum_abs * 65536.0 + __builtin_fabs(g) + (double)nbk[k];
+            const double eps = 0.5 * sum_abs * (1.0 + 0x1p-19) + mu * 0x1p-21 +
+                               (form[k].mag + __builtin_fabs(lo[k])) * sc[k] * 0x1p-44;
+            ok = ok && (eps < 0.125);                      // (NaN fails)
+            gf[c][k] = uniform_f((float)g);
+            const float e32 = (float)(eps * 1.01);         // (covers the rounding of this conversion and of 1 - e32)
+            ef[c][k] = uniform_f(e32);
+            omf[c][k] = uniform_f(1.0f - e32);
+          }
+          use_q = use_q && (uniform_i(ok ? 1 : 0) != 0);
+        }
+        if (!use_q) load(vfirst < v1 ? vfirst : vlast);    // (the float stream's first unit, late this once)
+        if (use_q && outer_layout && NOBS == 1 && (unsigned)st[0] * nbk[0] == B) {
+          outer = true;
+          oS = (unsigned)st[0];
+          oSp = oS | 1u;
+          oinvS = 1.0f / (float)oS;
+        }
+      }
+    }
 
     if (!use_q) {
       // ================================================================ the float columns, one unit in flight
@@ -1558,96 +1604,65 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
         }
       }
     } else if constexpr (kCodes) {
-      // ================================================================ the codes, kDepth units in flight
-      // ---- the program composed, per chain, into single-precision coefficients over the codes (AffineForm)
-      float af[NCHAIN][NG][NQ], gf[NCHAIN][NG], ef[NCHAIN][NG], omf[NCHAIN][NG];
-      unsigned nbk[NG];
-      bool cok[NCHAIN];
-#pragma unroll
-      for (int k = 0; k < NOBS; k++) nbk[k] = (unsigned)d.nbins[k];
-#pragma unroll
-      for (int c = 0; c < NCHAIN; c++) {
-        AffineForm<NQ> form[NQ];
-#pragma unroll
-        for (int m = 0; m < NQ; m++) {
-#pragma unroll
-          for (int n = 0; n < NQ; n++) form[m].a[n] = (m == n) ? 1.0 : 0.0;
-          form[m].c = 0.0;
-          const double wlo = d.qbase[m], whi = d.qbase[m] + 65534.0 * d.qstep[m];
-          form[m].mag = __builtin_fmax(__builtin_fabs(wlo), __builtin_fabs(whi));
-        }
-        run_affine<NQ, ORD>(form, craw[c], PROG{}, Seq{});
-        bool ok = !wild[c];
-#pragma unroll
-        for (int k = 0; k < NOBS; k++) {
-          double sum_abs = 0.0, g = form[k].c - lo[k];
-#pragma unroll
-          for (int m = 0; m < NQ; m++) {
-            const double alpha = form[k].a[m] * d.qstep[m] * sc[k];
-            sum_abs = sum_abs + __builtin_fabs(alpha);
-            g = g + form[k].a[m] * (d.qbase[m] + 0.5 * d.qstep[m]);
-            af[c][k][m] = uniform_f((float)alpha);
-          }
-          g = g * sc[k];
-          // half a code step per field (+ the slack of the table's own check) | the single-precision evaluation of
-          // u: coefficients rounded to 24 bits times codes below 2^16, NQ + 1 roundings of partial sums no larger
-          // than mu | the reference's double arithmetic: <= 8 operations' roundings, each amplified no more than
-          // `mag` grows (2^-53 each; 2^-44 leaves a factor 64 for the composition's own roundings)
-          const double mu = sum_abs * 65536.0 + __builtin_fabs(g) + (double)nbk[k];
-          const double eps = 0.5 * sum_abs * (1.0 + 0x1p-19) + mu * 0x1p-21 +
-                             (form[k].mag + __builtin_fabs(lo[k])) * sc[k] * 0x1p-44;
-          ok = ok && (eps < 0.125);                      // (NaN fails)
-          gf[c][k] = uniform_f((float)g);
-          const float e32 = (float)(eps * 1.01);         // (covers the rounding of this conversion and of 1 - e32)
-          ef[c][k] = uniform_f(e32);
-          omf[c][k] = uniform_f(1.0f - e32);
-        }
-        cok[c] = uniform_i(ok ? 1 : 0) != 0;
-      }
+      // ================================================================ the codes, kRing - 1 units in flight
+      unsigned nrow = 0u, ngran = 0u;                      // entries in the wave's queues (wave-uniform)
 
-      // ---- one row with the reference's arithmetic on its float values (an ambiguous sample)
-      auto exact_one = [&](int c, unsigned row, unsigned offcode) {
-        double f[NSLOT][SXMC_VEC];
+      // ---- a granule left to the float columns: one entry in the wave's queue (there is room: the loop below
+      // empties the queues before a round of the ring could overfill them)
+      const unsigned vwave32 = vfirst32 - lane;
+      auto push_granule = [&](int c, unsigned it, unsigned code) {
+        if (lane == 0) {
+          qgran[2u * ngran] = (vwave32 + it * step32) | ((unsigned)c << 28);
+          qgran[2u * ngran + 1u] = code;
+        }
+        ngran += 1u;
+      };
+      // ---- the ambiguous rows of one granule of one chain (bit q of `rare`: the lane's q-th sample) into the
+      // wave's queue; false: they do not fit
+      auto push_rows = [&](int c, unsigned rare, unsigned v, unsigned offcode) -> bool {
+        unsigned long long mask[SXMC_VEC];
+        unsigned total = 0u;
 #pragma unroll
-        for (int k = 0; k < NSTREAM; k++) {
-          const double x = (double)((gptr<const float>)col[k])[row];
-          f[k][0] = f[k][1] = f[k][2] = f[k][3] = x;
+        for (int q = 0; q < SXMC_VEC; q++) {
+          mask[q] = __builtin_amdgcn_ballot_w64(((rare >> q) & 1u) != 0u);
+          total += (unsigned)__builtin_popcountll(mask[q]);
         }
-        f[ORD][0] = f[ORD][1] = f[ORD][2] = f[ORD][3] = 0.0;
-        run_static_part<NSLOT, ORD, false>(f, craw[c], PROG{}, Seq{});
-        bool ind = true;
-        int bin = (int)offcode;
+        if (nrow + total > rq_cap) return false;
 #pragma unroll
-        for (int k = 0; k < NOBS; k++) {
-          const double x = f[k][0];
-          ind = ind & (x >= lo[k]) & (x < hi[k]);
-          const int idx = (int)((x - lo[k]) * sc[k]);
-          bin = mad24(idx, stv[k], bin);
+        for (int q = 0; q < SXMC_VEC; q++) {
+          if (mask[q] == 0ull) continue;
+          const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask[q] >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask[q], 0u));
+          if ((rare >> q) & 1u) {
+            const unsigned pos = nrow + below;
+            qrows[2u * pos] = v * SXMC_VEC + (unsigned)q;
+            qrows[2u * pos + 1u] = NCHAIN > 1 ? (offcode | ((unsigned)c << 28)) : offcode;
+          }
+          nrow += (unsigned)__builtin_popcountll(mask[q]);
         }
-        vcnt[c] += (ind && !((unsigned)bin < B)) ? 1u : 0u;   // (the others are counted with the histogram)
-        if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
-          __hip_atomic_fetch_add(&hist[(unsigned)c * cstride + myrep + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        return true;
       };
 
-      // ---- one granule of one chain from its codes.  Written for the vector unit's instruction count, which is
-      // what bounds this path: no in-domain counter (the norm is the histogram's sum), no range check of the flat
-      // index (the caller sends granules whose offset could push it past the end down the exact path), the rows
-      // marked "ask the exact columns" / "never counted" found with one test per lane.
+      // ---- one granule of one chain from its codes, general form.  No predication (a sample that is not counted
+      // adds to the lane's spare word, so the lane's four samples are four independent instruction chains), no
+      // in-domain counter (the norm is the histogram's sum), no range check of the flat index (the caller sends
+      // granules whose offset could push it past the end to the float columns), no memory access but the four LDS
+      // additions: ambiguous rows go into the wave's queue.
       const unsigned spare = (unsigned)NCHAIN * cstride + lane;   // (one of the 64 spare words behind the histograms)
-      auto coarse_granule = [&](int c, const vuint4g (&w)[QW], unsigned vunit, unsigned offcode) {
+      auto coarse_granule = [&](int c, const vuint4g (&w)[QW], unsigned it, unsigned v, unsigned offcode,
+                                unsigned code) {
         int base = (int)offcode;
         asm volatile("" : "+v"(base));
         const unsigned cbase = (unsigned)c * cstride + myrep;
-        unsigned rare = 0u;                              // bit q: the lane's q-th sample goes to the exact path
+        unsigned word[SXMC_VEC];
+        unsigned rare = 0u;                              // bit q: the lane's q-th sample is ambiguous
 #pragma unroll
         for (int q = 0; q < SXMC_VEC; q++) {
           float cv[NQ];
 #pragma unroll
           for (int m = 0; m < NQ; m++) {
-            const unsigned word = w[m >> 1][q];
-            cv[m] = (float)((m & 1) ? (word & 0xFFFFu) : (word >> 16));
+            const unsigned cw = w[m >> 1][q];
+            cv[m] = (float)((m & 1) ? (cw & 0xFFFFu) : (cw >> 16));
           }
           bool amb = false, ind = true;
           int bin = base;
@@ -1662,76 +1677,122 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
             ind = ind & ((unsigned)idx < nbk[k]);
             bin = mad24(idx, stv[k], bin);
           }
-          // (no predication: a sample that is not counted adds to the lane's spare word instead, so the four samples
-          // of the lane are four independent instruction chains the vector unit can interleave -- with 3 or 4 waves
-          // per SIMD it is their latency, not their number, that this path waits for)
-          const unsigned word = (ind && !amb && !(dbg & 4u)) ? cbase + lds_slot((unsigned)bin) : spare;
-          __hip_atomic_fetch_add(&hist[word], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          word[q] = (ind && !amb && !(dbg & 4u)) ? cbase + lds_slot((unsigned)bin) : spare;
           rare |= amb ? (1u << q) : 0u;
         }
-        // rows with a special code in the high half of word 0 (their arithmetic above meant nothing: if it counted
-        // them, that is taken back here)
+        // rows with a special code in the high half of word 0: one test per lane
         const unsigned wmax = max(max(w[0][0], w[0][1]), max(w[0][2], w[0][3]));
         const bool special = wmax >= ((unsigned)SXMC_QCODE_EXACT << 16);
-        if (__builtin_amdgcn_ballot_w64(rare != 0u || special) != 0ull) {   // (a few steps in a hundred)
+        if (__builtin_amdgcn_ballot_w64(rare != 0u || special) != 0ull) {   // (one step in seven at config 3)
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) {
-            const bool sp = w[0][q] >= ((unsigned)SXMC_QCODE_EXACT << 16);
-            if (sp && !((rare >> q) & 1u)) {
-              // counted from codes that were no codes: recompute that bin and take the count back
-              float cv[NQ];
-#pragma unroll
-              for (int m = 0; m < NQ; m++) {
-                const unsigned word = w[m >> 1][q];
-                cv[m] = (float)((m & 1) ? (word & 0xFFFFu) : (word >> 16));
-              }
-              bool ind = true;
-              int bin = base;
-#pragma unroll
-              for (int k = 0; k < NOBS; k++) {
-                float u = gf[c][k];
-#pragma unroll
-                for (int m = 0; m < NQ; m++) u = __builtin_fmaf(af[c][k][m], cv[m], u);
-                const int idx = (int)__builtin_floorf(u);
-                ind = ind & ((unsigned)idx < nbk[k]);
-                bin = mad24(idx, stv[k], bin);
-              }
-              if (ind && !(dbg & 4u)) {
-                __hip_atomic_fetch_sub(&hist[cbase + lds_slot((unsigned)bin)], 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-              }
-            }
-            if (!(((rare >> q) & 1u) || sp)) continue;
-            if (w[0][q] >= ((unsigned)SXMC_QCODE_NEVER << 16)) continue;   // not finite: never counted
-            const unsigned row = vunit * SXMC_VEC + (unsigned)q;
-            unsigned slot = qcap;
-            if (qcap != 0u) {
-              slot = __hip_atomic_fetch_add(&qhead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (slot < qcap) {
-              qent[2u * slot] = row;
-              qent[2u * slot + 1u] = NCHAIN > 1 ? (offcode | ((unsigned)c << 28)) : offcode;
-            } else {
-              exact_one(c, row, offcode);                // (queue full, or none: here and now)
+            const unsigned hi16 = w[0][q] >> 16;
+            if (hi16 >= SXMC_QCODE_EXACT) {              // the arithmetic above meant nothing for this row
+              word[q] = spare;
+              rare = hi16 >= SXMC_QCODE_NEVER ? (rare & ~(1u << q)) : (rare | (1u << q));
             }
           }
+          if (!push_rows(c, rare, v, offcode)) {         // more than the queue holds: the whole granule, later
+            push_granule(c, it, code);
+            return;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          __hip_atomic_fetch_add(&hist[word[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+
+      // ---- the same in the padded form of the histogram (`outer`): per sample two conversions, two multiply-adds,
+      // the fraction, two subtractions whose result's SIGN says "ambiguous", a shift that spreads that sign, the
+      // floor as an integer, an OR and a clamp that send ambiguous and out-of-domain samples to the guard rows, one
+      // multiply-add for the LDS address -- 12 vector instructions, no compare, no mask, no select.
+      const float ohalf = uniform_f(0.5f - ef[0][0]);     // (chain 0; the others below)
+      float ohm[NCHAIN];
+#pragma unroll
+      for (int c = 0; c < NCHAIN; c++) ohm[c] = uniform_f(0.5f - ef[c][0]);
+      (void)ohalf;
+      const int oS4 = (int)(4u * oSp);
+      const int oclamp = (dbg & 4u) ? -1 : (int)nbk[0];   // (measurement hook: everything to the guard row)
+      auto coarse_outer = [&](int c, const vuint4g (&w)[QW], unsigned it, unsigned v, unsigned offcode,
+                              unsigned code) {
+        // byte address of (idx = -1, r): the header words, the chain's replica, the granule's offset
+        int base4 = (int)(4u * (4u + (unsigned)c * cstride + myrep + offcode) + 4u * oSp);
+        asm volatile("" : "+v"(base4));
+        int addr[SXMC_VEC];
+        int amb[SXMC_VEC];
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          float cv[NQ];
+#pragma unroll
+          for (int m = 0; m < NQ; m++) {
+            const unsigned cw = w[m >> 1][q];
+            cv[m] = (float)((m & 1) ? (cw & 0xFFFFu) : (cw >> 16));
+          }
+          float u = gf[c][0];
+#pragma unroll
+          for (int m = 0; m < NQ; m++) u = __builtin_fmaf(af[c][0][m], cv[m], u);
+          const float fr = __builtin_amdgcn_fractf(u);
+          const float t = ohm[c] - __builtin_fabsf(fr - 0.5f);      // < 0: closer to a bin edge than eps
+          amb[q] = __builtin_bit_cast(int, t) >> 31;                 // all ones: ambiguous
+          int idx;
+          asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(idx) : "v"(u));
+          int ie;
+          asm("v_med3_i32 %0, %1, -1, %2" : "=v"(ie) : "v"(idx | amb[q]), "s"(oclamp));
+          addr[q] = mad24(ie, oS4, base4);
+        }
+        const unsigned wmax = max(max(w[0][0], w[0][1]), max(w[0][2], w[0][3]));
+        const bool special = wmax >= ((unsigned)SXMC_QCODE_EXACT << 16);
+        const int anyamb = (amb[0] | amb[1]) | (amb[2] | amb[3]);
+        if (__builtin_amdgcn_ballot_w64(anyamb != 0 || special) != 0ull) {   // (one step in seven at config 3)
+          unsigned rare = 0u;
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            rare |= amb[q] ? (1u << q) : 0u;
+            const unsigned hi16 = w[0][q] >> 16;
+            if (hi16 >= SXMC_QCODE_EXACT) {              // the arithmetic above meant nothing for this row
+              addr[q] = base4 - oS4;                     // (the guard row)
+              rare = hi16 >= SXMC_QCODE_NEVER ? (rare & ~(1u << q)) : (rare | (1u << q));
+            }
+          }
+          if (!push_rows(c, rare, v, offcode)) {
+            push_granule(c, it, code);
+            return;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          unsigned* wp = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + addr[q]);
+          __hip_atomic_fetch_add(wp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       };
 
       // largest value the per-sample part can add to a granule's offset: a granule whose offset + span stays below
-      // the histogram's size needs no range check per sample
+      // the histogram's size needs no range check per sample (padded form: the offset must also lie inside a row)
       unsigned span = 0u;
 #pragma unroll
       for (int k = 0; k < NOBS; k++) span += (nbk[k] - 1u) * (unsigned)st[k];
 
-      auto process_unit = [&](unsigned long long it, const vuint4g (&w)[QW], unsigned pre) {
-        const unsigned v = vfirst32 + (unsigned)it * step32;
-        const int j = (int)(it & 63ull);
-        if (j == 0) granule_codes(it);
+      // ---- per block of 64 units: the granules' codes in the ordered observable (granule_codes) and their words
+      unsigned pre64 = 0u;
+      auto granule_words = [&](unsigned it) {
+        unsigned vg = vwave32 + (it + lane) * step32;
+        vg = vg < vlast32 ? vg : vlast32;
+        pre64 = precol[vg >> 6];
+        asm volatile("" : "+v"(pre64));   // (the wait goes here, once per block, not into the inner loop)
+      };
+
+      // (OUTER: compile-time copy of `outer`, so that the stream loop exists once per form, without the other form's
+      // code between its branches; `limit`: a granule whose offset reaches it cannot be binned from codes)
+      const unsigned climit = outer ? oS : (B > span ? B - span : 0u);
+      auto process_unit = [&](auto OUTER, unsigned it, const vuint4g (&w)[QW]) {
+        constexpr bool kOuter = decltype(OUTER)::value != 0;
+        const unsigned v = vfirst32 + it * step32;
+        const int j = (int)(it & 63u);
         unsigned code[NCHAIN];
 #pragma unroll
         for (int c = 0; c < NCHAIN; c++) code[c] = (unsigned)__builtin_amdgcn_readlane((int)codes[c], j);
-        const unsigned prebits = (unsigned)uniform_i((int)pre);
+        const unsigned prebits = (unsigned)__builtin_amdgcn_readlane((int)pre64, j);
         if (dbg & 1u) {
 #pragma unroll
           for (int q = 0; q < QW; q++) sink += (w[q][0] == 12345u) ? 1u : 0u;
@@ -1741,65 +1802,161 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
         const unsigned off = prebits & 0xFFFFFFu;
 #pragma unroll
         for (int c = 0; c < NCHAIN; c++) {
-          if (code[c] == kOrdSkip) continue;          // (wave-uniform) outside the ordered observable's domain
-          const bool mixed = code[c] == kOrdMixed;
-          if (mixed || !cok[c] || !(off + code[c] + span < B)) {
-            // a granule that straddles an edge of the ordered observable, a chain whose coefficients rule the codes
-            // out, an offset from which the flat index could leave the histogram: this once the float columns
-            // are read (loads and waits sit in here, off the common path)
-            const unsigned vc = v < vlast32 ? v : vlast32;
-            vfloat4 rawf[NS], rawo = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < NSTREAM; k++) rawf[k] = __builtin_nontemporal_load(&col[k][vc]);
-            if (mixed) rawo = __builtin_nontemporal_load(&col[ORD][vc]);
-            double f0[NS][SXMC_VEC];
-#pragma unroll
-            for (int k = 0; k < NSTREAM; k++) {
-              f0[k][0] = (double)rawf[k].x;
-              f0[k][1] = (double)rawf[k].y;
-              f0[k][2] = (double)rawf[k].z;
-              f0[k][3] = (double)rawf[k].w;
-            }
-            exact_granule(IntC<0>{}, c, mixed, f0, rawo, off, code[c]);
-          } else {
-            coarse_granule(c, w, v, off + code[c]);
+          const unsigned offcode = off + code[c];
+          if (code[c] < kOrdMixed && offcode < climit) {
+            if constexpr (kOuter) coarse_outer(c, w, it, v, offcode, code[c]);
+            else coarse_granule(c, w, it, v, offcode, code[c]);
+          } else if (code[c] != kOrdSkip) {
+            // a granule that straddles an edge of the ordered observable, or an offset from which the flat index
+            // could leave the histogram (or its row): the float columns decide, after the stream
+            // (kOrdSkip, wave-uniform: outside the ordered observable's domain, nothing to count)
+            push_granule(c, it, code[c]);
           }
+          // (several chains: one after the other, not interleaved -- the registers of one chain's four samples are
+          // all the launch bound of 1024 lanes leaves room for)
+          if constexpr (NCHAIN > 1) __builtin_amdgcn_sched_barrier(0);
         }
       };
 
-      for (unsigned long long it0 = 0; it0 < niter; it0 += 2 * kDepth) {
-        arrive(0);
-        issue(1, it0 + kDepth);
+      // ---- what the queues hold, decided with the reference's arithmetic on the float columns
+      auto drain = [&]() {
+        if (dbg & 16u) nrow = ngran = 0u;                  // (measurement hook: what the queues hold is dropped)
+        // (a memory round trip per batch of rows and per granule, with nothing else of this wave's in flight: the
+        // first granule's loads are issued together with the first rows', so the two share one)
+        vfloat4 rawf[NS], rawo = {0.0f, 0.0f, 0.0f, 0.0f};
+        unsigned prew = 0u, gcode = 0u, gc = 0u;
+        auto load_granule = [&](unsigned g) {
+          const unsigned w0 = (unsigned)uniform_i((int)qgran[2u * g]);
+          gcode = (unsigned)uniform_i((int)qgran[2u * g + 1u]);
+          gc = w0 >> 28;
+          const unsigned vw = w0 & 0x0FFFFFFFu;
+          const unsigned vc = vw + lane < vlast32 ? vw + lane : vlast32;
 #pragma unroll
-        for (int i = 0; i < kDepth; i++) {
-          if (it0 + (unsigned long long)i < niter) process_unit(it0 + (unsigned long long)i, rq[0][i], rp[0][i]);
+          for (int k = 0; k < NSTREAM; k++) rawf[k] = __builtin_nontemporal_load(&col[k][vc]);
+          if (gcode == kOrdMixed) rawo = __builtin_nontemporal_load(&col[ORD][vc]);
+          prew = precol[vc >> 6];
+        };
+        unsigned row = 0u, w1 = 0u;
+        float rowf[NS];
+        const bool myrow = lane < nrow;
+        if (myrow) {
+          row = qrows[2u * lane];
+          w1 = qrows[2u * lane + 1u];
+#pragma unroll
+          for (int k = 0; k < NSTREAM; k++) rowf[k] = ((gptr<const float>)col[k])[row];
         }
-        arrive(1);
-        issue(0, it0 + 2 * kDepth);
+        if (ngran != 0u) load_granule(0u);
+        // ---- rows: one row with the reference's arithmetic on its float values (an ambiguous sample)
+        auto exact_row = [&](int c, unsigned offcode) {
+          double f[NSLOT][SXMC_VEC];
 #pragma unroll
-        for (int i = 0; i < kDepth; i++) {
-          if (it0 + (unsigned long long)(kDepth + i) < niter) {
-            process_unit(it0 + (unsigned long long)(kDepth + i), rq[1][i], rp[1][i]);
+          for (int k = 0; k < NSTREAM; k++) f[k][0] = f[k][1] = f[k][2] = f[k][3] = (double)rowf[k];
+          f[ORD][0] = f[ORD][1] = f[ORD][2] = f[ORD][3] = 0.0;
+          run_static_part<NSLOT, ORD, false>(f, craw[c], PROG{}, Seq{});
+          bool ind = true;
+          int bin = (int)offcode;
+#pragma unroll
+          for (int k = 0; k < NOBS; k++) {
+            const double x = f[k][0];
+            ind = ind & (x >= lo[k]) & (x < hi[k]);
+            const int idx = (int)((x - lo[k]) * sc[k]);
+            bin = mad24(idx, stv[k], bin);
+          }
+          vcnt[c] += (ind && !((unsigned)bin < B)) ? 1u : 0u;   // (the others are counted with the histogram)
+          if (ind && ((unsigned)bin < B) && !(dbg & 4u)) {
+            __hip_atomic_fetch_add(&hist[(unsigned)c * cstride + myrep + codes_word((unsigned)bin)], 1u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        };
+        for (unsigned i0 = 0; i0 < nrow; i0 += kWave) {
+          if (i0 != 0u && i0 + lane < nrow) {              // (further batches: their own round trip)
+            row = qrows[2u * (i0 + lane)];
+            w1 = qrows[2u * (i0 + lane) + 1u];
+#pragma unroll
+            for (int k = 0; k < NSTREAM; k++) rowf[k] = ((gptr<const float>)col[k])[row];
+          }
+          if (i0 + lane < nrow) {
+            const unsigned cc = NCHAIN > 1 ? w1 >> 28 : 0u, oc = NCHAIN > 1 ? (w1 & 0x0FFFFFFFu) : w1;
+#pragma unroll
+            for (int c = 0; c < NCHAIN; c++) {
+              if (cc == (unsigned)c) exact_row(c, oc);
+            }
           }
         }
-      }
-
-      // ---- the ambiguous rows, all lanes at once
-      if (qcap != 0u) {
-        __syncthreads();
-        const unsigned pushed = qhead[0];
-        const unsigned nq = pushed < qcap ? pushed : qcap;
-        for (unsigned i = tid; i < nq; i += nthreads) {
-          const unsigned row = qent[2u * i], w1 = qent[2u * i + 1u];
-          const unsigned cc = NCHAIN > 1 ? w1 >> 28 : 0u, oc = NCHAIN > 1 ? (w1 & 0x0FFFFFFFu) : w1;
+        // ---- whole granules
+        for (unsigned g = 0; g < ngran; g++) {
+          if (g != 0u) load_granule(g);
+          const bool mixed = gcode == kOrdMixed;
+          const unsigned off = (unsigned)uniform_i((int)prew) & 0xFFFFFFu;
+          double f0[NS][SXMC_VEC];
+#pragma unroll
+          for (int k = 0; k < NSTREAM; k++) {
+            f0[k][0] = (double)rawf[k].x;
+            f0[k][1] = (double)rawf[k].y;
+            f0[k][2] = (double)rawf[k].z;
+            f0[k][3] = (double)rawf[k].w;
+          }
 #pragma unroll
           for (int c = 0; c < NCHAIN; c++) {
-            if (cc == (unsigned)c) exact_one(c, row, oc);
+            if (gc == (unsigned)c) exact_granule(IntC<0>{}, c, mixed, f0, rawo, off, gcode);
           }
         }
-        __syncthreads();
-        if (tid == 0) qhead[0] = 0u;
+        nrow = ngran = 0u;
+      };
+
+      // ---- the stream.  The inner loop holds no memory access but the ring's own loads and the LDS additions, so the
+      // wait for a unit is a counted one (the loads of the kRing - 1 younger units stay in flight); it ends at every
+      // 64th unit (the next granules' codes and words: loads and a wait) and when the granule queue could not take
+      // another round (the queues are then emptied: loads and waits too).  A unit's registers are re-loaded right
+      // after it has been worked on.
+      const unsigned niter32 = (unsigned)niter;
+      const unsigned vfirst16 = vfirst32 * 16u, vlast16 = vlast32 * 16u, step16 = step32 * 16u;
+      auto issue = [&](int slot, unsigned it) {
+        unsigned o = vfirst16 + it * step16;               // (it * step16: scalar)
+        o = o < vlast16 ? o : vlast16;
+        if ((dbg & 2u) && it >= (unsigned)kRing) o = vlast16;
+#pragma unroll
+        for (int w = 0; w < QW; w++) {
+          rq[slot][w] = __builtin_nontemporal_load((gptr<const vuint4g>)((gptr<const char>)qcol[w] + (unsigned long long)o));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto stream = [&](auto OUTER) {
+        unsigned it = 0u;
+#pragma unroll
+        for (int i = 0; i < kRing; i++) issue(i, (unsigned)i);
+        while (it < niter32) {
+          if ((it & 63u) == 0u) {
+            granule_codes((unsigned long long)it);
+            granule_words(it);
+          }
+          const unsigned block_end = niter32 < (it | 63u) + 1u ? niter32 : (it | 63u) + 1u;
+          bool full = false;
+          while (it < block_end && !full) {
+#pragma unroll
+            for (int i = 0; i < kRing; i++) {
+#pragma unroll
+              for (int q = 0; q < QW; q++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) asm volatile("" : "+v"(rq[i][q][e]));   // (the wait for this unit goes here)
+              }
+              if (it + (unsigned)i < block_end) process_unit(OUTER, it + (unsigned)i, rq[i]);
+              issue(i, it + (unsigned)(i + kRing));     // (unconditional: the waits above count on it)
+            }
+            // (only the segment's last round can be a partial one: blocks end at multiples of 64)
+            it = block_end - it < (unsigned)kRing ? block_end : it + (unsigned)kRing;
+            full = ngran + (unsigned)(kRing * NCHAIN) > gq_cap;
+          }
+          if (full) drain();
+        }
+      };
+      if constexpr (NOBS == 1) {
+        if (outer) stream(IntC<1>{});
+        else stream(IntC<0>{});
+      } else {
+        stream(IntC<0>{});
       }
+      drain();
     }
 
 #if SXMC_WG_STAMPS
@@ -1830,8 +1987,25 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       const bool more = si + 1u < seg_end;
       const unsigned wend = (B + 63u) & ~63u;
       unsigned total = 0u;
+      if (outer) {
+        // the padded form: word (idx + 1) * S' + r of a replica is bin idx * S + r; the guard rows and the pad word
+        // of each row (r = S, when S is even) are not bins
+        const unsigned nwords = (unsigned)d.nbins[0] * oSp;
+        const float invSp = 1.0f / (float)oSp;
 #pragma unroll 4
-      for (unsigned w = tid; LDS_HIST && w < wend; w += nthreads) {
+        for (unsigned w = tid; w < nwords; w += nthreads) {
+          const unsigned idx = (unsigned)(((float)w + 0.5f) * invSp);   // w / S' (exact: S' * (nbins + 1) < 2^22)
+          const unsigned r = w - idx * oSp;
+          unsigned n = 0u;
+          for (unsigned rep = 0; rep < R; rep++) n += hist[(unsigned)c * cstride + rep * rstride + oSp + w];
+          if (r < oS) {
+            total += n;
+            if (n != 0u) __hip_atomic_fetch_add(&gbins[idx * oS + r], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+#pragma unroll 4
+      for (unsigned w = tid; LDS_HIST && !outer && w < wend; w += nthreads) {
         unsigned n = 0u;
         for (unsigned r = 0; r < R; r++) n += hist[(unsigned)c * cstride + r * rstride + w];
         total += n;

@@ -297,6 +297,8 @@ struct LaunchClass {
   bool runs_mode = false;  // bucketed tables laid out in per-wave runs; the sparse flavour runs fill_sparse_kernel
   int teams = 1;           // teams of workgroups per member over a bucketed table (sxplan::interleaved_segments)
   bool codes = false;      // ordered tables: the streamed columns go as 16-bit codes (fill_ordered_body's CODES)
+  unsigned padded_rstride = 0;  // ... with the LDS histogram in the padded form: words between its replicas (0: not)
+  unsigned plain_rstride = 0;   // ordered tables: words between the replicas of the LDS histogram in its swizzled form
 };
 
 void free_class(LaunchClass& c) {
@@ -754,20 +756,28 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   return SXMC_OK;
 }
 
+// ... in the padded form the codes path uses when ONE observable is binned per sample and it is the histogram's
+// outermost dimension (fill_ordered_body, `outer`): (nbins + 2) rows of S' words, S' = S | 1, a guard row either side
+unsigned ordered_rstride_padded(int total_bins, int outer_bins) {
+  const unsigned S = (unsigned)(total_bins / outer_bins), Sp = S | 1u;
+  const unsigned words = ((unsigned)outer_bins + 2u) * Sp;
+  return ((words + 63u) & ~63u) + 16u;
+}
 // LDS of fill_ordered_body's queue of ambiguous rows: 4 header words + 2 words per entry
 size_t ordered_queue_bytes(unsigned qlog) { return qlog ? (4 + ((size_t)2 << qlog)) * 4 : 0; }
-// the largest queue (<= 2048 entries, >= 64) that fits `room` bytes, as log2(entries); 0: none
+// the largest set of queues (512 .. 2048 entries: every wave of the workgroup owns an equal slice) that fits `room`
+// bytes, as log2(entries); 0: none, the launch then streams the float columns
+constexpr unsigned kMinQueueLog = 9;
 unsigned ordered_queue_log(size_t room) {
   unsigned qlog = 11;
-  // (test hook, read whenever a plan is built: SXMC_CODES_QUEUE_LOG = 6 .. 11 caps the queue, 0 = no queue at all --
-  // every ambiguous row is then decided where it is met; the results do not depend on it)
+  // (test hook, read whenever a plan is built: SXMC_CODES_QUEUE_LOG = 9 .. 11 caps the queues, so that they fill up and
+  // are emptied in the middle of the stream, and whole granules are handed to the float columns; the results do not
+  // depend on it)
   if (const char* e = std::getenv("SXMC_CODES_QUEUE_LOG")) {
-    const int v = std::atoi(e);
-    if (v <= 0) return 0;
-    qlog = (unsigned)std::min(std::max(v, 6), 11);
+    qlog = (unsigned)std::min(std::max(std::atoi(e), (int)kMinQueueLog), 11);
   }
-  while (qlog >= 6 && ordered_queue_bytes(qlog) > room) qlog--;
-  return qlog >= 6 ? qlog : 0;
+  while (qlog >= kMinQueueLog && ordered_queue_bytes(qlog) > room) qlog--;
+  return qlog >= kMinQueueLog ? qlog : 0;
 }
 
 // The evaluator's event bins grouped by the buckets of a sort (fill_sparse_kernel): per bucket key an
@@ -1288,13 +1298,40 @@ int group_rebuild(sxmc_group* g) {
       // replicas of the LDS histogram (fill_ordered_body): as many as the workgroup's share of LDS holds, up to 4
       unsigned rlog = 0;
       const size_t share = (size_t)props.lds_per_cu / (size_t)std::max(1, bpc);
-      while (rlog < 2 && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) <= share) rlog++;
+      const size_t qreserve = c.codes ? ordered_queue_bytes(kMinQueueLog) : 0;   // (room for the smallest queues)
+      while (rlog < 2 && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) + qreserve <= share) rlog++;
       c.shape.lds_layout = ordered_rstride(cls_max_bins) | (rlog << 24);
       c.shape.lds_bytes = ordered_lds_bytes(cls_max_bins, 1, rlog);
-      if (c.codes) {   // the queue of ambiguous rows, in what the replicas leave of the workgroup's share
+      c.plain_rstride = ordered_rstride(cls_max_bins);
+      if (c.codes) {
+        // the padded form of the histogram where every member qualifies (one observable binned per sample, the
+        // outermost dimension) and it fits with room for the smallest queue; then the queues of ambiguous rows, in
+        // what the replicas leave of the workgroup's share
+        c.padded_rstride = 0;
+        if (c.shape.nobs == 1) {
+          unsigned rs = 0;
+          bool all = true;
+          for (size_t q = 0; q < c.member_idx.size(); q++) {
+            const sxmc_hist* h = g->members[(size_t)c.member_idx[q]];
+            const long long S = descs[q].bin_stride[0], nb = descs[q].nbins[0];   // (slot 0 of the compacted problem)
+            all = all && S >= 1 && nb >= 1 && S * nb == (long long)h->total_nbins && S * (nb + 2) < (1ll << 22);
+            if (all) rs = std::max(rs, ordered_rstride_padded(h->total_nbins, (int)nb));
+          }
+          if (all && rs) {
+            unsigned prl = 0;
+            auto bytes = [&](unsigned rl) { return (4 + ((size_t)rs << rl) + 64) * 4 + ordered_queue_bytes(kMinQueueLog); };
+            if (bytes(0) <= share) {
+              while (prl < 2 && bytes(prl + 1) <= share) prl++;
+              c.padded_rstride = rs;
+              c.shape.lds_layout = rs | (prl << 24) | (1u << 27);
+              c.shape.lds_bytes = (4 + ((size_t)rs << prl) + 64) * 4;
+            }
+          }
+        }
         const unsigned qlog = share > c.shape.lds_bytes ? ordered_queue_log(share - c.shape.lds_bytes) : 0;
         c.shape.lds_layout |= qlog << 28;
         c.shape.lds_bytes += ordered_queue_bytes(qlog);
+        if (!qlog) c.codes = false;   // (no room for queues: the kernel streams the float columns)
       }
     }
     unsigned long long grid = (unsigned long long)props.cus * bpc;
@@ -3136,12 +3173,20 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
     size_t lds = (4 + C * hist_words + 64) * 4;
     if (c0.shape.pre_width == 5) {
       // ordered fill: the kernel argument is the replica layout; as many replicas as fit beside the other chains'
-      const size_t rstride = c0.shape.lds_layout & 0xFFFFFFu;
+      // (codes: the padded form of the histograms if the chains' histograms fit that way with the smallest queues)
+      size_t rstride = c0.plain_rstride;
+      bool padded = false;
+      if (c0.codes && c0.padded_rstride &&
+          (4 + C * (size_t)c0.padded_rstride + 64) * 4 + ordered_queue_bytes(kMinQueueLog) <= (size_t)props.lds_per_cu) {
+        rstride = c0.padded_rstride;
+        padded = true;
+      }
+      const size_t reserve = c0.codes ? ordered_queue_bytes(kMinQueueLog) : 0;
       unsigned rlog = 0;
-      while (rlog < 2 && (4 + (C * rstride << (rlog + 1)) + 64) * 4 <= (size_t)props.lds_per_cu) rlog++;
+      while (rlog < 2 && (4 + (C * rstride << (rlog + 1)) + 64) * 4 + reserve <= (size_t)props.lds_per_cu) rlog++;
       lds = (4 + (C * rstride << rlog) + 64) * 4;
-      hist_words = rstride | ((size_t)rlog << 24);
-      if (c0.codes) {   // the queue of ambiguous rows (fill_ordered_body's CODES), shared by the chains
+      hist_words = rstride | ((size_t)rlog << 24) | (padded ? (size_t)1 << 27 : 0);
+      if (c0.codes) {   // the queues of ambiguous rows (fill_ordered_body's CODES), shared by the chains
         const unsigned qlog = (size_t)props.lds_per_cu > lds ? ordered_queue_log((size_t)props.lds_per_cu - lds) : 0;
         lds += ordered_queue_bytes(qlog);
         hist_words |= (size_t)qlog << 28;

@@ -204,7 +204,7 @@ def test_codes_with_large_and_wild_parameters():
     group.close()
 
 
-@pytest.mark.parametrize("queue_log", ["6", "0"])
+@pytest.mark.parametrize("queue_log", ["9", "10"])
 def test_codes_queue_overflow(queue_log, monkeypatch):
     """A queue of 64 ambiguous rows per workgroup, and none at all: the rows that do not fit are decided where they
     are met; the counts do not change."""
