@@ -257,6 +257,8 @@ class Leg:
         m.group.SetPrebinning(not args.no_prebin)
         m.group.SetBucketing(not args.no_bucket)
         m.group.SetOrdering(not args.no_order)
+        if args.no_codes:
+            m.group.SetCodes(False)
         m.group.SetTailKernel(not args.no_tail)
         m.group.SetRuntimeKernels(not args.no_rtc)
         m.group.SetSparse(not args.no_sparse)
@@ -436,6 +438,7 @@ class Leg:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else "") +
                                        ("_no_order" if args.no_order and not args.no_bucket else "") +
+                                       ("_no_codes" if args.no_codes and not (args.no_order or args.no_bucket) else "") +
                                        ("_lookahead" if self.la is not None else ""))
             if args.extra_ctscale or args.no_sparse:
                 t = None
@@ -844,7 +847,7 @@ def parse_args(argv=None):
     ap.add_argument("--exp-concurrent", type=int, default=4,
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
-                    help="sub-records measured after the headline: comma list of c3_lookahead, c3_lut_materialized, c2, c5, "
+                    help="sub-records measured after the headline: comma list of c3_float_stream, c3_lookahead, c3_lut_materialized, c2, c5, "
                          "c2_float_columns, bench_pdfz, bench_pdfz_group, cpp_host, c3_dropin, c3_1e5_walk, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
                          "GPU, cpp_multi_gpu (sxmc::ensemble_multi_gpu over the same cards) at N > 1; none = skip")
     ap.add_argument("--also-steps", type=int, default=200, help="timed steps of each sub-record (C5: a quarter)")
@@ -867,6 +870,9 @@ def parse_args(argv=None):
                          "HBM-bound one the roofline figures are about")
     ap.add_argument("--no-order", action="store_true",
                     help="bucketed tables without the ordered observable (every written observable is streamed)")
+    ap.add_argument("--no-codes", action="store_true",
+                    help="ordered tables streamed as float columns (8 B/sample at config 3) instead of 16-bit codes with an "
+                         "exact recheck of the samples near a bin edge (4 B/sample); the sub-record c3_float_stream")
     ap.add_argument("--no-bucket", action="store_true",
                     help="stream the table in the caller's row order (no copy grouped by the untouched observables' bins)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
@@ -1075,6 +1081,7 @@ def main():
     cfg.update({
         "prewarm_steps": args.prewarm, "debug_mode": args.debug_mode, "partition": args.partition,
         "prebinning": not args.no_prebin, "bucketing": not args.no_bucket, "ordering": not (args.no_order or args.no_bucket),
+        "codes": not (args.no_codes or args.no_order or args.no_bucket),
         "launch": args.launch,
         "sharding": "experiment-per-rank replicas, no data-path collective; RCCL all_gather of intervals at end",
         "samples_per_sec": value * w.nsamples_total,
@@ -1123,7 +1130,8 @@ def main():
         full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and not args.debug_mode
         also = "none"
         if full_c3 and want_cpu and args.form == "graph" and world == 1:
-            also = "c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,bench_pdfz,bench_pdfz_group,cpp_host,c3_dropin,c3_1e5_walk"
+            also = ("c3_float_stream,c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,bench_pdfz,bench_pdfz_group,"
+                    "cpp_host,c3_dropin,c3_1e5_walk")
         elif full_c3 and args.form == "graph" and world > 1:
             also = "cpp_multi_gpu"        # the C++ one-process runner over the same N cards
     if world > 1:
@@ -1145,6 +1153,9 @@ def main():
             if name == "c3_lookahead":            # the same walk taken one or two steps per pass (two evaluations per pass)
                 recs[name] = also_record(args, torch, dev, "c3", "graph", False, 3 * args.also_steps, 20, exp_seed, "all",
                                          lookahead=True)
+            elif name == "c3_float_stream":       # the headline's walk with the ordered table's FLOAT columns streamed
+                recs[name] = also_record(args, torch, dev, "c3", "graph", False, args.also_steps, 20, exp_seed, "all",
+                                         overrides={"no_codes": True})
             elif name == "c3_lut_materialized":
                 recs[name] = also_record(args, torch, dev, "c3", "graph", True, args.also_steps, 20, exp_seed, "all")
             elif name == "c2":
