@@ -703,7 +703,12 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   if (b->codes_tried) return SXMC_OK;
   b->codes_tried = true;
   const int nq = (int)b->fields.size() - 1;
-  if (nq < 2 || nq > SXMC_MAX_QSLOTS || b->ngranules == 0 || !b->sort || b->sort->ordered < 0) return SXMC_OK;
+  // (below 2^22 granules a unit's byte offset into a column of codes fits 32 bits, and a unit number 28: what the
+  // kernel's addressing and its queue entries assume)
+  if (nq < 2 || nq > SXMC_MAX_QSLOTS || b->ngranules == 0 || b->ngranules >= ((size_t)1 << 22) || !b->sort ||
+      b->sort->ordered < 0) {
+    return SXMC_OK;
+  }
   const unsigned long long n = (unsigned long long)b->ngranules * 256ull;
   float mm[2 * SXMC_MAX_NFIELDS];
   SX_HIP(sx_column_minmax(b->d_cols, b->pitch, nq, n, mm, nullptr));

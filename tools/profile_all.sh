@@ -10,6 +10,7 @@ if [ "$2" = "c5" ]; then
   exit 0
 fi
 bash tools/profile_on_gpu.sh ${P}_c3 --also none --experiments 0 || exit 1
+bash tools/profile_on_gpu.sh ${P}_c3_no_codes --no-codes --also none --experiments 0 || exit 7
 bash tools/profile_on_gpu.sh ${P}_c3_lookahead --lookahead --also none --experiments 0 || exit 2
 bash tools/profile_on_gpu.sh ${P}_c3_no_order --no-order --also none --experiments 0 || exit 3
 bash tools/profile_on_gpu.sh ${P}_c2 --workload c2 --also none --experiments 0 || exit 4
