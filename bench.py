@@ -677,7 +677,8 @@ def cpp_host_records(args, want, lut_materialized_value=None, nsteps=4000):
     argv = ["--scale", "1.0", "--graph-steps", args.graph_steps, "--walks", ",".join(walks), "--burnin", "0.1",
             "--sync-interval", "10000"]
     if "cpp_host" in want:
-        argv += ["--experiments", 16, "--exp-steps", 2000, "--chains", 4, "--sets", 2]
+        # (a fill per chain, 8 experiments in flight: over codes the lockstep passes no longer pay)
+        argv += ["--experiments", 16, "--exp-steps", 2000, "--chains", 1, "--sets", 8]
     lines, failure = run_bench_cpp(argv, 420)
     if failure:
         return {name: dict(failure) for name in want}
@@ -688,9 +689,9 @@ def cpp_host_records(args, want, lut_materialized_value=None, nsteps=4000):
     out = {}
     if "cpp_host" in want:
         rec = dict(by_walk[("lookahead", nsteps)])
-        ens = [ln for ln in lines if "ensemble_lockstep" in ln.get("driver", "")]
+        ens = [ln for ln in lines if "ensemble_" in ln.get("driver", "")]
         if ens:
-            rec["ensemble_lockstep"] = ens[0]     # 16 whole fake experiments as 2 lockstep sets of 4 chains: two per lane
+            rec["ensemble"] = ens[0]              # 16 whole fake experiments, 8 in flight with a fill each: two per lane
         rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
         rec["note"] = "whole walk of %d steps including set-up, re-tuning and flushes; host = C++ only" % nsteps
         out["cpp_host"] = rec
@@ -757,7 +758,8 @@ def pdfz_record(args, torch, dev, name, exp_seed):
 
 def cpp_multi_gpu_record(args, ngpus, collective):
     """BASELINE config 4's shape from the C++ host layer, ONE process: sxmc::ensemble_multi_gpu -- a host thread per
-    GPU with its own replica of the evaluators, experiment k on device k mod G in lockstep sets, ONE RCCL all-gather
+    GPU with its own replica of the evaluators, experiment k on device k mod G, eight in flight per card with a fill
+    each (over codes the lockstep passes no longer pay), ONE RCCL all-gather
     of the intervals (sxmc_comm_allgather_f32) -- over the full-size C3 tables.  Run by rank 0 after the Python
     ranks have finished and released their cards.  In a rehearsal (ranks sharing a card over gloo) the device threads
     run on the same cards as the ranks did and their blocks meet through host memory: RCCL refuses two ranks on one
@@ -767,7 +769,7 @@ def cpp_multi_gpu_record(args, ngpus, collective):
     devices = ",".join(str(d["device_index"]) for d in collective["devices"])
     extra = [] if collective["backend"] == "nccl" else ["--host-staging"]
     argv = ["--scale", args.scale, "--no-walk", "--graph-steps", args.graph_steps, "--experiments", nexp,
-            "--exp-steps", args.exp_steps, "--chains", 4, "--sets", 2, "--device-list", devices] + extra
+            "--exp-steps", args.exp_steps, "--chains", 1, "--sets", 8, "--device-list", devices] + extra
     # Measured with one set-up lock PER CARD (graph recording stays exclusive for the process: MultiGpuOptions::
     # PER_DEVICE) -- with ONE lock for the process, the library's default until a run on more than one card is on
     # record, the cards' set-ups take turns and the runner's rate says more about the lock than about the cards.  Should

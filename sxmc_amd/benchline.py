@@ -164,7 +164,7 @@ def compact_also(rec):
     cpu = rec.get("cpu_baseline")
     if isinstance(cpu, dict):
         out["cpu_evals_per_sec"] = _num(cpu.get("value"))
-    for sub in ("ensemble_lockstep", "sequential", "lookahead_walk"):
+    for sub in ("ensemble", "ensemble_lockstep", "sequential", "lookahead_walk"):
         if isinstance(rec.get(sub), dict):
             out[sub] = {k: _num(v) for k, v in rec[sub].items()
                         if k in ("experiments", "steps_each", "chains_per_fill", "sets", "seconds", "experiments_per_sec",

@@ -712,39 +712,11 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   const unsigned long long n = (unsigned long long)b->ngranules * 256ull;
   float mm[2 * SXMC_MAX_NFIELDS];
   SX_HIP(sx_column_minmax(b->d_cols, b->pitch, nq, n, mm, nullptr));
-  double ulo = 0, uhi = -1;   // union of the observables' windows
+  sxplan::CodeWindows cw;   // (sxmc_plan.h: pure, tested without a device)
+  sxplan::code_windows(mm, nq, cd.nobs, cd.lower, cd.upper, cw);
   for (int m = 0; m < nq; m++) {
-    double wlo = mm[2 * m], whi = mm[2 * m + 1];
-    const bool none = !(wlo <= whi);
-    if (m < cd.nobs) {
-      const double lo = cd.lower[m], hi = cd.upper[m], w = hi - lo;
-      wlo = none ? lo - w : std::max(wlo, lo - w);
-      whi = none ? hi + w : std::min(whi, hi + w);
-      if (!(wlo < whi)) {   // (no finite value near the domain)
-        wlo = lo - w;
-        whi = hi + w;
-      }
-      if (uhi < ulo) {
-        ulo = wlo;
-        uhi = whi;
-      } else {
-        ulo = std::min(ulo, wlo);
-        uhi = std::max(uhi, whi);
-      }
-    } else if (none) {
-      wlo = 0;
-      whi = 1;
-    } else if (ulo <= uhi) {
-      const double w = uhi - ulo, clo = std::max(wlo, ulo - 3 * w), chi = std::min(whi, uhi + 3 * w);
-      if (clo < chi) {
-        wlo = clo;
-        whi = chi;
-      }
-    }
-    double step = (whi - wlo) / 65532.0;   // (the largest value lands in code 65532 of 0 .. 65533)
-    if (!(step > 0) || !std::isfinite(step)) step = std::max(std::fabs(wlo), 1.0) * 0x1p-20;
-    b->qbase[m] = wlo;
-    b->qstep[m] = step;
+    b->qbase[m] = cw.base[(size_t)m];
+    b->qstep[m] = cw.step[(size_t)m];
   }
   SX_HIP(hipMalloc((void**)&b->d_qcol, sizeof(unsigned) * b->pitch * (size_t)((nq + 1) / 2)));
   unsigned long long tally[2] = {0, 0};
@@ -761,15 +733,8 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   return SXMC_OK;
 }
 
-// ... in the padded form the codes path uses when ONE observable is binned per sample and it is the histogram's
-// outermost dimension (fill_ordered_body, `outer`): (nbins + 2) rows of S' words, S' = S | 1, a guard row either side
-unsigned ordered_rstride_padded(int total_bins, int outer_bins) {
-  const unsigned S = (unsigned)(total_bins / outer_bins), Sp = S | 1u;
-  const unsigned words = ((unsigned)outer_bins + 2u) * Sp;
-  return ((words + 63u) & ~63u) + 16u;
-}
-// LDS of fill_ordered_body's queue of ambiguous rows: 4 header words + 2 words per entry
-size_t ordered_queue_bytes(unsigned qlog) { return qlog ? (4 + ((size_t)2 << qlog)) * 4 : 0; }
+using sxplan::ordered_rstride_padded;
+using sxplan::ordered_queue_bytes;
 // the largest set of queues (512 .. 2048 entries: every wave of the workgroup owns an equal slice) that fits `room`
 // bytes, as log2(entries); 0: none, the launch then streams the float columns
 constexpr unsigned kMinQueueLog = 9;

@@ -440,4 +440,66 @@ inline void event_classes(const std::vector<const std::vector<int>*>& arr, size_
     for (size_t k = 0; k < o.K; k++) o.tables[j * o.K + k] = (*arr[j])[o.first[k]];
 }
 
+// CODES (fill_ordered_body): the window [base, base + 65532 step] of every streamed field of an ordered table, from the
+// fields' finite ranges in the table (minmax[2m], minmax[2m + 1]; min > max: no finite value) and the domains of the
+// observables among them (fields 0 .. nobs-1).  An observable's window is its finite range cut to its domain widened by
+// its own width on either side -- a value further out needs a scale or shift of the order of the whole domain to come
+// back in, and its row is marked "ask the exact columns" instead; a field that is only read gets its finite range, cut
+// to three widths of the observables' windows around them when the two overlap at all.  step > 0 and finite, always.
+struct CodeWindows {
+  std::vector<double> base, step;
+};
+inline void code_windows(const float* minmax, int nfields, int nobs, const double* lower, const double* upper,
+                         CodeWindows& o) {
+  o.base.assign((size_t)nfields, 0.0);
+  o.step.assign((size_t)nfields, 1.0);
+  double ulo = 0, uhi = -1;   // union of the observables' windows
+  for (int m = 0; m < nfields; m++) {
+    double wlo = minmax[2 * m], whi = minmax[2 * m + 1];
+    const bool none = !(wlo <= whi);
+    if (m < nobs) {
+      const double lo = lower[m], hi = upper[m], w = hi - lo;
+      wlo = none ? lo - w : std::max(wlo, lo - w);
+      whi = none ? hi + w : std::min(whi, hi + w);
+      if (!(wlo < whi)) {   // (no finite value near the domain)
+        wlo = lo - w;
+        whi = hi + w;
+      }
+      if (uhi < ulo) {
+        ulo = wlo;
+        uhi = whi;
+      } else {
+        ulo = std::min(ulo, wlo);
+        uhi = std::max(uhi, whi);
+      }
+    } else if (none) {
+      wlo = 0;
+      whi = 1;
+    } else if (ulo <= uhi) {
+      const double w = uhi - ulo, clo = std::max(wlo, ulo - 3 * w), chi = std::min(whi, uhi + 3 * w);
+      if (clo < chi) {
+        wlo = clo;
+        whi = chi;
+      }
+    }
+    double step = (whi - wlo) / 65532.0;   // (the largest value lands in code 65532 of 0 .. 65533)
+    if (!(step > 0) || !std::isfinite(step)) step = std::max(std::fabs(wlo), 1.0) * 0x1p-20;
+    o.base[(size_t)m] = wlo;
+    o.step[(size_t)m] = step;
+  }
+}
+
+// LDS of fill_ordered_body (histograms in LDS): 4 header words, per chain 2^rlog replicas `rstride` words apart, 64
+// spare words, then the queues of the codes path: 4 words + 2 per entry, (1 << qlog) entries shared out over the waves.
+inline unsigned ordered_rstride_plain(int max_bins) { return (((unsigned)max_bins + 63u) & ~63u) + 16u; }
+// ... in the padded form the codes path uses when ONE observable is binned per sample and it is the histogram's
+// outermost dimension: (nbins + 2) rows of S' words, S' = S | 1 (odd: lanes that differ in the index hit different
+// banks), a guard row either side; + 16 mod 64 like the plain form (a bin's replicas in different banks)
+inline unsigned ordered_rstride_padded(int total_bins, int outer_bins) {
+  const unsigned S = (unsigned)(total_bins / outer_bins), Sp = S | 1u;
+  const unsigned words = ((unsigned)outer_bins + 2u) * Sp;
+  return ((words + 63u) & ~63u) + 16u;
+}
+inline size_t ordered_queue_bytes(unsigned qlog) { return qlog ? (4 + ((size_t)2 << qlog)) * 4 : 0; }
+
 }  // namespace sxplan

@@ -355,21 +355,29 @@ static int run(int argc, char** argv) {
       for (sxmc::Signal& sg : signals) sg.nexpected = 8000.0;   // ~1e5 events per fake data set
     for (int pass = 0; pass < 2; pass++) {   // pass 0 (one round) compiles the lockstep kernel and warms up
       std::vector<unsigned> part(ks.begin(),
-                                 pass == 0 ? ks.begin() + std::min<size_t>(ks.size(), opt.L * opt.S) : ks.end());
+                                 pass == 0 ? ks.begin() + std::min<size_t>(ks.size(), std::max(1u, opt.L) * opt.S) : ks.end());
       sxmc::SetupLock lock;
       const auto t0 = std::chrono::steady_clock::now();
-      std::vector<sxmc::ExperimentResult> res = sxmc::ensemble_lockstep(
-          part, base_seed, sources, signals, systematics, observables, pass == 0 ? std::min(300u, opt.esteps) : opt.esteps,
-          burnin, opt.L, opt.S, cl, opt.esteps, opt.graph_steps, -1, &lock, error_type);
+      // --chains 1: a fill per chain, --sets experiments in flight (ensemble_concurrent) -- the faster form where the
+      // fill streams codes; --chains 2..4: lockstep sets, one pass over the tables per step for the chains of a set
+      const unsigned esteps_now = pass == 0 ? std::min(300u, opt.esteps) : opt.esteps;
+      std::vector<sxmc::ExperimentResult> res =
+          opt.L < 2 ? sxmc::ensemble_concurrent(part, base_seed, sources, signals, systematics, observables, esteps_now,
+                                                burnin, std::max(1u, opt.S), cl, opt.esteps, opt.graph_steps, -1, &lock,
+                                                error_type)
+                    : sxmc::ensemble_lockstep(part, base_seed, sources, signals, systematics, observables, esteps_now,
+                                              burnin, opt.L, opt.S, cl, opt.esteps, opt.graph_steps, -1, &lock,
+                                              error_type);
       const double sec = seconds_since(t0);
       if (pass == 1) {
-        std::printf("{\"driver\": \"sxmc::ensemble_lockstep (C++)\", \"experiments\": %zu, \"steps_each\": %u, "
+        std::printf("{\"driver\": \"sxmc::%s (C++)\", \"experiments\": %zu, \"steps_each\": %u, "
                     "\"chains_per_fill\": %u, \"sets\": %u, \"seconds\": %.4f, \"experiments_per_sec\": %.4f, "
                     "\"steps_per_sec_inside\": %.1f, \"nevents_first\": %zu, "
                     "\"phase_seconds_summed_over_experiments\": %s, "
                     "\"setup_lock\": {\"waited_seconds_summed_over_lanes\": %.4f, \"held_seconds\": %.4f, "
                     "\"acquisitions\": %llu, \"lanes\": %u}}\n",
-                    res.size(), opt.esteps, opt.L, opt.S, sec, res.size() / sec, res.size() * (double)opt.esteps / sec,
+                    opt.L < 2 ? "ensemble_concurrent" : "ensemble_lockstep", res.size(), opt.esteps, opt.L, opt.S, sec,
+                    res.size() / sec, res.size() * (double)opt.esteps / sec,
                     res.empty() ? (size_t)0 : res[0].nevents, phases_json(res).c_str(), lock.waited_seconds(),
                     lock.held_seconds(), lock.count(),
                     opt.L * opt.S);
@@ -393,9 +401,9 @@ static int run(int argc, char** argv) {
     mo.cl = cl;
     mo.sync_interval = opt.esteps;
     mo.graph_steps = opt.graph_steps;
-    mo.lockstep_chains = opt.L;
+    mo.lockstep_chains = opt.L;      // (< 2: ensemble_concurrent with --sets experiments in flight per device)
     mo.lockstep_sets = opt.S;
-    mo.nconcurrent = std::max(1u, opt.L * opt.S);
+    mo.nconcurrent = opt.L < 2 ? std::max(1u, opt.S) : std::max(1u, opt.L * opt.S);
     mo.error_type = error_type;
     if (opt.host_staging) mo.exchange = sxmc::MultiGpuOptions::HOST_STAGING;
     if (opt.per_device_locks) mo.locking = sxmc::MultiGpuOptions::PER_DEVICE;

@@ -4,6 +4,7 @@
 // then walked exactly as the kernels walk them (same hashes, same probe sequences, same loop bounds), checking that
 // nothing is missed, counted twice or addressed out of range.  Plain g++; run by tests/test_plan_cpu.py in a plain
 // build and under AddressSanitizer + UndefinedBehaviorSanitizer.  No HIP header, no device.
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -428,6 +429,91 @@ TEST(Plan, EventClassesKeepTheSumOverEvents) {
     }
     EXPECT_EQ(E, total);
     EXPECT_TRUE(by_event == by_class);
+  }
+}
+
+// CODES: the windows the table's 16-bit codes are taken in, and the LDS arithmetic of the padded histogram -- what
+// column_codes_kernel and fill_ordered_body assume of them.
+TEST(Plan, CodeWindowsHoldEveryValueTheyClaimAndTheirStepsArePositive) {
+  Rng r(11);
+  for (int trial = 0; trial < 400; trial++) {
+    const int nfields = 2 + (int)r.below(3), nobs = 1 + (int)r.below((uint64_t)nfields - 1);
+    std::vector<double> lo((size_t)nobs), hi((size_t)nobs);
+    std::vector<float> mm(2 * (size_t)nfields);
+    for (int k = 0; k < nobs; k++) {
+      lo[(size_t)k] = (r.uni() - 0.5) * (r.below(3) ? 20.0 : 2e6);
+      hi[(size_t)k] = lo[(size_t)k] + (r.below(4) ? 1.0 + 9.0 * r.uni() : 1e-3);
+    }
+    for (int m = 0; m < nfields; m++) {
+      const int kind = (int)r.below(6);
+      const double c = m < nobs ? lo[(size_t)m] : lo[0], w = m < nobs ? hi[(size_t)m] - lo[(size_t)m] : hi[0] - lo[0];
+      double a = c - w * r.uni(), b = c + w * (1 + r.uni());
+      if (kind == 0) { a = 1; b = -1; }                       // no finite value at all
+      if (kind == 1) { a = b = c + 0.3 * w; }                 // one value
+      if (kind == 2) { a = -3e38; b = 3e38; }                 // outliers at the ends of the float range
+      if (kind == 3) { a = c + 50 * w; b = c + 60 * w; }      // everything far from the domain
+      mm[2 * (size_t)m] = (float)a;
+      mm[2 * (size_t)m + 1] = (float)b;
+    }
+    sxplan::CodeWindows cw;
+    sxplan::code_windows(mm.data(), nfields, nobs, lo.data(), hi.data(), cw);
+    EXPECT_EQ((size_t)nfields, cw.base.size());
+    for (int m = 0; m < nfields; m++) {
+      const double base = cw.base[(size_t)m], step = cw.step[(size_t)m];
+      EXPECT_TRUE(step > 0 && std::isfinite(step) && std::isfinite(base));
+      const double top = base + 65532.0 * step;
+      EXPECT_TRUE(std::isfinite(top));
+      // the kernel's bound on a field's magnitude inside the window is finite
+      EXPECT_TRUE(std::isfinite(std::max(std::fabs(base), std::fabs(base + 65534.0 * step))));
+      if (m < nobs) {
+        // an observable's window never reaches further than one domain width beyond the domain ...
+        const double w = hi[(size_t)m] - lo[(size_t)m];
+        EXPECT_TRUE(base >= lo[(size_t)m] - w * (1 + 1e-12) && top <= hi[(size_t)m] + w * (1 + 1e-9));
+        // ... and holds every finite value of the table inside that reach: code = floor((x - base) / step) <= 65533
+        const double a = mm[2 * (size_t)m], b = mm[2 * (size_t)m + 1];
+        if (a <= b) {
+          const double x0 = std::max(a, lo[(size_t)m] - w), x1 = std::min(b, hi[(size_t)m] + w);
+          if (x0 <= x1) {
+            EXPECT_TRUE((x0 - base) / step >= 0.0 && (x1 - base) / step < 65534.0);
+          }
+        }
+      }
+    }
+  }
+}
+
+TEST(Plan, PaddedHistogramRowsDoNotOverlapAndFitTheirReplica) {
+  // fill_ordered_body, `outer`: bin idx * S + r lives in word (idx + 1) * S' + r, S' = S | 1; rows -1 and nbins are
+  // guard rows; the flush walks words S' .. (nbins + 1) * S' - 1 and skips the pad word r = S of every row
+  Rng r(13);
+  for (int trial = 0; trial < 300; trial++) {
+    const int nb = 1 + (int)r.below(200), S = 1 + (int)r.below(trial % 3 ? 500 : 40000 / nb);
+    const int B = nb * S;
+    if (B > 40832) continue;
+    const unsigned Sp = (unsigned)S | 1u, rs = sxplan::ordered_rstride_padded(B, nb);
+    EXPECT_TRUE(Sp >= (unsigned)S && (Sp & 1u) == 1u);
+    EXPECT_TRUE(rs >= ((unsigned)nb + 2u) * Sp && rs % 64u == 16u);
+    std::set<unsigned> words;
+    for (int idx = -1; idx <= nb; idx++) {
+      for (int rr = 0; rr < S; rr += 1 + (int)r.below(7)) {
+        const unsigned w = (unsigned)(idx + 1) * Sp + (unsigned)rr;
+        EXPECT_TRUE(w < rs);
+        EXPECT_TRUE(words.insert(w).second);              // no two (idx, r) share a word
+        if (idx >= 0 && idx < nb) {
+          // the flush's way back: idx = (w - S') / S' with a single-precision reciprocal, r = the rest
+          const unsigned wf = w - Sp;
+          const unsigned q = (unsigned)(((float)wf + 0.5f) * (1.0f / (float)Sp));
+          EXPECT_EQ((unsigned)idx, q);
+          EXPECT_EQ((unsigned)rr, wf - q * Sp);
+          // ... and the exact path's way there: word of bin b = b + S' + (S' - S) * (b / S)
+          const unsigned b = (unsigned)idx * (unsigned)S + (unsigned)rr;
+          const unsigned qb = (unsigned)(((float)b + 0.5f) * (1.0f / (float)S));
+          EXPECT_EQ((unsigned)idx, qb);
+          EXPECT_EQ(w, b + Sp + (Sp - (unsigned)S) * qb);
+        }
+      }
+    }
+    EXPECT_TRUE(sxplan::ordered_queue_bytes(9) == (4 + 1024) * 4 && sxplan::ordered_queue_bytes(0) == 0);
   }
 }
 

@@ -28,7 +28,7 @@ def test_host_planners_device_free(exe):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([os.path.join(CPP, exe)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    assert "7 tests, 0 failed" in r.stdout
+    assert "9 tests, 0 failed" in r.stdout
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
 
 
