@@ -702,11 +702,12 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   SampleStore::Bucketed* b = const_cast<SampleStore::Bucketed*>(bkc);
   if (b->codes_tried) return SXMC_OK;
   b->codes_tried = true;
-  const int nq = (int)b->fields.size() - 1;
+  // (an ordered copy: every field but the ordered observable's, the last; an unordered one -- the sparse counting over
+  // runs -- : every field)
+  const int nq = (int)b->fields.size() - ((b->sort && b->sort->ordered >= 0) ? 1 : 0);
   // (below 2^22 granules a unit's byte offset into a column of codes fits 32 bits, and a unit number 28: what the
-  // kernel's addressing and its queue entries assume)
-  if (nq < 2 || nq > SXMC_MAX_QSLOTS || b->ngranules == 0 || b->ngranules >= ((size_t)1 << 22) || !b->sort ||
-      b->sort->ordered < 0) {
+  // ordered kernel's addressing and its queue entries assume)
+  if (nq < 2 || nq > SXMC_MAX_QSLOTS || b->ngranules == 0 || b->ngranules >= ((size_t)1 << 22) || !b->sort) {
     return SXMC_OK;
   }
   const unsigned long long n = (unsigned long long)b->ngranules * 256ull;
@@ -718,7 +719,19 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
     b->qbase[m] = cw.base[(size_t)m];
     b->qstep[m] = cw.step[(size_t)m];
   }
-  SX_HIP(hipMalloc((void**)&b->d_qcol, sizeof(unsigned) * b->pitch * (size_t)((nq + 1) / 2)));
+  // Do they pay?  A sample is ambiguous when a bin coordinate lies within ~half a code step (in bins) of an integer:
+  // about sum_k nbins_k * step_k / (upper_k - lower_k) of the samples for systematics near their means.  Beyond 2 in
+  // 10^3, four 256-sample units in ten hold an ambiguous sample and the queues' traffic eats what the codes save
+  // (measured at 200 bins per observable: slower than the float stream): such tables keep their float stream.
+  double ambiguous = 0;
+  for (int m = 0; m < nq && m < cd.nobs; m++) ambiguous += (double)cd.nbins[m] * cw.step[(size_t)m] / (cd.upper[m] - cd.lower[m]);
+  if (!(ambiguous <= 2e-3)) return SXMC_OK;
+  // (the codes are an extra: a table they do not fit beside -- +4 bytes per row and pair of fields -- keeps its float stream)
+  if (hipMalloc((void**)&b->d_qcol, sizeof(unsigned) * b->pitch * (size_t)((nq + 1) / 2)) != hipSuccess) {
+    (void)hipGetLastError();
+    b->d_qcol = nullptr;
+    return SXMC_OK;
+  }
   unsigned long long tally[2] = {0, 0};
   hipError_t e = sx_column_codes(b->d_cols, b->pitch, nq, b->qbase, b->qstep, n, b->d_qcol, tally, nullptr);
   if (e != hipSuccess || (double)tally[0] > 0.02 * (double)std::max<size_t>(b->nkept, 1)) {
@@ -1228,6 +1241,11 @@ int group_rebuild(sxmc_group* g) {
         g->member_bucket[(size_t)idx] = bk;
         // CODES: ordered table, histogram in LDS, 2 to 4 streamed fields, every systematic on them affine (one
         // coefficient) -- the conditions fill_ordered_body's kCodes states at compile time
+        // (Histograms beyond LDS, counted at the event bins over run-walked tables -- BASELINE config 5 -- were given
+        // codes too and measured: bit-identical, and SLOWER, 4.0 ms against 2.1-2.6.  With 200 bins per written
+        // observable a code step is 1/220 of a bin, 0.8 % of the samples are ambiguous and 87 % of the 256-sample
+        // units hold one; the fix-up then runs almost everywhere.  Codes pay where bins are coarse against 2^-16 of
+        // the window: not offered there.)
         bool affine = ordered && c.shape.lds_hist && c.shape.nobs >= 1 && c.shape.nslot - 1 >= 2 &&
                       c.shape.nslot - 1 <= SXMC_MAX_QSLOTS && !c.runs_mode && codes_enabled(g);
         for (unsigned w : c.prog) affine = affine && ((int)((w >> 4) & 15u) == c.shape.nslot - 1 || ((w >> 12) & 15u) == 0u);
