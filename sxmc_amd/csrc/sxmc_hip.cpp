@@ -388,6 +388,7 @@ struct sxmc_group {
   unsigned* d_ticket = nullptr;  // arrival counter of the fused step end, zeroed by the zero kernel
   double* d_step_sums = nullptr; // 1024 partial sums of the fused step
   std::vector<char> h_tail;          // fused step (fill_step_kernel): the step end's arguments, passed to the kernel by value
+  int cfg_seen_fused = -2;
   int cfg_fused = -1;                // the whole step in ONE launch where the fill has that form (-1: SXMC_FUSED_STEP, default OFF: measured slower)
   unsigned long long* d_coop_slots = nullptr;  // cooperative step end: one hand-over slot per worker (step_end_kernel)
   double* d_coop_last = nullptr;               // ... and the last partial of each that was not NaN
@@ -829,6 +830,16 @@ void compact_desc(const SxSignalDesc& full, const std::vector<int>& keep, int no
   }
 }
 
+// The whole step in one launch (fill_step_kernel), when asked for: its role workgroups carry the fill's LDS allotment
+// and need 16 KB of their own beside it, which the plan of an ordered fill then leaves free.
+bool fused_step_requested(const sxmc_group* g) {
+  static const int env_default = [] {
+    const char* e = std::getenv("SXMC_FUSED_STEP");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return (g->cfg_fused < 0 ? env_default : g->cfg_fused) != 0;
+}
+
 int group_rebuild(sxmc_group* g) {
   TraceRange trace("sxmc: launch plan (tables, partitions, kernels)");
   // Descriptors may still be read by kernels in flight on another stream: rebuilds are rare
@@ -1205,7 +1216,7 @@ int group_rebuild(sxmc_group* g) {
         c.shape.threads = 1024;
       }
     }
-    const int threads = c.shape.threads;  // (shadows the group-wide default above)
+    int threads = c.shape.threads;  // (shadows the group-wide default above)
 
     // ---- the members' descriptors; bucketed members: lay the table out now that the shape is known
     std::vector<SxSignalDesc> descs;
@@ -1267,6 +1278,9 @@ int group_rebuild(sxmc_group* g) {
       descs.push_back(d);
     }
     c.total_vec = prefix;
+    // (over codes a lane has half the bytes per unit in flight: 768 lanes per CU where nothing was asked for -- config 3:
+    // 85 us against 112-124 with 512; sxmc_group_optimize tries 512 to 1024)
+    if (c.codes && g->cfg_threads <= 0) threads = c.shape.threads = 768;
     // Waves per CU.  The fill is a stream: HBM delivers most with about 32 KiB of loads in flight per CU,
     // which is 512 lanes with one unit (3-4 columns x 16 bytes) each; more waves only queue up (measured
     // -8 % at BASELINE config 3).  Members whose per-sample arithmetic is long (a run-time decoded program
@@ -1285,7 +1299,7 @@ int group_rebuild(sxmc_group* g) {
     if (ordered && c.shape.lds_hist) {
       // replicas of the LDS histogram (fill_ordered_body): as many as the workgroup's share of LDS holds, up to 4
       unsigned rlog = 0;
-      const size_t share = (size_t)props.lds_per_cu / (size_t)std::max(1, bpc);
+      const size_t share = (size_t)props.lds_per_cu / (size_t)std::max(1, bpc) - (fused_step_requested(g) ? 16 * 1024 : 0);
       const size_t qreserve = c.codes ? ordered_queue_bytes(kMinQueueLog) : 0;   // (room for the smallest queues)
       while (rlog < 2 && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) + qreserve <= share) rlog++;
       c.shape.lds_layout = ordered_rstride(cls_max_bins) | (rlog << 24);
@@ -1410,6 +1424,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_order = g->cfg_order;
   g->cfg_seen_rtc = g->cfg_rtc;
   g->cfg_seen_codes = g->cfg_codes;
+  g->cfg_seen_fused = g->cfg_fused;
   g->plan_generation++;
   g->built = true;
   return SXMC_OK;
@@ -1446,7 +1461,8 @@ int group_refresh(sxmc_group* g) {
                g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_teams != g->cfg_teams ||
                g->cfg_seen_prebin != g->cfg_prebin ||
                g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc ||
-               g->cfg_seen_order != g->cfg_order || g->cfg_seen_codes != g->cfg_codes;
+               g->cfg_seen_order != g->cfg_order || g->cfg_seen_codes != g->cfg_codes ||
+               g->cfg_seen_fused != g->cfg_fused;
   bool points = false;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
@@ -2576,7 +2592,11 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
   hipEvent_t e0, e1;
   SX_HIP(hipEventCreate(&e0));
   SX_HIP(hipEventCreate(&e1));
-  const int candidates[] = {512, 448, 576, 640, 768};
+  // (over codes a lane has half the bytes per unit in flight: the larger shapes are the candidates there)
+  bool has_codes = false;
+  for (const LaunchClass& c : g->classes) has_codes = has_codes || c.codes;
+  const std::vector<int> candidates = has_codes ? std::vector<int>{512, 640, 768, 896, 1024}
+                                                : std::vector<int>{512, 448, 576, 640, 768};
   int best_threads = 0;
   float best_ms = 0;
   int failure = SXMC_OK;
@@ -2602,8 +2622,9 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
     }
   }
   // the default shape is what 0, 0 means: keep the configuration "automatic" when it won
-  g->cfg_threads = (failure == SXMC_OK && best_threads != 512) ? best_threads : 0;
-  g->cfg_bpc = (failure == SXMC_OK && best_threads != 512) ? 1 : 0;
+  const int auto_threads = has_codes ? 768 : 512;   // (what group_rebuild takes where nothing is asked for)
+  g->cfg_threads = (failure == SXMC_OK && best_threads != auto_threads) ? best_threads : 0;
+  g->cfg_bpc = (failure == SXMC_OK && best_threads != auto_threads) ? 1 : 0;
   // second choice, for bucketed tables: one team of workgroups per member or three (see group_rebuild: which is
   // faster differs from box to box by ~3 % either way); three must win by 1.5 % to be taken
   bool has_bucketed = false;
@@ -2627,6 +2648,29 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
       ms_of[pass] = ms;
     }
     g->cfg_teams = (failure == SXMC_OK && ms_of[1] < 0.985f * ms_of[0]) ? 3 : 0;
+  }
+  // third choice, where the plan streams codes by default: the codes against the float columns, at the parameters
+  // that are bound now.  Whether they pay was estimated from the binning (get_bucket_codes); this is the measurement:
+  // the float stream is taken if it wins by 3 %.
+  if (failure == SXMC_OK && has_codes && g->cfg_codes < 0) {
+    float ms_of[2] = {1e30f, 1e30f};
+    for (int pass = 0; pass < 2 && failure == SXMC_OK; pass++) {
+      g->cfg_codes = pass == 0 ? -1 : 0;
+      if ((failure = group_refresh(g)) != SXMC_OK) break;
+      float ms = 1e30f;
+      for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {
+        hipError_t e = hipEventRecord(e0, st);
+        if (e == hipSuccess) failure = group_fill(g, st, false);
+        if (failure == SXMC_OK && e == hipSuccess) e = hipEventRecord(e1, st);
+        if (failure == SXMC_OK && e == hipSuccess) e = hipEventSynchronize(e1);
+        float t = 0;
+        if (failure == SXMC_OK && e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (failure == SXMC_OK && e != hipSuccess) failure = fail(SXMC_ERR_HIP, std::string("optimize: ") + hipGetErrorString(e));
+        if (rep > 0 && t < ms) ms = t;
+      }
+      ms_of[pass] = ms;
+    }
+    g->cfg_codes = (failure == SXMC_OK && ms_of[1] < 0.97f * ms_of[0]) ? 0 : -1;
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -2962,11 +3006,7 @@ bool step_end_is_cooperative(const sxmc_group* g, unsigned long long ne) {
 // pre-binned column: config 2), the vectors are short enough for the finisher's staged form, and the fill's LDS leaves
 // room for the roles' own.
 bool step_is_fused(const sxmc_group* g, bool sparse, unsigned long long ne, int nparameters) {
-  static const int env_default = [] {
-    const char* e = std::getenv("SXMC_FUSED_STEP");
-    return (e && e[0] == '1') ? 1 : 0;
-  }();
-  const int on = g->cfg_fused < 0 ? env_default : g->cfg_fused;
+  const int on = fused_step_requested(g) ? 1 : 0;
   if (!on || sparse || g->classes.size() != 1 || (g->debug_mode & ~8)) return false;   // (8: the fused launch without its roles)
   if (step_end_takes_tail(g, sparse, ne) || !step_end_is_cooperative(g, ne)) return false;
   if (nparameters > 256 || g->members.size() > 256) return false;

@@ -857,7 +857,7 @@ def test_optimize_keeps_results_and_only_acts_on_pure_streams():
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], systs, params, nfields=5)   # x 8 B: long
     group = nll.EvalGroup(evs)
     chosen = group.Optimize()
-    assert chosen in (448, 512, 576, 640, 768)
+    assert chosen in (448, 512, 576, 640, 768, 896, 1024)           # (the larger shapes: tables streamed as codes)
     group.EvalAsync(False)
     group.EvalFinished()
     o = oracle_eval(tabs[3], 5, [0.0] * 3, [1.0] * 3, [20, 20, 20], systs, params)
