@@ -1301,7 +1301,13 @@ int group_rebuild(sxmc_group* g) {
       unsigned rlog = 0;
       const size_t share = (size_t)props.lds_per_cu / (size_t)std::max(1, bpc) - (fused_step_requested(g) ? 16 * 1024 : 0);
       const size_t qreserve = c.codes ? ordered_queue_bytes(kMinQueueLog) : 0;   // (room for the smallest queues)
-      while (rlog < 2 && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) + qreserve <= share) rlog++;
+      // (SXMC_ORDERED_REPLICAS_LOG2, measurement: fewer replicas leave LDS for a second workgroup per CU -- of another
+      // chain's launch, say)
+      static const unsigned rlog_max = [] {
+        const char* e = std::getenv("SXMC_ORDERED_REPLICAS_LOG2");
+        return e ? (unsigned)std::min(std::max(std::atoi(e), 0), 2) : 2u;
+      }();
+      while (rlog < rlog_max && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) + qreserve <= share) rlog++;
       c.shape.lds_layout = ordered_rstride(cls_max_bins) | (rlog << 24);
       c.shape.lds_bytes = ordered_lds_bytes(cls_max_bins, 1, rlog);
       c.plain_rstride = ordered_rstride(cls_max_bins);
@@ -1323,7 +1329,7 @@ int group_rebuild(sxmc_group* g) {
             unsigned prl = 0;
             auto bytes = [&](unsigned rl) { return (4 + ((size_t)rs << rl) + 64) * 4 + ordered_queue_bytes(kMinQueueLog); };
             if (bytes(0) <= share) {
-              while (prl < 2 && bytes(prl + 1) <= share) prl++;
+              while (prl < rlog_max && bytes(prl + 1) <= share) prl++;
               c.padded_rstride = rs;
               c.shape.lds_layout = rs | (prl << 24) | (1u << 27);
               c.shape.lds_bytes = (4 + ((size_t)rs << prl) + 64) * 4;
