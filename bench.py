@@ -49,7 +49,7 @@ def source_fingerprints():
             if os.path.exists(path):
                 h.update(n.encode() + b"\0" + open(path, "rb").read())
         return h.hexdigest()[:16]
-    return {"kernels": digest(["fill_kernels.inc.h", "pdfz_kernels.hip", "sxmc_device_types.h"]),
+    return {"kernels": digest(["fill_kernels.inc.h", "pdfz_kernels.hip", "sxmc_device_types.h", "layout_kernels.hip"]),
             "planner": digest(["sxmc_hip.cpp", "sxmc_plan.h"])}
 
 
