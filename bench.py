@@ -290,7 +290,7 @@ class Leg:
         if self.lookahead:
             from sxmc_amd.mcmc import LookaheadWalk
             lt, lb = (int(x) for x in args.launch.split(","))
-            self.la = LookaheadWalk(m, threads=lt if lt else 1024, blocks_per_cu=lb if lt else 1)
+            self.la = LookaheadWalk(m, threads=lt if lt else 768, blocks_per_cu=lb if lt else 1)
             self.la.bind()
         # untimed: clocks and graph replay settle over the first few hundred steps, whatever --warmup says
         for lo in range(0, args.prewarm, 100):

@@ -89,6 +89,9 @@ void sx_tail_args_fill(void* image, const SxSignalDesc* lookup_descs, const SxSi
 struct SxRtcSpec {
   int nobs, nslot, lds_hist, pre_width, sparse_runs;
   int nchain;                    // > 1: the lockstep-chains kernel (fill_multi_body), histograms in LDS
+  int max_threads;               // launch bound of the kernel (0 = 1024): several chains over an ordered table need more
+                                 // registers than 1024 lanes leave (spills inside the stream loop: every reload drains
+                                 // the loads in flight), so their kernels are compiled for the workgroup they get
   int nops;
   unsigned ops[SXMC_MAX_SYST];   // type | obs_slot << 4 | extra_slot << 8 | npars << 12 (0 = one coefficient)
 };

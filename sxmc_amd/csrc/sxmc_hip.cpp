@@ -3236,6 +3236,8 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
     k.lds_hist = 1;
     k.pre_width = c0.shape.pre_width;
     k.nchain = (int)C;
+    // (ordered tables: the kernel is compiled for the workgroup size of the plan -- 512, 768 or 1024 lanes)
+    k.max_threads = c0.shape.pre_width == 5 ? (c0.shape.threads <= 512 ? 512 : c0.shape.threads <= 768 ? 768 : 1024) : 0;
     k.nops = (int)c0.prog.size();
     for (size_t q = 0; q < c0.prog.size(); q++) k.ops[q] = c0.prog[q];
     std::string err;

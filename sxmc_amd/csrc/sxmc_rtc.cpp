@@ -54,7 +54,8 @@ std::string kernel_source(const SxRtcSpec& k) {
     const std::string targs = std::to_string(k.nobs) + ", " + std::to_string(k.nslot) + ", " + prog + ", " +
                               std::to_string(k.nchain > 1 ? k.nchain : 1);
     if (k.nchain > 1) {
-      s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(SxChainDescs chains, "
+      const int bound = k.max_threads > 0 ? k.max_threads : 1024;
+      s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(bound) + ") void sx_rtc_fill(SxChainDescs chains, "
            "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";
       s += "  fill_ordered_body<" + targs + ">(chains, segs, blk_off, w, dbg);\n}\n";
     } else {
@@ -88,7 +89,8 @@ std::string kernel_source(const SxRtcSpec& k) {
 
 std::string spec_key(const SxRtcSpec& k) {
   std::string s = std::to_string(k.nobs) + "/" + std::to_string(k.nslot) + "/" + std::to_string(k.lds_hist) + "/" +
-                  std::to_string(k.pre_width) + "/" + std::to_string(k.sparse_runs) + "/" + std::to_string(k.nchain) + ":";
+                  std::to_string(k.pre_width) + "/" + std::to_string(k.sparse_runs) + "/" + std::to_string(k.nchain) + "/" +
+                  std::to_string(k.max_threads) + ":";
   for (int i = 0; i < k.nops; i++) s += std::to_string(k.ops[i]) + ",";
   return s;
 }

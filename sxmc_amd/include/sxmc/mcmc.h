@@ -484,9 +484,10 @@ class MCMC {
       }
       check(sxmc_group_create(handles.data(), (int)handles.size(), &shadow_group));
       check(sxmc_group_set_lut_output(shadow_group, 0));
-      // a pass of two evaluations is bound by vector issue and LDS, not by the stream: all the waves a CU holds
-      check(sxmc_group_set_launch_config(group, 1024, 1));
-      check(sxmc_group_set_launch_config(shadow_group, 1024, 1));
+      // a pass of two evaluations is bound by vector issue and needs more registers than 1024 lanes leave each
+      // (spills inside the stream loop drain the loads in flight): 768 lanes, the kernel compiled for that bound
+      check(sxmc_group_set_launch_config(group, 768, 1));
+      check(sxmc_group_set_launch_config(shadow_group, 768, 1));
       sxmc_group_t both[2] = {group, shadow_group};
       check(sxmc_multigroup_create(both, 2, &pair));
     }

@@ -380,14 +380,15 @@ class LookaheadWalk:
     chain: an MCMC(lut_output=False, consume=True, stream=...) after setup(); a shadow set of evaluators over the
     same tables is created here."""
 
-    def __init__(self, chain, threads=1024, blocks_per_cu=1):
+    def __init__(self, chain, threads=768, blocks_per_cu=1):
         assert chain.consume and chain.stream is not None, "the look-ahead walk needs consume=True and a created stream"
         self.chain = chain
         self.shadow = MCMC(chain.w, seed=1, fused=True, stream=chain.stream, share_with=chain, lut_output=False,
                            consume=True)
         # threads > 0: lanes per workgroup for BOTH sets of evaluators (their launch plans must agree; a pass of two
-        # evaluations is bound by vector issue and LDS and wants all the waves a CU holds: 1 024 measured best at
-        # config 3, 152 us per pass against 179 with 512).  0: leave both as they are (defaults agree).
+        # evaluations is bound by vector issue and needs more registers than 1 024 lanes leave each -- spills inside
+        # the stream loop drain the loads in flight --: 768, the kernel being compiled for that bound).  0: leave both
+        # as they are (defaults agree).
         self._threads, self._bpc = threads, blocks_per_cu
         self.cap = DeviceArray.zeros(1, np.int32)
         self._graph, self._graph_passes = None, 0
