@@ -238,6 +238,9 @@ int sxmc_group_set_launch_config(sxmc_group_t g, int bin_threads, int bin_blocks
  * which count wins differs from one box to the next).  Only acts when every member is a pure stream and no
  * launch configuration was set by hand; results never depend on the shape.  The members' histograms and
  * normalisation slots hold counts of the trial runs afterwards (the next evaluation zeroes them as usual).
+ * Where the plan streams codes (sxmc_group_set_codes left at its default) the candidates run to 1024 lanes and the
+ * codes are then timed against the float columns at the parameters bound now: the float stream is taken if it wins
+ * by 3 % (whether codes pay is otherwise estimated from the binning when the table is laid out).
  * *chosen_threads (optional): the lane count kept, 0 when nothing was tried. */
 int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads);
 /* How the fill kernel's work is cut over workgroups: 0 = automatic, 1 = sliced (each workgroup one

@@ -2071,8 +2071,11 @@ __global__ __launch_bounds__(1024) void fill_sparse_kernel(const SxSignalDesc* _
   fill_sparse_body<NOBS, NSLOT, PROG>(descs, segs, blk_off, smax, dbg);
 }
 
+#ifndef SXMC_ORDERED_BOUND
+#define SXMC_ORDERED_BOUND 1024   // (measurement builds: make VARIANT=_b768 EXTRA=-DSXMC_ORDERED_BOUND=768)
+#endif
 template <int NOBS, int NSLOT, typename PROG, bool LDS_HIST = true>
-__global__ __launch_bounds__(1024) void fill_ordered_kernel(const SxSignalDesc* __restrict__ descs,
+__global__ __launch_bounds__(SXMC_ORDERED_BOUND) void fill_ordered_kernel(const SxSignalDesc* __restrict__ descs,
                                                             const SxSegment* __restrict__ segs,
                                                             const unsigned* __restrict__ blk_off, unsigned layout,
                                                             unsigned dbg) {
