@@ -1278,9 +1278,19 @@ int group_rebuild(sxmc_group* g) {
       descs.push_back(d);
     }
     c.total_vec = prefix;
-    // (over codes a lane has half the bytes per unit in flight: 768 lanes per CU where nothing was asked for -- config 3:
-    // 85 us against 112-124 with 512; sxmc_group_optimize tries 512 to 1024)
-    if (c.codes && g->cfg_threads <= 0) threads = c.shape.threads = 768;
+    // Over codes, where nothing was asked for: TWO workgroups of 512 lanes per CU, each with half the replicas of the
+    // LDS histogram.  One of 768 or 1024 with all four replicas is as fast alone (config 3, alternating on one box:
+    // 81.0-81.6 us against 81.3-81.4 and 79.6-82.8), but with other chains' launches in flight -- the fake experiments
+    // of an ensemble -- two workgroups per CU let one launch's tail run under the next one's start: 13 280 chain-steps/s
+    // against 12 430 and 12 840 (profiles/r04b_codes_shapes_ab.log).  A histogram too large for two workgroups' LDS:
+    // one of 768.  sxmc_group_optimize times these shapes on the box it runs on.
+    const bool codes_auto = c.codes && g->cfg_threads <= 0 && g->cfg_bpc <= 0;
+    bool codes_two = false;
+    if (codes_auto) {
+      const size_t one = std::max(c.shape.lds_bytes, ordered_lds_bytes(cls_max_bins, 1, 0)) + ordered_queue_bytes(kMinQueueLog);
+      codes_two = 2 * (one + 2048) <= (size_t)props.lds_per_cu && c.shape.nobs == 1;   // (+ the padded form's guard rows)
+      threads = c.shape.threads = codes_two ? 512 : 768;
+    }
     // Waves per CU.  The fill is a stream: HBM delivers most with about 32 KiB of loads in flight per CU,
     // which is 512 lanes with one unit (3-4 columns x 16 bytes) each; more waves only queue up (measured
     // -8 % at BASELINE config 3).  Members whose per-sample arithmetic is long (a run-time decoded program
@@ -1291,7 +1301,7 @@ int group_rebuild(sxmc_group* g) {
                        (c.shape.static_prog >= 0 || c.shape.rtc_fill || cls_nsyst <= 1) &&
                        stream_bytes >= 2.0e8;  // (short launches are ramp-bound: they take all the waves)
     c.light = light;
-    int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : std::max(1, (light ? 512 : 1024) / threads);
+    int bpc = g->cfg_bpc > 0 ? g->cfg_bpc : codes_auto ? (codes_two ? 2 : 1) : std::max(1, (light ? 512 : 1024) / threads);
     const size_t lds_need = std::max(c.shape.lds_bytes, c.shape.sparse_lds_bytes);
     const int lds_limit = std::max(1, (int)((size_t)props.lds_per_cu / std::max<size_t>(lds_need, 1)));
     bpc = std::min(bpc, lds_limit);
@@ -2601,14 +2611,18 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
   // (over codes a lane has half the bytes per unit in flight: the larger shapes are the candidates there)
   bool has_codes = false;
   for (const LaunchClass& c : g->classes) has_codes = has_codes || c.codes;
-  const std::vector<int> candidates = has_codes ? std::vector<int>{512, 640, 768, 896, 1024}
-                                                : std::vector<int>{512, 448, 576, 640, 768};
-  int best_threads = 0;
+  // (threads, workgroups per CU; the first is what group_rebuild takes where nothing is asked for)
+  typedef std::pair<int, int> Shape;
+  const std::vector<Shape> candidates =
+      has_codes ? std::vector<Shape>{{512, 2}, {768, 1}, {1024, 1}, {896, 1}, {640, 1}}
+                : std::vector<Shape>{{512, 1}, {448, 1}, {576, 1}, {640, 1}, {768, 1}};
+  int best_threads = 0, best_bpc = 0;
   float best_ms = 0;
   int failure = SXMC_OK;
-  for (int cand : candidates) {
+  for (const Shape& shape : candidates) {
+    const int cand = shape.first;
     g->cfg_threads = cand;
-    g->cfg_bpc = 1;
+    g->cfg_bpc = shape.second;
     if ((failure = group_refresh(g)) != SXMC_OK) break;
     float ms = 1e30f;
     for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {  // first repetition warms up; the minimum of seven counts
@@ -2624,13 +2638,14 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
     if (failure != SXMC_OK) break;
     if (best_threads == 0 || ms < best_ms) {
       best_threads = cand;
+      best_bpc = shape.second;
       best_ms = ms;
     }
   }
   // the default shape is what 0, 0 means: keep the configuration "automatic" when it won
-  const int auto_threads = has_codes ? 768 : 512;   // (what group_rebuild takes where nothing is asked for)
-  g->cfg_threads = (failure == SXMC_OK && best_threads != auto_threads) ? best_threads : 0;
-  g->cfg_bpc = (failure == SXMC_OK && best_threads != auto_threads) ? 1 : 0;
+  const bool is_auto = best_threads == candidates[0].first && best_bpc == candidates[0].second;
+  g->cfg_threads = (failure == SXMC_OK && !is_auto) ? best_threads : 0;
+  g->cfg_bpc = (failure == SXMC_OK && !is_auto) ? best_bpc : 0;
   // second choice, for bucketed tables: one team of workgroups per member or three (see group_rebuild: which is
   // faster differs from box to box by ~3 % either way); three must win by 1.5 % to be taken
   bool has_bucketed = false;
@@ -3207,21 +3222,24 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
     size_t lds = (4 + C * hist_words + 64) * 4;
     if (c0.shape.pre_width == 5) {
       // ordered fill: the kernel argument is the replica layout; as many replicas as fit beside the other chains'
-      // (codes: the padded form of the histograms if the chains' histograms fit that way with the smallest queues)
+      // (codes: the padded form of the histograms if the chains' histograms fit that way with the smallest queues; a plan
+      // with two workgroups per CU leaves each of them half the CU's LDS)
+      const size_t per_cu = (size_t)std::max(1, c0.shape.grid / std::max(1, props.cus));
+      const size_t lds_share = (size_t)props.lds_per_cu / std::min<size_t>(per_cu, 2);
       size_t rstride = c0.plain_rstride;
       bool padded = false;
       if (c0.codes && c0.padded_rstride &&
-          (4 + C * (size_t)c0.padded_rstride + 64) * 4 + ordered_queue_bytes(kMinQueueLog) <= (size_t)props.lds_per_cu) {
+          (4 + C * (size_t)c0.padded_rstride + 64) * 4 + ordered_queue_bytes(kMinQueueLog) <= lds_share) {
         rstride = c0.padded_rstride;
         padded = true;
       }
       const size_t reserve = c0.codes ? ordered_queue_bytes(kMinQueueLog) : 0;
       unsigned rlog = 0;
-      while (rlog < 2 && (4 + (C * rstride << (rlog + 1)) + 64) * 4 + reserve <= (size_t)props.lds_per_cu) rlog++;
+      while (rlog < 2 && (4 + (C * rstride << (rlog + 1)) + 64) * 4 + reserve <= lds_share) rlog++;
       lds = (4 + (C * rstride << rlog) + 64) * 4;
       hist_words = rstride | ((size_t)rlog << 24) | (padded ? (size_t)1 << 27 : 0);
       if (c0.codes) {   // the queues of ambiguous rows (fill_ordered_body's CODES), shared by the chains
-        const unsigned qlog = (size_t)props.lds_per_cu > lds ? ordered_queue_log((size_t)props.lds_per_cu - lds) : 0;
+        const unsigned qlog = lds_share > lds ? ordered_queue_log(lds_share - lds) : 0;
         lds += ordered_queue_bytes(qlog);
         hist_words |= (size_t)qlog << 28;
       }
