@@ -1706,11 +1706,9 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       // the fraction, two subtractions whose result's SIGN says "ambiguous", a shift that spreads that sign, the
       // floor as an integer, an OR and a clamp that send ambiguous and out-of-domain samples to the guard rows, one
       // multiply-add for the LDS address -- 12 vector instructions, no compare, no mask, no select.
-      const float ohalf = uniform_f(0.5f - ef[0][0]);     // (chain 0; the others below)
-      float ohm[NCHAIN];
+      float ohm[NCHAIN];                                  // (1/2 - eps per chain)
 #pragma unroll
       for (int c = 0; c < NCHAIN; c++) ohm[c] = uniform_f(0.5f - ef[c][0]);
-      (void)ohalf;
       const int oS4 = (int)(4u * oSp);
       const int oclamp = (dbg & 4u) ? -1 : (int)nbk[0];   // (measurement hook: everything to the guard row)
       auto coarse_outer = [&](int c, const vuint4g (&w)[QW], unsigned it, unsigned v, unsigned offcode) {
