@@ -256,3 +256,45 @@ def test_codes_lookup_and_tables_shared_between_groups():
     for j, t in enumerate(tabs):
         o = oracle_eval(t, 5, [0.0] * 3, [1.0] * 3, [20, 20, 20], C3, [0.1, 0.2, -0.3])
         assert np.array_equal(shared[j].GetBins(), o["bins"]) and norms2.get()[j] == o["norm"]
+
+
+def test_codes_degenerate_columns():
+    """Columns the windows cannot be cut from in the ordinary way: one value only, no finite value at all, values at the
+    ends of the float range, a truth field in other units (no overlap with the observable's window), tables of a few rows."""
+    rng = np.random.default_rng(163)
+    nb = [12, 5, 4]
+    geom = oracle.HistGeometry([0.0] * 3, [1.0] * 3, nb)
+    cases = {}
+    for name in ("constant-truth", "nan-truth", "huge-values", "other-units", "tiny"):
+        n = 7 if name == "tiny" else 150001
+        tab = table(rng, n, 5)
+        if name == "constant-truth":
+            tab[:, 3] = np.float32(0.4375)
+        if name == "nan-truth":
+            tab[:, 3] = np.nan
+        if name == "huge-values":
+            big = rng.uniform(size=n) < 0.01
+            tab[big, 0] = rng.choice(np.array([3e38, -3e38, 1e30, -1e-30, 1e-45], np.float32), size=int(big.sum()))
+            tab[big, 3] = rng.choice(np.array([3e38, -3e38, 7e20], np.float32), size=int(big.sum()))
+        if name == "other-units":
+            tab[:, 3] = (tab[:, 3] * 1000.0 + 5000.0).astype(np.float32)
+        cases[name] = tab
+    for name, tab in cases.items():
+        ev = pdfz.EvalHist(tab, 5, 3, [0.0] * 3, [1.0] * 3, nb)
+        for s in C3:
+            ev.AddSystematic(make_systematic(s))
+        norm, pbuf = DeviceArray.zeros(1, np.uint32), DeviceArray(np.zeros(3))
+        ev.SetNormalizationBuffer(norm)
+        ev.SetParameterBuffer(pbuf)
+        group = nll.EvalGroup([ev])
+        group.SetOrdering(True, force=True)
+        for pv in ([0.0, 0.0, 0.0], [0.03, -0.02, 0.1], [-0.2, 0.4, -0.6], [0.0, 0.0, 1e-4]):
+            pbuf.set(np.array(pv))
+            bins, nrm = oracle.bin_samples(geom, tab, 5, C3, np.array(pv))
+            for codes in (True, False):
+                group.SetCodes(codes)
+                group.EvalAsync(False)
+                group.EvalFinished()
+                assert np.array_equal(ev.GetBins(), bins) and norm.get()[0] == nrm, (name, codes, pv)
+        group.close()
+        ev.close()
