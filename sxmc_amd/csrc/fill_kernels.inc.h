@@ -1239,6 +1239,14 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   constexpr bool kCodes = LDS_HIST && NOBS >= 1 && NSTREAM >= 2 && NSTREAM <= SXMC_MAX_QSLOTS && prog_is_affine<ORD>(PROG{});
   constexpr int NQ = kCodes ? NSTREAM : 1, QW = (NQ + 1) / 2;
   constexpr int kRing = 4;             // units of codes a lane holds: one being worked on, the others in flight
+#ifndef SXMC_DRAIN_BATCH
+#define SXMC_DRAIN_BATCH 1
+#endif
+  // Granules whose float columns the drain loads together.  ONE: measured on one box, alternating
+  // (profiles/r04b_drain_batch_ab.log), two cost 8 us and three 12 us of an 82 us launch instead of saving round
+  // trips -- the kernel sits at 123 of its 128 registers, a second granule's 13 spill (76 bytes of scratch, none of it
+  // inside the stream loop, and still).
+  constexpr int kDrain = NCHAIN > 1 ? 1 : SXMC_DRAIN_BATCH;
   static_assert(64 % kRing == 0, "a block of 64 units is a whole number of rounds of the ring");
   typedef typename MakeISeq<PROG::n>::type Seq;
   extern __shared__ unsigned lds[];
@@ -1479,7 +1487,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
 
     // ---- codes: the program composed, per chain, into single-precision coefficients over the codes (AffineForm);
     // a chain whose parameters rule that out sends the whole evaluation back to the float columns
-    float af[NCHAIN][NG][NQ], gf[NCHAIN][NG], ef[NCHAIN][NG], omf[NCHAIN][NG];
+    float af[NCHAIN][NG][NQ], gf[NCHAIN][NG], thr[NCHAIN][NG];
     unsigned nbk[NG];
     bool use_q = want_q;
     if constexpr (kCodes) {
@@ -1514,14 +1522,18 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
             // of u: coefficients rounded to 24 bits times codes below 2^16, NQ + 1 roundings of partial sums no
             // larger than mu | the reference's double arithmetic: <= 8 systematics' roundings, each amplified no more
             // than `mag` grows (2^-53 each; 2^-44 leaves a factor 64 for the composition's own roundings)
-            const double mu = sum_abs * 65536.0 + __builtin_fabs(g) + (double)nbk[k];
+            // (+ 0.25: the constant term carries e < 0.13 besides, see below)
+            const double mu = sum_abs * 65536.0 + __builtin_fabs(g) + (double)nbk[k] + 0.25;
             const double eps = 0.5 * sum_abs * (1.0 + 0x1p-19) + mu * 0x1p-21 +
                                (form[k].mag + __builtin_fabs(lo[k])) * sc[k] * 0x1p-44;
             ok = ok && (eps < 0.125);                      // (NaN fails)
-            gf[c][k] = uniform_f((float)g);
-            const float e32 = (float)(eps * 1.01);         // (covers the rounding of this conversion and of 1 - e32)
-            ef[c][k] = uniform_f(e32);
-            omf[c][k] = uniform_f(1.0f - e32);
+            // The kernel evaluates u' = u + e (e = 1.01 eps, added to the constant term: no instruction) and asks ONE
+            // question, fract(u') >= 2e: the reference's value lies in [u' - 2e, u'], so if u' is at least 2e above
+            // floor(u') both have the same floor.  (1.01: the roundings of these conversions, of the constant term
+            // with e in it and of the sums that are e larger; 2^-23: the rounding of fract() of a negative u'.)
+            const double e = eps * 1.01;
+            gf[c][k] = uniform_f((float)(g + e));
+            thr[c][k] = uniform_f((float)(2.0 * e + 0x1p-23));
           }
           use_q = use_q && (uniform_i(ok ? 1 : 0) != 0);
         }
@@ -1671,7 +1683,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
 #pragma unroll
             for (int m = 0; m < NQ; m++) u = __builtin_fmaf(af[c][k][m], cv[m], u);
             const float fr = __builtin_amdgcn_fractf(u);            // u - floor(u), in [0, 1)
-            amb = amb | !((fr >= ef[c][k]) & (fr <= omf[c][k]));   // (NaN: ambiguous)
+            amb = amb | !(fr >= thr[c][k]);                          // (NaN: ambiguous)
             const int idx = (int)__builtin_floorf(u);
             ind = ind & ((unsigned)idx < nbk[k]);
             bin = mad24(idx, stv[k], bin);
@@ -1702,13 +1714,10 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
         }
       };
 
-      // ---- the same in the padded form of the histogram (`outer`): per sample two conversions, two multiply-adds,
-      // the fraction, two subtractions whose result's SIGN says "ambiguous", a shift that spreads that sign, the
-      // floor as an integer, an OR and a clamp that send ambiguous and out-of-domain samples to the guard rows, one
-      // multiply-add for the LDS address -- 12 vector instructions, no compare, no mask, no select.
-      float ohm[NCHAIN];                                  // (1/2 - eps per chain)
-#pragma unroll
-      for (int c = 0; c < NCHAIN; c++) ohm[c] = uniform_f(0.5f - ef[c][0]);
+      // ---- the same in the padded form of the histogram (`outer`): per sample two conversions, the multiply-adds
+      // (two samples per packed instruction), the fraction, ONE compare (fract(u') against 2e, see above) whose mask
+      // stays in scalar registers, the floor as an integer, a select and a clamp that send ambiguous and
+      // out-of-domain samples to the guard rows, one multiply-add for the LDS address.
       const int oS4 = (int)(4u * oSp);
       const int oclamp = (dbg & 4u) ? -1 : (int)nbk[0];   // (measurement hook: everything to the guard row)
       auto coarse_outer = [&](int c, const vuint4g (&w)[QW], unsigned it, unsigned v, unsigned offcode) {
@@ -1716,7 +1725,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
         int base4 = (int)(4u * (4u + (unsigned)c * cstride + myrep + offcode) + 4u * oSp);
         asm volatile("" : "+v"(base4));
         int addr[SXMC_VEC];
-        int amb[SXMC_VEC];
+        bool amb[SXMC_VEC];
         // (the multiply-adds of two samples in one packed instruction: v_pk_fma_f32, IEEE per component)
         float us[SXMC_VEC];
 #pragma unroll
@@ -1736,19 +1745,17 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
 #pragma unroll
         for (int q = 0; q < SXMC_VEC; q++) {
           const float u = us[q];
-          const float fr = __builtin_amdgcn_fractf(u);
-          const float t = ohm[c] - __builtin_fabsf(fr - 0.5f);      // < 0: closer to a bin edge than eps
-          amb[q] = __builtin_bit_cast(int, t) >> 31;                 // all ones: ambiguous
+          amb[q] = !(__builtin_amdgcn_fractf(u) >= thr[c][0]);      // closer to a bin edge than the bound (or NaN)
           int idx;
           asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(idx) : "v"(u));
           int ie;
-          asm("v_med3_i32 %0, %1, -1, %2" : "=v"(ie) : "v"(idx | amb[q]), "s"(oclamp));
+          asm("v_med3_i32 %0, %1, -1, %2" : "=v"(ie) : "v"(amb[q] ? -1 : idx), "s"(oclamp));
           addr[q] = mad24(ie, oS4, base4);
         }
         const unsigned wmax = max(max(w[0][0], w[0][1]), max(w[0][2], w[0][3]));
         const bool special = wmax >= ((unsigned)SXMC_QCODE_EXACT << 16);
-        const int anyamb = (amb[0] | amb[1]) | (amb[2] | amb[3]);
-        if (__builtin_amdgcn_ballot_w64(anyamb != 0 || special) != 0ull) {   // (one step in seven at config 3)
+        const bool anyamb = (amb[0] | amb[1]) | (amb[2] | amb[3]);
+        if (__builtin_amdgcn_ballot_w64(anyamb || special) != 0ull) {   // (one step in seven at config 3)
           unsigned rare = 0u;
 #pragma unroll
           for (int q = 0; q < SXMC_VEC; q++) {
@@ -1831,20 +1838,21 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       // ---- what the queues hold, decided with the reference's arithmetic on the float columns
       auto drain = [&]() {
         if (dbg & 16u) nrow = ngran = 0u;                  // (measurement hook: what the queues hold is dropped)
-        // (a memory round trip per batch of rows and per granule, with nothing else of this wave's in flight: the
-        // first granule's loads are issued together with the first rows', so the two share one)
-        vfloat4 rawf[NS], rawo = {0.0f, 0.0f, 0.0f, 0.0f};
-        unsigned prew = 0u, gcode = 0u, gc = 0u;
-        auto load_granule = [&](unsigned g) {
+        // (nothing else of this wave's is in flight here, so every wait is a whole memory round trip: the loads of
+        // the first kDrain granules go out with the first rows' and share one)
+        vfloat4 rawf[kDrain][NS], rawo[kDrain];
+        unsigned prew[kDrain], gcode[kDrain], gc[kDrain];
+        auto load_granule = [&](int s, unsigned g) {
           const unsigned w0 = (unsigned)uniform_i((int)qgran[2u * g]);
-          gcode = (unsigned)uniform_i((int)qgran[2u * g + 1u]);
-          gc = w0 >> 28;
+          gcode[s] = (unsigned)uniform_i((int)qgran[2u * g + 1u]);
+          gc[s] = w0 >> 28;
           const unsigned vw = w0 & 0x0FFFFFFFu;
           const unsigned vc = vw + lane < vlast32 ? vw + lane : vlast32;
 #pragma unroll
-          for (int k = 0; k < NSTREAM; k++) rawf[k] = __builtin_nontemporal_load(&col[k][vc]);
-          if (gcode == kOrdMixed) rawo = __builtin_nontemporal_load(&col[ORD][vc]);
-          prew = precol[vc >> 6];
+          for (int k = 0; k < NSTREAM; k++) rawf[s][k] = __builtin_nontemporal_load(&col[k][vc]);
+          rawo[s] = vfloat4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (gcode[s] == kOrdMixed) rawo[s] = __builtin_nontemporal_load(&col[ORD][vc]);
+          prew[s] = precol[vc >> 6];
         };
         unsigned row = 0u, w1 = 0u;
         float rowf[NS];
@@ -1855,7 +1863,10 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
 #pragma unroll
           for (int k = 0; k < NSTREAM; k++) rowf[k] = ((gptr<const float>)col[k])[row];
         }
-        if (ngran != 0u) load_granule(0u);
+#pragma unroll
+        for (int s = 0; s < kDrain; s++) {
+          if ((unsigned)s < ngran) load_granule(s, (unsigned)s);
+        }
         // ---- rows: one row with the reference's arithmetic on its float values (an ambiguous sample)
         auto exact_row = [&](int c, unsigned offcode) {
           double f[NSLOT][SXMC_VEC];
@@ -1894,21 +1905,30 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
           }
         }
         // ---- whole granules
-        for (unsigned g = 0; g < ngran; g++) {
-          if (g != 0u) load_granule(g);
-          const bool mixed = gcode == kOrdMixed;
-          const unsigned off = (unsigned)uniform_i((int)prew) & 0xFFFFFFu;
-          double f0[NS][SXMC_VEC];
+        for (unsigned g0 = 0; g0 < ngran; g0 += (unsigned)kDrain) {
+          if (g0 != 0u) {
 #pragma unroll
-          for (int k = 0; k < NSTREAM; k++) {
-            f0[k][0] = (double)rawf[k].x;
-            f0[k][1] = (double)rawf[k].y;
-            f0[k][2] = (double)rawf[k].z;
-            f0[k][3] = (double)rawf[k].w;
+            for (int s = 0; s < kDrain; s++) {
+              if (g0 + (unsigned)s < ngran) load_granule(s, g0 + (unsigned)s);
+            }
           }
 #pragma unroll
-          for (int c = 0; c < NCHAIN; c++) {
-            if (gc == (unsigned)c) exact_granule(IntC<0>{}, c, mixed, f0, rawo, off, gcode);
+          for (int s = 0; s < kDrain; s++) {
+            if (g0 + (unsigned)s >= ngran) break;
+            const bool mixed = gcode[s] == kOrdMixed;
+            const unsigned off = (unsigned)uniform_i((int)prew[s]) & 0xFFFFFFu;
+            double f0[NS][SXMC_VEC];
+#pragma unroll
+            for (int k = 0; k < NSTREAM; k++) {
+              f0[k][0] = (double)rawf[s][k].x;
+              f0[k][1] = (double)rawf[s][k].y;
+              f0[k][2] = (double)rawf[s][k].z;
+              f0[k][3] = (double)rawf[s][k].w;
+            }
+#pragma unroll
+            for (int c = 0; c < NCHAIN; c++) {
+              if (gc[s] == (unsigned)c) exact_granule(IntC<0>{}, c, mixed, f0, rawo[s], off, gcode[s]);
+            }
           }
         }
         nrow = ngran = 0u;

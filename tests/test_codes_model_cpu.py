@@ -90,6 +90,9 @@ def encode(tab, fields, base, step):
     return codes, mark
 
 
+EPS_FACTOR = [1.0]      # (the negative control shrinks the bound through this)
+
+
 def compose(systs, params, fields, base, step, lo, hi, nb, binned):
     """The kernel's AffineForm, coefficient by coefficient; returns per binned observable (alpha32[], gamma32, eps32)
     or None when the bound rules the codes out."""
@@ -129,11 +132,13 @@ def compose(systs, params, fields, base, step, lo, hi, nb, binned):
         alpha = a[k] * step * sc
         sum_abs = float(np.sum(np.abs(alpha)))
         g = (c[k] - lo[obs] + float(np.sum(a[k] * (base + 0.5 * step)))) * sc
-        mu = sum_abs * 65536.0 + abs(g) + nb[obs]
+        mu = sum_abs * 65536.0 + abs(g) + nb[obs] + 0.25
         eps = 0.5 * sum_abs * (1.0 + 2.0 ** -19) + mu * 2.0 ** -21 + (mag[k] + abs(lo[obs])) * sc * 2.0 ** -44
         if not eps < 0.125:
             return None
-        out.append((alpha.astype(np.float32), np.float32(g), np.float32(eps * 1.01)))
+        # the kernel evaluates u' = u + e (e in the constant term) and asks fract(u') >= 2e + 2^-23
+        e = eps * 1.01 * EPS_FACTOR[0]
+        out.append((alpha.astype(np.float32), np.float32(g + e), np.float32(2.0 * e + 2.0 ** -23)))
     return out
 
 
@@ -146,13 +151,14 @@ def classify(codes, coef):
     """The kernel's per-sample test: (index per binned observable, unambiguous, in every domain)."""
     n = codes.shape[0]
     idx, clear, inside = [], np.ones(n, bool), np.ones(n, bool)
-    for (alpha, g, e32), nbk in coef:
+    for (alpha, g, thr32), nbk in coef:
         u = np.full(n, g, np.float32)
         for m in reversed(range(codes.shape[1])):            # (the order does not matter to the bound)
             u = fma32(np.full(n, alpha[m], np.float32), codes[:, m].astype(np.float32), u)
         fl = np.floor(u)
-        fr = (u - fl).astype(np.float32)
-        clear &= (fr >= e32) & (fr <= np.float32(1.0) - e32)
+        with np.errstate(all="ignore"):
+            fr = np.minimum((u - fl).astype(np.float32), np.float32(1.0 - 2.0 ** -24))   # (v_fract_f32's clamp)
+        clear &= fr >= thr32
         i = fl.astype(np.int64)
         inside &= (i >= 0) & (i < nbk)
         idx.append(i)
@@ -293,10 +299,13 @@ def test_the_bound_is_needed():
         params = rng.normal(0, 0.05, npar)
         base, step = windows(tab, fields, nobs, lo, hi)
         codes, mark = encode(tab, fields, base, step)
-        coef = compose(systs, params, fields, base, step, lo, hi, nb, binned)
-        if coef is None:
+        EPS_FACTOR[0] = 0.01
+        try:
+            small = compose(systs, params, fields, base, step, lo, hi, nb, binned)
+        finally:
+            EPS_FACTOR[0] = 1.0
+        if small is None:
             continue
-        small = [(a, g, np.float32(e * 0.01)) for a, g, e in coef]
         idx_ref, ind_ref, ind_k = reference_bins(tab, systs, params, lo, hi, nb)
         idx, clear, inside = classify(codes, [(c, nb[obs]) for c, obs in zip(small, binned)])
         decided = clear & (mark == 0) & inside
