@@ -704,7 +704,9 @@ __device__ __forceinline__ void run_static_part(double (&f)[NSLOT][SXMC_VEC], co
 // and an error bound eps[k] that covers the half code step, the single-precision evaluation of u and the double
 // roundings of the reference's own arithmetic (bounded through `mag`, a bound on every intermediate's magnitude).
 // A sample with eps <= frac(u_k) <= 1 - eps in every observable is binned from its codes: floor(u_k) IS the
-// reference's index (or outside the domain when it is not in [0, nbins)).  Any other sample -- about 2 eps of them,
+// reference's index (or outside the domain when it is not in [0, nbins)).  (The kernel asks it one-sidedly: it
+// evaluates u' = u + e, e = 1.01 eps in the constant term, and tests fract(u') >= 2e; the reference's value lies in
+// [u' - 2e, u'].)  Any other sample -- about 2 eps of them,
 // a few in 10^4 -- is "ambiguous": its row number goes into a queue in LDS, and at the end of the stream the
 // workgroup reads those rows' float values and bins them with the reference's arithmetic (exact_one).  Coefficients
 // that are not finite, or so large that eps reaches 1/8, switch the codes off for that evaluation: the float
