@@ -272,7 +272,8 @@ class Leg:
         args, m = self.args, self.m
         # (the jump buffer holds every step between two flushes: the longest run here, the post-timed sample included)
         m.setup(sync_interval=max(steps, warmup + 1, min(args.prewarm, 100) + 1, 2 * ROOFLINE_LAUNCHES + 8, 1))
-        m.group.SetDebugMode(args.debug_mode)
+        if args.debug_mode:               # (measurement build only: SXMC_HIP_LIB=.../libsxmc_hip_measure.so)
+            m.group.SetDebugMode(args.debug_mode)
         if self.form == "pdfz":
             # bench_sxmc evaluates at params = 0 (bench_sxmc.cpp:66, 166): the evaluators stay bound to the proposal
             # vector, which is put back to the means (the systematics' are 0) and never stepped
@@ -465,7 +466,15 @@ class Leg:
                                               "compiled kernels as sx_rtc_fill)",
             "launch_plan": info.strip().split("\n"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # `frac` is on the bytes THIS kernel must move (codes: 4 B/sample at config 3).  SURVEY.md 8(d) counts 4 bytes for
+            # every column the computation needs (16 B/sample there): on those bytes the same launch time is a multiple of
+            # the peak -- the kernel does not stream them, it streams a 16-bit code per field and reads float values only
+            # for the samples its error bound cannot decide
+            "frac_survey_8d": (survey_bytes / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fill_ms > 0 else 0.0,
             "traffic": traffic, "traffic_provenance": traffic_note,
+            # (PMC counters cannot be read inside this run: separate rocprofv3 --pmc passes, tools/profile_on_gpu.sh)
+            "traffic_source": ("profiles/traffic.json: " + str(traffic_note.get("from"))) if traffic_note else None,
+            "streams": "u16 codes (f32 filter) + f64 exact fallback" if "ordered+codes" in info else "f32 columns (f64 arithmetic)",
             "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
             "avg_launch_ms": fill_ms, "launches_timed": self.nfill, "sample": self.roofline_sample,
             "timing": "HIP events stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop events) on the stream the "
@@ -879,7 +888,8 @@ def parse_args(argv=None):
                     help="stream the table in the caller's row order (no copy grouped by the untouched observables' bins)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
     ap.add_argument("--debug-mode", type=int, default=0,
-                    help="roofline measurement hook (wrong results): 1 stream only, 2 compute only, 4 no histogram")
+                    help="kernel measurement hooks (WRONG RESULTS; needs SXMC_HIP_LIB=sxmc_amd/csrc/libsxmc_hip_measure.so): "
+                         "1 stream only, 2 compute only, 4 no histogram, 16 no drain, 32 no LDS additions")
     return ap.parse_args(argv)
 
 
@@ -1104,7 +1114,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        # the arithmetic the path computes in.  Every bin index is the reference's f64 result (bit-exact against the oracle);
+        # where the plan streams CODES, 99.9 % of the samples get there through a filter -- f32 multiply-adds on 16-bit
+        # codes plus an error bound -- and only the ambiguous ones through the f64 operations themselves
+        "dtype": ("f64 exact; f32-on-u16-codes filter decides the unambiguous samples" if "ordered+codes" in m.group.LaunchInfo()
+                  else "f64"),
+        "dtype_filter": "f32-on-u16-codes" if "ordered+codes" in m.group.LaunchInfo() else None,
         "data": "synthetic",
         "config": cfg,
         "roofline": leg.roofline(world),
@@ -1181,6 +1196,11 @@ def main():
             if isinstance(recs.get(name), dict) and "failed" in recs[name]:
                 failed_leg = name
         result["also"] = recs
+        fs = recs.get("c3_float_stream")
+        if isinstance(fs, dict) and "value" in fs:
+            # the pure-f64 figure, named where the headline's fraction is read: the same walk streaming float columns
+            result["roofline"]["f64_stream"] = {"evals_per_sec": fs["value"], "fill_kernel_us": fs.get("fill_kernel_us"),
+                                                "frac": fs.get("frac"), "record": "also.c3_float_stream"}
 
     if rank == 0:
         emit(result, json_out)

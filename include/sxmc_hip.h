@@ -222,6 +222,18 @@ int sxmc_hist_random_sample(sxmc_hist_t h, size_t nobserved, unsigned long long 
                             const float* uppers, float* h_events);
 int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s);
 
+/* EvalHist's `optimize` constructor argument (pdfz.cpp:188; default 1).  The reference's evaluator runs its launch-shape
+ * trials (Optimize, pdfz.cpp:622-814) inside its first EvalAsync once it has evaluation points (:441-448), never while
+ * CreateHistogram evaluates (:503-504).  Here the trials are those of the BATCH the library forms behind the
+ * per-evaluator calls (sxmc_group_optimize: a few timed fills pick lanes per CU, teams and codes on the box it runs on),
+ * at the batch's first lookup evaluation, when EVERY member has optimize on; 0 pins the analytic launch shape. */
+int sxmc_hist_set_optimize(sxmc_hist_t h, int enable);
+/* EvalHist::Optimize (pdfz.cpp:622-628) called by hand: the trials run (again) at the next lookup evaluation of every
+ * batch `h` is part of.  Nothing without evaluation points, as in the reference. */
+int sxmc_hist_optimize(sxmc_hist_t h);
+/* The launch plan of the batch the evaluator's evaluations go into (one line per fill launch, as
+ * sxmc_group_launch_info) and a last line "tuned=<0|1> trial_launches=<n>".  Empty before the first evaluation. */
+int sxmc_hist_launch_info(sxmc_hist_t h, char* out, size_t n);
 /* Replaces EvalHist::Optimize/OptimizeBin/OptimizeEval (pdfz.cpp:622-814): the launch shape
  * is sized analytically from the device; 0 keeps the default.  threads: a multiple of 64 up to 1024. */
 int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_per_cu);
@@ -317,6 +329,14 @@ int sxmc_group_set_codes(sxmc_group_t g, int enable);
  * "ask the exact columns" (outside a window) and rows marked "never counted" (not finite, or granule padding). */
 int sxmc_group_codes_info(sxmc_group_t g, int* members, unsigned long long* rows, unsigned long long* exact_rows,
                           unsigned long long* never_rows);
+/* The windows the codes of member `member` were cut from: field m of the streamed ones has code
+ * floor((x - base[m]) / step[m]); *nfields = how many (0: the member's fill does not stream codes).  base, step: room for
+ * SXMC_MAX_QSLOTS (4) doubles each.  For tests that place samples relative to the code cells. */
+int sxmc_group_codes_windows(sxmc_group_t g, int member, int* nfields, double* base, double* step);
+/* Cap on the per-workgroup queues of ambiguous rows of a fill over codes: 2^log2_entries entries, 9 .. 11; 0 (default):
+ * as many as fit beside the histogram.  Smaller queues fill up and are emptied in the middle of the stream, and whole
+ * granules are handed to the float columns; the RESULTS do not depend on it (tests/test_gpu_codes.py). */
+int sxmc_group_set_codes_queue_log(sxmc_group_t g, int log2_entries);
 /* Run-time kernels (default on).  The fill is fastest as straight-line code with the program of systematics
  * (apply_systematic, pdfz.cpp:306-331: which systematic writes which column, in which order, with how many
  * polynomial coefficients) fixed at compile time.  The library carries such kernels for a handful of programs;
@@ -338,11 +358,6 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n);
  * rounding (the terms are added in another order); the work no longer grows with the number of
  * events.  sxmc_group_eval_async always writes the table. */
 int sxmc_group_set_lut_output(sxmc_group_t g, int enable);
-/* Measurement hook for roofline analysis (RESULTS ARE WRONG when mode != 0; default 0):
- * bit 0 = histogram-fill kernel streams its columns but skips arithmetic and histogram,
- * bit 1 = arithmetic and histogram run but every reload hits one cached address,
- * bit 2 = skip only the histogram update. */
-int sxmc_group_set_debug_mode(sxmc_group_t g, int mode);
 int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s);
 /* As sxmc_group_eval_async(g, 1, s) followed by nll_event_chunks (nll_kernels.cpp:89-116) over
  * the members' lookup table, with the table lookup and the event sum fused in one kernel: the
@@ -598,12 +613,26 @@ int sxmc_comm_allgather_f32(sxmc_comm_t c, const float* d_send, float* d_recv, s
 int sxmc_comm_destroy(sxmc_comm_t c);
 const char* sxmc_comm_last_error(void);
 
-/* Test hook: d_out[k] = d_x[k]^i as the polynomial systematics form it (p = sum_i c_i * pow(x, i),
- * pdfz.cpp:310-314): the power rounded ONCE, like libm's pow for small integer exponents -- not the i - 1
- * roundings of repeated multiplication.  Exact for i <= 1, the plain product for i = 2. */
+/* ---------------------------------------------------------------------------------------------------------------
+ * MEASUREMENT BUILD ONLY.  libsxmc_hip.so does not export what follows (tests/test_abi.py checks); it is compiled into
+ * libsxmc_hip_measure.so (make -C sxmc_amd/csrc VARIANT=_measure EXTRA=-DSXMC_MEASURE=1), the library behind the
+ * roofline decompositions in profiles/ and behind the tests that need a look inside (known answers of the generator
+ * and of the rounded powers, the margin of the codes' error bound). */
+#ifdef SXMC_MEASURE
+/* Hooks of the histogram-fill kernels.  RESULTS ARE WRONG when mode != 0.
+ * bit 0 = stream the columns, skip arithmetic and histogram; bit 1 = arithmetic and histogram run but every reload
+ * hits one cached address; bit 2 = skip only the histogram update; bit 3 = stream the float columns regardless of
+ * codes (fused step: the fill's part of the launch alone); bit 4 = drop what the queues of ambiguous rows hold;
+ * bit 5 = no LDS additions; bits 8-15 = 1 + 64 s: the roundings' share of the codes' error bound scaled by s;
+ * bits 16-23 = 1 + 64 t: the whole threshold scaled by t (fill_kernels.inc.h, "THE BOUND"). */
+int sxmc_group_set_debug_mode(sxmc_group_t g, int mode);
+/* d_out[k] = d_x[k]^i as the polynomial systematics form it (p = sum_i c_i * pow(x, i), pdfz.cpp:310-314): the power
+ * rounded ONCE, like libm's pow for small integer exponents -- not the i - 1 roundings of repeated multiplication.
+ * Exact for i <= 1, the plain product for i = 2. */
 int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out);
-/* Test hook: raw Philox4x32-10 output of d_state[0], 4 words per draw; advances the state. */
+/* Raw Philox4x32-10 output of d_state[0], 4 words per draw; advances the state. */
 int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws);
+#endif
 
 #ifdef __cplusplus
 }

@@ -52,10 +52,15 @@ def compact_roofline(rf):
     if not isinstance(rf, dict):
         return None
     out = {"bound": rf.get("bound"), "kernel": _kernel_name(rf), "unit": rf.get("unit")}
-    for k in ("achieved", "peak", "frac", "traffic", "algorithmic_bytes_per_launch", "survey_bytes_per_launch",
-              "avg_launch_ms", "launches_timed", "whole_step_frac", "evaluations_per_launch"):
+    for k in ("achieved", "peak", "frac", "frac_survey_8d", "traffic", "algorithmic_bytes_per_launch",
+              "survey_bytes_per_launch", "avg_launch_ms", "launches_timed", "whole_step_frac", "evaluations_per_launch"):
         if k in rf:
             out[k] = _num(rf[k])
+    for k in ("traffic_source", "streams"):
+        if isinstance(rf.get(k), str):
+            out[k] = rf[k][:96]
+    if isinstance(rf.get("f64_stream"), dict):      # the conservative, pure-f64 figure (also.c3_float_stream)
+        out["f64_stream"] = _pick(rf["f64_stream"], ("evals_per_sec", "fill_kernel_us", "frac"))
     if isinstance(rf.get("sample"), str) and len(rf["sample"]) <= 48:
         out["sample"] = rf["sample"]
     prov = rf.get("traffic_provenance")
@@ -178,7 +183,7 @@ def compact(result):
     r = result
     out = {}
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data"):
+              "vs_baseline", "dtype", "dtype_filter", "data"):
         if k in r:
             out[k] = _num(r[k], 7)
     out["config"] = compact_config(r.get("config"))

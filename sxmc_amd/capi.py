@@ -102,6 +102,9 @@ SIGNATURES = {
     "sxmc_hist_random_sample": [_vp, _sz, _ull, _vp, _vp, _vp],
     "sxmc_hist_get_stream": [_vp, _pvp],
     "sxmc_hist_set_launch_config": [_vp, _i, _i],
+    "sxmc_hist_set_optimize": [_vp, _i],
+    "sxmc_hist_optimize": [_vp],
+    "sxmc_hist_launch_info": [_vp, C.c_char_p, _sz],
     "sxmc_group_create": [_vp, _i, _pvp],
     "sxmc_group_destroy": [_vp],
     "sxmc_group_set_launch_config": [_vp, _i, _i],
@@ -114,10 +117,11 @@ SIGNATURES = {
     "sxmc_group_set_ordering": [_vp, _i],
     "sxmc_group_set_codes": [_vp, _i],
     "sxmc_group_codes_info": [_vp, _pi, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)],
+    "sxmc_group_codes_windows": [_vp, _i, _pi, _pd, _pd],
+    "sxmc_group_set_codes_queue_log": [_vp, _i],
     "sxmc_group_set_runtime_kernels": [_vp, _i],
     "sxmc_group_launch_info": [_vp, C.c_char_p, _sz],
     "sxmc_group_set_lut_output": [_vp, _i],
-    "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_group_eval_async": [_vp, _i, _vp],
     "sxmc_group_eval_nll_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi],
     "sxmc_group_mcmc_step_async": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp,
@@ -161,10 +165,16 @@ SIGNATURES = {
     "sxmc_comm_abort": [_vp],
     "sxmc_comm_allgather_f32": [_vp, _vp, _vp, _sz, _vp],
     "sxmc_comm_destroy": [_vp],
+}
+STRING_GETTERS = ("sxmc_last_error", "sxmc_version", "sxmc_comm_last_error")
+# The measurement build (libsxmc_hip_measure.so: include/sxmc_hip.h, "MEASUREMENT BUILD ONLY") exports these besides;
+# the product library must NOT (tests/test_abi.py).
+MEASURE_SIGNATURES = {
+    "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_debug_pow_int": [_vp, _i, _i, _vp],
     "sxmc_debug_philox_dump": [_vp, _vp, _i],
 }
-STRING_GETTERS = ("sxmc_last_error", "sxmc_version", "sxmc_comm_last_error")
+MEASURE_LIB_PATH = os.path.join(_HERE, "csrc", "libsxmc_hip_measure.so")
 
 _lib = None
 
@@ -185,8 +195,37 @@ def load():
     for name in STRING_GETTERS:
         getattr(lib, name).restype = C.c_char_p
         getattr(lib, name).argtypes = []
+    for name, argtypes in MEASURE_SIGNATURES.items():   # (present when SXMC_HIP_LIB names the measurement build)
+        if hasattr(lib, name):
+            getattr(lib, name).argtypes = argtypes
+            getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+def is_measurement_build():
+    """Does the loaded library carry the kernels' measurement hooks (SXMC_HIP_LIB = .../libsxmc_hip_measure.so)?"""
+    return hasattr(load(), "sxmc_group_set_debug_mode")
+
+
+_measure = None
+
+
+def measure_lib():
+    """The measurement build as a SECOND handle beside the product library, for the tests' look inside (known answers of
+    the generator and of the rounded powers): its hooks take plain device pointers, whichever library allocated them."""
+    global _measure
+    if _measure is None:
+        if not os.path.exists(MEASURE_LIB_PATH):
+            raise ImportError("libsxmc_hip_measure.so not found at %s: __graft_entry__.build() builds it"
+                              % MEASURE_LIB_PATH)
+        lib = C.CDLL(MEASURE_LIB_PATH)
+        for name, argtypes in MEASURE_SIGNATURES.items():
+            getattr(lib, name).argtypes = argtypes
+            getattr(lib, name).restype = C.c_int
+        lib.sxmc_last_error.restype = C.c_char_p
+        _measure = lib
+    return _measure
 
 
 def last_error():

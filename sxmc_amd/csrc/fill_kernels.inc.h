@@ -9,7 +9,18 @@
 
 #pragma clang fp contract(off)
 
+// MEASUREMENT BUILD (make VARIANT=_measure EXTRA=-DSXMC_MEASURE=1 -> libsxmc_hip_measure.so; the run-time kernels of
+// such a library are compiled the same way).  The kernels take a word `dbg` of measurement hooks -- the stream alone,
+// the arithmetic alone, no histogram update, no drain, a scale on the codes' error bound: RESULTS ARE WRONG with any of
+// them set.  The product library is built with SXMC_MEASURE 0: sx_dbg() is then the constant 0, every branch on it is
+// folded away at compile time, and nothing in the product ABI can set it (tests/test_abi.py).
+#ifndef SXMC_MEASURE
+#define SXMC_MEASURE 0
+#endif
+
 namespace sxfill {
+
+__device__ __forceinline__ constexpr unsigned sx_dbg(unsigned dbg_arg) { return SXMC_MEASURE ? dbg_arg : 0u; }
 
 // (stand-ins for std::integral_constant / std::index_sequence)
 template <int N>
@@ -382,7 +393,8 @@ __device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr
 // is unpredicated vector code (no exec-mask juggling on the scalar unit).
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>
 __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs, const SxSegment* __restrict__ segs,
-                                          const unsigned* __restrict__ blk_off, unsigned hist_words, unsigned dbg) {
+                                          const unsigned* __restrict__ blk_off, unsigned hist_words, unsigned dbg_arg) {
+  const unsigned dbg = sx_dbg(dbg_arg);   // (0 in the product build: see SXMC_MEASURE)
   extern __shared__ unsigned lds[];
   const unsigned tid = threadIdx.x;
   const unsigned nthreads = blockDim.x;
@@ -504,7 +516,7 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
         }
       }
       if constexpr (PREW != 0) asm volatile("" : "+v"(prebits));
-      // dbg is a measurement hook (sxmc_group_set_debug_mode), 0 in production:
+      // dbg: measurement hooks (libsxmc_hip_measure.so's sxmc_group_set_debug_mode), the constant 0 in the product:
       //   bit 1: every reload hits one cached address -> the kernel without its HBM stream
       //   bit 0: skip the arithmetic and the histogram -> the HBM stream alone
       //   bit 2: skip only the histogram update
@@ -788,7 +800,8 @@ typedef unsigned vuint4g __attribute__((ext_vector_type(4)));
 template <int NOBS, int NSLOT, typename PROG, bool ORDERED = false>
 __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict__ descs,
                                                  const SxSegment* __restrict__ segs,
-                                                 const unsigned* __restrict__ blk_off, unsigned smax, unsigned dbg) {
+                                                 const unsigned* __restrict__ blk_off, unsigned smax, unsigned dbg_arg) {
+  const unsigned dbg = sx_dbg(dbg_arg);   // (0 in the product build: see SXMC_MEASURE)
   static_assert(!PROG::dynamic, "static programs only");
   // ORDERED: the table's last slot is an ordered observable (see fill_ordered_body further down): its index
   // contribution is one constant per granule, worked out from the granule's end values, except in the granules
@@ -1228,7 +1241,8 @@ __device__ __forceinline__ void fill_multi_body(SxChainDescs chains, const SxSeg
 template <int NOBS, int NSLOT, typename PROG, int NCHAIN, bool LDS_HIST = true>
 __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxSegment* __restrict__ segs,
                                                   const unsigned* __restrict__ blk_off, unsigned layout,
-                                                  unsigned dbg) {
+                                                  unsigned dbg_arg) {
+  const unsigned dbg = sx_dbg(dbg_arg);   // (0 in the product build: see SXMC_MEASURE)
   static_assert(!PROG::dynamic && NSLOT >= 1 && NOBS >= 0 && NOBS < NSLOT && NCHAIN >= 1 && NCHAIN <= 4, "unsupported");
   // LDS_HIST false: a histogram beyond LDS capacity, one global atomic per counted sample (the dense evaluation of
   // such a table: CreateHistogram; evaluations for lookup run fill_sparse_body); the granule word is then the
@@ -1520,22 +1534,56 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
               af[c][k][m] = uniform_f((float)alpha);
             }
             g = g * sc[k];
-            // half a code step per field (+ the slack of the table's own check) | the single-precision evaluation
-            // of u: coefficients rounded to 24 bits times codes below 2^16, NQ + 1 roundings of partial sums no
-            // larger than mu | the reference's double arithmetic: <= 8 systematics' roundings, each amplified no more
-            // than `mag` grows (2^-53 each; 2^-44 leaves a factor 64 for the composition's own roundings)
-            // (+ 0.25: the constant term carries e < 0.13 besides, see below)
+            // THE BOUND, term by term.  Claim: |u_codes - u_ref| <= eps, where u_ref is the product (x - lo) * scale as
+            // the reference's double arithmetic forms it for this sample (pdfz.cpp:306-331, 388-398) and u_codes =
+            // g + sum_m alpha_m * code_m as the lanes evaluate it in single precision (before e is added).
+            //  Q  the codes: the table keeps code_m only for rows with |x_m - centre_m| <= qstep_m / 2 * (1 + 2^-20), checked
+            //     per row in double when the table is built (column_codes_kernel; other rows carry SXMC_QCODE_EXACT), so
+            //     in real arithmetic |sum_m A_km (x_m - centre_m)| * scale <= sum_abs / 2 * (1 + 2^-20).  Not a margin: a
+            //     sample sits anywhere in its cell, the worst case is reached.  The 2^-19 here leaves another 2^-20 for
+            //     the roundings of that check itself (centre_m: two, <= 2^-52 |centre_m|), where |centre_m| / qstep_m <=
+            //     2^31; a window further from zero than that borrows from D below (8 of its 512 units).
+            //  S  single precision, in units of 2^-24 mu (mu bounds every partial sum: |g| + e + sum_abs * 65534, with
+            //     nbins + 0.25 to spare):  1  alpha_m rounded to 24 bits, times codes below 2^16, summed over m
+            //                              1  the constant term g + e rounded to 24 bits
+            //                              NQ one rounding per fused multiply-add (codes convert exactly)
+            //     <= NQ + 2 <= 6 units; budget 8 units = mu * 2^-21.
+            //  D  double precision, in units of 2^-53 (mag + |lo|) scale (`mag` bounds the slot's value at every point of
+            //     the program for field values inside the windows; an operation's rounding is <= 2^-53 of its result,
+            //     and what follows amplifies it by no more than it grows mag -- induction over apply_affine's cases):
+            //                              32 the reference's program: <= 8 systematics, <= 4 roundings each (ctscale:
+            //                                 x - 1, 1 + p, the product, + 1)
+            //                              2  the reference's x - lo and * scale
+            //                              32 this composition of A and C (the same operations on the coefficients)
+            //                              11 g (2 NQ + 3 operations) and alpha (2 each, relative: below 2^-52 mu)
+            //                              8  borrowed by Q, see there
+            //     <= 85 units; budget 512 units = 2^-44 (mag + |lo|) scale.
+            // eps = Q + S + D.  Measured on the GPU (tests/test_gpu_codes_margin.py): with S + D and
+            // the slack below scaled by s, samples built to sit on the threshold are binned as the CPU restatement bins them down to
+            // s = s_min < 1/2; Q scaled by anything below 1 misplaces samples, as it must.
             const double mu = sum_abs * 65536.0 + __builtin_fabs(g) + (double)nbk[k] + 0.25;
-            const double eps = 0.5 * sum_abs * (1.0 + 0x1p-19) + mu * 0x1p-21 +
-                               (form[k].mag + __builtin_fabs(lo[k])) * sc[k] * 0x1p-44;
+            const double epsq = 0.5 * sum_abs * (1.0 + 0x1p-19);
+            const double eps = epsq + mu * 0x1p-21 + (form[k].mag + __builtin_fabs(lo[k])) * sc[k] * 0x1p-44;
             ok = ok && (eps < 0.125);                      // (NaN fails)
             // The kernel evaluates u' = u + e (e = 1.01 eps, added to the constant term: no instruction) and asks ONE
-            // question, fract(u') >= 2e: the reference's value lies in [u' - 2e, u'], so if u' is at least 2e above
-            // floor(u') both have the same floor.  (1.01: the roundings of these conversions, of the constant term
-            // with e in it and of the sums that are e larger; 2^-23: the rounding of fract() of a negative u'.)
-            const double e = eps * 1.01;
+            // question, fract(u') >= 2e: u_ref lies in (u' - 2e, u'), so if u' is at least 2e above floor(u') both have
+            // the same floor -- and a u_ref within eps of 0 or nbins, where the reference's domain test (on x, before the
+            // subtraction) could disagree with the index, is never trusted.  The slack: 1.01 for the conversion of 2e to
+            // single precision (it may round down: 2^-24 relative; the e inside the sums is mu's + 0.25); 2^-23 because
+            // v_fract_f32 of a negative u' rounds (1 - 2^-30 becomes the largest value below 1).
+            double e = eps * 1.01, slack = 0x1p-23;
+#if SXMC_MEASURE
+            // (measurement build: dbg bits 8-15 = 1 + 64 * the scale on everything but Q, bits 16-23 = 1 + 64 * a scale on
+            // the whole threshold; 0 = unscaled.  RESULTS ARE WRONG below the bound: that is what is being measured.)
+            {
+              const unsigned fr = (dbg >> 8) & 0xFFu, ft = (dbg >> 16) & 0xFFu;
+              const double rs = fr ? (double)(fr - 1u) / 64.0 : 1.0, ts = ft ? (double)(ft - 1u) / 64.0 : 1.0;
+              e = (epsq + rs * (e - epsq)) * ts;
+              slack = slack * rs * ts;
+            }
+#endif
             gf[c][k] = uniform_f((float)(g + e));
-            thr[c][k] = uniform_f((float)(2.0 * e + 0x1p-23));
+            thr[c][k] = uniform_f((float)(2.0 * e + slack));
           }
           use_q = use_q && (uniform_i(ok ? 1 : 0) != 0);
         }

@@ -30,7 +30,11 @@ __global__ void init_rngs_kernel(int n, unsigned long long seed, sxmc_rng_state*
   state[idx].reserved = 0;
 }
 
-// Raw generator output for tests: out[4*i..4*i+3] = draw i of state[0]
+#ifndef SXMC_MEASURE
+#define SXMC_MEASURE 0
+#endif
+#if SXMC_MEASURE
+// (measurement build only) raw generator output for tests: out[4*i..4*i+3] = draw i of state[0]
 __global__ void philox_dump_kernel(sxmc_rng_state* state, unsigned* out, int ndraws) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   for (int i = 0; i < ndraws; i++) {
@@ -38,6 +42,7 @@ __global__ void philox_dump_kernel(sxmc_rng_state* state, unsigned* out, int ndr
     out[4 * i + 0] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------ kernels
 __global__ void pick_new_vector_kernel(int nthreads, sxmc_rng_state* rng, const float* jump_width,
@@ -146,10 +151,12 @@ hipError_t sx_nll_init_rngs(int grid, int block, hipStream_t s, int n, unsigned 
   return hipGetLastError();
 }
 
+#if SXMC_MEASURE
 hipError_t sx_nll_philox_dump(hipStream_t s, sxmc_rng_state* st, unsigned* out, int ndraws) {
   hipLaunchKernelGGL(philox_dump_kernel, dim3(1), dim3(64), 0, s, st, out, ndraws);
   return hipGetLastError();
 }
+#endif
 
 hipError_t sx_nll_pick_new_vector(int grid, int block, hipStream_t s, int n, sxmc_rng_state* rng,
                                   const float* jw, const double* cur, double* prop) {

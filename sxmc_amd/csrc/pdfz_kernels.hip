@@ -691,7 +691,7 @@ __device__ __forceinline__ void fill_step_body(unsigned nfill, const SxTailArgs&
     return;
   }
   if (threadIdx.x >= 128u) return;   // (whole waves: the roles are workgroups of 128)
-  if (dbg & 8u) return;              // measurement hook (RESULTS ARE WRONG): the fill's part of the launch alone
+  if (sxfill::sx_dbg(dbg) & 8u) return;   // measurement build only (RESULTS ARE WRONG): the fill's part of the launch alone
   SX_WG_STAMP(0);                    // (measurement build: a role's entry, its sight of the fill's end, its exit)
   extern __shared__ double sh_tail[];
   const unsigned role_index = blockIdx.x - nfill;            // 0: the finisher, 1 ..: workers
@@ -933,7 +933,8 @@ __global__ __launch_bounds__(256) void prebin_kernel(const SxSignalDesc* __restr
   }
 }
 
-// test hook: out[k] = x[k]^i as the polynomial systematics form it
+#if SXMC_MEASURE
+// (measurement build only) test hook: out[k] = x[k]^i as the polynomial systematics form it
 __global__ void pow_int_kernel(const double* __restrict__ x, int n, int i, double* __restrict__ out) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     double h = 1.0, l = 0.0;
@@ -941,6 +942,7 @@ __global__ void pow_int_kernel(const double* __restrict__ x, int n, int i, doubl
     out[k] = h;
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------ layout
 // Row-major [n][F] -> column-major with pitch; pads [n, nvec*4) with NaN in every column.
@@ -1437,11 +1439,13 @@ hipError_t sx_launch_chain_ends(const SxChainEnds& e, int nchains, int nsig, int
   return hipGetLastError();
 }
 
+#if SXMC_MEASURE
 hipError_t sx_launch_pow_int(const double* x, int n, int i, double* out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(pow_int_kernel, dim3((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), dim3(256), 0, s, x, n, i, out);
   return hipGetLastError();
 }
+#endif
 
 hipError_t sx_launch_transpose(const float* aos, float* cols, unsigned long long nsamples, int nfields,
                                unsigned long long col_pitch, hipStream_t s) {

@@ -53,6 +53,22 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+// MEASUREMENT BUILD (make VARIANT=_measure EXTRA=-DSXMC_MEASURE=1): the kernels' `dbg` hooks, the entry points that set
+// them and the environment switches that exist for A/B runs only.  The product library has none of them: measure_env()
+// is the constant nullptr there, and what remains readable from the environment are documented defaults that the ABI
+// can set too (SXMC_ROCTX, SXMC_CODES, SXMC_DEFER_EVAL, SXMC_LAZY_FINISH, SXMC_COOP_STEP_END, SXMC_FUSED_STEP).
+#ifndef SXMC_MEASURE
+#define SXMC_MEASURE 0
+#endif
+inline const char* measure_env(const char* name) {
+#if SXMC_MEASURE
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // Host-side roctx ranges around the phases of a step (tracing): what rocprofv3 --marker-trace
 // shows beside the kernel trace.  Off unless SXMC_ROCTX=1 is in the environment or sxmc_set_tracing(1) was called: a
 // step makes three of them, and config 2's step is 21 us.
@@ -237,6 +253,7 @@ struct sxmc_hist {
   unsigned long long version = 1;
   sxmc_group* self = nullptr;
   int cfg_threads = 0, cfg_bpc = 0;
+  bool want_optimize = true;       // EvalHist's `optimize` (pdfz.cpp:188, 441-448): trial launches at the first evaluation
   // sparse counting (histogram too large for LDS): one counter per distinct event bin
   unsigned* d_cnt = nullptr;       // [ntargets]
   int* d_read_slot = nullptr;      // [npoints]: counter slot of each event, or -1 / -2
@@ -352,10 +369,12 @@ struct sxmc_group {
   int cfg_order = 1, cfg_seen_order = -1;          // ... with the rows of a bucket ordered by a monotonically written observable
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   int cfg_codes = -1, cfg_seen_codes = -2;         // ordered tables streamed as 16-bit codes (-1: SXMC_CODES, default on)
+  int cfg_queue_log = 0, cfg_seen_queue_log = -1;  // ... cap on the queues of ambiguous rows, log2(entries) (0: what fits)
   std::string rtc_note;                            // why a run-time specialisation could not be had (last failure)
   std::string plan_note;                           // why a launch of the plan took a slower general path (for launch_info)
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
   bool tuned = false;                              // a deferred batch's group: the launch-shape trials have run
+  int trial_launches = 0;                          // fills sxmc_group_optimize has launched for this group (all calls)
   int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default on)
   int last_step_launches = 0;                      // kernels the last sxmc_group_step_async launched
   unsigned long long plan_generation = 0;          // counts launch plans built (a multigroup re-validates on change)
@@ -727,7 +746,7 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   double ambiguous = 0;
   for (int m = 0; m < nq && m < cd.nobs; m++) ambiguous += (double)cd.nbins[m] * cw.step[(size_t)m] / (cd.upper[m] - cd.lower[m]);
   static const bool gate_lifted = [] {   // (SXMC_CODES_GATE=1, measurement: tools/codes_gate_probe.py)
-    const char* e = std::getenv("SXMC_CODES_GATE");
+    const char* e = measure_env("SXMC_CODES_GATE");
     return e && e[0] == '1';
   }();
   if (!(ambiguous <= 2e-3) && !gate_lifted) return SXMC_OK;
@@ -756,14 +775,11 @@ using sxplan::ordered_queue_bytes;
 // the largest set of queues (512 .. 2048 entries: every wave of the workgroup owns an equal slice) that fits `room`
 // bytes, as log2(entries); 0: none, the launch then streams the float columns
 constexpr unsigned kMinQueueLog = 9;
-unsigned ordered_queue_log(size_t room) {
+unsigned ordered_queue_log(size_t room, int cap = 0) {
   unsigned qlog = 11;
-  // (test hook, read whenever a plan is built: SXMC_CODES_QUEUE_LOG = 9 .. 11 caps the queues, so that they fill up and
-  // are emptied in the middle of the stream, and whole granules are handed to the float columns; the results do not
-  // depend on it)
-  if (const char* e = std::getenv("SXMC_CODES_QUEUE_LOG")) {
-    qlog = (unsigned)std::min(std::max(std::atoi(e), (int)kMinQueueLog), 11);
-  }
+  // (sxmc_group_set_codes_queue_log caps the queues at 2^9 .. 2^11 entries -- smaller queues fill up and are emptied in
+  // the middle of the stream, and whole granules are handed to the float columns; the results do not depend on it)
+  if (cap > 0) qlog = (unsigned)std::min(std::max(cap, (int)kMinQueueLog), 11);
   while (qlog >= kMinQueueLog && ordered_queue_bytes(qlog) > room) qlog--;
   return qlog >= kMinQueueLog ? qlog : 0;
 }
@@ -1318,7 +1334,7 @@ int group_rebuild(sxmc_group* g) {
       // (SXMC_ORDERED_REPLICAS_LOG2, measurement: fewer replicas leave LDS for a second workgroup per CU -- of another
       // chain's launch, say)
       static const unsigned rlog_max = [] {
-        const char* e = std::getenv("SXMC_ORDERED_REPLICAS_LOG2");
+        const char* e = measure_env("SXMC_ORDERED_REPLICAS_LOG2");
         return e ? (unsigned)std::min(std::max(std::atoi(e), 0), 2) : 2u;
       }();
       while (rlog < rlog_max && ordered_lds_bytes(cls_max_bins, 1, rlog + 1) + qreserve <= share) rlog++;
@@ -1350,7 +1366,7 @@ int group_rebuild(sxmc_group* g) {
             }
           }
         }
-        const unsigned qlog = share > c.shape.lds_bytes ? ordered_queue_log(share - c.shape.lds_bytes) : 0;
+        const unsigned qlog = share > c.shape.lds_bytes ? ordered_queue_log(share - c.shape.lds_bytes, g->cfg_queue_log) : 0;
         c.shape.lds_layout |= qlog << 28;
         c.shape.lds_bytes += ordered_queue_bytes(qlog);
         if (!qlog) c.codes = false;   // (no room for queues: the kernel streams the float columns)
@@ -1411,7 +1427,7 @@ int group_rebuild(sxmc_group* g) {
         // 128.4 against 124.9 on another, each consistently over alternating runs), so the default is one team and
         // sxmc_group_optimize tries three on the box it runs on (SXMC_PART_GROUPS forces a count for A/B runs).
         static const int forced_groups = [] {
-          const char* e = std::getenv("SXMC_PART_GROUPS");
+          const char* e = measure_env("SXMC_PART_GROUPS");
           return e ? std::atoi(e) : 0;
         }();
         const int groups = (bucketed && c.shape.lds_hist)
@@ -1444,6 +1460,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_order = g->cfg_order;
   g->cfg_seen_rtc = g->cfg_rtc;
   g->cfg_seen_codes = g->cfg_codes;
+  g->cfg_seen_queue_log = g->cfg_queue_log;
   g->cfg_seen_fused = g->cfg_fused;
   g->plan_generation++;
   g->built = true;
@@ -1482,7 +1499,7 @@ int group_refresh(sxmc_group* g) {
                g->cfg_seen_prebin != g->cfg_prebin ||
                g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc ||
                g->cfg_seen_order != g->cfg_order || g->cfg_seen_codes != g->cfg_codes ||
-               g->cfg_seen_fused != g->cfg_fused;
+               g->cfg_seen_queue_log != g->cfg_queue_log || g->cfg_seen_fused != g->cfg_fused;
   bool points = false;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {
     if (g->seen[i] != g->members[i]->version) stale = true;
@@ -1669,7 +1686,7 @@ std::atomic<unsigned long long> g_deferred_launches{0}, g_deferred_evaluations{0
 std::atomic<int> g_captures_in_progress{0};
 hipStream_t batch_stream(const std::vector<sxmc_hist*>& m) {
   static const bool own = [] {
-    const char* e = std::getenv("SXMC_DEFER_STREAM");
+    const char* e = measure_env("SXMC_DEFER_STREAM");
     return e && std::string(e) == "own";
   }();
   const bool legacy_ok = g_captures_in_progress.load(std::memory_order_acquire) == 0;
@@ -1681,7 +1698,7 @@ hipStream_t batch_stream(const std::vector<sxmc_hist*>& m) {
 // BASELINE config 3, 4 450-4 480 against 4 530-4 570 steps/s: the runtime's own wait already spins.)
 hipError_t wait_for_stream(hipStream_t s) {
   static const long spin_us = [] {
-    const char* e = std::getenv("SXMC_FINISH_SPIN_US");
+    const char* e = measure_env("SXMC_FINISH_SPIN_US");
     return e ? std::atol(e) : 0L;
   }();
   if (spin_us > 0) {
@@ -1732,22 +1749,36 @@ int flush_deferred() {
   fl->stream = batch_stream(m);
   t_flushing = true;    // (the group calls below are themselves flush points)
   int rc = SXMC_OK;
+  // EvalHist's `optimize` (pdfz.cpp:188, 441-448, 622-628): the reference's evaluator runs its launch-shape trials
+  // inside its first EvalAsync, once it has evaluation points, unless it was constructed with optimize = false -- and
+  // never while making a histogram (pdfz.cpp:503-504: CreateHistogram switches it off around its EvalAsync(false)).
+  // Here the trials are the BATCH's (sxmc_group_optimize: a few timed fills choose lanes per CU, teams and codes for
+  // this box; only a long pure stream has anything to choose, it returns at once otherwise): at the batch's first
+  // lookup evaluation, when every member asks for it.  The evaluation proper follows and zeroes what the trials counted.
+  bool want = do_eval_pdf != 0;
+  for (sxmc_hist* h : m) want = want && h->want_optimize && h->has_points;
   if (m.size() == 1 || m[0]->cfg_threads > 0 || m[0]->cfg_bpc > 0) {
     g->cfg_threads = m[0]->cfg_threads;   // (a launch shape set by hand on the evaluators)
     g->cfg_bpc = m[0]->cfg_bpc;
-  } else if (m.size() >= 2 && !g->tuned) {
-    // EvalHist's `optimize` (pdfz.cpp:622-727: trial launches at construction pick the launch shape) for the batch, at
-    // its first launch: a few trial fills choose the lane count per CU for this box.  Only a long pure stream has
-    // anything to choose (sxmc_group_optimize returns at once otherwise); the evaluation proper follows and zeroes
-    // what the trials counted.
+  } else if (m.size() >= 2 && !g->tuned && want) {
     g->tuned = true;
     rc = sxmc_group_optimize(g, fl->stream, nullptr);
   }
   if (rc == SXMC_OK) rc = sxmc_group_eval_async(g, do_eval_pdf, fl->stream);
+  if (rc != SXMC_OK && g->built) {
+    // trial fills (or a fill whose lookup then failed) have counted into the members' histograms and normalisations:
+    // a failed evaluation leaves them zeroed, not half-counted (the error code is what the caller gets)
+    const std::string why = g_last_error;
+    (void)sx_launch_zero(g->d_descs, (int)g->members.size(), g->max_bins, g->d_ticket, fl->stream);
+    (void)hipGetLastError();
+    g_last_error = why;
+  }
   t_flushing = false;
   for (sxmc_hist* h : m) h->inflight = rc == SXMC_OK ? fl : nullptr;
-  g_deferred_launches.fetch_add(1, std::memory_order_relaxed);
-  g_deferred_evaluations.fetch_add(m.size(), std::memory_order_relaxed);
+  if (rc == SXMC_OK) {
+    g_deferred_launches.fetch_add(1, std::memory_order_relaxed);
+    g_deferred_evaluations.fetch_add(m.size(), std::memory_order_relaxed);
+  }
   return rc;
 }
 
@@ -2199,6 +2230,7 @@ int sxmc_hist_create_shared(sxmc_hist_t base, sxmc_hist_t* out) {
   h->systs = base->systs;
   h->cfg_threads = base->cfg_threads;
   h->cfg_bpc = base->cfg_bpc;
+  h->want_optimize = base->want_optimize;
   hipError_t e = hipStreamCreate(&h->stream);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_bins, sizeof(unsigned) * (size_t)h->total_nbins);
   if (e == hipSuccess) e = hipMemset(h->d_bins, 0, sizeof(unsigned) * (size_t)h->total_nbins);
@@ -2528,6 +2560,53 @@ int sxmc_hist_get_stream(sxmc_hist_t h, sxmc_stream_t* s) {
   *s = h->stream;
   return SXMC_OK;
 }
+int sxmc_hist_set_optimize(sxmc_hist_t h, int enable) {
+  SX_REQUIRE(h, "null evaluator");
+  h->want_optimize = enable != 0;
+  return SXMC_OK;
+}
+
+// EvalHist::Optimize (pdfz.cpp:622-628), called by hand: the trials run (again) at the next lookup evaluation of every
+// batch this evaluator is part of -- they need the bindings of an evaluation, which an evaluator has then.
+int sxmc_hist_optimize(sxmc_hist_t h) {
+  SX_REQUIRE(h, "null evaluator");
+  if (h->deferred) SX_FLUSH();
+  if (!h->has_points) return SXMC_OK;        // (pdfz.cpp:623: nothing without evaluation points)
+  h->want_optimize = true;
+  std::lock_guard<std::mutex> lock(g_auto_mutex);
+  for (AutoGroup& a : g_auto_groups) {
+    if (std::find(a.members.begin(), a.members.end(), h) != a.members.end()) {
+      a.g->tuned = false;
+      a.g->cfg_threads = a.g->cfg_bpc = a.g->cfg_teams = 0;   // (what earlier trials chose)
+      a.g->cfg_codes = -1;
+    }
+  }
+  return SXMC_OK;
+}
+
+// The launch plan of the batch the evaluator's last deferred evaluation went into (or of its own launches), as
+// sxmc_group_launch_info prints it, + "tuned=<0|1> trial_launches=<n>" for the group.
+int sxmc_hist_launch_info(sxmc_hist_t h, char* out, size_t n) {
+  SX_REQUIRE(h && out && n > 0, "null argument");
+  SX_FLUSH();
+  sxmc_group* g = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    for (AutoGroup& a : g_auto_groups)
+      if (std::find(a.members.begin(), a.members.end(), h) != a.members.end()) g = a.g;
+  }
+  if (!g) g = h->self;
+  if (!g) {
+    std::snprintf(out, n, "%s", "");
+    return SXMC_OK;
+  }
+  std::vector<char> buf(8192);
+  int rc = sxmc_group_launch_info(g, buf.data(), buf.size());
+  if (rc) return rc;
+  std::snprintf(out, n, "%stuned=%d trial_launches=%d\n", buf.data(), g->tuned ? 1 : 0, g->trial_launches);
+  return SXMC_OK;
+}
+
 int sxmc_hist_set_launch_config(sxmc_hist_t h, int bin_threads, int bin_blocks_per_cu) {
   SX_REQUIRE(h, "null evaluator");
   SX_REQUIRE(bin_threads == 0 || (bin_threads >= 64 && bin_threads <= 1024 && bin_threads % 64 == 0),
@@ -2623,14 +2702,12 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
   int best_threads = 0, best_bpc = 0;
   float best_ms = 0;
   int failure = SXMC_OK;
-  for (const Shape& shape : candidates) {
-    const int cand = shape.first;
-    g->cfg_threads = cand;
-    g->cfg_bpc = shape.second;
-    if ((failure = group_refresh(g)) != SXMC_OK) break;
+  // one candidate's time: eight fills of the current plan, the first warms up, the minimum of the other seven counts
+  auto timed_fill = [&]() -> float {
     float ms = 1e30f;
-    for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {  // first repetition warms up; the minimum of seven counts
+    for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {
       hipError_t e = hipEventRecord(e0, st);
+      g->trial_launches++;
       if (e == hipSuccess) failure = group_fill(g, st, false);
       if (failure == SXMC_OK && e == hipSuccess) e = hipEventRecord(e1, st);
       if (failure == SXMC_OK && e == hipSuccess) e = hipEventSynchronize(e1);
@@ -2639,6 +2716,14 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
       if (failure == SXMC_OK && e != hipSuccess) failure = fail(SXMC_ERR_HIP, std::string("optimize: ") + hipGetErrorString(e));
       if (rep > 0 && t < ms) ms = t;
     }
+    return ms;
+  };
+  for (const Shape& shape : candidates) {
+    const int cand = shape.first;
+    g->cfg_threads = cand;
+    g->cfg_bpc = shape.second;
+    if ((failure = group_refresh(g)) != SXMC_OK) break;
+    const float ms = timed_fill();
     if (failure != SXMC_OK) break;
     if (best_threads == 0 || ms < best_ms) {
       best_threads = cand;
@@ -2659,17 +2744,7 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
     for (int pass = 0; pass < 2 && failure == SXMC_OK; pass++) {
       g->cfg_teams = pass == 0 ? 0 : 3;
       if ((failure = group_refresh(g)) != SXMC_OK) break;
-      float ms = 1e30f;
-      for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {
-        hipError_t e = hipEventRecord(e0, st);
-        if (e == hipSuccess) failure = group_fill(g, st, false);
-        if (failure == SXMC_OK && e == hipSuccess) e = hipEventRecord(e1, st);
-        if (failure == SXMC_OK && e == hipSuccess) e = hipEventSynchronize(e1);
-        float t = 0;
-        if (failure == SXMC_OK && e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
-        if (failure == SXMC_OK && e != hipSuccess) failure = fail(SXMC_ERR_HIP, std::string("optimize: ") + hipGetErrorString(e));
-        if (rep > 0 && t < ms) ms = t;
-      }
+      const float ms = timed_fill();
       ms_of[pass] = ms;
     }
     g->cfg_teams = (failure == SXMC_OK && ms_of[1] < 0.985f * ms_of[0]) ? 3 : 0;
@@ -2682,17 +2757,7 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
     for (int pass = 0; pass < 2 && failure == SXMC_OK; pass++) {
       g->cfg_codes = pass == 0 ? -1 : 0;
       if ((failure = group_refresh(g)) != SXMC_OK) break;
-      float ms = 1e30f;
-      for (int rep = 0; rep < 8 && failure == SXMC_OK; rep++) {
-        hipError_t e = hipEventRecord(e0, st);
-        if (e == hipSuccess) failure = group_fill(g, st, false);
-        if (failure == SXMC_OK && e == hipSuccess) e = hipEventRecord(e1, st);
-        if (failure == SXMC_OK && e == hipSuccess) e = hipEventSynchronize(e1);
-        float t = 0;
-        if (failure == SXMC_OK && e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
-        if (failure == SXMC_OK && e != hipSuccess) failure = fail(SXMC_ERR_HIP, std::string("optimize: ") + hipGetErrorString(e));
-        if (rep > 0 && t < ms) ms = t;
-      }
+      const float ms = timed_fill();
       ms_of[pass] = ms;
     }
     g->cfg_codes = (failure == SXMC_OK && ms_of[1] < 0.97f * ms_of[0]) ? 0 : -1;
@@ -2748,6 +2813,14 @@ int sxmc_group_set_codes(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_codes_queue_log(sxmc_group_t g, int log2_entries) {
+  SX_REQUIRE(g, "null group");
+  SX_REQUIRE(log2_entries == 0 || (log2_entries >= (int)kMinQueueLog && log2_entries <= 11),
+             "the queues of ambiguous rows hold 2^9 .. 2^11 entries (0: as many as fit)");
+  g->cfg_queue_log = log2_entries;
+  return SXMC_OK;
+}
+
 int sxmc_group_codes_info(sxmc_group_t g, int* members, unsigned long long* rows, unsigned long long* exact_rows,
                           unsigned long long* never_rows) {
   SX_REQUIRE(g && members && rows && exact_rows && never_rows, "null argument");
@@ -2764,6 +2837,27 @@ int sxmc_group_codes_info(sxmc_group_t g, int* members, unsigned long long* rows
       *rows += (unsigned long long)bk->ngranules * 256ull;
       *exact_rows += bk->q_exact_rows;
       *never_rows += bk->q_never_rows;
+    }
+  }
+  return SXMC_OK;
+}
+
+int sxmc_group_codes_windows(sxmc_group_t g, int member, int* nfields, double* base, double* step) {
+  SX_REQUIRE(g && nfields && base && step, "null argument");
+  SX_REQUIRE(member >= 0 && member < (int)g->members.size(), "no such member");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  *nfields = 0;
+  for (const LaunchClass& c : g->classes) {
+    if (!c.codes) continue;
+    for (int idx : c.member_idx) {
+      const SampleStore::Bucketed* bk = g->member_bucket[(size_t)idx];
+      if (idx != member || !bk || !bk->d_qcol) continue;
+      *nfields = bk->nq;
+      for (int m = 0; m < bk->nq; m++) {
+        base[m] = bk->qbase[m];
+        step[m] = bk->qstep[m];
+      }
     }
   }
   return SXMC_OK;
@@ -2804,11 +2898,14 @@ int sxmc_group_set_lut_output(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
+#if SXMC_MEASURE
+// measurement build only: the kernels' hooks (fill_kernels.inc.h: SXMC_MEASURE).  RESULTS ARE WRONG with a mode set.
 int sxmc_group_set_debug_mode(sxmc_group_t g, int mode) {
   SX_REQUIRE(g, "null group");
   g->debug_mode = mode;
   return SXMC_OK;
 }
+#endif
 
 int sxmc_group_eval_async(sxmc_group_t g, int do_eval_pdf, sxmc_stream_t s) {
   SX_FLUSH();
@@ -3243,7 +3340,7 @@ bool multigroup_prepare(sxmc_multigroup* mg) {
       lds = (4 + (C * rstride << rlog) + 64) * 4;
       hist_words = rstride | ((size_t)rlog << 24) | (padded ? (size_t)1 << 27 : 0);
       if (c0.codes) {   // the queues of ambiguous rows (fill_ordered_body's CODES), shared by the chains
-        const unsigned qlog = lds_share > lds ? ordered_queue_log(lds_share - lds) : 0;
+        const unsigned qlog = lds_share > lds ? ordered_queue_log(lds_share - lds, g0->cfg_queue_log) : 0;
         lds += ordered_queue_bytes(qlog);
         hist_words |= (size_t)qlog << 28;
       }
@@ -3282,7 +3379,7 @@ int sxmc_multigroup_create(const sxmc_group_t* groups, int ngroups, sxmc_multigr
   for (int i = 0; i < ngroups; i++) SX_REQUIRE(groups[i], "null group");
   sxmc_multigroup* mg = new sxmc_multigroup;
   mg->groups.assign(groups, groups + ngroups);
-  if (const char* e = std::getenv("SXMC_JOINT_STEP_END")) mg->joint_ends = std::atoi(e) != 0;   // (A/B runs of whole programs)
+  if (const char* e = measure_env("SXMC_JOINT_STEP_END")) mg->joint_ends = std::atoi(e) != 0;   // (A/B runs of whole programs)
   *out = mg;
   return SXMC_OK;
 }
@@ -3829,7 +3926,8 @@ int sxmc_launch_finish_nll_jump_pick_combo(int grid, int block, sxmc_stream_t s,
   return SXMC_OK;
 }
 
-// test hook: d_out[k] = d_x[k]^i, formed as the polynomial systematics form it
+#if SXMC_MEASURE
+// (measurement build only) test hook: d_out[k] = d_x[k]^i, formed as the polynomial systematics form it
 int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out) {
   SX_FLUSH();
   SX_REQUIRE(d_x && d_out && n >= 0 && i >= 0 && i < 64, "bad arguments");
@@ -3838,12 +3936,13 @@ int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out) {
   return SXMC_OK;
 }
 
-// test hook: raw Philox output of state[0] (advances it by ndraws)
+// (measurement build only) test hook: raw Philox output of state[0] (advances it by ndraws)
 int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws) {
   SX_FLUSH();
   SX_HIP(sx_nll_philox_dump(nullptr, d_state, d_out, ndraws));
   SX_HIP(hipDeviceSynchronize());
   return SXMC_OK;
 }
+#endif
 
 }  // extern "C"

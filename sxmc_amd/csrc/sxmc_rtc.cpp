@@ -114,6 +114,9 @@ bool compile(const SxRtcSpec& k, std::vector<char>& code, std::string& err) {
 #if defined(SXMC_CACHED_LOADS) && SXMC_CACHED_LOADS
   opts.push_back("-DSXMC_CACHED_LOADS=1");
 #endif
+#if defined(SXMC_MEASURE) && SXMC_MEASURE
+  opts.push_back("-DSXMC_MEASURE=1");   // (the measurement build's run-time kernels carry the hooks too)
+#endif
   r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;

@@ -7,8 +7,10 @@
 // hand-written gfx950 kernels.  Differences, all forced by what is absent here:
 //   * ROOT-returning methods (CreateHistogram, CreateHistogramProjection, DefaultHistogram,
 //     RandomSample) are replaced by plain-array accessors (GetBins, GetNormalizedHistogram);
-//   * Optimize/OptimizeBin/OptimizeEval (brute-force launch autotuning, pdfz.cpp:622-814) are no-ops:
-//     launch shapes are sized analytically from the device;
+//   * Optimize/OptimizeBin/OptimizeEval (brute-force launch autotuning, pdfz.cpp:622-814): the constructor's
+//     `optimize` flag and Optimize() keep their meaning -- trial launches at the first evaluation with evaluation
+//     points -- but the trials are those of the BATCH the library forms behind the per-evaluator calls
+//     (sxmc_hist_set_optimize, include/sxmc_hip.h); the lookup's launch shape has nothing to choose;
 //   * a systematic's parameter-index array is read when AddSystematic is called (the reference keeps
 //     the pointer and reads it at every evaluation, pdfz.cpp:143).
 #pragma once
@@ -136,10 +138,10 @@ class EvalHist : public Eval {
            const std::vector<double>& upper, const std::vector<int>& nbins, unsigned dataset = 0,
            bool optimize = true)
       : Eval(samples, nfields, nobservables, lower, upper, dataset) {
-    (void)optimize;
     throw_on(sxmc_hist_create(samples.data(), samples.size(), 0, nfields, nobservables, lower.data(),
                               lower.size(), upper.data(), upper.size(), nbins.data(), nbins.size(), dataset,
                               &handle));
+    throw_on(sxmc_hist_set_optimize(handle, optimize ? 1 : 0));   // needs_optimization(optimize), pdfz.cpp:188
   }
   /** A second evaluator over the SAME sample table as `base` (nothing copied; own histogram, event bins
    *  and bindings; systematics as attached to `base` so far): one per concurrent chain on a GPU. */
@@ -205,9 +207,19 @@ class EvalHist : public Eval {
     if (param_buffer) throw_on(sxmc_hist_set_parameter_buffer(handle, param_buffer->readOnlyPtr(), param_offset, param_stride));
   }
 
-  virtual void Optimize() {}
-  virtual void OptimizeBin() {}
+  /** pdfz.cpp:622-628: trial launches choose the launch shape -- here at the next lookup evaluation of the batch this
+   *  evaluator is evaluated in (they need an evaluation's bindings).  OptimizeBin (:630-727) is that choice for the fill;
+   *  OptimizeEval (:729-814) tuned the lookup kernel, whose shape is one lane per evaluation point here: nothing to try. */
+  virtual void Optimize() { throw_on(sxmc_hist_optimize(handle)); }
+  virtual void OptimizeBin() { throw_on(sxmc_hist_optimize(handle)); }
   virtual void OptimizeEval() {}
+
+  /** The launch plan of the batch this evaluator's evaluations run in + "tuned=.. trial_launches=.." (tests, logs). */
+  std::string LaunchInfo() {
+    std::vector<char> buf(16384);
+    throw_on(sxmc_hist_launch_info(handle, buf.data(), buf.size()));
+    return std::string(buf.data());
+  }
 
   /** pdfz.h:542-556 */
   void GetSamples(std::vector<float>& sv) {

@@ -142,8 +142,24 @@ class EvalGroup:
         capi.call("sxmc_group_set_lut_output", self._g, int(bool(enable)))
 
     def SetDebugMode(self, mode):
-        """Measurement hook (results are wrong when mode != 0), see include/sxmc_hip.h."""
+        """The kernels' measurement hooks (RESULTS ARE WRONG when mode != 0): only the measurement build has them
+        (SXMC_HIP_LIB=.../libsxmc_hip_measure.so; include/sxmc_hip.h, "MEASUREMENT BUILD ONLY")."""
+        if not capi.is_measurement_build():
+            raise capi.SxmcError(capi.ERR_STATE, "sxmc_group_set_debug_mode exists in libsxmc_hip_measure.so only: "
+                                                 "run with SXMC_HIP_LIB pointing at it")
         capi.call("sxmc_group_set_debug_mode", self._g, int(mode))
+
+    def SetCodesQueueLog(self, log2_entries):
+        """Cap on the queues of ambiguous rows of a fill over codes (2^9 .. 2^11 entries, 0: what fits); results do not
+        depend on it."""
+        capi.call("sxmc_group_set_codes_queue_log", self._g, int(log2_entries))
+
+    def CodesWindows(self, member):
+        """(base[], step[]) of the windows member `member`'s codes were cut from; empty when its fill streams none."""
+        n = C.c_int(0)
+        base, step = (C.c_double * 4)(), (C.c_double * 4)()
+        capi.call("sxmc_group_codes_windows", self._g, int(member), C.byref(n), base, step)
+        return list(base[:n.value]), list(step[:n.value])
 
     def EvalAsync(self, do_eval_pdf=True, stream=None):
         capi.call("sxmc_group_eval_async", self._g, int(bool(do_eval_pdf)), ptr(stream))

@@ -13,10 +13,20 @@ from sxmc_amd import capi, pdfz
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(measure_section=False):
+    """Entry points include/sxmc_hip.h declares: the product's, or those inside its `#ifdef SXMC_MEASURE` section."""
     text = open(os.path.join(ROOT, "include", "sxmc_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sxmc_[a-z0-9_]+)\s*\(", text)))
+    inside = re.findall(r"#ifdef SXMC_MEASURE\n(.*?)#endif", text, flags=re.S)
+    assert len(inside) == 1
+    if not measure_section:
+        text = text.replace(inside[0], "")
+    return sorted(set(re.findall(r"\b(sxmc_[a-z0-9_]+)\s*\(", inside[0] if measure_section else text)))
+
+
+def exported(path):
+    out = os.popen("nm -D --defined-only %s" % path).read()
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
 
 
 def test_library_exports_every_declared_symbol():
@@ -29,6 +39,29 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_table_matches_header():
     assert set(declared_symbols()) == set(capi.SIGNATURES) | set(capi.STRING_GETTERS)
+    assert set(declared_symbols(measure_section=True)) == set(capi.MEASURE_SIGNATURES)
+
+
+def test_product_library_has_no_measurement_hooks():
+    """The entry points whose header comment says RESULTS ARE WRONG, the test hooks and anything else named *debug* live
+    in libsxmc_hip_measure.so only; the product exports exactly what the header's product part declares."""
+    product = exported(os.path.join(ROOT, "sxmc_amd", "csrc", "libsxmc_hip.so"))
+    hooks = set(declared_symbols(measure_section=True))
+    assert hooks == {"sxmc_group_set_debug_mode", "sxmc_debug_pow_int", "sxmc_debug_philox_dump"}
+    assert not (hooks & product)
+    assert not [n for n in product if "debug" in n and n.startswith("sxmc_")]
+    assert {n for n in product if n.startswith("sxmc_")} == set(declared_symbols())
+    # no kernel of the product carries a hook either: sx_dbg() is the constant 0 there
+    src = open(os.path.join(ROOT, "sxmc_amd", "csrc", "fill_kernels.inc.h")).read()
+    assert "return SXMC_MEASURE ? dbg_arg : 0u;" in src and "#define SXMC_MEASURE 0" in src
+
+
+def test_measurement_build_exports_the_hooks_and_the_product_abi():
+    path = capi.MEASURE_LIB_PATH
+    assert os.path.exists(path), "__graft_entry__.build() builds libsxmc_hip_measure.so"
+    measure = exported(path)
+    assert set(declared_symbols(measure_section=True)) <= measure
+    assert set(declared_symbols()) <= measure
 
 
 def test_no_oracle_in_product():

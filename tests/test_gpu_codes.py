@@ -204,17 +204,17 @@ def test_codes_with_large_and_wild_parameters():
     group.close()
 
 
-@pytest.mark.parametrize("queue_log", ["9", "10"])
-def test_codes_queue_overflow(queue_log, monkeypatch):
-    """A queue of 64 ambiguous rows per workgroup, and none at all: the rows that do not fit are decided where they
-    are met; the counts do not change."""
-    monkeypatch.setenv("SXMC_CODES_QUEUE_LOG", queue_log)
+@pytest.mark.parametrize("queue_log", [9, 10])
+def test_codes_queue_overflow(queue_log):
+    """Queues capped at 2^9 and 2^10 entries per workgroup (sxmc_group_set_codes_queue_log): they fill up and are emptied
+    in the middle of the stream, whole granules are handed to the float columns; the counts do not change."""
     rng = np.random.default_rng(157)
     sizes = [500001, 30001]
     nbins = [20, 6, 5]
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, nbins, C3, [0.0, 0.0, 0.0], nfields=5)
     group = nll.EvalGroup(evs)
     group.SetOrdering(True, force=True)
+    group.SetCodesQueueLog(queue_log)
     assert "ordered+codes" in group.LaunchInfo()
     for params in ([0.0, 30.0, 0.0], [0.02, -0.01, 0.07], [0.0, -20.0, 15.0]):
         pbuf.set(np.asarray(params, np.float64))

@@ -91,18 +91,31 @@ def test_philox_known_answers_and_stream_layout():
            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    hooks = capi.measure_lib()      # (the raw words: a test hook of the measurement build, same nll_device.h)
     for ctr, key, want in kat:
         assert philox4x32_10(ctr, key) == want
         st = np.array([key[0] | (key[1] << 32), ctr[2] | (ctr[3] << 32), ctr[0] | (ctr[1] << 32), 0],
                       dtype=np.uint64)
         d_st, d_out = DeviceArray(st), DeviceArray.zeros(8, np.uint32)
-        capi.call("sxmc_debug_philox_dump", capi.ptr(d_st), capi.ptr(d_out), 2)
+        assert hooks.sxmc_debug_philox_dump(capi.ptr(d_st), capi.ptr(d_out), 2) == capi.OK, hooks.sxmc_last_error()
         got = d_out.get()
         assert tuple(int(v) for v in got[:4]) == want
         nxt = (ctr[0] | (ctr[1] << 32)) + 1 & 0xFFFFFFFFFFFFFFFF
         assert tuple(int(v) for v in got[4:]) == philox4x32_10(
             (nxt & 0xFFFFFFFF, nxt >> 32, ctr[2], ctr[3]), key)
         assert int(d_st.get()[2]) == (ctr[0] | (ctr[1] << 32)) + 2 & 0xFFFFFFFFFFFFFFFF
+        # ... and through the PRODUCT library's own entry point: pick_new_vector (nll_kernels.cpp:30-53) of one
+        # parameter at 0 with width 1 proposes the unit normal of exactly those words (Box-Muller in double)
+        d_st = DeviceArray(st)
+        cur, prop = DeviceArray(np.zeros(1)), DeviceArray(np.zeros(1))
+        width = DeviceArray(np.ones(1, np.float32))
+        capi.call("sxmc_launch_pick_new_vector", 1, 64, None, 1, capi.ptr(d_st), capi.ptr(width), capi.ptr(cur),
+                  capi.ptr(prop))
+        capi.synchronize()
+        u1, u2 = (want[0] + 1.0) * 2.0 ** -32, want[1] * 2.0 ** -32
+        normal = math.sqrt(-2.0 * math.log(u1)) * math.cos(2.0 * math.pi * u2)
+        assert abs(prop.get()[0] - normal) <= 1e-12 * max(1.0, abs(normal))
+        assert int(d_st.get()[2]) == (ctr[0] | (ctr[1] << 32)) + 1 & 0xFFFFFFFFFFFFFFFF
 
 
 def test_init_rngs_and_proposal_statistics():

@@ -679,8 +679,9 @@ def test_polynomial_powers_are_rounded_once_like_libm_pow():
                         rng.uniform(-3, 12, 6000) * (1 + rng.normal(0, 1e-3, 6000))])        # ... and transformed ones
     dx, dout = DeviceArray(x), DeviceArray.zeros(x.size, np.float64)
     naive_off = libm_off = 0
-    for i in range(0, 8):
-        capi.call("sxmc_debug_pow_int", capi.ptr(dx), x.size, i, capi.ptr(dout))
+    hooks = capi.measure_lib()      # (a test hook of the measurement build: pow_step of the same fill_kernels.inc.h; the
+    for i in range(0, 8):           #  product's use of it is what the polynomial cases below hold against the oracle)
+        assert hooks.sxmc_debug_pow_int(capi.ptr(dx), x.size, i, capi.ptr(dout)) == capi.OK, hooks.sxmc_last_error()
         got = dout.get()
         exact = np.array([float(Fraction(v) ** i) for v in x])          # Fraction -> float rounds correctly
         assert np.array_equal(got, exact), "x^%d is not the correctly rounded power" % i
