@@ -50,7 +50,7 @@ def source_fingerprints():
                 h.update(n.encode() + b"\0" + open(path, "rb").read())
         return h.hexdigest()[:16]
     return {"kernels": digest(["fill_kernels.inc.h", "pdfz_kernels.hip", "sxmc_device_types.h", "layout_kernels.hip"]),
-            "planner": digest(["sxmc_hip.cpp", "sxmc_plan.h"])}
+            "planner": digest(["sxmc_launch_plan.cpp", "sxmc_host.h", "sxmc_plan.h"])}
 
 
 def make_c3_on_gpu(torch, dev, scale, seed, nevents):
@@ -666,8 +666,9 @@ def cpp_host_records(args, want, lut_materialized_value=None, nsteps=4000):
     """BASELINE config 3 at full size walked entirely by the C++ host layer (tests/cpp/bench_cpp: sxmc::build_pdfz +
     sxmc::MCMC over the C ABI, no Python in that process): the north star's "host code stays C++".  ONE child process
     builds the tables once and walks, as asked for in `want`:
-      cpp_host     -- the look-ahead walk, 4 000 steps incl. set-up, both burn-in re-tunings and the flushes, then 16
-                      whole fake experiments as 2 lockstep sets of 4 chains;
+      cpp_host     -- the walk sxmc::MCMC chooses by itself (lookahead_auto: one evaluation per step where the plan
+                      streams codes, the look-ahead pass where it streams float columns), 4 000 steps incl. set-up, both
+                      burn-in re-tunings and the flushes, then 16 whole fake experiments, 8 in flight with a fill each;
       c3_dropin    -- mcmc.cpp:264-271 + 314-348 AS WRITTEN (S x EvalAsync, S x EvalFinished, nll_event_chunks,
                       finish_nll_jump_pick_combo; lookup table materialised; legacy default stream; no graph, no group
                       call): what an unchanged caller gets, the library batching the S evaluations behind the API;
@@ -678,17 +679,24 @@ def cpp_host_records(args, want, lut_materialized_value=None, nsteps=4000):
     t0 = time.perf_counter()
     walks = []
     if "cpp_host" in want:
-        walks.append("lookahead=%d" % nsteps)
+        walks.append("auto=%d" % nsteps)
     if "c3_dropin" in want:
         walks.append("reference=3000")
     if "c3_1e5_walk" in want:
         walks += ["sequential=100000", "lookahead=100000"]
-    argv = ["--scale", "1.0", "--graph-steps", args.graph_steps, "--walks", ",".join(walks), "--burnin", "0.1",
-            "--sync-interval", "10000"]
+    argv = ["--scale", "1.0", "--graph-steps", args.graph_steps, "--burnin", "0.1", "--sync-interval", "10000"]
+    if walks:
+        argv += ["--walks", ",".join(walks)]
     if "cpp_host" in want:
         # (a fill per chain, 8 experiments in flight: over codes the lockstep passes no longer pay)
         argv += ["--experiments", 16, "--exp-steps", 2000, "--chains", 1, "--sets", 8]
-    lines, failure = run_bench_cpp(argv, 420)
+    if "c4_per_gpu" in want:
+        # BASELINE config 4's per-GPU share AS WRITTEN: 8 whole fake experiments of config 3's 1e5 steps each, all eight in
+        # flight on this GPU with a fill each (sxmc::ensemble_concurrent; sxmc.cpp:59-145 with fit.nsteps = 1e5)
+        argv += ["--c4", "8x100000"]
+    if not walks:
+        argv += ["--no-walk"]
+    lines, failure = run_bench_cpp(argv, 560)
     if failure:
         return {name: dict(failure) for name in want}
     by_walk = {}
@@ -697,8 +705,8 @@ def cpp_host_records(args, want, lut_materialized_value=None, nsteps=4000):
             by_walk[(ln["walk"], ln["steps"])] = ln
     out = {}
     if "cpp_host" in want:
-        rec = dict(by_walk[("lookahead", nsteps)])
-        ens = [ln for ln in lines if "ensemble_" in ln.get("driver", "")]
+        rec = dict(by_walk[("auto", nsteps)])
+        ens = [ln for ln in lines if "ensemble_" in ln.get("driver", "") and ln.get("leg") != "c4_per_gpu"]
         if ens:
             rec["ensemble"] = ens[0]              # 16 whole fake experiments, 8 in flight with a fill each: two per lane
         rec["value"], rec["unit"] = rec["steps_per_sec"], "evals/s"
@@ -727,6 +735,23 @@ def cpp_host_records(args, want, lut_materialized_value=None, nsteps=4000):
             "note": "BASELINE config 3 as written: sxmc::MCMC (C++ host) walks 1e5 steps, burn-in fraction 0.1 (widths "
                     "re-tuned from the chain at 1e4 and 2e4 steps, rows before 2e4 dropped), sync_interval 10 000 "
                     "(mcmc.cpp:261-378); `seconds` includes the walk's set-up; top level = one evaluation per step"}
+    if "c4_per_gpu" in want:
+        c4 = [ln for ln in lines if ln.get("leg") == "c4_per_gpu"]
+        if not c4:
+            out["c4_per_gpu"] = {"failed": "bench_cpp printed no c4_per_gpu record"}
+        else:
+            rec = dict(c4[0])
+            lo, hi = 0.124, 0.133        # DESIGN.md section 6, written before this was first measured (round 4)
+            v = rec["experiments_per_sec"]
+            rec.update({"value": v, "unit": "experiments/s (1e5 steps each, one GPU)",
+                        "predicted_experiments_per_sec": [lo, hi],
+                        "within_5_percent_of_prediction": bool(0.95 * lo <= v <= 1.05 * hi),
+                        "eight_gpu_projection_experiments_per_sec": 8 * v,
+                        "note": "BASELINE config 4 = nexperiments = 256 x config 3 (1e5 steps each) over 8 GPUs: this is ONE "
+                                "GPU's share run as written -- 8 experiments in flight on the card, each a fake data set "
+                                "drawn on the device, a 1e5-step walk with burn-in re-tuning and flushes every 1e4 steps, "
+                                "contour intervals; 256 experiments on 8 such GPUs = 32 per GPU = 4 rounds of this"})
+            out["c4_per_gpu"] = rec
     share = (time.perf_counter() - t0) / max(len(out), 1)
     for rec in out.values():
         rec["leg_seconds"] = share
@@ -859,7 +884,7 @@ def parse_args(argv=None):
                     help="fake experiments in flight per GPU in the ensemble leg (one stream each, shared MC tables)")
     ap.add_argument("--also", default="auto",
                     help="sub-records measured after the headline: comma list of c3_float_stream, c3_lookahead, c3_lut_materialized, c2, c5, "
-                         "c2_float_columns, bench_pdfz, bench_pdfz_group, cpp_host, c3_dropin, c3_1e5_walk, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
+                         "c2_float_columns, bench_pdfz, bench_pdfz_group, cpp_host, c3_dropin, c3_1e5_walk, c4_per_gpu, cpp_multi_gpu; auto = the single-GPU ones when the headline is the full-size C3 on one "
                          "GPU, cpp_multi_gpu (sxmc::ensemble_multi_gpu over the same cards) at N > 1; none = skip")
     ap.add_argument("--also-steps", type=int, default=200, help="timed steps of each sub-record (C5: a quarter)")
     ap.add_argument("--partition", type=int, default=0, help="0 auto, 1 sliced, 2 interleaved")
@@ -1148,7 +1173,7 @@ def main():
         also = "none"
         if full_c3 and want_cpu and args.form == "graph" and world == 1:
             also = ("c3_float_stream,c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,bench_pdfz,bench_pdfz_group,"
-                    "cpp_host,c3_dropin,c3_1e5_walk")
+                    "cpp_host,c3_dropin,c3_1e5_walk,c4_per_gpu")
         elif full_c3 and args.form == "graph" and world > 1:
             also = "cpp_multi_gpu"        # the C++ one-process runner over the same N cards
     if world > 1:
@@ -1165,7 +1190,7 @@ def main():
             leg.close()
         recs = {}
         names = [x.strip() for x in also.split(",") if x.strip()]
-        cpp_names = [n for n in names if n in ("cpp_host", "c3_dropin", "c3_1e5_walk")]
+        cpp_names = [n for n in names if n in ("cpp_host", "c3_dropin", "c3_1e5_walk", "c4_per_gpu")]
         for name in names:
             if name == "c3_lookahead":            # the same walk taken one or two steps per pass (two evaluations per pass)
                 recs[name] = also_record(args, torch, dev, "c3", "graph", False, 3 * args.also_steps, 20, exp_seed, "all",

@@ -153,10 +153,14 @@ def compact_also(rec):
               "rows_kept", "lookahead", "samples_per_sec", "vs_published", "experiments_per_sec",
               "experiments_per_sec_after_setup", "steps_per_sec_inside", "ranks", "rccl_nranks", "exchange",
               "chain_identical_to_group_path", "ratio_to_lut_materialized", "launches_per_step", "budget_seconds",
-              "within_budget", "nsteps", "locking"):
+              "within_budget", "nsteps", "locking", "experiments", "steps_each", "within_5_percent_of_prediction",
+              "eight_gpu_projection_experiments_per_sec", "sync_interval"):
         if k in rec and not isinstance(rec[k], (dict, list)):
             v = rec[k]
             out[k] = (v if len(v) <= 48 else v[:45] + "...") if isinstance(v, str) else _num(v)
+    for k in ("gathered_shape", "predicted_experiments_per_sec"):
+        if isinstance(rec.get(k), list) and len(rec[k]) <= 4:
+            out[k] = [_num(x) for x in rec[k]]
     if rec.get("per_device_locks_failed"):
         out["per_device_locks_failed"] = str(rec["per_device_locks_failed"].get("failed"))[:100]
     rf = rec.get("roofline")

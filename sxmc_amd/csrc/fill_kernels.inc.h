@@ -383,7 +383,7 @@ __device__ __forceinline__ void load_columns(Columns<NSLOT, PREW>& c, const gptr
 
 // The histogram fill.  grid = a few workgroups per CU.  The host cuts the 4-sample units of all
 // members into SEGMENTS (member, first unit, end unit, step) and gives each workgroup a short list of
-// them (sxmc_hip.cpp: build_partition): either one strided segment of one member ("interleaved":
+// them (sxmc_launch_plan.cpp: build_partition): either one strided segment of one member ("interleaved":
 // workgroups that share a member read neighbouring 8 KiB chunks at the same time, like a grid-stride
 // copy) or a contiguous slice that may span members ("sliced", for many tiny members).
 //
@@ -857,7 +857,7 @@ __device__ __forceinline__ void fill_sparse_body(const SxSignalDesc* __restrict_
     };
     load(vfirst < v1 ? vfirst : vlast);
 
-    // The host sends this kernel only geometries whose bin counts AND strides are below 2^23 (sxmc_hip.cpp:
+    // The host sends this kernel only geometries whose bin counts AND strides are below 2^23 (sxmc_launch_plan.cpp:
     // group_rebuild, `narrow`), so idx * stride + bin is ONE v_mad_i32_i24 (24-bit signed operands, 32-bit result);
     // round 2 formed it from two 24-bit products of a split stride: 5 vector instructions per observable and sample.
     double lo[NOBS], hi[NOBS], sc[NOBS];
@@ -1262,7 +1262,21 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   // (profiles/r04b_drain_batch_ab.log), two cost 8 us and three 12 us of an 82 us launch instead of saving round
   // trips -- the kernel sits at 123 of its 128 registers, a second granule's 13 spill (76 bytes of scratch, none of it
   // inside the stream loop, and still).
-  constexpr int kDrain = NCHAIN > 1 ? 1 : SXMC_DRAIN_BATCH;
+  constexpr int kDrainStream = 1;                                  // ... by a drain in the middle of the stream
+#ifndef SXMC_DRAIN_FINAL
+#define SXMC_DRAIN_FINAL SXMC_DRAIN_BATCH
+#endif
+  constexpr int kDrainFinal = NCHAIN > 1 ? 1 : SXMC_DRAIN_FINAL;   // ... by the one after it (the ring's registers are free)
+#ifndef SXMC_DRAIN_EVERY
+#define SXMC_DRAIN_EVERY 0
+#endif
+  // units between early drains of the queues (a power of two, a multiple of the ring; 0: only when a queue is full and
+  // at the end of the stream).  MEASURED, one box, alternating, three rounds (profiles/r05_early_drain_ab.log): every 64,
+  // 32 or 16 units, with one or several granules loaded together by the last drain -- 81.0-83.2 us whatever the form,
+  // the spread of the product build's own three runs (81.0-82.6).  The queues' round trips are not what is left of the
+  // launch; the product build drains only when it must.
+  constexpr int kDrainEvery = NCHAIN > 1 ? 0 : SXMC_DRAIN_EVERY;
+  static_assert(kDrainEvery == 0 || (kDrainEvery % kRing == 0 && (kDrainEvery & (kDrainEvery - 1)) == 0), "bad SXMC_DRAIN_EVERY");
   static_assert(64 % kRing == 0, "a block of 64 units is a whole number of rounds of the ring");
   typedef typename MakeISeq<PROG::n>::type Seq;
   extern __shared__ unsigned lds[];
@@ -1886,7 +1900,8 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       };
 
       // ---- what the queues hold, decided with the reference's arithmetic on the float columns
-      auto drain = [&]() {
+      auto drain = [&](auto KD) {
+        constexpr int kDrain = decltype(KD)::value;        // granules whose float columns are loaded together
         if (dbg & 16u) nrow = ngran = 0u;                  // (measurement hook: what the queues hold is dropped)
         // (nothing else of this wave's is in flight here, so every wait is a whole memory round trip: the loads of
         // the first kDrain granules go out with the first rows' and share one)
@@ -2026,8 +2041,14 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
             // (only the segment's last round can be a partial one: blocks end at multiples of 64)
             it = block_end - it < (unsigned)kRing ? block_end : it + (unsigned)kRing;
             full = ngran + (unsigned)(kRing * NCHAIN) > gq_cap;
+            // EARLY DRAIN (measurement builds: -DSXMC_DRAIN_EVERY=32; off in the product, see kDrainEvery): what the queues
+            // hold is also decided every kDrainEvery units, in the middle of the stream -- the wave stalls for the round
+            // trips of its rows and granules while the CU's other waves keep the stream going
+            if constexpr (kDrainEvery > 0) {
+              full = full || ((it & (unsigned)(kDrainEvery - 1)) == 0u && (nrow | ngran) != 0u && it < niter32);
+            }
           }
-          if (full) drain();
+          if (full) drain(IntC<kDrainStream>{});
         }
       };
       if constexpr (NOBS == 1) {
@@ -2041,7 +2062,7 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
       // takes granules w, w + W, ... of all queues, every load issued before any wait -- was built and measured on one
       // box, alternating: 87.9 us against 81.3: the barrier makes every wave wait for the slowest one before any of the
       // work starts, whereas now the early waves empty their queues under the others' streaming.)
-      drain();
+      drain(IntC<kDrainFinal>{});
     }
 
 #if SXMC_WG_STAMPS

@@ -10,7 +10,7 @@
 // change a single count: results stay bit-identical (the parity tests compare with the
 // unbucketed evaluation and with the CPU restatement of the reference).
 //
-// Steps (host side: sxmc_hip.cpp build_bucketed): key per sample -> stable radix sort of (key, row) ->
+// Steps (host side: sxmc_launch_plan.cpp, get_bucket_sort / get_bucketed): key per sample -> stable radix sort of (key, row) ->
 // first row of every key -> host lays the granules out -> gather of the streamed columns.
 #include "nll_device.h"
 

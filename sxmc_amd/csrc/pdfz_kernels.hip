@@ -1416,6 +1416,18 @@ hipError_t sx_launch_step_end2(const SxSignalDesc* lookup_a, const SxSignalDesc*
   return hipGetLastError();
 }
 
+// Workgroups of the cooperative step end the device holds at once (the runtime's occupancy figure for step_end_kernel
+// with this launch's LDS x the CU count; 0: could not be asked) -- what the host's residency check counts against
+int sx_step_end_resident_capacity(int nsig, int cus) {
+  const size_t shmem = 16 * sizeof(double) + (size_t)((nsig + 15) / 16 * 16) * sizeof(EvalMember);
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_end_kernel, 128, shmem) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return per_cu * cus;
+}
+
 // the cooperative step end's slots start out empty
 hipError_t sx_step_end_slots_init(unsigned long long* slots, double* last_good, int n) {
   std::vector<unsigned long long> h((size_t)n, kSlotEmpty);

@@ -11,6 +11,10 @@
 
 #include "../../include/sxmc_hip.h"
 
+// (sxmc_runtime.cpp) launches the calling thread's deferred evaluations and waits for a lazily finished batch unless `s`
+// orders with it by itself: the collectives read buffers those evaluations may still be writing
+int sx_flush_and_order(hipStream_t s);
+
 struct sxmc_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1, device = 0;
@@ -120,6 +124,7 @@ int sxmc_comm_abort(sxmc_comm_t c) {
 
 int sxmc_comm_allgather_f32(sxmc_comm_t c, const float* d_send, float* d_recv, size_t count, sxmc_stream_t s) {
   if (!c || !d_send || !d_recv) return comm_fail(SXMC_ERR_INVALID, "null argument");
+  if (int rc = sx_flush_and_order((hipStream_t)s)) return comm_fail(rc, sxmc_last_error());
   ncclResult_t r = ncclAllGather(d_send, d_recv, count, ncclFloat32, c->comm, (hipStream_t)s);
   if (r != ncclSuccess) return comm_fail(SXMC_ERR_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(r));
   return SXMC_OK;

@@ -117,6 +117,7 @@ hipError_t sx_launch_step_end2(const SxSignalDesc* lookup_a, const SxSignalDesc*
                                double* last_good, unsigned* sync, int nvb, const unsigned* norms_b, double* v_b,
                                const int* cap, const SxStepArgs& a, hipStream_t s);
 hipError_t sx_step_end_slots_init(unsigned long long* slots, double* last_good, int n);
+int sx_step_end_resident_capacity(int nsig, int cus);
 hipError_t sx_launch_chain_ends(const SxChainEnds& e, int nchains, int nsig, int max_bins, int block, hipStream_t s);
 hipError_t sx_launch_finish_zero(const SxSignalDesc* d_descs, int nsig, int max_bins, size_t npartial,
                                  const double* sums, unsigned* ticket, const SxStepArgs& a, int block, hipStream_t s);

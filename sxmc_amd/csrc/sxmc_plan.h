@@ -1,5 +1,5 @@
 // sxmc_plan.h -- the HOST PLANNERS of libsxmc_hip.so: every table the gfx950 kernels index blindly is laid out by
-// one of these functions, from plain vectors into plain vectors, with no HIP call and no library state.  sxmc_hip.cpp
+// one of these functions, from plain vectors into plain vectors, with no HIP call and no library state.  sxmc_launch_plan.cpp
 // calls them and uploads what they return; tests/cpp/test_plan.cpp calls the same functions with randomized shapes
 // under AddressSanitizer + UndefinedBehaviorSanitizer, replays the kernels' addressing against the results and
 // checks that nothing is missed, counted twice or addressed out of range -- without a device.

@@ -480,6 +480,39 @@ inline unsigned long long experiment_seed(unsigned long long base_seed, unsigned
   return x;
 }
 
+/** Where the lanes of ensemble_concurrent meet, twice per round of experiments: when every lane's walk is set up (before
+ *  any of them queues its first long run of steps) and when every lane's last step has finished (before any tears
+ *  down).  Set-up and tear-down synchronise the whole device; beside a chain that has a second of graph replays queued
+ *  each of those calls waits that second out, under the set-up lock the other lanes need -- which is how eight lanes came
+ *  to walk one at a time at 1e5 steps per experiment.  A lane that fails breaks the barrier: nobody waits for it. */
+class LaneBarrier {
+ public:
+  void arrive_and_wait(size_t expected) {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return;
+    const unsigned long long gen = generation;
+    if (++count >= expected) {
+      count = 0;
+      generation++;
+      cv.notify_all();
+      return;
+    }
+    cv.wait(lk, [&] { return generation != gen || broken; });
+  }
+  void break_all() {
+    std::lock_guard<std::mutex> lk(m);
+    broken = true;
+    cv.notify_all();
+  }
+
+ private:
+  std::mutex m;
+  std::condition_variable cv;
+  size_t count = 0;
+  unsigned long long generation = 0;
+  bool broken = false;
+};
+
 /** One iteration of sxmc.cpp:59-145: fake data -> MCMC -> intervals, on `stream` (null: default). */
 inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed, std::vector<Source>& sources,
                                        std::vector<Signal>& signals, std::vector<Systematic>& systematics,
@@ -487,7 +520,8 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
                                        float cl, unsigned sync_interval, unsigned graph_steps = 0,
                                        sxmc_stream_t stream = nullptr, SetupLock* exclusive = nullptr,
                                        LockstepSet* lockstep = nullptr, size_t lockstep_index = 0,
-                                       ErrorType error_type = ERROR_CONTOUR) {
+                                       ErrorType error_type = ERROR_CONTOUR, LaneBarrier* meet = nullptr,
+                                       size_t meet_lanes = 0) {
   const unsigned long long x = experiment_seed(base_seed, k);
   std::mt19937_64 rng(x);
   // `exclusive` (one chain per host thread): held over everything that allocates, copies through the
@@ -510,10 +544,33 @@ inline ExperimentResult run_experiment(unsigned k, unsigned long long base_seed,
   mcmc->lockstep = lockstep;
   mcmc->lockstep_index = lockstep_index;
   if (lockstep) mcmc->optimize = false;   // chains that share a fill pass share ONE launch shape: the default one
+  // (lanes of one round meet when all are set up and when all have stepped; a walk that ends without having passed a
+  // meeting point -- a throw, a form that has none -- passes it afterwards, so that nobody waits for it)
+  bool met_setup = false, met_steps = false;
+  if (meet && meet_lanes > 1) {
+    mcmc->on_setup_done = [&]() {
+      met_setup = true;
+      meet->arrive_and_wait(meet_lanes);
+    };
+    mcmc->on_steps_done = [&]() {
+      met_steps = true;
+      meet->arrive_and_wait(meet_lanes);
+    };
+  }
   r.phases.construct = since(t);
   if (exclusive) lock.unlock();   // the walk takes it itself
   t = PhaseClock::now();
-  Chain chain = (*mcmc)(data, nsteps, burnin_fraction, false, sync_interval);
+  Chain chain;
+  try {
+    chain = (*mcmc)(data, nsteps, burnin_fraction, false, sync_interval);
+  } catch (...) {
+    if (meet) meet->break_all();
+    throw;
+  }
+  if (meet && meet_lanes > 1) {
+    if (!met_setup) meet->arrive_and_wait(meet_lanes);
+    if (!met_steps) meet->arrive_and_wait(meet_lanes);
+  }
   r.phases.walk_setup = chain.setup_seconds;
   r.phases.steps = chain.steps_seconds;
   r.phases.walk_teardown = since(t) - chain.setup_seconds - chain.steps_seconds;
@@ -581,6 +638,7 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
   // device's lock so that lanes of the same card started from different calls still take turns)
   SetupLock own_exclusive;
   SetupLock& exclusive = device_exclusive ? *device_exclusive : own_exclusive;
+  LaneBarrier meet;    // the lanes walk in ROUNDS: set up one after the other, step side by side, tear down
   std::vector<std::thread> threads;
   for (size_t t = 0; t < lanes; t++) {
     threads.emplace_back([&, t]() {
@@ -598,11 +656,14 @@ inline std::vector<ExperimentResult> ensemble_concurrent(const std::vector<unsig
         std::vector<Systematic> sys = systematics;
         std::vector<Observable> obs = observables;
         for (size_t i = t; i < experiments.size(); i += lanes) {
+          // (lanes in this round: all of them, or what is left of the list in its last round)
+          const size_t round_lanes = std::min(lanes, experiments.size() - (i - t));
           out[i] = run_experiment(experiments[i], base_seed, src, mine, sys, obs, nsteps, burnin_fraction, cl,
-                                  sync_interval, graph_steps, strm, &exclusive, nullptr, 0, error_type);
+                                  sync_interval, graph_steps, strm, &exclusive, nullptr, 0, error_type, &meet, round_lanes);
         }
       } catch (...) {
         errors[t] = std::current_exception();
+        meet.break_all();
       }
       {
         std::lock_guard<SetupLock> lock(exclusive);

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <shared_mutex>
 #include <stdexcept>
@@ -252,8 +253,19 @@ class MCMC {
   bool lookahead = false;       //!< batched, consuming form, one chain: the LOOK-AHEAD WALK.  Every pass over the tables
                                 //!< evaluates the step's proposal AND the vector the next step proposes after a rejection
                                 //!< (a second set of evaluators over the same tables), and the step end decides one or two
-                                //!< steps (sxmc_multigroup_lookahead_step_async).  Same chain bit for bit, ~25 % more
-                                //!< steps per second at BASELINE config 3.
+                                //!< steps (sxmc_multigroup_lookahead_step_async).  Same chain bit for bit; +25 % steps
+                                //!< per second where the fill streams float columns (it is bound by the stream, and the
+                                //!< pass streams once for two evaluations), SLOWER where it streams 16-bit codes (the
+                                //!< pass is then bound by its arithmetic: BASELINE config 3, 9 380 against 10 290).
+  bool lookahead_auto = false;  //!< let the walk decide: the look-ahead pass where the launch plan streams float columns,
+                                //!< one evaluation per step where it streams codes (what the measurements above say)
+  /** Hooks for a driver that runs several walks side by side (sxmc::ensemble_concurrent): called once the walk's
+   *  set-up is over -- buffers, first evaluation, launch plan, recorded graph; the set-up lock released -- and BEFORE
+   *  its first long run of steps is queued; and once its last step has finished, before its tear-down.  An ensemble's
+   *  lanes meet at both: set-up and tear-down synchronise the whole device (allocation, launch plans), and beside a
+   *  chain that has a second of replays queued every one of those calls waits that second out -- measured at 1e5
+   *  steps per experiment: eight lanes walked ONE AT A TIME, 10 500 steps/s for the card (profiles/r05_c4_lanes.log). */
+  std::function<void()> on_setup_done, on_steps_done;
   bool lut_output = false;      //!< materialise the lookup table in the batched step (nothing reads it; when
                                 //!< false the event sum runs over distinct event-bin tuples, see sxmc_hip.h)
   unsigned long long seed = 0;  //!< gRandom->GetSeed() in the reference (mcmc.cpp:125)
@@ -443,7 +455,14 @@ class MCMC {
     const unsigned gsteps = (batched && reevaluate && !in_lockstep) ? graph_steps : 0;
 
     // ---- look-ahead walk: a shadow set of evaluators over the same tables, bound to the look-ahead vector
-    bool ahead = lookahead && batched && reevaluate && consume && !in_lockstep && !lut_output && nparameters <= 256;
+    bool ahead = (lookahead || lookahead_auto) && batched && reevaluate && consume && !in_lockstep && !lut_output &&
+                 nparameters <= 256;
+    if (ahead && lookahead_auto && !lookahead) {
+      int members = 0;
+      unsigned long long rows = 0, exact_rows = 0, never_rows = 0;
+      check(sxmc_group_codes_info(group, &members, &rows, &exact_rows, &never_rows));
+      ahead = members == 0;     // (a plan over codes walks sequentially)
+    }
     if (ahead) {
       // not every shape is offered the look-ahead pass (histograms beyond LDS; problems so small that the sequential
       // step ends in the one-workgroup form, whose event sum is partitioned differently): those walk sequentially
@@ -492,6 +511,7 @@ class MCMC {
       check(sxmc_multigroup_create(both, 2, &pair));
     }
     bool ahead_planned = false;   // the look-ahead pair has launched once: its plans exist
+    bool setup_announced = false; // on_setup_done has been called
     sxmc_stream_t strm = stream;
     sxmc_graph_t graph = nullptr;
     const bool own_stream = gsteps > 0 && !strm;
@@ -586,25 +606,32 @@ class MCMC {
       while (!flush_due(f)) f++;
       unsigned n = f - i + 1;
       resolve();
-      if (!ahead && gsteps > 0 && i > 0 && n >= gsteps) {
-        if (!graph) {  // record gsteps steps once; the launch plan is current after the eager step 0
-          RecordingScope recording(exclusive, excl.owns_lock());
-          check(sxmc_graph_begin_capture(strm));
-          try {
-            for (unsigned k = 0; k < gsteps; k++) one_step();
-          } catch (...) {
-            sxmc_graph_end_capture(strm, &graph);
-            throw;
-          }
-          check(sxmc_graph_end_capture(strm, &graph));
+      const bool replay = !ahead && gsteps > 0 && i > 0 && n >= gsteps;
+      if (replay && !graph) {  // record gsteps steps once; the launch plan is current after the eager step 0
+        RecordingScope recording(exclusive, excl.owns_lock());
+        check(sxmc_graph_begin_capture(strm));
+        try {
+          for (unsigned k = 0; k < gsteps; k++) one_step();
+        } catch (...) {
+          sxmc_graph_end_capture(strm, &graph);
+          throw;
         }
-        check(sxmc_graph_launch(graph, strm, (int)(n / gsteps)));
-        n %= gsteps;
+        check(sxmc_graph_end_capture(strm, &graph));
       }
       // set-up is over once the first run of steps after step 0 has its graph (or needs none); a lockstep chain
       // must not hold the lock while it waits for its partners, who need it for their own set-up.  The look-ahead
       // walk builds its plans in its first pass and records its graph further down: it keeps the lock until then.
+      // The lock goes BEFORE the run is queued: a run is up to sync_interval steps -- a second of device work at
+      // config 3 -- and whoever holds the lock while that is queued keeps every other chain's set-up waiting.
       if ((i > 0 || in_lockstep) && !ahead && excl.owns_lock()) excl.unlock();
+      if (i > 0 && !ahead && !setup_announced) {
+        setup_announced = true;
+        if (on_setup_done) on_setup_done();     // (an ensemble's lanes meet here: see MCMC::on_setup_done)
+      }
+      if (replay) {
+        check(sxmc_graph_launch(graph, strm, (int)(n / gsteps)));
+        n %= gsteps;
+      }
       if (in_lockstep) {
         // this run of steps together with the other chains of the set (recorded and replayed there)
         sxmc_step_args a;
@@ -745,6 +772,7 @@ class MCMC {
     }
     if (strm) check(sxmc_stream_synchronize(strm));
     chain.steps_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - steps_t0).count();
+    if (on_steps_done) on_steps_done();
     if (lockstep) lockstep->leave(lockstep_index);
     // the evaluators borrowed this walk's arrays (lookup table, normalisations, parameter vectors): un-bind them
     // before they die, or the next evaluation of an evaluator would touch destroyed arrays

@@ -37,11 +37,12 @@ LO, HI, NB = [0.3, 0.0, -1.0], [9.1, 6.0, 1.0], [20, 20, 20]       # e, r, c
 SYSTS = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
          dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]
 NFIELDS = 5
+R_VALUES = [1.05, 2.55, 3.45, 4.65]                                 # middles of bins of r
 T_RANGE = (-3.0, 15.0)                                              # the truth field's values (pins its window)
-PARAM_SETS = [[0.02, 0.01, 0.05], [-0.03, -0.02, -0.07], [0.0, 0.1, 0.3], [0.01, -0.05, -0.4], [0.0, 0.0, 0.11],
+PARAM_SETS = [[0.02, 0.01, 0.05], [-0.03, -0.02, -0.07], [0.0, 0.1, 0.3], [0.01, -0.05, -0.4], [0.0, 0.0, 0.1137],
               [0.04, 0.3, 0.02]]
 ROUNDING_SCALES = [1.0, 0.75, 0.5, 0.375, 0.25, 0.125, 0.0625, 0.03125, 0.015625, 0.0]
-TOTAL_SCALES = [0.75, 0.5]
+TOTAL_SCALES = [0.85, 0.75, 0.5]
 
 
 def background(rng, n):
@@ -52,7 +53,10 @@ def background(rng, n):
     t = rng.uniform(T_RANGE[0] + 1.0, T_RANGE[1] - 1.0, n)
     tab[:, 3] = t
     tab[:, 0] = t + rng.normal(0, 0.4, n)
-    tab[:, 1] = 6.0 * rng.uniform(size=n) ** (1.0 / 3.0)
+    # r (the ordered observable) takes four values only: inside a bucket the rows are sorted by r, and a 256-row granule
+    # whose rows straddle an r-bin edge takes the float path whatever the codes say -- with runs of equal r nearly every
+    # granule is decided from its codes (the built rows below join these runs)
+    tab[:, 1] = np.array(R_VALUES, np.float32)[rng.integers(0, 4, n)]
     tab[:, 2] = rng.uniform(-1.0, 1.0, n)
     tab[0, 0], tab[1, 0] = LO[0] - 2 * w, HI[0] + 2 * w            # beyond the window: marked "ask the exact columns"
     tab[2, 3], tab[3, 3] = T_RANGE
@@ -70,8 +74,9 @@ def reference_u(e, t, p1, p2, sc):
     return (x - LO[0]) * sc, x
 
 
-def adversarial(rng, base, step, params, nmax=6000):
-    """Rows built to sit on the threshold of the codes' test, both kinds (see the module docstring)."""
+def adversarial(rng, base, step, params, nmax=6000, tol_t=0.01):
+    """Rows built to sit on the threshold of the codes' test, both kinds (see the module docstring): columns e, truth
+    value, kind (0: A, 1: B), the bin edge k they sit on."""
     p0, p1, p2 = params
     sc = NB[0] / (HI[0] - LO[0])
     a_e, a_t = (1 + p1) * (1 + p2), -p2
@@ -91,24 +96,31 @@ def adversarial(rng, base, step, params, nmax=6000):
             # e at the edge of its cell that moves the cell's centre in the direction `side` (in u)
             at_low = (alpha_e > 0) == (side > 0)
             e_real = base[0] + (q + (0.0 if at_low else 1.0)) * step[0]
+            # the FIRST float32 inside the cell from that edge (a cell holds ~1000 of them): checked against the table's
+            # own coding, code = floor((x - base) / step) in double
             e32 = e_real.astype(np.float32)
-            for _ in range(2):                                          # one or two floats INSIDE the cell
-                e32 = np.nextafter(e32, np.float32(1e9 if at_low else -1e9)).astype(np.float32)
-            delta = rng.uniform(0.0, 0.02, q.size) * rprime
+            if at_low:
+                e32 = np.where(e32.astype(np.float64) < e_real, np.nextafter(e32, np.float32(1e9)), e32).astype(np.float32)
+            else:
+                e32 = np.where(e32.astype(np.float64) >= e_real, np.nextafter(e32, np.float32(-1e9)), e32).astype(np.float32)
+            coded = np.floor((e32.astype(np.float64) - base[0]) / step[0]) == q
+            delta = rng.uniform(0.0, 0.002, q.size) * rprime
             target = k - side * delta                                   # u_true
             # a_e e - p2 t = lo + target / sc
             t_real = (a_e * e32.astype(np.float64) - LO[0] - target / sc) / p2
             ft = (t_real - base[1]) / step[1]
             frac = ft - np.floor(ft)
             t_low = (alpha_t > 0) == (side > 0)
-            near = (frac < 0.04) if t_low else (frac > 0.96)
+            near = ((frac < tol_t) if t_low else (frac > 1.0 - tol_t)) & coded
             inside = (t_real > T_RANGE[0] + 0.01) & (t_real < T_RANGE[1] - 0.01)
             sel = near & inside
             if not sel.any():
                 continue
-            rows.append(np.stack([e32[sel], t_real[sel].astype(np.float32)], axis=1))
+            rows.append(np.stack([e32[sel], t_real[sel].astype(np.float32),
+                                  np.full(int(sel.sum()), 0.0 if side > 0 else 1.0, np.float32),
+                                  np.full(int(sel.sum()), float(k), np.float32)], axis=1))
     if not rows:
-        return np.zeros((0, 2), np.float32)
+        return np.zeros((0, 4), np.float32)
     rows = np.concatenate(rows)
     if rows.shape[0] > nmax:
         rows = rows[rng.choice(rows.shape[0], nmax, replace=False)]
@@ -139,20 +151,28 @@ def one_parameter_set(rng, params, nbackground, scales=True):
     ev.close()
     assert len(base) == 2
     adv = adversarial(rng, base, step, params)
-    # the built rows: e, truth, r and c fixed in the middle of a bin (a few values: their granules are then not mixed)
+    # the built rows: e, truth; r one of the four values of the runs, c in the middle of a bin.  Every (edge, kind) gets
+    # (r, c) bins OF ITS OWN: the comparison is between histograms, and there misplaced rows cancel -- at one edge a
+    # kind A row moves a count from bin k - 1 to k and a kind B row one from k to k - 1; at neighbouring edges one row's
+    # gain is the next one's loss.  Edge k -> c bin k (edge 20 shares c bin 0 under another r), kind -> r.
     rows = np.zeros((adv.shape[0], NFIELDS), np.float32)
     rows[:, 0], rows[:, 3] = adv[:, 0], adv[:, 1]
-    which = rng.integers(0, 4, adv.shape[0])
-    rows[:, 1] = np.array([1.05, 2.55, 3.45, 4.65], np.float32)[which]
-    rows[:, 2] = np.array([-0.75, -0.25, 0.25, 0.75], np.float32)[which]
+    kind, edge = adv[:, 2].astype(np.int64), adv[:, 3].astype(np.int64)
+    rows[:, 1] = np.array(R_VALUES, np.float32)[2 * kind + (edge == NB[0])]
+    rows[:, 2] = (LO[2] + ((edge % NB[2]) + 0.5) * (HI[2] - LO[2]) / NB[2]).astype(np.float32)
+    # (shuffled: rows of equal r keep their table order inside a bucket, and rows appended at the end of the table would
+    # all sit at the END of their run -- in the one granule that straddles the next r value and takes the float path)
     tab = np.concatenate([tab0, rows])
+    order = rng.permutation(tab.shape[0])
+    tab, rows = tab[order], None
     ev, group, norm, pbuf = make(tab)
     base2, step2 = group.CodesWindows(0)
     assert base2 == base and step2 == step, "the built rows moved the windows"
     want_bins, want_norm = oracle.bin_samples(geom, tab, NFIELDS, SYSTS, np.asarray(params, np.float64))
     # how close to the edges the built rows are, by the reference's own arithmetic
     sc = NB[0] / (HI[0] - LO[0])
-    u, _ = reference_u(rows[:, 0], rows[:, 3], params[1], params[2], sc)
+    built = np.flatnonzero(order >= tab0.shape[0])
+    u, _ = reference_u(tab[built, 0], tab[built, 3], params[1], params[2], sc)
     dist = np.abs(u - np.rint(u))
 
     def misplaced(mode):
@@ -164,7 +184,7 @@ def one_parameter_set(rng, params, nbackground, scales=True):
         return int(np.abs(got.astype(np.int64) - want_bins.astype(np.int64)).sum() // 2 +
                    abs(int(norm.get()[0]) - int(want_norm)))
 
-    out = {"params": list(params), "rows_built": int(rows.shape[0]), "rows": int(tab.shape[0]),
+    out = {"params": list(params), "rows_built": int(built.size), "rows": int(tab.shape[0]),
            "median_distance_to_edge_bins": float(np.median(dist)) if dist.size else None,
            "windows": {"base": base, "step": step},
            "unscaled": misplaced(0)}
@@ -199,6 +219,7 @@ def main():
     print(json.dumps({"sets": sets, "s_min": s_min, "rounding_scales": ROUNDING_SCALES,
                       "misplaced_at_zero": sum(r["rounding_scale"]["0.0"] for r in sets),
                       "misplaced_at_half_threshold": sum(r["total_scale"]["0.5"] for r in sets),
+                      "misplaced_at_85_percent_threshold": sum(r["total_scale"]["0.85"] for r in sets),
                       "misplaced_unscaled": sum(r["unscaled"] for r in sets),
                       "rows_built": sum(r["rows_built"] for r in sets)}))
 

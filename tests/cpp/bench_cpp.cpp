@@ -4,14 +4,19 @@
 // sets on one GPU, or sharded over the GPUs of the node with sxmc::ensemble_multi_gpu (BASELINE config 4: a host
 // thread per GPU, ONE RCCL all-gather of the intervals).  One JSON line per leg on stdout.
 //
-//   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk] [--reference-form | --sequential]
+//   bench_cpp [--scale 1.0] [--steps 2000] [--graph-steps 10] [--no-walk] [--reference-form | --sequential | --lookahead]
 //             [--burnin 0.1] [--sync-interval 10000] [--walks lookahead=100000,sequential=100000,reference=3000]
-//             [--experiments 0] [--exp-steps 2000] [--chains 4] [--sets 2]
+//             [--experiments 0] [--exp-steps 2000] [--chains 4] [--sets 2] [--c4 8x100000]
 //             [--devices G | --device-list 0,0] [--host-staging] [--per-device-locks] [--config fit.json] [--output-dir d]
 //
 // --reference-form: the walk issues mcmc.cpp:264-271 + 314-348 as written (S x EvalAsync, S x EvalFinished,
 //   nll_event_chunks, finish_nll_jump_pick_combo; lookup table materialised, legacy default stream, no graph): what an
-//   unchanged mcmc.cpp gets from this library.  --sequential: the batched step without the look-ahead pass.
+//   unchanged mcmc.cpp gets from this library.  --sequential: the batched step, one evaluation per step.  --lookahead:
+//   the look-ahead pass (two evaluations per pass over the tables).  Neither: the walk decides ("auto": look-ahead where
+//   the launch plan streams float columns, sequential where it streams codes -- MCMC::lookahead_auto).
+// --c4 NxSTEPS: a SECOND ensemble leg on the current device after the first: N whole fake experiments of STEPS steps
+//   each, N in flight with a fill each (ensemble_concurrent) -- BASELINE config 4's per-GPU share as written: "ensemble
+//   of config (3)" = 1e5 steps per experiment (sxmc.cpp:59-145 with fit.nsteps).
 // --devices G: the ensemble leg runs on devices 0..G-1 through ensemble_multi_gpu (needs --experiments).
 // --host-staging: the blocks meet through host memory instead of RCCL (rehearsal of G ranks on fewer cards).
 // --config: signals, observables, systematics, rates and sample tables come from a fit configuration
@@ -40,12 +45,14 @@ struct Options {
   bool walk = true;
   bool reference_form = false;   // the walk issues the reference's own call sequence (mcmc.cpp:264-271, 314-348)
   bool sequential = false;       // ... or the batched step, one evaluation per step (no look-ahead)
-  // --walks name=steps,...: several timed walks in ONE process over the same tables (names: lookahead, sequential,
-  // reference), each preceded by a short warm-up walk of its own form
+  bool lookahead = false;        // ... or the look-ahead pass wherever the library offers it
+  // --walks name=steps,...: several timed walks in ONE process over the same tables (names: auto, lookahead,
+  // sequential, reference), each preceded by a short warm-up walk of its own form
   std::vector<std::pair<std::string, unsigned>> walks;
   float burnin = 0.1f;
   unsigned sync_interval = 10000;
   unsigned nexp = 0, esteps = 2000, L = 4, S = 2;
+  unsigned c4_nexp = 0, c4_steps = 0;   // --c4 NxSTEPS: config 4's per-GPU share as written (a second ensemble leg)
   std::vector<int> devices;
   bool host_staging = false;
   bool per_device_locks = false;   // ensemble_multi_gpu: one set-up lock per card instead of one for the process
@@ -89,12 +96,20 @@ Options parse(int argc, char** argv) {
     }
     else if (a == "--reference-form") o.reference_form = true;
     else if (a == "--sequential") o.sequential = true;
+    else if (a == "--lookahead") o.lookahead = true;
     else if (a == "--burnin") o.burnin = (float)std::atof(next());
     else if (a == "--sync-interval") o.sync_interval = (unsigned)std::atoi(next());
     else if (a == "--experiments") o.nexp = (unsigned)std::atoi(next());
     else if (a == "--exp-steps") o.esteps = (unsigned)std::atoi(next());
     else if (a == "--chains") o.L = (unsigned)std::atoi(next());
     else if (a == "--sets") o.S = (unsigned)std::atoi(next());
+    else if (a == "--c4") {
+      const std::string v = next();
+      const size_t x = v.find('x');
+      if (x == std::string::npos) throw std::runtime_error("--c4 wants <experiments>x<steps>");
+      o.c4_nexp = (unsigned)std::atoi(v.c_str());
+      o.c4_steps = (unsigned)std::atoi(v.c_str() + x + 1);
+    }
     else if (a == "--devices") {
       const int g = std::atoi(next());
       for (int d = 0; d < g; d++) o.devices.push_back(d);
@@ -295,21 +310,19 @@ static int run(int argc, char** argv) {
   for (const std::vector<float>& t : tabs) rows_total += t.size() / F;
 
   // ---- evaluators on the current device (the single walk and the one-GPU ensemble leg)
-  if (opt.walk || (opt.nexp > 0 && !multi)) {
+  if (opt.walk || ((opt.nexp > 0 || opt.c4_nexp > 0) && !multi)) {
     for (size_t j = 0; j < signals.size(); j++) sxmc::build_pdfz(signals[j], tabs[j], (int)F, observables, systematics);
   }
 
   if (opt.walk) {
     std::vector<std::pair<std::string, unsigned>> walks = opt.walks;
-    const char* la_env = std::getenv("SXMC_BENCH_LOOKAHEAD");
     if (walks.empty()) {
-      // SXMC_BENCH_LOOKAHEAD=0 / --sequential: one evaluation per step; default: the look-ahead walk (two per pass)
-      const bool la = !(la_env && la_env[0] == '0') && !opt.sequential && !opt.reference_form;
-      walks.emplace_back(opt.reference_form ? "reference" : la ? "lookahead" : "sequential", opt.nsteps);
+      walks.emplace_back(opt.reference_form ? "reference" : opt.sequential ? "sequential" : opt.lookahead ? "lookahead" : "auto",
+                         opt.nsteps);
     }
     for (const auto& wk : walks) {
-      const bool reference_form = wk.first == "reference", lookahead = wk.first == "lookahead";
-      if (!reference_form && !lookahead && wk.first != "sequential") throw std::runtime_error("unknown walk " + wk.first);
+      const bool reference_form = wk.first == "reference", lookahead = wk.first == "lookahead", automatic = wk.first == "auto";
+      if (!reference_form && !lookahead && !automatic && wk.first != "sequential") throw std::runtime_error("unknown walk " + wk.first);
       const unsigned nsteps = wk.second;
       // the reference's sequence launches its NLL kernels on the legacy default stream (mcmc.cpp:314-348), which is
       // what the evaluators' own streams order with; the batched forms walk on a stream of their own
@@ -319,6 +332,7 @@ static int run(int argc, char** argv) {
         sxmc::MCMC mcmc(sources, signals, systematics, observables, 1234 + pass, strm);
         mcmc.graph_steps = reference_form ? 0 : opt.graph_steps;
         mcmc.lookahead = lookahead;
+        mcmc.lookahead_auto = automatic;
         mcmc.reference_form = reference_form;
         unsigned long long l0 = 0, e0 = 0, l1 = 0, e1 = 0;
         sxmc::check(sxmc_deferred_eval_stats(&l0, &e0));
@@ -338,7 +352,7 @@ static int run(int argc, char** argv) {
                       wk.first.c_str(), rows_total, signals.size(), data.size() / (observables.size() + 1), nsteps,
                       mcmc.graph_steps, sec, nsteps / sec, chain.setup_seconds, chain.steps_seconds,
                       nsteps / chain.steps_seconds, (double)opt.burnin, opt.sync_interval, chain.accepted, chain.nrows(),
-                      lookahead ? "true" : "false", mcmc.LookaheadPasses(), l1 - l0, e1 - e0);
+                      mcmc.LookaheadPasses() ? "true" : "false", mcmc.LookaheadPasses(), l1 - l0, e1 - e0);
           std::fflush(stdout);
         }
       }
@@ -347,44 +361,49 @@ static int run(int argc, char** argv) {
   }
 
   // ---- ensemble leg: whole fake experiments (fake data drawn on the device, walk with burn-in re-tuning, contour
-  // intervals), in lockstep sets of L chains (S sets in flight per GPU)
-  if (opt.nexp > 0 && !multi) {
+  // intervals), in lockstep sets of L chains (S sets in flight per GPU); then, with --c4, config 4's per-GPU share
+  auto ensemble_leg = [&](unsigned nexp, unsigned esteps, unsigned L, unsigned S, const char* tag) {
     std::vector<unsigned> ks;
-    for (unsigned k = 0; k < opt.nexp; k++) ks.push_back(k);
+    for (unsigned k = 0; k < nexp; k++) ks.push_back(k);
     if (opt.config.empty())
       for (sxmc::Signal& sg : signals) sg.nexpected = 8000.0;   // ~1e5 events per fake data set
     for (int pass = 0; pass < 2; pass++) {   // pass 0 (one round) compiles the lockstep kernel and warms up
       std::vector<unsigned> part(ks.begin(),
-                                 pass == 0 ? ks.begin() + std::min<size_t>(ks.size(), std::max(1u, opt.L) * opt.S) : ks.end());
+                                 pass == 0 ? ks.begin() + std::min<size_t>(ks.size(), std::max(1u, L) * S) : ks.end());
       sxmc::SetupLock lock;
       const auto t0 = std::chrono::steady_clock::now();
-      // --chains 1: a fill per chain, --sets experiments in flight (ensemble_concurrent) -- the faster form where the
-      // fill streams codes; --chains 2..4: lockstep sets, one pass over the tables per step for the chains of a set
-      const unsigned esteps_now = pass == 0 ? std::min(300u, opt.esteps) : opt.esteps;
+      // L < 2: a fill per chain, S experiments in flight (ensemble_concurrent) -- the faster form where the fill streams
+      // codes; L = 2..4: lockstep sets, one pass over the tables per step for the chains of a set
+      const unsigned esteps_now = pass == 0 ? std::min(300u, esteps) : esteps;
+      // (the jump buffer is flushed every sync_interval steps, mcmc.cpp:351-377: the walk's own setting, capped by its length)
+      const unsigned sync = std::min(esteps, std::max(opt.sync_interval, 1u));
       std::vector<sxmc::ExperimentResult> res =
-          opt.L < 2 ? sxmc::ensemble_concurrent(part, base_seed, sources, signals, systematics, observables, esteps_now,
-                                                burnin, std::max(1u, opt.S), cl, opt.esteps, opt.graph_steps, -1, &lock,
-                                                error_type)
-                    : sxmc::ensemble_lockstep(part, base_seed, sources, signals, systematics, observables, esteps_now,
-                                              burnin, opt.L, opt.S, cl, opt.esteps, opt.graph_steps, -1, &lock,
-                                              error_type);
+          L < 2 ? sxmc::ensemble_concurrent(part, base_seed, sources, signals, systematics, observables, esteps_now,
+                                            burnin, std::max(1u, S), cl, sync, opt.graph_steps, -1, &lock, error_type)
+                : sxmc::ensemble_lockstep(part, base_seed, sources, signals, systematics, observables, esteps_now,
+                                          burnin, L, S, cl, sync, opt.graph_steps, -1, &lock, error_type);
       const double sec = seconds_since(t0);
       if (pass == 1) {
-        std::printf("{\"driver\": \"sxmc::%s (C++)\", \"experiments\": %zu, \"steps_each\": %u, "
-                    "\"chains_per_fill\": %u, \"sets\": %u, \"seconds\": %.4f, \"experiments_per_sec\": %.4f, "
-                    "\"steps_per_sec_inside\": %.1f, \"nevents_first\": %zu, "
+        double steps_sec = 0;      // (the walks' stepping phases, summed over the experiments: they overlap)
+        for (const sxmc::ExperimentResult& r : res) steps_sec += r.phases.steps;
+        std::printf("{\"driver\": \"sxmc::%s (C++)\", \"leg\": \"%s\", \"experiments\": %zu, \"steps_each\": %u, "
+                    "\"chains_per_fill\": %u, \"sets\": %u, \"sync_interval\": %u, \"seconds\": %.4f, "
+                    "\"experiments_per_sec\": %.5f, "
+                    "\"steps_per_sec_inside\": %.1f, \"nevents_first\": %zu, \"gathered_shape\": [%zu, %zu, 4], "
                     "\"phase_seconds_summed_over_experiments\": %s, "
                     "\"setup_lock\": {\"waited_seconds_summed_over_lanes\": %.4f, \"held_seconds\": %.4f, "
                     "\"acquisitions\": %llu, \"lanes\": %u}}\n",
-                    opt.L < 2 ? "ensemble_concurrent" : "ensemble_lockstep", res.size(), opt.esteps, opt.L, opt.S, sec,
-                    res.size() / sec, res.size() * (double)opt.esteps / sec,
-                    res.empty() ? (size_t)0 : res[0].nevents, phases_json(res).c_str(), lock.waited_seconds(),
-                    lock.held_seconds(), lock.count(),
-                    opt.L * opt.S);
+                    L < 2 ? "ensemble_concurrent" : "ensemble_lockstep", tag, res.size(), esteps, L, S, sync, sec,
+                    res.size() / sec, res.size() * (double)esteps / sec,
+                    res.empty() ? (size_t)0 : res[0].nevents, res.size(), res.empty() ? (size_t)0 : res[0].intervals.size(),
+                    phases_json(res).c_str(), lock.waited_seconds(), lock.held_seconds(), lock.count(),
+                    std::max(1u, L) * S);
         std::fflush(stdout);
       }
     }
-  }
+  };
+  if (opt.nexp > 0 && !multi) ensemble_leg(opt.nexp, opt.esteps, opt.L, opt.S, "ensemble");
+  if (opt.c4_nexp > 0 && !multi) ensemble_leg(opt.c4_nexp, opt.c4_steps, 1, opt.c4_nexp, "c4_per_gpu");
   for (sxmc::Signal& s : signals) {
     delete s.histogram;
     s.histogram = nullptr;

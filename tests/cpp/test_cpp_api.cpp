@@ -536,6 +536,32 @@ TEST_F(SmallFit, LookaheadWalkIsTheSequentialChain) {
   }
 }
 
+TEST_F(SmallFit, AutoWalkTakesTheLookaheadPassOnlyWhereThePlanStreamsFloatColumns) {
+  // MCMC::lookahead_auto: the walk decides -- the look-ahead pass where the fill streams float columns (this small
+  // fit), one evaluation per step where it streams codes; the chain is the sequential one either way
+  sxmc::MCMC a(sources, signals, systematics, observables, 7);
+  sxmc::Chain ca = a(data, 200, 0.2f, false, 100);
+  sxmc::MCMC b(sources, signals, systematics, observables, 7);
+  b.lookahead_auto = true;
+  sxmc::Chain cb = b(data, 200, 0.2f, false, 100);
+  EXPECT_EQ(ca.accepted, cb.accepted);
+  bool same = ca.rows.size() == cb.rows.size();
+  for (size_t k = 0; same && k < ca.rows.size(); k++) same = ca.rows[k] == cb.rows[k];
+  EXPECT_TRUE(same);
+  // what the plan of this fit's evaluators streams decides which walk it was
+  std::vector<sxmc_hist_t> handles;
+  for (const sxmc::Signal& s : signals) handles.push_back(dynamic_cast<pdfz::EvalHist*>(s.histogram)->Handle());
+  sxmc_group_t g = nullptr;
+  sxmc::check(sxmc_group_create(handles.data(), (int)handles.size(), &g));
+  int members = 0, supported = 0;
+  unsigned long long rows = 0, exact_rows = 0, never_rows = 0;
+  sxmc::check(sxmc_group_set_lut_output(g, 0));
+  sxmc::check(sxmc_group_codes_info(g, &members, &rows, &exact_rows, &never_rows));
+  sxmc::check(sxmc_group_lookahead_supported(g, &supported));
+  sxmc::check(sxmc_group_destroy(g));
+  EXPECT_EQ(b.LookaheadPasses() > 0, members == 0 && supported != 0);
+}
+
 TEST(NllLaunch, ReferenceSpelling) {
   // the launch macro with the reference's argument order (mcmc.cpp:396-414)
   const size_t ne = 5, ns = 2, np = 2;

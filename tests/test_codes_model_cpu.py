@@ -41,7 +41,7 @@ def reference_bins(tab, systs, params, lo, hi, nb):
 
 
 def windows(tab, fields, nobs, lo, hi):
-    """get_bucket_codes (sxmc_hip.cpp): a window per streamed field."""
+    """get_bucket_codes (sxmc_launch_plan.cpp): a window per streamed field."""
     base, step = [], []
     ulo, uhi = 0.0, -1.0
     for m, fld in enumerate(fields):

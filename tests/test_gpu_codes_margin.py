@@ -36,9 +36,9 @@ def test_rows_built_on_the_threshold_are_binned_like_the_oracle():
     for params in worker.PARAM_SETS:
         rec = worker.one_parameter_set(rng, params, 60000, scales=False)
         assert rec["unscaled"] == 0, rec
-        assert rec["rows_built"] > 500 and rec["median_distance_to_edge_bins"] < 2e-3, rec
+        assert rec["rows_built"] > 100 and rec["median_distance_to_edge_bins"] < 2e-3, rec
         built += rec["rows_built"]
-    assert built > 10000
+    assert built > 8000
 
 
 def test_margin_of_the_bound_and_negative_control():
@@ -50,7 +50,7 @@ def test_margin_of_the_bound_and_negative_control():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "codes_margin.json"), "w") as f:
         json.dump(rec, f, indent=1)
-    assert rec["rows_built"] > 10000
+    assert rec["rows_built"] > 8000
     # the bound as shipped: nothing misplaced
     assert rec["misplaced_unscaled"] == 0
     for s in rec["sets"]:
@@ -58,10 +58,15 @@ def test_margin_of_the_bound_and_negative_control():
     # MEASURED MARGIN: the hand-set part of the bound (everything but the half code step) can be halved -- at least --
     # before a single one of these samples is misplaced
     assert rec["s_min"] is not None and rec["s_min"] <= 0.5, rec["s_min"]
-    # ... and the samples do sit on the threshold: with no room for roundings at all some ARE misplaced
-    assert rec["misplaced_at_zero"] > 0, rec
-    # NEGATIVE CONTROL: a threshold half as large as the bound (the half code step included) misplaces samples by the
-    # thousand -- a bound that is 2 x too small is seen by these tests
+    # ... and it is a MEASUREMENT, not a test that cannot fail: below s_min samples ARE misplaced (the roundings the
+    # bound provides for are real: with no room for them at all, s = 0, a good part of the built rows goes wrong)
+    below = [x for x in rec["rounding_scales"] if x < rec["s_min"]]
+    assert below and rec["misplaced_at_zero"] > 0, rec
+    assert sum(st["rounding_scale"][str(max(below))] for st in rec["sets"]) > 0, rec
+    # NEGATIVE CONTROL on the whole threshold: the bound is Q + R with R about a tenth of Q, so a threshold at 85 % of
+    # the bound is already below the half code step and misplaces samples; one half as large as the bound misplaces them
+    # by the thousand -- a bound that is too small does not get past these tests
+    assert rec["misplaced_at_85_percent_threshold"] > 100, rec
     assert rec["misplaced_at_half_threshold"] > 1000, rec
-    for s in rec["sets"]:
-        assert s["total_scale"]["0.5"] > 0 and s["total_scale"]["0.75"] > 0, s
+    for st in rec["sets"]:
+        assert st["total_scale"]["0.5"] > 0 and st["total_scale"]["0.75"] > 0, st

@@ -268,3 +268,91 @@ def test_lazy_finish_is_not_observable_through_the_abi(lazy):
             p.close()
     finally:
         capi.call("sxmc_set_lazy_finish", 1)
+
+
+def test_results_in_pinned_host_memory_are_there_when_evalfinished_returns():
+    """EvalFinished of a batch on the legacy stream normally does not stop the host (the device orders what follows);
+    a batch with an output buffer the HOST reads directly -- pinned memory here -- must wait, as the reference's
+    EvalFinished does (pdfz.cpp:491-495): the normalisations are read straight from the pinned words, no copy, no
+    synchronisation of any kind between EvalFinished and the read.  """
+    w = workloads.config3(0.02, nevents=1500)
+    pdfs, lut, norms, pars, vec, events = make_evaluators(w)
+    want_lut, want_norms, _ = oracle_rows(w, vec, events)
+    pinned = C.c_void_p(0)
+    capi.call("sxmc_host_alloc", C.byref(pinned), 4 * w.nsignals)
+    words = (C.c_uint32 * w.nsignals).from_address(pinned.value)
+    for j, p in enumerate(pdfs):
+        p.SetNormalizationBuffer(pinned.value, j)
+    for rep in range(6):                              # (the first batch is launched at EvalFinished, the later ones at the
+        for j in range(w.nsignals):                   #  last sibling's EvalAsync: the device is busy when the host reads)
+            words[j] = 0xFFFFFFFF
+        for p in pdfs:
+            p.EvalAsync()
+        for p in pdfs:
+            p.EvalFinished()
+        got = np.array([words[j] for j in range(w.nsignals)], np.uint32)      # straight from host memory
+        assert np.array_equal(got, want_norms), (rep, got, want_norms)
+    assert np.array_equal(lut.get().view(np.uint32), want_lut.view(np.uint32))
+    for p in pdfs:
+        p.close()
+    capi.call("sxmc_host_free", pinned)
+
+
+def launch_info(ev):
+    buf = C.create_string_buffer(16384)
+    capi.call("sxmc_hist_launch_info", ev.handle, buf, len(buf))
+    return buf.value.decode()
+
+
+def test_optimize_flag_of_the_evaluators_decides_the_batchs_trial_launches():
+    """EvalHist's `optimize` (pdfz.cpp:188, 441-448, 622-628): trial launches at the first evaluation with evaluation
+    points -- here the batch's (sxmc_group_optimize), when every member has the flag on.  optimize = False pins the
+    analytic launch shape: no trial launch, the plan the planner makes by itself; Optimize() by hand asks for the
+    trials again; results are the oracle's either way."""
+    w = workloads.config3(0.3, nevents=3000)         # (long enough a stream for the planner to have something to choose)
+    want = None
+    plans = {}
+    for flag in (False, True):
+        pdfs, lut, norms, pars, vec, events = make_evaluators(w)
+        if want is None:
+            want = oracle_rows(w, vec, events)
+        for p in pdfs:
+            capi.call("sxmc_hist_set_optimize", p.handle, int(flag))
+        for rep in range(2):
+            for p in pdfs:
+                p.EvalAsync()
+            for p in pdfs:
+                p.EvalFinished()
+        info = launch_info(pdfs[0])
+        plans[flag] = info
+        assert ("tuned=1" in info) == flag, info
+        trials = int(info.strip().split("trial_launches=")[1])
+        assert (trials > 0) == flag, info
+        if not flag:
+            # the analytic default over codes: two workgroups of 512 lanes per CU (group_rebuild)
+            assert "threads=512" in info and "ordered+codes" in info, info
+            # Optimize() by hand: the trials run at the next lookup evaluation
+            capi.call("sxmc_hist_optimize", pdfs[0].handle)
+            for p in pdfs:
+                capi.call("sxmc_hist_set_optimize", p.handle, 1)
+            for p in pdfs:
+                p.EvalAsync()
+            for p in pdfs:
+                p.EvalFinished()
+            again = launch_info(pdfs[0])
+            assert "tuned=1" in again and int(again.strip().split("trial_launches=")[1]) > 0, again
+        assert np.array_equal(lut.get().view(np.uint32), want[0].view(np.uint32))
+        assert np.array_equal(norms.get(), want[1])
+        # a fill-only evaluation (CreateHistogram's) never runs trials (pdfz.cpp:503-504)
+        for p in pdfs:
+            p.close()
+    pdfs, lut, norms, pars, vec, events = make_evaluators(w)
+    for rep in range(2):
+        for p in pdfs:
+            p.EvalAsync(False)
+        for p in pdfs:
+            p.EvalFinished()
+    info = launch_info(pdfs[0])
+    assert "tuned=0" in info and info.strip().endswith("trial_launches=0"), info
+    for p in pdfs:
+        p.close()

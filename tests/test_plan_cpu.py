@@ -33,12 +33,13 @@ def test_host_planners_device_free(exe):
 
 
 def test_planner_header_needs_no_hip():
-    """sxmc_plan.h is what sxmc_hip.cpp uploads from: it must stay free of HIP and of library state, or the
+    """sxmc_plan.h is what the library's host side (sxmc_launch_plan.cpp, sxmc_evaluator.cpp) uploads from: it must stay free of HIP and of library state, or the
     device-free test above stops covering what runs in production."""
     text = open(os.path.join(ROOT, "sxmc_amd", "csrc", "sxmc_plan.h")).read()
     code = "\n".join(line.split("//")[0] for line in text.splitlines())      # (comments may name HIP)
     assert "hip" not in code.lower() and "#include <hip" not in text
-    src = open(os.path.join(ROOT, "sxmc_amd", "csrc", "sxmc_hip.cpp")).read()
+    src = "".join(open(os.path.join(ROOT, "sxmc_amd", "csrc", f)).read()
+                  for f in ("sxmc_launch_plan.cpp", "sxmc_evaluator.cpp", "sxmc_host.h"))
     for fn in ("build_partition", "interleaved_segments", "apportion_workgroups", "build_sparse_tables", "eval_point_bins",
                "bucket_granules", "bucket_key_offsets", "bucketed_layout", "bucket_tables", "event_classes"):
         assert "sxplan::" + fn in src, fn + " is not what the library calls"
