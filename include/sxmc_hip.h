@@ -455,9 +455,9 @@ int sxmc_multigroup_destroy(sxmc_multigroup_t mg);
 int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc_step_args* args);
 /* The chains' step ends (lookup + event sum; finish_nll_jump_pick_combo + clearing) share two launches for the whole
  * set -- chain = blockIdx.y, every workgroup doing what it does for a chain stepped alone, so the chains are the
- * same bit for bit -- instead of two launches per chain.  Default 1; 0: chain by chain (measurement / tests;
- * SXMC_JOINT_STEP_END=0 in the environment makes that the default of multigroups created afterwards, for A/B runs
- * of whole programs: tools/joint_ends_ab.sh). */
+ * same bit for bit -- instead of two launches per chain.  Default 1; 0: chain by chain (measurement / tests; in the
+ * measurement build SXMC_JOINT_STEP_END=0 in the environment makes that the default of multigroups created afterwards,
+ * for A/B runs of whole programs: profiles/r03_lockstep_step_ends.log). */
 int sxmc_multigroup_set_joint_step_end(sxmc_multigroup_t mg, int enable);
 /* LOOK-AHEAD WALK: one chain, two likelihood evaluations per pass over the tables.  A Metropolis step that rejects
  * (jump_decider, nll_kernels.cpp:56-86) leaves the chain where it was, and the next proposal -- current vector +

@@ -260,7 +260,7 @@ typedef float vfloat4 __attribute__((ext_vector_type(4)));  // one 16-byte load 
 // replay hit on die, were 5-7 % SLOWER at every launch shape (profiles/r03_c2_sweep_policy_x_shape.log: 33 300
 // against 35 700 evals/s at 1024 x 1).  A library built with -DSXMC_CACHED_LOADS=1 (make VARIANT=_cached
 // EXTRA=-DSXMC_CACHED_LOADS=1; SXMC_HIP_LIB selects it) repeats that measurement.
-// Measurement build only (make VARIANT=_stamps EXTRA=-DSXMC_WG_STAMPS=1, tools/wg_tail_study.py): every workgroup of
+// Measurement build only (make VARIANT=_stamps EXTRA=-DSXMC_WG_STAMPS=1; profiles/r04b_wg_tail_codes.log): every workgroup of
 // the ordered fill leaves the 100 MHz real-time counter at its entry, at the end of its stream and at its exit.
 #ifndef SXMC_WG_STAMPS
 #define SXMC_WG_STAMPS 0

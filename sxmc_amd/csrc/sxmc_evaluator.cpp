@@ -81,77 +81,10 @@ hipError_t wait_for_stream(hipStream_t s) {
   return hipStreamSynchronize(s);
 }
 
-// A BATCH AS A GRAPH.  An unchanged caller's step is five launches on the legacy stream -- the batch's zero, fill and
-// lookup, then the caller's nll_event_chunks and finish_nll_jump_pick_combo (mcmc.cpp:264-348) -- against four replayed
-// from a graph for a caller of the group API; launched one by one, every boundary between dependent kernels costs the
-// queue a couple of microseconds.  The batch's own three launches never change between steps (descriptors and
-// parameters live in device memory), so from its third evaluation on the batch is RECORDED once, on its first member's
-// stream, and replayed into the stream it is due on; a new launch plan or new evaluation points drop the recording.
-// Not while the group's fills are being timed, not inside a caller's own recording, only for batches on the legacy
-// stream (the others are the rare fall-back).  SXMC_BATCH_GRAPH=0 (measurement build) launches one by one.
-int batch_launch(sxmc_group* g, int do_eval_pdf, hipStream_t st, sxmc_hist* first) {
-  static const bool graphs = [] {
-    const char* e = measure_env("SXMC_BATCH_GRAPH");
-    return !(e && e[0] == '0');
-  }();
-  const int k = do_eval_pdf ? 1 : 0;
-  if (!graphs || st != nullptr || g->members.size() < 2 || g->prof || t_capturing || !first->stream) {
-    return sxmc_group_eval_async(g, do_eval_pdf, st);
-  }
-  int rc = group_refresh(g);
-  if (rc) return rc;
-  rc = group_check_bound(g, do_eval_pdf != 0);
-  if (rc) return rc;
-  if (g->batch_graph[k] &&
-      (g->batch_graph_plan[k] != g->plan_generation || g->batch_graph_points[k] != g->points_generation)) {
-    (void)hipGraphExecDestroy(g->batch_graph[k]);
-    g->batch_graph[k] = nullptr;
-    g->batch_launches[k] = 0;
-  }
-  if (!g->batch_graph[k]) {
-    // (the first evaluations go out launch by launch: the plan settles -- trial launches, run-time kernels -- first)
-    if (++g->batch_launches[k] < 3) return sxmc_group_eval_async(g, do_eval_pdf, st);
-    hipStream_t cs = first->stream;
-    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      (void)hipGetLastError();
-      return sxmc_group_eval_async(g, do_eval_pdf, st);
-    }
-    t_capturing = true;
-    t_capture_epoch++;
-    t_capture_groups.clear();
-    rc = sxmc_group_eval_async(g, do_eval_pdf, cs);
-    t_capturing = false;
-    for (sxmc_group* q : t_capture_groups) q->prezeroed = 0;   // nothing recorded has run yet
-    t_capture_groups.clear();
-    hipGraph_t graph = nullptr;
-    const hipError_t ended = hipStreamEndCapture(cs, &graph);
-    hipGraphExec_t exec = nullptr;
-    if (rc == SXMC_OK && ended == hipSuccess && graph) {
-      if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
-    }
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    if (!exec) {                      // (could not be recorded: this batch keeps going out launch by launch)
-      g->batch_launches[k] = -1000000;
-      return rc ? rc : sxmc_group_eval_async(g, do_eval_pdf, st);
-    }
-    g->batch_graph[k] = exec;
-    g->batch_graph_plan[k] = g->plan_generation;
-    g->batch_graph_points[k] = g->points_generation;
-  }
-  SX_HIP(hipGraphLaunch(g->batch_graph[k], st));
-  // what the launches' own bookkeeping would have noted (group_prepare_fill, sxmc_group_eval_async)
-  const bool sparse = do_eval_pdf && g->sparse_ready && g->cfg_sparse;
-  for (sxmc_hist* h : g->members) {
-    h->cleared_by = nullptr;
-    h->bins_valid = h->total_nbins > kLdsMaxBins ? !sparse : true;
-  }
-  g->prezeroed = 0;
-  g->last_sparse = sparse;
-  g->last_stream = st;
-  return SXMC_OK;
-}
-
+// (A batch as a GRAPH -- its zero, fill and lookup recorded once and replayed into the legacy stream -- was built and
+// measured against the three launches one by one, alternating on one box: 8 490-8 540 steps/s of the unchanged caller's
+// walk at config 3 against 8 910-8 940.  hipGraphLaunch into the legacy stream costs more than the two kernel boundaries
+// it saves; the batch goes out launch by launch.  profiles/r05_dropin_ab.log.)
 // Launches the calling thread's batch, if any.  Every entry point that could observe a deferred evaluation calls this
 // first (SX_FLUSH).
 int flush_deferred() {
@@ -204,7 +137,7 @@ int flush_deferred() {
     g->tuned = true;
     rc = sxmc_group_optimize(g, fl->stream, nullptr);
   }
-  if (rc == SXMC_OK) rc = batch_launch(g, do_eval_pdf, fl->stream, m[0]);
+  if (rc == SXMC_OK) rc = sxmc_group_eval_async(g, do_eval_pdf, fl->stream);
   if (rc != SXMC_OK && g->built) {
     // trial fills (or a fill whose lookup then failed) have counted into the members' histograms and normalisations:
     // a failed evaluation leaves them zeroed, not half-counted (the error code is what the caller gets)

@@ -40,8 +40,6 @@ int sxmc_group_destroy(sxmc_group_t g) {
   if (!g) return SXMC_OK;
   (void)hipDeviceSynchronize();
   if (g->coop_fits >= 0) g_stepping_groups.fetch_sub(1, std::memory_order_acq_rel);
-  for (int k = 0; k < 2; k++)
-    if (g->batch_graph[k]) (void)hipGraphExecDestroy(g->batch_graph[k]);
   for (LaunchClass& c : g->classes) free_class(c);
   if (g->d_descs) (void)hipFree(g->d_descs);
   if (g->d_descs_sparse) (void)hipFree(g->d_descs_sparse);

@@ -336,11 +336,6 @@ struct sxmc_group {
   int cfg_tail = 1;                                // sxmc_group_step_async: the one-workgroup step end where it fits
   bool tuned = false;                              // a deferred batch's group: the launch-shape trials have run
   int trial_launches = 0;                          // fills sxmc_group_optimize has launched for this group (all calls)
-  // a deferred batch's launches (zero, fills, lookup) recorded once and replayed: [0] fill only, [1] with lookup
-  hipGraphExec_t batch_graph[2] = {nullptr, nullptr};
-  unsigned long long batch_graph_plan[2] = {0, 0}, batch_graph_points[2] = {0, 0};   // ... what they were recorded for
-  int batch_launches[2] = {0, 0};                  // ... and how often the batch went out launch by launch before
-  unsigned long long points_generation = 0;        // counts group_update_points (the lookup's grid follows the points)
   int cfg_coop = -1;                               // ... and the cooperative one-launch step end (-1: SXMC_COOP_STEP_END, default on)
   int coop_fits = -1;                              // ... decided at the group's first step: do the step ends of all chains
                                                    //     stepping in this process fit the device many times over?

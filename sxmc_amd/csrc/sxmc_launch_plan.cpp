@@ -351,7 +351,7 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   // (measured at 200 bins per observable: slower than the float stream): such tables keep their float stream.
   double ambiguous = 0;
   for (int m = 0; m < nq && m < cd.nobs; m++) ambiguous += (double)cd.nbins[m] * cw.step[(size_t)m] / (cd.upper[m] - cd.lower[m]);
-  static const bool gate_lifted = [] {   // (SXMC_CODES_GATE=1, measurement: tools/codes_gate_probe.py)
+  static const bool gate_lifted = [] {   // (SXMC_CODES_GATE=1, measurement build: profiles/r04b_codes_gate_probe.log)
     const char* e = measure_env("SXMC_CODES_GATE");
     return e && e[0] == '1';
   }();
@@ -1028,7 +1028,7 @@ int group_rebuild(sxmc_group* g) {
         // (sxplan::interleaved_segments): a workgroup of a team of 7 sees a third of the histogram's bins, and the
         // flush -- one memory-side atomic per non-zero bin of every workgroup, 1.3 M per launch at config 3 -- sends
         // a third of the atomics, against a coarser interleaving of the stream.  Which wins depends on the BOX
-        // (tools/part_groups_sweep.sh, profiles/r03_c3_teams_sweep.log: 3 teams 129.4 us against 133.4-134.4 on one,
+        // (profiles/r03_c3_teams_sweep.log: 3 teams 129.4 us against 133.4-134.4 on one,
         // 128.4 against 124.9 on another, each consistently over alternating runs), so the default is one team and
         // sxmc_group_optimize tries three on the box it runs on (SXMC_PART_GROUPS forces a count for A/B runs).
         static const int forced_groups = [] {
@@ -1095,7 +1095,6 @@ int group_update_points(sxmc_group* g) {
     SX_HIP(hipMemcpy(g->d_descs_sparse, g->h_descs_sparse.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
   }
   g->ec[0].descs_valid = g->ec[1].descs_valid = false;
-  g->points_generation++;
   return SXMC_OK;
 }
 

@@ -126,12 +126,26 @@ class RcclComm:
         h = C.c_void_p(0)
         lib = capi.load()
         device = C.c_int(-1)
-        lib.sxmc_get_device(C.byref(device))
+        # (the rank's card, asked of the runtime BEFORE the helper thread exists: a thread that could not be bound to it
+        # would join the communicator on card 0 -- a duplicate device, reported by RCCL much later or never)
+        rc = lib.sxmc_get_device(C.byref(device))
+        if rc != capi.OK or device.value < 0:
+            raise capi.SxmcError(rc if rc != capi.OK else capi.ERR_HIP,
+                                 "RcclComm: the current device could not be asked for: %s" % lib.sxmc_last_error().decode())
         result = {}
 
         def join_communicator():          # (a new host thread starts on device 0: bind it to this rank's card first)
-            lib.sxmc_set_device(device.value)
-            result["rc"] = lib.sxmc_comm_init_rank(box[0], 128, world, rank, C.byref(h))
+            try:
+                rc_dev = lib.sxmc_set_device(device.value)
+                if rc_dev != capi.OK:
+                    result["rc"] = rc_dev
+                    result["why"] = "sxmc_set_device(%d): %s" % (device.value, lib.sxmc_last_error().decode())
+                    return
+                result["rc"] = lib.sxmc_comm_init_rank(box[0], 128, world, rank, C.byref(h))
+                if result["rc"] != capi.OK:
+                    result["why"] = lib.sxmc_comm_last_error().decode()
+            except BaseException as exc:      # noqa: BLE001 (re-raised on the caller's thread)
+                result["exc"] = exc
 
         t = threading.Thread(target=join_communicator, daemon=True)
         t.start()
@@ -141,8 +155,11 @@ class RcclComm:
             print("sxmc_amd.dist: rank %d is still inside ncclCommInitRank after %.0f s (a peer failed or never "
                   "arrived); ending the job" % (rank, init_timeout), file=sys.stderr, flush=True)
             os._exit(70)
+        if "exc" in result:
+            raise result["exc"]
         if result.get("rc") != capi.OK:
-            raise capi.SxmcError(result.get("rc", capi.ERR_HIP), lib.sxmc_comm_last_error().decode())
+            raise capi.SxmcError(result.get("rc", capi.ERR_HIP), result.get("why") or "RcclComm: the helper thread "
+                                 "returned nothing")
         self.h = h
 
     def query(self):
