@@ -562,6 +562,44 @@ TEST_F(SmallFit, AutoWalkTakesTheLookaheadPassOnlyWhereThePlanStreamsFloatColumn
   EXPECT_EQ(b.LookaheadPasses() > 0, members == 0 && supported != 0);
 }
 
+TEST(LaneBarrier, RoundsOfUnequalSizeAndABrokenBarrier) {
+  // the meeting point of ensemble_concurrent's lanes: every round's participants leave together, a last round with
+  // fewer lanes works, and a lane that fails releases everybody for good
+  sxmc::LaneBarrier meet;
+  const size_t lanes = 4, experiments = 10;     // rounds of 4, 4 and 2
+  std::atomic<int> inside{0}, worst{0};
+  std::vector<std::thread> threads;
+  for (size_t t = 0; t < lanes; t++) {
+    threads.emplace_back([&, t]() {
+      for (size_t i = t; i < experiments; i += lanes) {
+        const size_t round_lanes = std::min(lanes, experiments - (i - t));
+        meet.arrive_and_wait(round_lanes);      // "all set up"
+        const int now = ++inside;
+        int seen = worst.load();
+        while (now > seen && !worst.compare_exchange_weak(seen, now)) {
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(2 + (int)t));
+        --inside;
+        meet.arrive_and_wait(round_lanes);      // "all stepped"
+      }
+    });
+  }
+  for (std::thread& th : threads) th.join();
+  EXPECT_TRUE(worst.load() >= 2 && worst.load() <= 4);
+  // a waiter is released by break_all, and nobody waits afterwards
+  std::atomic<bool> released{false};
+  std::thread waiter([&]() {
+    meet.arrive_and_wait(2);
+    released = true;
+  });
+  std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  EXPECT_TRUE(!released.load());
+  meet.break_all();
+  waiter.join();
+  EXPECT_TRUE(released.load());
+  meet.arrive_and_wait(5);                       // returns at once
+}
+
 TEST(NllLaunch, ReferenceSpelling) {
   // the launch macro with the reference's argument order (mcmc.cpp:396-414)
   const size_t ne = 5, ns = 2, np = 2;
