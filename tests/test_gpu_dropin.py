@@ -356,3 +356,4 @@ def test_optimize_flag_of_the_evaluators_decides_the_batchs_trial_launches():
     assert "tuned=0" in info and info.strip().endswith("trial_launches=0"), info
     for p in pdfs:
         p.close()
+

@@ -146,3 +146,31 @@ def test_fused_steps_of_several_chains_share_the_device():
         assert acc == alone[k][1] and np.array_equal(rows.view(np.uint32), alone[k][0].view(np.uint32))
     for m in chains[::-1]:
         close(m)
+
+
+def test_many_stepping_chains_fall_back_to_two_launches_and_walk_the_same_chain():
+    """RESIDENCY.  The waits inside the cooperative step end need the waited-for workgroups resident; the
+    library takes that form only while the step ends of ALL chains stepping in the process fit half of what the device
+    holds of that kernel (129 workgroups per chain against the runtime's occupancy figure x CUs), decided at a group's
+    first step.  Here so many chains step that the later ones must take the two-launch form -- and every chain, whichever
+    form it got, walks the chain it walks alone."""
+    w = workloads.config3(0.004, nevents=3000)
+    want = walk(w, True, 40, seed=77)
+    assert want[2] == 2 and want[3] == 0
+    base = MCMC(w, seed=77, lut_output=False, consume=True, stream=capi.new_stream())
+    chains = [base] + [MCMC(w, seed=77, lut_output=False, consume=True, stream=capi.new_stream(), share_with=base)
+                       for _ in range(39)]
+    forms = []
+    for m in chains:
+        chain, acc = m.walk(w.events, 40, 0.1, sync_interval=50)
+        forms.append(m.group.LastStepLaunches())
+        assert m.group.StepEndTimeouts() == 0
+        assert acc == want[1] and np.array_equal(chain.view(np.uint32), want[0].view(np.uint32))
+    # the first chains end their steps in one launch (2 per step), the late ones in two (3 per step)
+    assert forms[0] == 2 and forms[-1] == 3, forms
+    assert forms == sorted(forms), forms
+    for m in chains[::-1]:
+        close(m)
+    # ... and once those groups are gone a new chain gets the cooperative form again
+    again = walk(w, True, 40, seed=77)
+    assert again[2] == 2 and np.array_equal(again[0].view(np.uint32), want[0].view(np.uint32))
