@@ -93,9 +93,10 @@ def encode(tab, fields, base, step):
 EPS_FACTOR = [1.0]      # (the negative control shrinks the bound through this)
 
 
-def compose(systs, params, fields, base, step, lo, hi, nb, binned):
+def compose(systs, params, fields, base, step, lo, hi, nb, binned, details=None):
     """The kernel's AffineForm, coefficient by coefficient; returns per binned observable (alpha32[], gamma32, eps32)
-    or None when the bound rules the codes out."""
+    or None when the bound rules the codes out.  details: a list that receives, per binned observable, the terms of
+    the bound (Q, S, D budgets), the double-precision constant g and the composed row of A."""
     nq = len(fields)
     slot = {fld: m for m, fld in enumerate(fields)}
     a = np.eye(nq)
@@ -139,6 +140,9 @@ def compose(systs, params, fields, base, step, lo, hi, nb, binned):
         # the kernel evaluates u' = u + e (e in the constant term) and asks fract(u') >= 2e + 2^-23
         e = eps * 1.01 * EPS_FACTOR[0]
         out.append((alpha.astype(np.float32), np.float32(g + e), np.float32(2.0 * e + 2.0 ** -23)))
+        if details is not None:
+            details.append(dict(Q=0.5 * sum_abs * (1.0 + 2.0 ** -19), S=mu * 2.0 ** -21,
+                                D=(mag[k] + abs(lo[obs])) * sc * 2.0 ** -44, g=g, e=e, a=a[k].copy(), c=c[k], sc=sc, mu=mu))
     return out
 
 
@@ -272,6 +276,69 @@ def test_unambiguous_samples_land_where_the_reference_puts_them(seed):
         if trial < 2:
             assert decided.mean() > 0.4
     assert used >= 2
+
+
+def reference_product(tab, systs, params, lo, nb, hi, obs):
+    """(x - lo) * scale of observable `obs` as bin_samples forms it in double, before the truncation (pdfz.cpp:388-398)."""
+    f = [tab[:, k].astype(np.float64) for k in range(tab.shape[1])]
+    with np.errstate(all="ignore"):
+        for s in systs:
+            p = 0.0 + params[s["pars"][0]] * 1.0
+            k = s["obs"]
+            if s["type"] == "shift":
+                f[k] = f[k] + p
+            elif s["type"] == "scale":
+                f[k] = f[k] * (1 + p)
+            elif s["type"] == "ctscale":
+                f[k] = 1 + (f[k] - 1) * (1 + p)
+            else:
+                f[k] = f[k] + (p * (f[k] - f[s["true_obs"]]))
+        return (f[obs] - lo[obs]) * (nb[obs] / (hi[obs] - lo[obs]))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_the_terms_of_the_bound_hold_one_by_one(seed):
+    """THE BOUND, term by term (fill_kernels.inc.h): u_codes - u_ref = (what the codes leave unknown) + (roundings).
+    The first part, evaluated in extended precision from the sample's position in its code cells, must stay within Q;
+    what is left -- the single-precision evaluation over the codes and the double roundings of the reference's own
+    arithmetic -- within S + D.  Measured on the way: how much of S + D random samples use (a few per cent -- what the
+    GPU measurement of tests/test_gpu_codes_margin.py finds with samples built on the threshold)."""
+    rng, nobs, nb, lo, hi, systs, npar, binned, fields, tab = make_case(8000 + seed)
+    base, step = windows(tab, fields, nobs, lo, hi)
+    codes, mark = encode(tab, fields, base, step)
+    worst_q = worst_r = 0.0
+    used = 0
+    for scale_of_params in (0.05, 0.4):
+        params = rng.normal(0, scale_of_params, npar)
+        det = []
+        coef = compose(systs, params, fields, base, step, lo, hi, nb, binned, details=det)
+        if coef is None:
+            continue
+        used += 1
+        ok = mark == 0
+        for (alpha32, g32, thr32), d, obs in zip(coef, det, binned):
+            # u_codes as the lanes form it, WITHOUT e: single-precision FMAs from the rounded constant term
+            u = np.full(tab.shape[0], np.float32(d["g"]), np.float32)
+            for m in range(codes.shape[1]):
+                u = fma32(np.full(tab.shape[0], alpha32[m], np.float32), codes[:, m].astype(np.float32), u)
+            with np.errstate(all="ignore"):
+                u_ref = reference_product(tab, systs, params, lo, nb, hi, obs)
+                # what the codes leave unknown, in extended precision: sum_m alpha_m ((c_m + 1/2) - (x_m - base_m) / step_m)
+                q = np.zeros(tab.shape[0], np.longdouble)
+                for m, fld in enumerate(fields):
+                    x = tab[:, fld].astype(np.longdouble)
+                    pos = (x - np.longdouble(base[m])) / np.longdouble(step[m])
+                    q += np.longdouble(d["a"][m]) * np.longdouble(step[m]) * np.longdouble(d["sc"]) * (codes[:, m] + np.longdouble(0.5) - pos)
+                r = u.astype(np.longdouble) - u_ref.astype(np.longdouble) - q
+            fin = ok & np.isfinite(u_ref) & (np.abs(u_ref) < 1e6)
+            assert fin.sum() > 0.5 * tab.shape[0]
+            assert np.all(np.abs(q[fin]) <= d["Q"]), (seed, obs, float(np.max(np.abs(q[fin]))), d["Q"])
+            assert np.all(np.abs(r[fin]) <= d["S"] + d["D"]), (seed, obs, float(np.max(np.abs(r[fin]))), d["S"] + d["D"])
+            worst_q = max(worst_q, float(np.max(np.abs(q[fin])) / d["Q"]))
+            worst_r = max(worst_r, float(np.max(np.abs(r[fin])) / (d["S"] + d["D"])))
+    assert used >= 1
+    assert worst_q > 0.9            # the half code step is reached: Q is no margin
+    assert worst_r < 0.5            # the roundings use a small part of what the bound provides for
 
 
 def test_reference_restatement_agrees_with_the_oracle():
