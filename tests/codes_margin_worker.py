@@ -201,13 +201,21 @@ def one_parameter_set(rng, params, nbackground, scales=True):
 
 
 def main():
+    """argv: [background rows] [number of RANDOM parameter sets instead of the fixed six] [seed]"""
     if not capi.is_measurement_build():
         raise SystemExit("codes_margin_worker.py needs SXMC_HIP_LIB = .../libsxmc_hip_measure.so")
     if capi.device_count() < 1:
         raise SystemExit("codes_margin_worker.py needs a GPU")
     nbackground = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
-    rng = np.random.default_rng(20251)
-    sets = [one_parameter_set(rng, p, nbackground) for p in PARAM_SETS]
+    nrandom = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 20251)
+    param_sets = PARAM_SETS
+    if nrandom > 0:
+        # shift of r small (its granules must stay in their bins), scale of e ordinary to large, resolution scale of
+        # either sign from small to large (never near 0: the truth value is solved for through it)
+        param_sets = [[float(rng.normal(0, 0.02)), float(rng.normal(0, 0.1)),
+                       float(rng.choice([-1.0, 1.0]) * rng.uniform(0.03, 0.5))] for _ in range(nrandom)]
+    sets = [one_parameter_set(rng, p, nbackground) for p in param_sets]
     ok = [s for s in ROUNDING_SCALES if all(r["rounding_scale"][str(s)] == 0 for r in sets)]
     # s_min: the smallest scale from which upwards nothing is misplaced
     s_min = None
