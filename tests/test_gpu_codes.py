@@ -298,3 +298,50 @@ def test_codes_degenerate_columns():
                 assert np.array_equal(ev.GetBins(), bins) and norm.get()[0] == nrm, (name, codes, pv)
         group.close()
         ev.close()
+
+
+@pytest.mark.parametrize("offset", [3.0e4, 1.0e6, -2.5e5])
+def test_codes_with_windows_far_from_zero(offset):
+    """A domain far from zero: the codes' windows then sit at |centre| / step of 10^8 .. 10^9 and beyond, where the
+    table's own check of a row's position in its cell (centre = base + (code + 1/2) step, in double) is itself rounded
+    at the level its 2^-20 slack was meant for -- the bound books that under its double-precision term
+    (fill_kernels.inc.h, "THE BOUND": Q borrows from D).  Histograms over codes, over the float columns and the
+    oracle's must agree bit for bit; float32 values are coarse out there (spacing 1/16 at 10^6), so many samples sit
+    exactly on transformed edges."""
+    rng = np.random.default_rng(163)
+    n, nb = 300000, [20, 6, 4]
+    lo, hi = [offset, 0.0, -1.0], [offset + 10.0, 6.0, 1.0]
+    tab = np.zeros((n, 5), np.float32)
+    t = offset + rng.uniform(-4.0, 14.0, n)
+    tab[:, 3] = t
+    tab[:, 0] = t + rng.normal(0, 0.6, n)
+    tab[:, 1] = np.array([0.5, 1.5, 2.5, 3.5, 4.5, 5.5], np.float32)[rng.integers(0, 6, n)]    # (runs of equal r)
+    tab[:, 2] = rng.uniform(-1.0, 1.0, n)
+    systs = [dict(type="shift", obs=1, pars=[0]), dict(type="scale", obs=0, pars=[1]),
+             dict(type="resolution_scale", obs=0, true_obs=3, pars=[2])]
+    geom = oracle.HistGeometry(lo, hi, nb)
+    ev = pdfz.EvalHist(tab, 5, 3, lo, hi, nb)
+    for s in systs:
+        ev.AddSystematic(make_systematic(s))
+    norm, pbuf = DeviceArray.zeros(1, np.uint32), DeviceArray(np.zeros(3))
+    ev.SetNormalizationBuffer(norm)
+    ev.SetParameterBuffer(pbuf)
+    group = nll.EvalGroup([ev])
+    group.SetOrdering(True, force=True)
+    group.SetCodes(True)
+    assert "ordered+codes" in group.LaunchInfo(), group.LaunchInfo()
+    base, step = group.CodesWindows(0)
+    assert len(base) == 2 and abs(base[0]) / step[0] > 5e7          # (far from zero in units of the code step)
+    rel = 1.0 / abs(offset)
+    for pv in ([0.0, 0.0, 0.0], [0.02, 2.0 * rel, 0.2], [-0.03, -3.0 * rel, -0.35], [0.0, 0.5 * rel, 1.5],
+               [0.01, 40.0 * rel, 0.05]):                            # (a scale of 40 / offset moves e by four bins)
+        pbuf.set(np.array(pv))
+        bins, nrm = oracle.bin_samples(geom, tab, 5, systs, np.array(pv))
+        for codes in (True, False):
+            group.SetCodes(codes)
+            group.EvalAsync(False)
+            group.EvalFinished()
+            assert np.array_equal(ev.GetBins(), bins) and norm.get()[0] == nrm, (offset, codes, pv)
+        assert nrm > 0.2 * n or pv[1] > 10 * rel
+    group.close()
+    ev.close()
