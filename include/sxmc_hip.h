@@ -632,6 +632,13 @@ int sxmc_group_set_debug_mode(sxmc_group_t g, int mode);
 int sxmc_debug_pow_int(const double* d_x, int n, int i, double* d_out);
 /* Raw Philox4x32-10 output of d_state[0], 4 words per draw; advances the state. */
 int sxmc_debug_philox_dump(sxmc_rng_state* d_state, unsigned* d_out, int ndraws);
+/* THE GATED STEP, an experiment ("one more look"): the group's next sxmc_group_step_async puts its
+ * fill on `fill_stream` -- ordered after the previous fill, not after the previous step end -- as step `node` (0 .. 15)
+ * of a recording; the fill does what does not depend on the proposal beside the step end and waits for it inside.
+ * fill_stream null: back to one stream.  sxmc_measure_stream_fork: `to` waits for what `from` has queued (inside a
+ * recording: brings `to` into it). */
+int sxmc_measure_set_gated_step(sxmc_group_t g, sxmc_stream_t fill_stream, int node);
+int sxmc_measure_stream_fork(sxmc_stream_t from, sxmc_stream_t to);
 #endif
 
 #ifdef __cplusplus

@@ -173,6 +173,8 @@ MEASURE_SIGNATURES = {
     "sxmc_group_set_debug_mode": [_vp, _i],
     "sxmc_debug_pow_int": [_vp, _i, _i, _vp],
     "sxmc_debug_philox_dump": [_vp, _vp, _i],
+    "sxmc_measure_set_gated_step": [_vp, _vp, _i],
+    "sxmc_measure_stream_fork": [_vp, _vp],
 }
 MEASURE_LIB_PATH = os.path.join(_HERE, "csrc", "libsxmc_hip_measure.so")
 

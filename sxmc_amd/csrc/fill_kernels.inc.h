@@ -1321,12 +1321,28 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     gptr<unsigned> gbins0 = to_global(d.bins);
 
     double craw[NCHAIN][NC];
+#if SXMC_MEASURE
+    // (measurement build, dbg bit 6: THE GATED STEP -- this fill was launched beside the previous step's step end and
+    // may do everything that does not depend on the proposal before that is written: its parameters are read further
+    // down, after the wait for the gate.  Node index of the step inside its recorded graph: dbg bits 24-27.)
+    const bool gated = (dbg & 64u) != 0u;
+    auto load_parameters = [&]() {
+#pragma unroll
+      for (int c = 0; c < NCHAIN; c++) {
+        const SxSignalDesc& dc = chains.d[c][sg.sig];
+#pragma unroll
+        for (int q = 0; q < PROG::ncoef; q++) craw[c][q] = to_global(dc.params)[(long)dc.coef_par[q] * dc.param_stride];
+      }
+    };
+    if (!gated) load_parameters();
+#else
 #pragma unroll
     for (int c = 0; c < NCHAIN; c++) {
       const SxSignalDesc& dc = chains.d[c][sg.sig];
 #pragma unroll
       for (int q = 0; q < PROG::ncoef; q++) craw[c][q] = to_global(dc.params)[(long)dc.coef_par[q] * dc.param_stride];
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 
     gptr<const vfloat4> col[NSLOT];
@@ -1390,6 +1406,30 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
     }
     const double olo = d.lower[NOBS], ohi = d.upper[NOBS], osc = d.scale[NOBS];
     const int ost = d.bin_stride[NOBS];
+#if SXMC_MEASURE
+    if (gated) {
+      // the gate: node 0 of a recorded graph follows the previous replay in stream order (it re-arms the gate), node s
+      // waits until the step end of node s - 1 has written the proposal.  Bounded: a wait that gives up goes on.
+      const unsigned node = (dbg >> 24) & 15u;
+      gptr<unsigned> gate = to_global(d.step_gate);
+      if (node == 0u) {
+        if (blockIdx.x == 0u && tid == 0u && si == blk_off[0]) {
+          __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        // (ONE lane of the workgroup polls, the others wait at the barrier: 3 072 waves polling one word at memory
+        // scope beside the step end slowed that kernel down -- 109.7 us per step against 101.3 ungated)
+        if (tid == 0u) {
+          for (unsigned spin = 0; spin < 100000u; spin++) {
+            if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= node) break;
+            __builtin_amdgcn_s_sleep(4);
+          }
+        }
+        __syncthreads();
+      }
+      load_parameters();
+    }
+#endif
     // a coefficient that is not finite: no claim about monotone maps, every granule takes the per-sample path
     bool wild[NCHAIN];
 #pragma unroll

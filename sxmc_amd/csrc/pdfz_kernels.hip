@@ -602,6 +602,14 @@ __device__ __forceinline__ void step_end_role(unsigned role, unsigned W, const S
                                       }
                                     });
     __syncthreads();
+#if SXMC_MEASURE
+    // (measurement build, the gated step: the next proposal is written -- published with a release at agent scope -- and
+    // the fill that waits for it beside this kernel may read it)
+    if (a.gate && threadIdx.x == 0) {
+      __threadfence();
+      __hip_atomic_store(a.gate, a.gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
     for (int j = threadIdx.x; j < nsig; j += (int)bdim) *hist_descs[j].norm = 0u;
     if (threadIdx.x == 0) sync[0] = 0u;   // (the ticket of the other step-end forms: as finish_zero_kernel leaves it)
     return;

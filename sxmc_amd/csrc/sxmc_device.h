@@ -31,6 +31,9 @@ struct SxStepArgs {
   const unsigned* n_mc;
   const short* source_id;
   const unsigned* norms;
+  // measurement build only (the gated step): the finisher stores gate_value to *gate once the next proposal is written
+  unsigned* gate = nullptr;
+  unsigned gate_value = 0;
 };
 
 // The step ends of the chains of a lockstep set, launched together (sxmc_multigroup_step_async): per chain what

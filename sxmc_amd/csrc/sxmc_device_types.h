@@ -102,6 +102,10 @@ struct SxSignalDesc {
   const unsigned* qcol;
   double qbase[SXMC_MAX_QSLOTS];
   double qstep[SXMC_MAX_QSLOTS];
+  // --- measurement build only (the gated step, DESIGN.md section 4 "one more look"): a word the step end of step k sets
+  //     to k + 1 when the next proposal is written; a fill launched beside it waits for that before it reads its
+  //     parameters.  Null otherwise; the product's kernels never look at it.
+  unsigned* step_gate;
 };
 
 // One piece of fill work: units v0 + tid, + step, ... < v1 of member `sig` (a unit = SXMC_VEC samples).

@@ -292,6 +292,24 @@ int sxmc_group_set_lut_output(sxmc_group_t g, int enable) {
 }
 
 #if SXMC_MEASURE
+// measurement build only, THE GATED STEP: the group's next sxmc_group_step_async puts its fill on `fill_stream` (null:
+// back to one stream) as step `node` (0 .. 15) of a recording; sxmc_measure_stream_fork makes `to` wait for what `from`
+// has queued so far (inside a recording: brings `to` into it).
+int sxmc_measure_set_gated_step(sxmc_group_t g, sxmc_stream_t fill_stream, int node) {
+  SX_REQUIRE(g && node >= 0 && node < 16, "bad arguments");
+  g->split_fill_stream = (hipStream_t)fill_stream;
+  g->split_node = node;
+  return SXMC_OK;
+}
+int sxmc_measure_stream_fork(sxmc_stream_t from, sxmc_stream_t to) {
+  SX_REQUIRE(from && to, "null stream");
+  hipEvent_t ev = nullptr;
+  SX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  SX_HIP(hipEventRecord(ev, (hipStream_t)from));
+  SX_HIP(hipStreamWaitEvent((hipStream_t)to, ev, 0));
+  return SXMC_OK;     // (the event lives as long as the process: a measurement build's leak)
+}
+
 // measurement build only: the kernels' hooks (fill_kernels.inc.h: SXMC_MEASURE).  RESULTS ARE WRONG with a mode set.
 int sxmc_group_set_debug_mode(sxmc_group_t g, int mode) {
   SX_REQUIRE(g, "null group");
@@ -654,6 +672,29 @@ int sxmc_group_step_async(sxmc_group_t g, sxmc_stream_t s, const double* d_means
     c.shape.tail = g->h_tail.data();
     c.shape.tail_blocks = nvb + 1;
   }
+#if SXMC_MEASURE
+  // THE GATED STEP (measurement build only; sxmc_measure_set_gated_step): the fill goes to a stream of its own, ordered
+  // after the previous FILL but not after the previous step end -- it runs its prologue beside that kernel and waits
+  // for the proposal inside (fill_ordered_body, dbg bit 6); the step end follows on `s` once the fill has ended.
+  if (g->split_fill_stream && !fused && !sparse && g->classes.size() == 1 && step_end_is_cooperative(g, ne) &&
+      !step_end_takes_tail(g, sparse, ne)) {
+    const int node = g->split_node & 15;
+    const int saved = g->debug_mode;
+    g->debug_mode = saved | 64 | (node << 24);
+    rc = group_fill(g, g->split_fill_stream, sparse);
+    g->debug_mode = saved;
+    if (rc) return rc;
+    hipEvent_t ev = nullptr;
+    SX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    g->split_events.push_back(ev);
+    SX_HIP(hipEventRecord(ev, g->split_fill_stream));
+    SX_HIP(hipStreamWaitEvent(st, ev, 0));
+    a.gate = g->d_ticket + 8;
+    a.gate_value = (unsigned)node + 1u;
+    g->last_step_launches = (int)g->classes.size() + (zero_launched ? 1 : 0);
+    return group_step_tail(g, st, sparse, descs, ne, weight, a);
+  }
+#endif
   rc = group_fill(g, st, sparse);
   if (fused) {
     g->classes[0].shape.tail = nullptr;

@@ -343,6 +343,11 @@ struct sxmc_group {
   unsigned long long plan_generation = 0;          // counts launch plans built (a multigroup re-validates on change)
   std::vector<const SampleStore::Bucketed*> member_bucket;  // per member: the copy its fill streams, or null
   int debug_mode = 0;
+  // measurement build only (the gated step): the stream this group's NEXT step puts its fill on, beside the step end of
+  // the step before (null: the step is launched on one stream, as always), and the step's index inside its recording
+  hipStream_t split_fill_stream = nullptr;
+  int split_node = 0;
+  std::vector<hipEvent_t> split_events;
   int max_bins = 0;
   unsigned long long max_points = 0;
   bool same_points = false;

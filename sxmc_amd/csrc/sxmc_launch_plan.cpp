@@ -900,6 +900,7 @@ int group_rebuild(sxmc_group* g) {
       }
       d.vec_start = prefix;
       prefix += d.nvec;
+      d.step_gate = g->d_ticket + 8;     // (read by the measurement build's gated fill only)
       descs.push_back(d);
     }
     c.total_vec = prefix;
@@ -934,7 +935,13 @@ int group_rebuild(sxmc_group* g) {
     if (ordered && c.shape.lds_hist) {
       // replicas of the LDS histogram (fill_ordered_body): as many as the workgroup's share of LDS holds, up to 4
       unsigned rlog = 0;
-      const size_t share = (size_t)props.lds_per_cu / (size_t)std::max(1, bpc) - (fused_step_requested(g) ? 16 * 1024 : 0);
+      // (SXMC_LDS_RESERVE, measurement build: bytes of the CU's LDS the fill leaves to other kernels' workgroups)
+      static const size_t lds_reserve = [] {
+        const char* e = measure_env("SXMC_LDS_RESERVE");
+        return e ? (size_t)std::max(0, std::atoi(e)) : (size_t)0;
+      }();
+      const size_t share = ((size_t)props.lds_per_cu - lds_reserve) / (size_t)std::max(1, bpc) -
+                           (fused_step_requested(g) ? 16 * 1024 : 0);
       const size_t qreserve = c.codes ? ordered_queue_bytes(kMinQueueLog) : 0;   // (room for the smallest queues)
       // (SXMC_ORDERED_REPLICAS_LOG2, measurement: fewer replicas leave LDS for a second workgroup per CU -- of another
       // chain's launch, say)

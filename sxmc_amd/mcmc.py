@@ -14,6 +14,8 @@ forms are offered:
                         evaluations into one batched launch (sxmc_hist_eval_async).  The reference form's chain.
 All produce the same numbers up to the order of the partial sums.
 """
+import os
+
 import numpy as np
 
 from . import capi, nll, pdfz
@@ -276,12 +278,26 @@ class MCMC:
         if self.stream is None:
             raise ValueError("graph capture needs a created stream (MCMC(stream=capi.new_stream()))")
         self._recording = True                  # (recorded steps run, and are counted, when the graph is launched)
+        # (measurement build + SXMC_GATED_STEP=1, an experiment: every step's fill on a second stream, beside the step
+        # end of the step before, waiting inside for the proposal -- include/sxmc_hip.h, sxmc_measure_set_gated_step)
+        gated = (os.environ.get("SXMC_GATED_STEP") == "1" and capi.is_measurement_build() and self.consume
+                 and k <= 16)
+        if gated and getattr(self, "_fill_stream", None) is None:
+            self._fill_stream = capi.new_stream()
         try:
             with capi.Graph.capture(self.stream) as g:
-                for _ in range(k):
+                if gated:
+                    capi.call("sxmc_measure_stream_fork", capi.ptr(self.stream), capi.ptr(self._fill_stream))
+                for q in range(k):
+                    if gated:
+                        capi.call("sxmc_measure_set_gated_step", self.group._g, capi.ptr(self._fill_stream), q)
                     self.step(debug_mode)
+                if gated:
+                    capi.call("sxmc_measure_set_gated_step", self.group._g, None, 0)
         finally:
             self._recording = False
+            if gated:
+                capi.call("sxmc_measure_set_gated_step", self.group._g, None, 0)
         return g
 
     def steps(self, n, graph_steps=0, debug_mode=False):
