@@ -259,6 +259,8 @@ class Leg:
         m.group.SetOrdering(not args.no_order)
         if args.no_codes:
             m.group.SetCodes(False)
+        if args.no_boxes:
+            m.group.SetBoxes(False)
         m.group.SetTailKernel(not args.no_tail)
         m.group.SetRuntimeKernels(not args.no_rtc)
         m.group.SetSparse(not args.no_sparse)
@@ -440,6 +442,7 @@ class Leg:
                 t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else "") +
                                        ("_no_order" if args.no_order and not args.no_bucket else "") +
                                        ("_no_codes" if args.no_codes and not (args.no_order or args.no_bucket) else "") +
+                                       ("_no_boxes" if args.no_boxes and not (args.no_codes or args.no_order or args.no_bucket) else "") +
                                        ("_lookahead" if self.la is not None else ""))
             if args.extra_ctscale or args.no_sparse:
                 t = None
@@ -456,7 +459,8 @@ class Leg:
         except (OSError, ValueError):
             pass
         info = m.group.LaunchInfo()
-        kname = ("fill_ordered_kernel" if "table=ordered" in info and "+runs" not in info
+        kname = ("fill_boxed_kernel" if "table=boxed" in info else
+                 "fill_ordered_kernel" if "table=ordered" in info and "+runs" not in info
                  else "fill_sparse_kernel" if "+runs" in info and not args.no_sparse else "fill_kernel")
         neval = 2 if self.la is not None else 1
         if self.la is not None:
@@ -474,7 +478,9 @@ class Leg:
             "traffic": traffic, "traffic_provenance": traffic_note,
             # (PMC counters cannot be read inside this run: separate rocprofv3 --pmc passes, tools/profile_on_gpu.sh)
             "traffic_source": ("profiles/traffic.json: " + str(traffic_note.get("from"))) if traffic_note else None,
-            "streams": "u16 codes (f32 filter) + f64 exact fallback" if "ordered+codes" in info else "f32 columns (f64 arithmetic)",
+            "streams": ("u16 codes of one observable (f32 filter), f64 interval arithmetic on the other's granule boxes, "
+                        "f64 exact fallback" if "boxed+codes" in info else
+                        "u16 codes (f32 filter) + f64 exact fallback" if "ordered+codes" in info else "f32 columns (f64 arithmetic)"),
             "algorithmic_bytes_per_launch": fill_bytes, "bytes_per_sample": ab["fill_read"] / max(w.nsamples_total, 1),
             "avg_launch_ms": fill_ms, "launches_timed": self.nfill, "sample": self.roofline_sample,
             "timing": "HIP events stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop events) on the stream the "
@@ -909,6 +915,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-codes", action="store_true",
                     help="ordered tables streamed as float columns (8 B/sample at config 3) instead of 16-bit codes with an "
                          "exact recheck of the samples near a bin edge (4 B/sample); the sub-record c3_float_stream")
+    ap.add_argument("--no-boxes", action="store_true",
+                    help="the ordered form with codes (4 B/sample at config 3: r ordered, e and e_true streamed as codes) "
+                         "instead of the boxed form (2 B/sample: e boxed, r streamed as codes); the sub-record "
+                         "c3_ordered_codes")
     ap.add_argument("--no-bucket", action="store_true",
                     help="stream the table in the caller's row order (no copy grouped by the untouched observables' bins)")
     ap.add_argument("--nsyst", type=int, default=-1, help="keep only the first K systematics (measurement only)")
@@ -1142,9 +1152,9 @@ def main():
         # the arithmetic the path computes in.  Every bin index is the reference's f64 result (bit-exact against the oracle);
         # where the plan streams CODES, 99.9 % of the samples get there through a filter -- f32 multiply-adds on 16-bit
         # codes plus an error bound -- and only the ambiguous ones through the f64 operations themselves
-        "dtype": ("f64 exact; f32-on-u16-codes filter decides the unambiguous samples" if "ordered+codes" in m.group.LaunchInfo()
+        "dtype": ("f64 exact; f32-on-u16-codes filter decides the unambiguous samples" if "+codes" in m.group.LaunchInfo()
                   else "f64"),
-        "dtype_filter": "f32-on-u16-codes" if "ordered+codes" in m.group.LaunchInfo() else None,
+        "dtype_filter": "f32-on-u16-codes" if "+codes" in m.group.LaunchInfo() else None,
         "data": "synthetic",
         "config": cfg,
         "roofline": leg.roofline(world),
@@ -1172,7 +1182,7 @@ def main():
         full_c3 = args.workload.lower() == "c3" and args.scale == 1.0 and not args.debug_mode
         also = "none"
         if full_c3 and want_cpu and args.form == "graph" and world == 1:
-            also = ("c3_float_stream,c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,bench_pdfz,bench_pdfz_group,"
+            also = ("c3_ordered_codes,c3_float_stream,c3_lookahead,c3_lut_materialized,c2,c2_float_columns,c5,bench_pdfz,bench_pdfz_group,"
                     "cpp_host,c3_dropin,c3_1e5_walk,c4_per_gpu")
         elif full_c3 and args.form == "graph" and world > 1:
             also = "cpp_multi_gpu"        # the C++ one-process runner over the same N cards
@@ -1198,6 +1208,9 @@ def main():
             elif name == "c3_float_stream":       # the headline's walk with the ordered table's FLOAT columns streamed
                 recs[name] = also_record(args, torch, dev, "c3", "graph", False, args.also_steps, 20, exp_seed, "all",
                                          overrides={"no_codes": True})
+            elif name == "c3_ordered_codes":      # ... with the ORDERED form over codes (rounds 4-5's headline kernel)
+                recs[name] = also_record(args, torch, dev, "c3", "graph", False, args.also_steps, 20, exp_seed, "all",
+                                         overrides={"no_boxes": True})
             elif name == "c3_lut_materialized":
                 recs[name] = also_record(args, torch, dev, "c3", "graph", True, args.also_steps, 20, exp_seed, "all")
             elif name == "c2":

@@ -325,6 +325,23 @@ int sxmc_group_set_ordering(sxmc_group_t g, int enable);
  * that overflow).  enable = 0: stream the float columns; 1: use the codes where they apply; -1: the library's
  * default (on unless the environment says SXMC_CODES=0). */
 int sxmc_group_set_codes(sxmc_group_t g, int enable);
+/* Boxes (default: where they pay; needs codes on, the histogram in LDS, exactly two written observables).  The ordered form
+ * makes an observable written by ONE-field systematics a per-granule constant.  An observable that is resolution-scaled
+ * (pdfz.cpp:326-329: x += p * (x - t), t a field nothing writes) depends on two fields and has no order -- but every
+ * IEEE operation of its program is monotone in each operand, so the reference's own operations applied to the CORNERS
+ * of a box [xmin, xmax] x [tmin, tmax] (the corner chosen by the coefficient's sign) bound the result of every row
+ * inside the box from both sides, exactly: interval arithmetic whose endpoints round the way the values between them do.
+ * The boxed copy sorts the rows of a bucket by (stratum of x - t, x), keeps the box of every 256-row granule (16 bytes), and
+ * the fill (fill_boxed_kernel) works out per evaluation, one lane per granule, whether both ends of the box's image land
+ * in one bin: then so does every row, and the observable costs nothing per sample.  Granules whose image straddles an
+ * edge (a few per cent at BASELINE config 3, more for large resolution parameters) are binned from their float columns
+ * with the reference's arithmetic.  The OTHER written observable is streamed as one 16-bit code per row (the codes above,
+ * one field): BASELINE config 3 streams 2 bytes per sample instead of 4.  Any value or coefficient that is not finite
+ * sends its granule (or the whole evaluation) to the float columns.  Histograms, norms and NLL stay bit-identical
+ * (tests/test_gpu_boxed.py: against the ordered form, the float stream and the CPU restatement).  enable = -1 (default):
+ * where it pays (at least four granules per bin of the boxed observable, stratum and bucket); 1: wherever it applies
+ * (tests); 0: never (the ordered / bucketed forms).  Lockstep sets and the look-ahead pass use the ordered form. */
+int sxmc_group_set_boxes(sxmc_group_t g, int enable);
 /* What the codes of the group's current plan amount to: members whose fill streams codes, rows they hold, rows marked
  * "ask the exact columns" (outside a window) and rows marked "never counted" (not finite, or granule padding). */
 int sxmc_group_codes_info(sxmc_group_t g, int* members, unsigned long long* rows, unsigned long long* exact_rows,

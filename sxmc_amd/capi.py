@@ -116,6 +116,7 @@ SIGNATURES = {
     "sxmc_group_set_bucketing": [_vp, _i],
     "sxmc_group_set_ordering": [_vp, _i],
     "sxmc_group_set_codes": [_vp, _i],
+    "sxmc_group_set_boxes": [_vp, _i],
     "sxmc_group_codes_info": [_vp, _pi, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)],
     "sxmc_group_codes_windows": [_vp, _i, _pi, _pd, _pd],
     "sxmc_group_set_codes_queue_log": [_vp, _i],

@@ -672,6 +672,7 @@ __device__ __forceinline__ void fill_body(const SxSignalDesc* __restrict__ descs
 // v_readlane: scalar from there on.  NCHAIN > 1: lockstep chains (see fill_multi_body), each with its own codes.
 // The kernel itself (fill_ordered_body) follows fill_multi_body below; fill_sparse_body has an ORDERED variant.
 constexpr int kPreOrdered = 5;
+constexpr int kPreBoxed = 6;     // bucketed table with a boxed observable (fill_boxed_body, further down)
 constexpr unsigned kOrdMixed = 0xFFFFFFFEu, kOrdSkip = 0xFFFFFFFFu;
 typedef float vfloat2 __attribute__((ext_vector_type(2)));
 
@@ -2088,7 +2089,14 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
               full = full || ((it & (unsigned)(kDrainEvery - 1)) == 0u && (nrow | ngran) != 0u && it < niter32);
             }
           }
-          if (full) drain(IntC<kDrainStream>{});
+          if (full) {
+            drain(IntC<kDrainStream>{});
+            // (what the drain's loads leave in the compiler's model of outstanding loads reached the loop header and made
+            // it wait for ALL of the ring's loads at the first unit of every round -- s_waitcnt vmcnt(0) where vmcnt(3)
+            // was meant.  An explicit full wait here, where nothing of the ring's is worth keeping in flight anyway,
+            // clears that model: the stream loop's waits are then the counted ones.)
+            __builtin_amdgcn_s_waitcnt(0);
+          }
         }
       };
       if constexpr (NOBS == 1) {
@@ -2184,6 +2192,486 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   SX_WG_STAMP(2);
 }
 
+// ================================================================================================ BOXED OBSERVABLE
+// fill_boxed_body: a bucketed table whose rows are grouped, inside every bucket, so that ONE observable with TWO input
+// fields -- written by one-coefficient shift / scale / cos-theta scale / resolution scale against a field nothing
+// writes (BASELINE config 3: e, scaled and resolution-scaled against e_true) -- is a per-granule constant, the way the
+// ordered observable of fill_ordered_body is, and the fill streams only the OTHER written observable: one field, as
+// 16-bit codes, 2 bytes per sample instead of 4.
+//   Layout (sxmc_launch_plan.cpp, layout_kernels.hip): rows of a bucket sorted by (stratum of x - t, x), x the boxed
+// observable's raw value and t its truth field, so that the 256 rows of a granule lie in a small BOX
+// [xmin, xmax] x [tmin, tmax], kept per granule (16 bytes).
+//   Per evaluation one lane per granule runs the reference's operations on the box in INTERVAL form: every IEEE
+// operation the program applies (x + p, x * (1 + p), 1 + (x - 1) * (1 + p), x + p * (x - t), then the domain test
+// and (int)((x - lo) * scale)) is monotone in each operand under round-to-nearest -- rounding never reverses an
+// order -- so the same operations on the box's corners, the corner chosen by the sign of the coefficient, bound every
+// row's result FROM BOTH SIDES, exactly, with no error term: interval arithmetic in which the endpoints round the way
+// the values between them do.  (A resolution scale with p < 0 uses x twice with opposite monotonicity; the interval
+// [xlo + p (xhi - tlo), xhi + p (xlo - thi)] is then wider than the image, never narrower.)  Every intermediate
+// endpoint must be finite and no coefficient NaN; then nothing between the endpoints is NaN either.  If both ends
+// land in the same bin (or outside the domain on the same side) so does every row of the granule: the observable
+// costs nothing per sample.  Otherwise ("mixed": the box straddles an edge; a few per cent of the granules) the
+// granule goes to a queue and is binned from its three float columns with the reference's arithmetic, as the
+// granules that straddle an edge of the ordered observable are in fill_ordered_body.
+//   The streamed observable: codes exactly as in fill_ordered_body (THE BOUND there, with NQ = 1), the LDS histogram
+// in the padded form with THAT observable as the outermost dimension of the LDS copy whatever its place in the real
+// histogram (the flush translates: a word (idx, hi * s + lo) is bin hi * s * nbins + idx * s + lo).
+// Slots: 0 the streamed observable, 1 the truth field, 2 the boxed observable (geometry at index 1).
+template <unsigned OPC, int XT>
+__device__ __forceinline__ void apply_box_interval(double& xl, double& xh, double tl, double th, bool& fin, const double* c) {
+  constexpr int type = (int)(OPC & 15u), E = (int)((OPC >> 8) & 15u);
+  static_assert(sx_op_npars(OPC) == 1, "not a one-coefficient systematic");
+  const double pc = 0.0 + c[0] * 1.0;   // (as apply_static)
+  if constexpr (type == SXMC_SYST_SHIFT) {
+    xl = xl + pc;
+    xh = xh + pc;
+  }
+  if constexpr (type == SXMC_SYST_SCALE) {
+    const double s = 1 + pc, a = xl * s, b = xh * s;
+    xl = s >= 0.0 ? a : b;
+    xh = s >= 0.0 ? b : a;
+  }
+  if constexpr (type == SXMC_SYST_CTSCALE) {
+    const double s = 1 + pc, a = 1 + (xl - 1) * s, b = 1 + (xh - 1) * s;
+    xl = s >= 0.0 ? a : b;
+    xh = s >= 0.0 ? b : a;
+  }
+  if constexpr (type == SXMC_SYST_RESOLUTION_SCALE) {
+    static_assert(E == XT, "the boxed observable reads one truth field");
+    const double dl = xl - th, dh = xh - tl;            // x - t, smallest and largest
+    const double a = pc * dl, b = pc * dh;
+    const double ml = pc >= 0.0 ? a : b, mh = pc >= 0.0 ? b : a;
+    fin = fin && (__builtin_fabs(dl) < __builtin_inf()) && (__builtin_fabs(dh) < __builtin_inf()) &&
+          (__builtin_fabs(ml) < __builtin_inf()) && (__builtin_fabs(mh) < __builtin_inf());
+    xl = xl + ml;
+    xh = xh + mh;
+  }
+  fin = fin && (__builtin_fabs(xl) < __builtin_inf()) && (__builtin_fabs(xh) < __builtin_inf());   // (NaN fails)
+}
+template <int BX, int XT, unsigned... OPS, unsigned long... I>
+__device__ __forceinline__ void run_box_interval(double& xl, double& xh, double tl, double th, bool& fin, const double* c,
+                                                 StaticProg<OPS...>, ISeq<I...>) {
+  ([&] {
+    if constexpr ((int)((OPS >> 4) & 15u) == BX) apply_box_interval<OPS, XT>(xl, xh, tl, th, fin, c + sx_prog_cstart<OPS...>((int)I));
+  }(), ...);
+}
+// can the program run that way?  The boxed observable's systematics have one coefficient and read at most slot XT,
+// which nothing writes; the others (composed into an affine map of their own field) have one coefficient too and
+// read nothing but their own slot
+template <int BX, int XT, unsigned... OPS>
+constexpr bool prog_is_boxable(StaticProg<OPS...>) {
+  return (true && ... &&
+          (sx_op_npars(OPS) == 1 && (int)((OPS >> 4) & 15u) != XT &&
+           ((int)(OPS & 15u) != SXMC_SYST_RESOLUTION_SCALE ||
+            ((int)((OPS >> 4) & 15u) == BX && (int)((OPS >> 8) & 15u) == XT))));
+}
+
+#ifndef SXMC_BOX_DRAIN
+#define SXMC_BOX_DRAIN 2
+#endif
+template <int NOBS, int NSLOT, typename PROG>
+__device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__ descs, const SxSegment* __restrict__ segs,
+                                                const unsigned* __restrict__ blk_off, unsigned layout, unsigned dbg_arg) {
+  const unsigned dbg = sx_dbg(dbg_arg);   // (0 in the product build: see SXMC_MEASURE)
+  static_assert(!PROG::dynamic && NOBS == 1 && NSLOT == 3, "one streamed observable, one truth field, the boxed observable");
+  constexpr int BX = 2, XT = 1;        // the boxed observable's slot, its truth field's
+  static_assert(prog_is_boxable<BX, XT>(PROG{}), "not a program the boxed form can run");
+  constexpr int NC = PROG::ncoef > 0 ? PROG::ncoef : 1;
+  constexpr int kRing = 8;             // units of codes (8 bytes each) a lane holds: one worked on, seven in flight
+  constexpr int kDrain = SXMC_BOX_DRAIN;   // queued granules whose float columns the drain loads together
+  static_assert(64 % kRing == 0, "a block of 64 units is a whole number of rounds of the ring");
+  typedef typename MakeISeq<PROG::n>::type Seq;
+  extern __shared__ unsigned lds[];
+  const unsigned tid = threadIdx.x;
+  const unsigned nthreads = blockDim.x;
+  const unsigned lane = tid & (kWave - 1);
+  // LDS as in fill_ordered_body's padded form: 4 header words, R replicas of (nbins + 2) rows of S' words, 64 spare
+  // words, the waves' queues.  `layout` = rstride | log2(R) << 24 | 1 << 27 | log2(queue entries) << 28.
+  unsigned* s_norm = lds;
+  unsigned* hist = lds + 4;
+  const unsigned rstride = layout & 0xFFFFFFu, rlog = (layout >> 24) & 7u, R = 1u << rlog;
+  const unsigned cstride = rstride << rlog;
+  const unsigned myrep = (lane & (R - 1u)) * rstride;
+  const unsigned qlog = layout >> 28;
+  const unsigned qwave = qlog ? (1u << qlog) / (nthreads / kWave) : 0u;      // entries per wave
+  // (half of a wave's slice for whole granules: at config 3 a few per cent of ~100 granules per wave)
+  const unsigned gq_min = (unsigned)kRing + 1u;
+  const unsigned gq_cap = qwave / 2u > gq_min ? qwave / 2u : gq_min, rq_cap = qwave > gq_cap ? qwave - gq_cap : 0u;
+  unsigned* qrows = lds + 4 + cstride + 64 + 4 + (tid / kWave) * (2u * qwave);
+  unsigned* qgran = qrows + 2u * rq_cap;
+
+  bool lds_clean = false;
+  const unsigned seg_end = blk_off[blockIdx.x + 1];
+  for (unsigned si = blk_off[blockIdx.x]; si < seg_end; ++si) {
+    const SxSegment& sg = segs[si];
+    const SxSignalDesc& d = descs[sg.sig];
+    const unsigned long long v0 = sg.v0, v1 = sg.v1, step = sg.step;
+    const unsigned B = (unsigned)d.total_nbins;
+    double craw[NC];
+#pragma unroll
+    for (int q = 0; q < PROG::ncoef; q++) craw[q] = to_global(d.params)[(long)d.coef_par[q] * d.param_stride];
+    __builtin_amdgcn_sched_barrier(0);
+
+    gptr<const vfloat4> col[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      col[k] = to_global(reinterpret_cast<const vfloat4*>(d.cols + (unsigned long long)d.slot_col[k] * d.col_pitch));
+    }
+    gptr<const unsigned> precol = to_global(reinterpret_cast<const unsigned*>(d.pre));
+    gptr<const vfloat4> boxes = to_global(reinterpret_cast<const vfloat4*>(d.boxes));
+    // (no table of codes: every granule goes to the float columns; the ring then loads from the first float column --
+    // twice as long -- so that its loads stay unconditional and its waits counted)
+    gptr<const vuint2g> qcol = to_global(d.qcol != nullptr ? reinterpret_cast<const vuint2g*>(d.qcol)
+                                                           : reinterpret_cast<const vuint2g*>(d.cols));
+    const unsigned vfirst32 = (unsigned)(v0 + tid), step32 = (unsigned)step, vlast32 = (unsigned)(v1 - 1);
+    const unsigned vwave32 = vfirst32 - lane;             // the wave's first unit: a granule boundary
+    const unsigned niter32 = (unsigned)((v1 - v0 + step - 1) / step);
+
+    if (!lds_clean) {
+      for (unsigned b = tid; b < cstride; b += nthreads) hist[b] = 0u;
+      if (tid < 4) s_norm[tid] = 0u;
+      __syncthreads();
+    }
+
+    // geometry: the streamed observable (index 0) and the boxed one (index NOBS)
+    const double lo = d.lower[0], hi = d.upper[0], sc = d.scale[0];
+    const int st = d.bin_stride[0];
+    const unsigned nbk = (unsigned)d.nbins[0];
+    const double olo = d.lower[NOBS], ohi = d.upper[NOBS], osc = d.scale[NOBS];
+    const int ost = d.bin_stride[NOBS];
+    int stv = st, ostv = ost;
+    asm volatile("" : "+v"(stv));
+    asm volatile("" : "+v"(ostv));
+    // the LDS copy of the histogram: row idx + 1 of S' words per index of the streamed observable, word hi * s + lo of a
+    // row for the bin hi * (s * nbins) + idx * s + lo (s: the observable's stride in the real histogram)
+    const unsigned s_in = (unsigned)st, s_out = s_in * nbk;          // strides of the index and of what lies above it
+    const unsigned oS = B / nbk, oSp = oS | 1u;
+    const float inv_in = 1.0f / (float)s_in, inv_out = 1.0f / (float)s_out;
+    // (x / y for x, y < 2^22, exact)
+    auto fdiv = [](unsigned x, float inv) -> unsigned { return (unsigned)(((float)x + 0.5f) * inv); };
+    // word of real bin `bin` (< B) inside a replica
+    auto hist_word = [&](unsigned bin) -> unsigned {
+      const unsigned h = fdiv(bin, inv_out), rem = bin - h * s_out, idx = fdiv(rem, inv_in);
+      return (idx + 1u) * oSp + h * s_in + (rem - idx * s_in);
+    };
+
+    bool wild = false;
+#pragma unroll
+    for (int q = 0; q < PROG::ncoef; q++) wild = wild || !(__builtin_fabs(craw[q]) < __builtin_inf());
+
+    // ---- the streamed observable's program composed into single precision over its code (fill_ordered_body, THE BOUND)
+    float af, gf, thr;
+    bool use_q = d.qcol != nullptr && rq_cap >= 8u && !wild;
+    {
+      AffineForm<1> form[1];
+      form[0].a[0] = 1.0;
+      form[0].c = 0.0;
+      const double wlo = d.qbase[0], whi = d.qbase[0] + 65534.0 * d.qstep[0];
+      form[0].mag = __builtin_fmax(__builtin_fabs(wlo), __builtin_fabs(whi));
+      run_affine<1, BX>(form, craw, PROG{}, Seq{});
+      const double alpha = form[0].a[0] * d.qstep[0] * sc;
+      const double sum_abs = __builtin_fabs(alpha);
+      double g = form[0].c - lo;
+      g = g + form[0].a[0] * (d.qbase[0] + 0.5 * d.qstep[0]);
+      g = g * sc;
+      const double mu = sum_abs * 65536.0 + __builtin_fabs(g) + (double)nbk + 0.25;
+      const double epsq = 0.5 * sum_abs * (1.0 + 0x1p-19);
+      const double eps = epsq + mu * 0x1p-21 + (form[0].mag + __builtin_fabs(lo)) * sc * 0x1p-44;
+      const bool ok = eps < 0.125;                       // (NaN fails)
+      const double e = eps * 1.01, slack = 0x1p-23;
+      af = uniform_f((float)alpha);
+      gf = uniform_f((float)(g + e));
+      thr = uniform_f((float)(2.0 * e + slack));
+      use_q = use_q && (uniform_i(ok ? 1 : 0) != 0);
+    }
+
+    unsigned vcnt = 0u;                      // in domain, flat index past the end: counted in the norm only
+    unsigned nrow = 0u, ngran = 0u;          // entries in the wave's queues (wave-uniform)
+
+    // ---- per block of 64 units, one lane per granule: the box through the program, and the granule's words
+    //   gword: kOrdSkip (outside the boxed observable's domain), kOrdMixed (the float columns decide), or the word
+    //          of (idx = -1, bin 0 of the granule's row part) inside a replica's padded copy;  greal: the granule's
+    //          offset in the real histogram (what the ambiguous rows' queue entries carry)
+    unsigned gword = kOrdSkip, greal = 0u;
+    auto granule_meta = [&](unsigned it) {
+      unsigned vg = vwave32 + (it + lane) * step32;
+      const bool live = vg <= vlast32;
+      vg = live ? vg : vlast32;
+      const vfloat4 bx = boxes[vg >> 6];
+      const unsigned pre = precol[vg >> 6];
+      double xl = (double)bx.x, xh = (double)bx.y;
+      const double tl = (double)bx.z, th = (double)bx.w;
+      bool fin = (__builtin_fabs(xl) < __builtin_inf()) && (__builtin_fabs(xh) < __builtin_inf()) &&
+                 (__builtin_fabs(tl) < __builtin_inf()) && (__builtin_fabs(th) < __builtin_inf());
+      run_box_interval<BX, XT>(xl, xh, tl, th, fin, craw, PROG{}, Seq{});
+      const int i0 = (int)((xl - olo) * osc), i1 = (int)((xh - olo) * osc);
+      const int e0 = !(xl >= olo) ? -1 : (!(xl < ohi) ? 0x7FFFFFFF : i0);
+      const int e1 = !(xh >= olo) ? -1 : (!(xh < ohi) ? 0x7FFFFFFF : i1);
+      const unsigned off = (pre & 0xFFFFFFu) + (unsigned)e0 * (unsigned)ost;    // (meaningless unless e0 is an index)
+      const unsigned h = fdiv(off, inv_out), rem = off - h * s_out;
+      // binned from codes only if every index of the streamed observable keeps the flat index canonical and in range
+      const bool canon = off < (1u << 22) && rem < s_in && (h + 1u) * s_out <= B;
+      const bool mixed = !use_q || !fin || e0 != e1 || !canon;
+      const bool skip = fin && e0 == e1 && (e0 < 0 || e0 == 0x7FFFFFFF);
+      gword = !live ? kOrdSkip : skip ? kOrdSkip : mixed ? kOrdMixed : h * s_in + rem;
+      greal = off;
+    };
+
+    // ---- queues (fill_ordered_body): a granule left to the float columns; the ambiguous rows of a granule
+    auto push_granule = [&](unsigned it) {
+      if (lane == 0) qgran[2u * ngran] = vwave32 + it * step32;
+      ngran += 1u;
+    };
+    auto push_rows = [&](unsigned rare, unsigned v, unsigned real_off) -> bool {
+      unsigned long long mask[SXMC_VEC];
+      unsigned total = 0u;
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        mask[q] = __builtin_amdgcn_ballot_w64(((rare >> q) & 1u) != 0u);
+        total += (unsigned)__builtin_popcountll(mask[q]);
+      }
+      if (nrow + total > rq_cap) return false;
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        if (mask[q] == 0ull) continue;
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask[q] >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask[q], 0u));
+        if ((rare >> q) & 1u) {
+          const unsigned pos = nrow + below;
+          qrows[2u * pos] = v * SXMC_VEC + (unsigned)q;
+          qrows[2u * pos + 1u] = real_off;
+        }
+        nrow += (unsigned)__builtin_popcountll(mask[q]);
+      }
+      return true;
+    };
+
+    // ---- one unit of codes: four samples of the streamed observable (coarse_outer of fill_ordered_body with one field)
+    const int oS4 = (int)(4u * oSp);
+    const int oclamp = (int)nbk;
+    auto coarse_unit = [&](const vuint2g& w, unsigned it, unsigned v, unsigned word0) {
+      int base4 = (int)(4u * (4u + myrep + word0) + 4u * oSp);      // byte address of (idx = -1 ... + 1 row = idx 0)
+      asm volatile("" : "+v"(base4));
+      const float c0 = (float)(w.x & 0xFFFFu), c1 = (float)(w.x >> 16), c2 = (float)(w.y & 0xFFFFu), c3 = (float)(w.y >> 16);
+      const vfloat2 a2 = {af, af}, g2 = {gf, gf};
+      const vfloat2 u01 = __builtin_elementwise_fma(a2, vfloat2{c0, c1}, g2);
+      const vfloat2 u23 = __builtin_elementwise_fma(a2, vfloat2{c2, c3}, g2);
+      const float us[SXMC_VEC] = {u01.x, u01.y, u23.x, u23.y};
+      int addr[SXMC_VEC];
+      bool amb[SXMC_VEC];
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        const float u = us[q];
+        amb[q] = !(__builtin_amdgcn_fractf(u) >= thr);               // closer to a bin edge than the bound (or NaN)
+        int idx;
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(idx) : "v"(u));
+        int ie;
+        asm("v_med3_i32 %0, %1, -1, %2" : "=v"(ie) : "v"(amb[q] ? -1 : idx), "s"(oclamp));
+        addr[q] = mad24(ie, oS4, base4);
+      }
+      const float cmax = __builtin_fmaxf(__builtin_fmaxf(c0, c1), __builtin_fmaxf(c2, c3));
+      const bool special = cmax >= (float)SXMC_QCODE_EXACT;
+      const bool anyamb = (amb[0] | amb[1]) | (amb[2] | amb[3]);
+      if (__builtin_amdgcn_ballot_w64(anyamb || special) != 0ull) {
+        const float cs[SXMC_VEC] = {c0, c1, c2, c3};
+        unsigned rare = 0u;
+#pragma unroll
+        for (int q = 0; q < SXMC_VEC; q++) {
+          rare |= amb[q] ? (1u << q) : 0u;
+          if (cs[q] >= (float)SXMC_QCODE_EXACT) {          // the arithmetic above meant nothing for this row
+            addr[q] = base4 - oS4;                         // (the guard row)
+            rare = cs[q] >= (float)SXMC_QCODE_NEVER ? (rare & ~(1u << q)) : (rare | (1u << q));
+          }
+        }
+        const unsigned real_off = (unsigned)__builtin_amdgcn_readlane((int)greal, (int)(it & 63u));
+        if (!push_rows(rare, v, real_off)) {               // more than the queue holds: the whole granule, later
+          push_granule(it);
+          return;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < SXMC_VEC; q++) {
+        unsigned* wp = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + addr[q]);
+        __hip_atomic_fetch_add(wp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    };
+
+    // ---- what the queues hold, with the reference's arithmetic on the float columns (pdfz.cpp:306-331, 388-398)
+    auto count_exact = [&](bool ind, int bin) {
+      vcnt += (ind && !((unsigned)bin < B)) ? 1u : 0u;     // (the others are counted with the histogram)
+      if (ind && ((unsigned)bin < B)) {
+        __hip_atomic_fetch_add(&hist[myrep + hist_word((unsigned)bin)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    };
+    auto drain = [&]() {
+      vfloat4 rawf[kDrain][NSLOT];
+      unsigned prew[kDrain];
+      auto load_granule = [&](int s, unsigned g) {
+        const unsigned vw = (unsigned)uniform_i((int)qgran[2u * g]);
+        const unsigned vc = vw + lane < vlast32 ? vw + lane : vlast32;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) rawf[s][k] = __builtin_nontemporal_load(&col[k][vc]);
+        prew[s] = precol[vc >> 6];
+      };
+      unsigned row = 0u, w1 = 0u;
+      float rowf = 0.0f;
+      if (lane < nrow) {
+        row = qrows[2u * lane];
+        w1 = qrows[2u * lane + 1u];
+        rowf = ((gptr<const float>)col[0])[row];
+      }
+#pragma unroll
+      for (int s = 0; s < kDrain; s++) {
+        if ((unsigned)s < ngran) load_granule(s, (unsigned)s);
+      }
+      // rows: the streamed observable of one row (its granule's other indices are the entry's offset)
+      for (unsigned i0 = 0; i0 < nrow; i0 += kWave) {
+        if (i0 != 0u && i0 + lane < nrow) {
+          row = qrows[2u * (i0 + lane)];
+          w1 = qrows[2u * (i0 + lane) + 1u];
+          rowf = ((gptr<const float>)col[0])[row];
+        }
+        if (i0 + lane < nrow) {
+          double f[NSLOT][SXMC_VEC];
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) f[k][0] = f[k][1] = f[k][2] = f[k][3] = 0.0;
+          f[0][0] = f[0][1] = f[0][2] = f[0][3] = (double)rowf;
+          run_static_part<NSLOT, BX, false>(f, craw, PROG{}, Seq{});
+          const double x = f[0][0];
+          const bool ind = (x >= lo) & (x < hi);
+          const int idx = (int)((x - lo) * sc);
+          count_exact(ind, mad24(idx, stv, (int)w1));
+        }
+      }
+      // whole granules: all three columns
+      for (unsigned g0 = 0; g0 < ngran; g0 += (unsigned)kDrain) {
+        if (g0 != 0u) {
+#pragma unroll
+          for (int s = 0; s < kDrain; s++) {
+            if (g0 + (unsigned)s < ngran) load_granule(s, g0 + (unsigned)s);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < kDrain; s++) {
+          if (g0 + (unsigned)s >= ngran) break;
+          const unsigned off = (unsigned)uniform_i((int)prew[s]) & 0xFFFFFFu;
+          double f[NSLOT][SXMC_VEC];
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) {
+            f[k][0] = (double)rawf[s][k].x;
+            f[k][1] = (double)rawf[s][k].y;
+            f[k][2] = (double)rawf[s][k].z;
+            f[k][3] = (double)rawf[s][k].w;
+          }
+          run_static<NSLOT>(f, craw, PROG{}, Seq{});
+#pragma unroll
+          for (int q = 0; q < SXMC_VEC; q++) {
+            const double x = f[0][q], y = f[BX][q];
+            const bool ind = (x >= lo) & (x < hi) & (y >= olo) & (y < ohi);      // (NaN fails: padding rows too)
+            const int idx = (int)((x - lo) * sc), oidx = (int)((y - olo) * osc);
+            count_exact(ind, mad24(oidx, ostv, mad24(idx, stv, (int)off)));
+          }
+        }
+      }
+      nrow = ngran = 0u;
+    };
+
+    // ---- the stream: a ring of kRing units of codes, counted waits (fill_ordered_body)
+    vuint2g rq[kRing];
+    const unsigned vfirst8 = vfirst32 * 8u, vlast8 = vlast32 * 8u, step8 = step32 * 8u;
+    auto issue = [&](int slot, unsigned it) {
+      unsigned o = vfirst8 + it * step8;
+      o = o < vlast8 ? o : vlast8;
+      rq[slot] = __builtin_nontemporal_load((gptr<const vuint2g>)((gptr<const char>)qcol + (unsigned long long)o));
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    const unsigned climit = oS;              // a granule word below this: binned from codes
+    {
+      unsigned it = 0u;
+#pragma unroll
+      for (int i = 0; i < kRing; i++) issue(i, (unsigned)i);
+      while (it < niter32) {
+        if ((it & 63u) == 0u) granule_meta(it);
+        const unsigned block_end = niter32 < (it | 63u) + 1u ? niter32 : (it | 63u) + 1u;
+        bool full = false;
+        while (it < block_end && !full) {
+#pragma unroll
+          for (int i = 0; i < kRing; i++) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) asm volatile("" : "+v"(rq[i][e]));   // (the wait for this unit goes here)
+            const unsigned iu = it + (unsigned)i;
+            if (iu < block_end) {
+              const unsigned word0 = (unsigned)__builtin_amdgcn_readlane((int)gword, (int)(iu & 63u));
+              if (word0 < climit) coarse_unit(rq[i], iu, vfirst32 + iu * step32, word0);
+              else if (word0 == kOrdMixed) push_granule(iu);
+            }
+            issue(i, iu + (unsigned)kRing);   // (unconditional: the waits above count on it)
+          }
+          it = block_end - it < (unsigned)kRing ? block_end : it + (unsigned)kRing;
+          full = ngran + (unsigned)kRing > gq_cap;
+        }
+#ifndef SXEXP_NOMID
+        if (full) {
+          drain();
+          __builtin_amdgcn_s_waitcnt(0);
+        }
+#endif
+      }
+    }
+#ifndef SXEXP_NOFINAL
+    drain();
+#endif
+
+    // in-domain counts: lane registers -> wave -> workgroup
+    {
+      unsigned t = vcnt;
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off, kWave);
+      if (lane == 0 && t != 0u) __hip_atomic_fetch_add(&s_norm[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    // flush: word (idx + 1) * S' + r of a replica, r = hi * s + lo < S, is bin hi * (s * nbins) + idx * s + lo; the guard
+    // rows and the pad word of each row (r = S, when S is even) are not bins
+    {
+      gptr<unsigned> gbins = to_global(d.bins);
+      const bool more = si + 1u < seg_end;
+      const unsigned nwords = nbk * oSp;
+      const float invSp = 1.0f / (float)oSp;
+      unsigned total = 0u;
+#pragma unroll 4
+      for (unsigned w = tid; w < nwords; w += nthreads) {
+        const unsigned idx = fdiv(w, invSp), r = w - idx * oSp;
+        unsigned n = 0u;
+        for (unsigned rep = 0; rep < R; rep++) n += hist[rep * rstride + oSp + w];
+        if (r < oS) {
+          total += n;
+          const unsigned h = fdiv(r, inv_in);
+          if (n != 0u) {
+            __hip_atomic_fetch_add(&gbins[h * s_out + idx * s_in + (r - h * s_in)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kWave);
+      if (lane == 0 && total != 0u) __hip_atomic_fetch_add(&s_norm[0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __syncthreads();
+      if (more) {
+        for (unsigned b = 4u * tid; b < cstride; b += 4u * nthreads) {
+          *reinterpret_cast<vuint4g*>(&hist[b]) = vuint4g{0u, 0u, 0u, 0u};
+        }
+      }
+      if (tid == 0) {
+        const unsigned n = s_norm[0];
+        if (n != 0u) __hip_atomic_fetch_add(to_global(d.norm), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_norm[0] = 0u;
+      }
+    }
+    __syncthreads();
+    lds_clean = true;
+  }
+  (void)dbg;
+}
+
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>
 __global__ __launch_bounds__(1024) void fill_kernel(const SxSignalDesc* __restrict__ descs,
                                                     const SxSegment* __restrict__ segs,
@@ -2211,6 +2699,14 @@ __global__ __launch_bounds__(SXMC_ORDERED_BOUND) void fill_ordered_kernel(const 
   SxChainDescs one;
   one.d[0] = one.d[1] = one.d[2] = one.d[3] = descs;
   fill_ordered_body<NOBS, NSLOT, PROG, 1, LDS_HIST>(one, segs, blk_off, layout, dbg);
+}
+
+template <int NOBS, int NSLOT, typename PROG>
+__global__ __launch_bounds__(SXMC_ORDERED_BOUND) void fill_boxed_kernel(const SxSignalDesc* __restrict__ descs,
+                                                          const SxSegment* __restrict__ segs,
+                                                          const unsigned* __restrict__ blk_off, unsigned layout,
+                                                          unsigned dbg) {
+  fill_boxed_body<NOBS, NSLOT, PROG>(descs, segs, blk_off, layout, dbg);
 }
 
 }  // namespace sxfill

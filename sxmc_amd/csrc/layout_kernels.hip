@@ -78,6 +78,73 @@ __global__ __launch_bounds__(256) void bucket_edges_kernel(const float* __restri
   }
 }
 
+// BOXED observable (fill_boxed_kernel): rows of a bucket are to lie in small boxes of (x, t) -- the observable's raw
+// value and the truth field its resolution scale reads.  Pass 1: key = x - t as an order-preserving pattern (its sorted
+// order gives the strata's boundaries: quantiles of x - t).  Pass 2: key = stratum of x - t in the top bits, x below:
+// inside a stratum rows ascend in x.  Any grouping is CORRECT (the boxes are taken from the rows themselves); this one
+// keeps them small in both directions.  Rows with a NaN sort last.
+struct BoxStrata {
+  int n;                 // strata (1 .. 16)
+  unsigned bound[16];    // ascending patterns: stratum = how many of bound[0 .. n-2] are <= the row's
+};
+__global__ __launch_bounds__(256) void box_key_kernel(const float* __restrict__ colx, const float* __restrict__ colt,
+                                                      unsigned long long n, int pass, BoxStrata strata,
+                                                      unsigned* __restrict__ keys, unsigned* __restrict__ rows) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const float x = colx[i], d = x - colt[i];
+    const unsigned ud = __float_as_uint(d), kd = (ud >> 31) ? ~ud : (ud | 0x80000000u);
+    unsigned key;
+    if (pass == 1) {
+      key = (d != d) ? 0xFFFFFFFFu : kd;
+    } else {
+      const unsigned ux = __float_as_uint(x), kx = (ux >> 31) ? ~ux : (ux | 0x80000000u);
+      unsigned s = 0;
+      for (int k = 0; k + 1 < strata.n; k++) s += strata.bound[k] <= kd ? 1u : 0u;
+      key = (d != d || x != x) ? 0xFFFFFFFFu : ((s << 28) | (kx >> 4));
+    }
+    keys[i] = key;
+    rows[i] = (unsigned)i;
+  }
+}
+
+// per granule: the box of its valid rows, {xmin, xmax, tmin, tmax}; NaN in all four if a valid row holds a value that
+// is not finite (such a granule is left to the float columns at every evaluation).  One wave per granule.
+__global__ __launch_bounds__(256) void bucket_boxes_kernel(const float* __restrict__ colx, const float* __restrict__ colt,
+                                                           const unsigned* __restrict__ valid,
+                                                           unsigned long long ngranules, float* __restrict__ boxes) {
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+  for (unsigned long long p = wave; p < ngranules; p += nwaves) {
+    const unsigned nv = valid[p];
+    float xl = __builtin_inff(), xh = -__builtin_inff(), tl = __builtin_inff(), th = -__builtin_inff();
+    bool bad = false;
+    for (unsigned i = lane; i < nv; i += 64u) {
+      const float x = colx[p * 256ull + i], t = colt[p * 256ull + i];
+      bad = bad || !(fabsf(x) < __builtin_inff()) || !(fabsf(t) < __builtin_inff());
+      xl = fminf(xl, x);
+      xh = fmaxf(xh, x);
+      tl = fminf(tl, t);
+      th = fmaxf(th, t);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      xl = fminf(xl, __shfl_down(xl, off, 64));
+      xh = fmaxf(xh, __shfl_down(xh, off, 64));
+      tl = fminf(tl, __shfl_down(tl, off, 64));
+      th = fmaxf(th, __shfl_down(th, off, 64));
+    }
+    const bool anybad = __ballot(bad) != 0ull || nv == 0u;
+    if (lane == 0) {
+      const float nanv = __int_as_float(0x7fc00000);
+      boxes[4 * p] = anybad ? nanv : xl;
+      boxes[4 * p + 1] = anybad ? nanv : xh;
+      boxes[4 * p + 2] = anybad ? nanv : tl;
+      boxes[4 * p + 3] = anybad ? nanv : th;
+    }
+  }
+}
+
 // first[k] = position of the first row with key k in the sorted order (first[] pre-filled with all ones)
 __global__ __launch_bounds__(256) void bucket_first_kernel(const unsigned* __restrict__ sorted_keys,
                                                            unsigned long long n, unsigned* __restrict__ first) {
@@ -190,6 +257,34 @@ __global__ __launch_bounds__(256) void column_codes_kernel(const float* __restri
   if (nnever) atomicAdd(&tally[1], nnever);
 }
 
+// ONE column as 16-bit codes, one per row (fill_boxed_kernel streams 8 bytes per lane and unit): the same window, check
+// and special values as above (0xFFFE: outside the window or failing the check, 0xFFFF: not finite)
+__global__ __launch_bounds__(256) void column_codes16_kernel(const float* __restrict__ col, double base, double qstep,
+                                                             unsigned long long n, unsigned short* __restrict__ qcol,
+                                                             unsigned* __restrict__ tally) {
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned nexact = 0u, nnever = 0u;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const double x = (double)col[i];
+    unsigned code;
+    if (!(fabs(x) < __builtin_inf())) {
+      code = SXMC_QCODE_NEVER;
+      nnever++;
+    } else {
+      const double t = (x - base) / qstep;
+      bool exact = !(t >= 0.0 && t < (double)(SXMC_QCODE_MAX + 1u));
+      const unsigned q = exact ? 0u : (unsigned)t;
+      const double centre = base + ((double)q + 0.5) * qstep;
+      if (!(fabs(x - centre) <= 0.5 * qstep * (1.0 + 0x1p-20))) exact = true;
+      code = exact ? SXMC_QCODE_EXACT : q;
+      nexact += exact ? 1u : 0u;
+    }
+    qcol[i] = (unsigned short)code;
+  }
+  if (nexact) atomicAdd(&tally[0], nexact);
+  if (nnever) atomicAdd(&tally[1], nnever);
+}
+
 // EvalHist::RandomSample (pdfz.cpp:817-922) without leaving the device: a bin is drawn with probability
 // proportional to its content (inverse CDF: `cdf` is the inclusive prefix sum of the histogram), then a point
 // uniform inside the bin (what TH1::GetRandom does); redrawn while it falls outside the cuts, as the reference
@@ -262,6 +357,26 @@ hipError_t sx_order_keys(const float* d_col, unsigned long long nsamples, unsign
                          hipStream_t s) {
   if (nsamples == 0) return hipSuccess;
   hipLaunchKernelGGL(order_key_kernel, dim3(grid_for(nsamples, 16384)), dim3(256), 0, s, d_col, nsamples, d_keys, d_rows);
+  return hipGetLastError();
+}
+
+hipError_t sx_box_keys(const float* d_colx, const float* d_colt, unsigned long long nsamples, int pass, int nstrata,
+                       const unsigned* bounds, unsigned* d_keys, unsigned* d_rows, hipStream_t s) {
+  if (nsamples == 0) return hipSuccess;
+  if (nstrata < 1 || nstrata > 16) return hipErrorInvalidValue;
+  BoxStrata st{};
+  st.n = nstrata;
+  for (int k = 0; k + 1 < nstrata; k++) st.bound[k] = bounds ? bounds[k] : 0u;
+  hipLaunchKernelGGL(box_key_kernel, dim3(grid_for(nsamples, 16384)), dim3(256), 0, s, d_colx, d_colt, nsamples, pass, st,
+                     d_keys, d_rows);
+  return hipGetLastError();
+}
+
+hipError_t sx_bucket_boxes(const float* d_colx, const float* d_colt, const unsigned* d_valid, unsigned long long ngranules,
+                           float* d_boxes, hipStream_t s) {
+  if (ngranules == 0) return hipSuccess;
+  hipLaunchKernelGGL(bucket_boxes_kernel, dim3(grid_for(ngranules * 64ull, 16384)), dim3(256), 0, s, d_colx, d_colt, d_valid,
+                     ngranules, d_boxes);
   return hipGetLastError();
 }
 
@@ -359,6 +474,28 @@ hipError_t sx_column_codes(const float* cols, unsigned long long pitch, int nslo
   e = hipMemsetAsync(d, 0, sizeof(unsigned) * 2, s);
   if (e == hipSuccess && n) {
     hipLaunchKernelGGL(column_codes_kernel, dim3(grid_for(n, 16384)), dim3(256), 0, s, cols, pitch, plan, n, qcol, d);
+    e = hipGetLastError();
+  }
+  unsigned h[2] = {0u, 0u};
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(d);
+  if (tally) {
+    tally[0] = h[0];
+    tally[1] = h[1];
+  }
+  return e != hipSuccess ? e : e2;
+}
+
+// one column as 16-bit codes, one per row (column_codes16_kernel); tally as above
+hipError_t sx_column_codes16(const float* col, double base, double step, unsigned long long n, unsigned short* qcol,
+                             unsigned long long* tally, hipStream_t s) {
+  unsigned* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, sizeof(unsigned) * 2);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d, 0, sizeof(unsigned) * 2, s);
+  if (e == hipSuccess && n) {
+    hipLaunchKernelGGL(column_codes16_kernel, dim3(grid_for(n, 16384)), dim3(256), 0, s, col, base, step, n, qcol, d);
     e = hipGetLastError();
   }
   unsigned h[2] = {0u, 0u};

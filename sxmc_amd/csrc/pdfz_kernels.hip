@@ -1158,6 +1158,28 @@ const OrderedEntry kOrderedPrograms[] = {
 };
 constexpr int kNumOrdered = (int)(sizeof(kOrderedPrograms) / sizeof(kOrderedPrograms[0]));
 
+// Boxed programs built in (bucketed table with a boxed observable, fill_boxed_kernel): slot 0 the observable binned per
+// sample, slot 1 the truth field, slot 2 the boxed observable.  Anything else: hiprtc.
+template <int NOBS, int NSLOT, typename PROG>
+hipError_t launch_fill_boxed_k(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
+                               const unsigned* blk_off, hipStream_t s) {
+  auto k = fill_boxed_kernel<NOBS, NSLOT, PROG>;
+  if (sh.lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  launch_fill(sh, k, dim3(sh.grid), dim3(sh.threads), sh.lds_bytes, s, descs, segs, blk_off, sh.lds_layout,
+              (unsigned)sh.debug_mode);
+  return hipGetLastError();
+}
+#define SX_B3(NO, NS, A, B, C) {NO, NS, 3, {A, B, C, 0}, launch_fill_boxed_k<NO, NS, StaticProg<A, B, C>>}
+const OrderedEntry kBoxedPrograms[] = {
+    // BASELINE config 3 bucketed: r (shift) binned per sample, e (scale + resolution_scale against e_true) boxed
+    SX_B3(1, 3, SX_SHIFT(0), SX_SCALE(2), SX_RES(2, 1)),
+};
+constexpr int kNumBoxed = (int)(sizeof(kBoxedPrograms) / sizeof(kBoxedPrograms[0]));
+
 template <int NOBS, int NSLOT>
 hipError_t launch_fill_dyn(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                            const unsigned* blk_off, hipStream_t s) {
@@ -1262,15 +1284,30 @@ int sx_fill_find_ordered_program(int nobs, int nslot, int nops, const unsigned* 
   return -1;
 }
 
+int sx_fill_find_boxed_program(int nobs, int nslot, int nops, const unsigned* ops) {
+  for (int i = 0; i < kNumBoxed; i++) {
+    const OrderedEntry& e = kBoxedPrograms[i];
+    if (e.nobs != nobs || e.nslot != nslot || e.nops != nops) continue;
+    bool same = true;
+    for (int k = 0; k < nops; k++) same = same && e.ops[k] == ops[k];
+    if (same) return i;
+  }
+  return -1;
+}
+
 hipError_t sx_launch_fill(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                           const unsigned* blk_off, hipStream_t s) {
   if (sh.grid <= 0) return hipSuccess;
+  if (sh.pre_width == kPreBoxed && !sh.rtc_fill) {
+    if (sh.static_prog < 0 || sh.static_prog >= kNumBoxed) return hipErrorInvalidValue;
+    return kBoxedPrograms[sh.static_prog].fn(sh, descs, segs, blk_off, s);
+  }
   if (sh.pre_width == kPreOrdered && !sh.rtc_fill) {
     if (sh.static_prog < 0 || sh.static_prog >= kNumOrdered) return hipErrorInvalidValue;
     return kOrderedPrograms[sh.static_prog].fn(sh, descs, segs, blk_off, s);
   }
   if (sh.rtc_fill) {
-    const unsigned hist_words = sh.pre_width == kPreOrdered ? sh.lds_layout
+    const unsigned hist_words = (sh.pre_width == kPreOrdered || sh.pre_width == kPreBoxed) ? sh.lds_layout
                                                             : (unsigned)(sh.lds_bytes / 4 - 4 - (sh.lds_hist ? 64 : 0));
     return sx_rtc_launch(sh.rtc_fill, sh.grid, sh.threads, sh.lds_bytes, descs, segs, blk_off, hist_words,
                          (unsigned)sh.debug_mode, s, sh.ev_start, sh.ev_stop);

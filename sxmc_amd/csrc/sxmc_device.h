@@ -71,6 +71,8 @@ struct SxLaunchShape {
   int pre_width;    // bytes per sample of the pre-binned column (1, 2, 4), 0 = none, 3 = bucketed table (one
                     // bin offset per 256-sample granule), 5 = bucketed table with an ordered observable
                     // (fill_ordered_kernel; static_prog then indexes the ordered programs built in)
+                    // 6 = bucketed table with a BOXED observable (fill_boxed_kernel; static_prog indexes the boxed
+                    // programs built in; lds_layout as for 5, always the padded form with queues)
   // profiling (sxmc_group_profile): when set, the fill is launched through hipExtLaunchKernelGGL /
   // hipExtModuleLaunchKernel with these two HIP events, which then carry the DISPATCH's own begin and end timestamps
   // -- the kernel's duration as rocprofv3 --kernel-trace reports it.  (Two hipEventRecord calls around the launch
@@ -149,6 +151,7 @@ bool sx_fill_static_supports_sparse_runs(int prog);
 bool sx_fill_has_specialization(int nobs, int nslot);
 int sx_fill_find_static_program(int nobs, int nslot, int nops, const unsigned* ops);
 int sx_fill_find_ordered_program(int nobs, int nslot, int nops, const unsigned* ops);
+int sx_fill_find_boxed_program(int nobs, int nslot, int nops, const unsigned* ops);
 bool sx_fill_static_supports(int prog, int lds_hist, int prebin);
 hipError_t sx_launch_prebin(const SxSignalDesc* d_desc, unsigned long long npad, unsigned mask, int width, void* out,
                             hipStream_t s);
@@ -160,6 +163,13 @@ hipError_t sx_order_keys(const float* d_col, unsigned long long nsamples, unsign
                          hipStream_t s);
 hipError_t sx_bucket_edges(const float* d_col, const unsigned* d_valid, unsigned long long ngranules, float* d_edges,
                            hipStream_t s);
+// boxed observable (fill_boxed_kernel): sort keys by (stratum of x - t, x); per-granule boxes; one column as u16 codes
+hipError_t sx_box_keys(const float* d_colx, const float* d_colt, unsigned long long nsamples, int pass, int nstrata,
+                       const unsigned* bounds, unsigned* d_keys, unsigned* d_rows, hipStream_t s);
+hipError_t sx_bucket_boxes(const float* d_colx, const float* d_colt, const unsigned* d_valid, unsigned long long ngranules,
+                           float* d_boxes, hipStream_t s);
+hipError_t sx_column_codes16(const float* col, double base, double step, unsigned long long n, unsigned short* qcol,
+                             unsigned long long* tally, hipStream_t s);
 hipError_t sx_bucket_sort(const unsigned* keys_in, unsigned* keys_out, const unsigned* rows_in, unsigned* rows_out,
                           unsigned long long n, int bits, hipStream_t s);
 hipError_t sx_bucket_first(const unsigned* sorted_keys, unsigned long long n, unsigned* d_first, hipStream_t s);

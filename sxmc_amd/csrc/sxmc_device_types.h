@@ -71,6 +71,11 @@ struct SxSignalDesc {
                                  // observable's value in the granule's first and last row; its geometry sits at
                                  // index `nobs` of lower / upper / scale / bin_stride / nbins, its column in slot
                                  // nslot - 1
+  const float* boxes;            // bucketed table with a BOXED observable (fill_boxed_kernel): per granule {xmin, xmax,
+                                 // tmin, tmax} of the observable's raw value and of the truth field its resolution
+                                 // scale reads, over the granule's rows (NaN: a row is not finite); geometry at index
+                                 // `nobs`, the observable in slot nslot - 1, the truth field in slot nslot - 2; `qcol`
+                                 // then holds ONE 16-bit code per row (slot 0)
   // --- sparse counting (histograms too large for LDS, evaluation for lookup only): `bins` then points
   //     at one counter per DISTINCT EVENT BIN, `read_bins` at the events' counter slots, and the fill maps
   //     a sample's flat bin index to its slot through a one-hash bit filter and an open-addressing table

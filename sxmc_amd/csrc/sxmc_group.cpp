@@ -131,7 +131,7 @@ int sxmc_group_optimize(sxmc_group_t g, sxmc_stream_t s, int* chosen_threads) {
   // second choice, for bucketed tables: one team of workgroups per member or three (see group_rebuild: which is
   // faster differs from box to box by ~3 % either way); three must win by 1.5 % to be taken
   bool has_bucketed = false;
-  for (const LaunchClass& c : g->classes) has_bucketed = has_bucketed || ((c.shape.pre_width == 3 || c.shape.pre_width == 5) && c.shape.lds_hist);
+  for (const LaunchClass& c : g->classes) has_bucketed = has_bucketed || ((c.shape.pre_width == 3 || c.shape.pre_width == 5 || c.shape.pre_width == 6) && c.shape.lds_hist);
   if (failure == SXMC_OK && has_bucketed && g->cfg_teams == 0) {
     float ms_of[2] = {best_ms, 1e30f};
     for (int pass = 0; pass < 2 && failure == SXMC_OK; pass++) {
@@ -197,6 +197,13 @@ int sxmc_group_set_bucketing(sxmc_group_t g, int enable) {
 int sxmc_group_set_ordering(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_order = enable == 2 ? 2 : enable ? 1 : 0;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_boxes(sxmc_group_t g, int enable) {
+  SX_REQUIRE(g, "null group");
+  g->cfg_box = enable < 0 ? -1 : enable ? 1 : 0;
+  g->box_blocked = false;
   return SXMC_OK;
 }
 
@@ -274,7 +281,7 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
     std::snprintf(line, sizeof line,
                   "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d teams=%d\n",
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
-                  c.shape.pre_width == 5 ? (c.codes ? "ordered+codes" : "ordered") : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
+                  c.shape.pre_width == 6 ? "boxed+codes" : c.shape.pre_width == 5 ? (c.codes ? "ordered+codes" : "ordered") : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
                   c.shape.grid, c.partition, c.teams);
     text += line;
@@ -869,10 +876,13 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
       // depends on the parameters; not counted -- and each granule has two end values besides its word)
       // (codes: the streamed fields at 16 bits each, two to a word; the float values of the ambiguous rows -- a few
       // in 10^4, which ones depends on the parameters -- are not counted either)
+      // (boxed: one 16-bit code per row, per granule the box (16 bytes) and the word; the three float columns of the
+      // granules whose box straddles an edge -- a few per cent, which ones depends on the parameters -- are not counted)
       const bool ord = bk->sort && bk->sort->ordered >= 0;
-      const double row_bytes = (codes && bk->d_qcol) ? 4.0 * (double)((bk->nq + 1) / 2)
+      const bool box = ord && bk->sort->box_truth >= 0;
+      const double row_bytes = (codes && bk->d_qcol) ? (bk->q16 ? 2.0 : 4.0 * (double)((bk->nq + 1) / 2))
                                                      : 4.0 * (double)(bk->fields.size() - (ord ? 1 : 0));
-      fr += (double)bk->nkept * row_bytes + ((ord ? 8.0 : 0.0) + (bk->runs > 1 ? 8.0 : 4.0)) * (double)bk->ngranules;
+      fr += (double)bk->nkept * row_bytes + ((box ? 16.0 : ord ? 8.0 : 0.0) + (bk->runs > 1 ? 8.0 : 4.0)) * (double)bk->ngranules;
     } else {
       fr += (double)h->nsamples * (4.0 * (d.nslot - pre_dims) + pre_w);
     }

@@ -151,6 +151,8 @@ struct SampleStore {
   struct BucketSort {
     unsigned mask = 0;
     int ordered = -1;               // observable whose raw value orders the rows inside every bucket, or -1
+    int box_truth = -1;             // >= 0: `ordered` is a BOXED observable (fill_boxed_kernel) and this the truth field
+                                    // its resolution scale reads: rows of a bucket go by (stratum of x - t, x)
     bool rejected = true;
     unsigned* d_rows = nullptr;     // [nsamples] row numbers in sorted order (rows outside the domain last)
     size_t nkept = 0;               // rows inside the domain of every untouched observable
@@ -173,6 +175,8 @@ struct SampleStore {
     unsigned* d_gpre = nullptr;     // [ngranules] bin offset of the granule
     unsigned* d_gkp = nullptr;      // [ngranules] pairs {bucket key, bin offset}
     float* d_gedge = nullptr;       // [ngranules] pairs {first, last} value of the sort's ordered observable
+    float* d_gbox = nullptr;        // [ngranules] {xmin, xmax, tmin, tmax} of the sort's boxed observable and its truth field
+    bool q16 = false;               // d_qcol holds ONE 16-bit code per row of field 0 (boxed tables)
     size_t ngranules = 0;           // physical granules (with the runs' padding)
     size_t nkept = 0;               // samples in the copy
     // CODES (fill_ordered_body): the streamed fields once more as 16-bit codes, two per word; built on demand
@@ -184,9 +188,9 @@ struct SampleStore {
   };
   std::vector<std::unique_ptr<BucketSort>> sorts;
   std::vector<std::unique_ptr<Bucketed>> bucketed;
-  BucketSort* find_sort(unsigned mask, int ordered) const {
+  BucketSort* find_sort(unsigned mask, int ordered, int box_truth = -1) const {
     for (const auto& b : sorts)
-      if (b->mask == mask && b->ordered == ordered) return b.get();
+      if (b->mask == mask && b->ordered == ordered && b->box_truth == box_truth) return b.get();
     return nullptr;
   }
   Bucketed* find_bucketed(const BucketSort* sort, const std::vector<int>& fields, int runs) const {
@@ -202,6 +206,7 @@ struct SampleStore {
       if (b->d_gpre) (void)hipFree(b->d_gpre);
       if (b->d_gkp) (void)hipFree(b->d_gkp);
       if (b->d_gedge) (void)hipFree(b->d_gedge);
+      if (b->d_gbox) (void)hipFree(b->d_gbox);
       if (b->d_qcol) (void)hipFree(b->d_qcol);
     }
     for (auto& b : sorts)
@@ -328,6 +333,8 @@ struct sxmc_group {
   int cfg_bucket = 1, cfg_seen_bucket = -1;        // stream a bucketed copy of the table where that pays
   bool order_blocked = false;                      // a plan with ordered tables beyond LDS could not be laid out in runs
   int cfg_order = 1, cfg_seen_order = -1;          // ... with the rows of a bucket ordered by a monotonically written observable
+  int cfg_box = -1, cfg_seen_box = -2;             // ... or grouped into boxes of a two-field observable (-1: where it pays, 1: wherever it applies)
+  bool box_blocked = false;                        // a plan with boxed tables found no room for its codes / LDS form: planned again without
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   int cfg_codes = -1, cfg_seen_codes = -2;         // ordered tables streamed as 16-bit codes (-1: SXMC_CODES, default on)
   int cfg_queue_log = 0, cfg_seen_queue_log = -1;  // ... cap on the queues of ambiguous rows, log2(entries) (0: what fits)

@@ -175,16 +175,27 @@ struct DevBuf {  // device temporary, freed on scope exit
   }
 };
 
+// strata of x - t inside a bucket of a boxed table (SXMC_BOX_STRATA, measurement build: 1 .. 16).  Four: with 256-row
+// granules the boxes of BASELINE config 3 are then about as wide in x as |p| times their width in x - t at the
+// resolution parameter's prior width (the CPU model behind DESIGN.md section 3, "boxed observable").
+int box_strata() {
+  static const int n = [] {
+    const char* e = measure_env("SXMC_BOX_STRATA");
+    return e ? std::min(std::max(std::atoi(e), 1), 16) : 4;
+  }();
+  return n;
+}
+
 // The rows of member `h`'s table sorted by their bin indices in the observables of `mask` (those no systematic
 // writes) and cut into 256-row granules, bucket by bucket.  Fetched from the table's cache or built; *out =
 // nullptr when bucketing does not pay for this table.  d_full_desc: the member's descriptor on the device.
 // `ordered` >= 0: inside every bucket the rows are in ascending order of that observable's raw value (NaN last).
 int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask, int ordered,
-                    const SampleStore::BucketSort** out) {
+                    const SampleStore::BucketSort** out, int box_truth = -1) {
   *out = nullptr;
   SampleStore& st = *h->store;
   std::lock_guard<std::mutex> lock(st.pre_mutex);
-  if (SampleStore::BucketSort* have = st.find_sort(mask, ordered)) {
+  if (SampleStore::BucketSort* have = st.find_sort(mask, ordered, box_truth)) {
     *out = have->rejected ? nullptr : have;
     return SXMC_OK;
   }
@@ -192,6 +203,7 @@ int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask
   SampleStore::BucketSort* b = st.sorts.back().get();
   b->mask = mask;
   b->ordered = ordered;
+  b->box_truth = box_truth;
   const size_t n = h->nsamples;
   if (n == 0 || n > 0x7FFFFF00ull) return SXMC_OK;
 
@@ -219,8 +231,26 @@ int get_bucket_sort(sxmc_hist* h, const SxSignalDesc* d_full_desc, unsigned mask
   if (ordered >= 0) {
     // rows by the ordered observable's value first; the stable sort by bucket below keeps that order inside a bucket
     SX_HIP(rows1.alloc(n * 4));
-    SX_HIP(sx_order_keys(st.d_cols + (size_t)ordered * h->pitch, n, keys0.as<unsigned>(),
-                         rows0.as<unsigned>(), nullptr));
+    if (box_truth >= 0) {
+      // BOXED observable: strata of x - t (their boundaries: quantiles, read off a first sort), x ascending inside
+      const float* colx = st.d_cols + (size_t)ordered * h->pitch;
+      const float* colt = st.d_cols + (size_t)box_truth * h->pitch;
+      const int nstrata = box_strata();
+      unsigned bounds[16] = {0};
+      if (nstrata > 1) {
+        SX_HIP(sx_box_keys(colx, colt, n, 1, 1, nullptr, keys0.as<unsigned>(), rows0.as<unsigned>(), nullptr));
+        SX_HIP(sx_bucket_sort(keys0.as<unsigned>(), keys1.as<unsigned>(), rows0.as<unsigned>(), rows1.as<unsigned>(), n, 32,
+                              nullptr));
+        for (int k = 0; k + 1 < nstrata; k++) {
+          SX_HIP(hipMemcpy(&bounds[k], keys1.as<unsigned>() + (size_t)((double)n * (k + 1) / nstrata), 4,
+                           hipMemcpyDeviceToHost));
+        }
+      }
+      SX_HIP(sx_box_keys(colx, colt, n, 2, nstrata, bounds, keys0.as<unsigned>(), rows0.as<unsigned>(), nullptr));
+    } else {
+      SX_HIP(sx_order_keys(st.d_cols + (size_t)ordered * h->pitch, n, keys0.as<unsigned>(),
+                           rows0.as<unsigned>(), nullptr));
+    }
     SX_HIP(sx_bucket_sort(keys0.as<unsigned>(), keys1.as<unsigned>(), rows0.as<unsigned>(), rows1.as<unsigned>(), n, 32,
                           nullptr));
     order_rows = rows1.as<unsigned>();
@@ -293,7 +323,14 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
   SX_HIP(hipMemcpy(dvalid.p, pvalid.data(), A * 4, hipMemcpyHostToDevice));
   SX_HIP(sx_bucket_gather(st.d_cols, h->pitch, (int)fields.size(), fields.data(), bs->d_rows, dsrc.as<unsigned>(),
                           dvalid.as<unsigned>(), P, b->d_cols, b->pitch, nullptr));
-  if (bs->ordered >= 0) {
+  if (bs->ordered >= 0 && bs->box_truth >= 0) {
+    // the boxed observable's column is the last of `fields`, its truth field the one before (group_rebuild)
+    SX_REQUIRE(fields.size() >= 2, "a boxed layout streams its observable and the truth field");
+    SX_HIP(hipMalloc((void**)&b->d_gbox, sizeof(float) * 4 * A));
+    SX_HIP(hipMemset(b->d_gbox, 0xFF, sizeof(float) * 4 * A));   // (NaN: a granule never written is left to the float columns)
+    SX_HIP(sx_bucket_boxes(b->d_cols + (fields.size() - 1) * b->pitch, b->d_cols + (fields.size() - 2) * b->pitch,
+                           dvalid.as<unsigned>(), P, b->d_gbox, nullptr));
+  } else if (bs->ordered >= 0) {
     // the ordered observable's column is the last of `fields` (group_rebuild)
     SX_HIP(hipMalloc((void**)&b->d_gedge, sizeof(float) * 2 * A));
     SX_HIP(hipMemset(b->d_gedge, 0, sizeof(float) * 2 * A));
@@ -330,10 +367,11 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   b->codes_tried = true;
   // (an ordered copy: every field but the ordered observable's, the last; an unordered one -- the sparse counting over
   // runs -- : every field)
-  const int nq = (int)b->fields.size() - ((b->sort && b->sort->ordered >= 0) ? 1 : 0);
+  const bool boxed = b->sort && b->sort->ordered >= 0 && b->sort->box_truth >= 0;
+  const int nq = (int)b->fields.size() - ((b->sort && b->sort->ordered >= 0) ? 1 : 0) - (boxed ? 1 : 0);
   // (below 2^22 granules a unit's byte offset into a column of codes fits 32 bits, and a unit number 28: what the
   // ordered kernel's addressing and its queue entries assume)
-  if (nq < 2 || nq > SXMC_MAX_QSLOTS || b->ngranules == 0 || b->ngranules >= ((size_t)1 << 22) || !b->sort) {
+  if ((boxed ? nq != 1 : nq < 2) || nq > SXMC_MAX_QSLOTS || b->ngranules == 0 || b->ngranules >= ((size_t)1 << 22) || !b->sort) {
     return SXMC_OK;
   }
   const unsigned long long n = (unsigned long long)b->ngranules * 256ull;
@@ -357,13 +395,17 @@ int get_bucket_codes(sxmc_hist* h, const SampleStore::Bucketed* bkc, const SxSig
   }();
   if (!(ambiguous <= 2e-3) && !gate_lifted) return SXMC_OK;
   // (the codes are an extra: a table they do not fit beside -- +4 bytes per row and pair of fields -- keeps its float stream)
-  if (hipMalloc((void**)&b->d_qcol, sizeof(unsigned) * b->pitch * (size_t)((nq + 1) / 2)) != hipSuccess) {
+  if (hipMalloc((void**)&b->d_qcol, boxed ? sizeof(unsigned short) * b->pitch
+                                          : sizeof(unsigned) * b->pitch * (size_t)((nq + 1) / 2)) != hipSuccess) {
     (void)hipGetLastError();
     b->d_qcol = nullptr;
     return SXMC_OK;
   }
   unsigned long long tally[2] = {0, 0};
-  hipError_t e = sx_column_codes(b->d_cols, b->pitch, nq, b->qbase, b->qstep, n, b->d_qcol, tally, nullptr);
+  b->q16 = boxed;
+  hipError_t e = boxed ? sx_column_codes16(b->d_cols, b->qbase[0], b->qstep[0], n, reinterpret_cast<unsigned short*>(b->d_qcol),
+                                           tally, nullptr)
+                       : sx_column_codes(b->d_cols, b->pitch, nq, b->qbase, b->qstep, n, b->d_qcol, tally, nullptr);
   if (e != hipSuccess || (double)tally[0] > 0.02 * (double)std::max<size_t>(b->nkept, 1)) {
     (void)hipFree(b->d_qcol);
     b->d_qcol = nullptr;
@@ -533,7 +575,7 @@ int group_rebuild(sxmc_group* g) {
     auto have_kernel = [&](int nobs_, int nslot_, int prew, int runs, const std::vector<unsigned>& words, int sp,
                            void** fn) {
       *fn = nullptr;
-      if (prew == 5) {   // (sp: index into the ordered programs built in: histograms in LDS, no runs)
+      if (prew == 5 || prew == 6) {   // (sp: index into the ordered / boxed programs built in: histograms in LDS, no runs)
         if (sp >= 0 && lds_hist && !runs) return true;
       } else if (runs ? sx_fill_static_supports_sparse_runs(sp) : sx_fill_static_supports(sp, lds_hist, prew)) {
         return true;
@@ -559,7 +601,8 @@ int group_rebuild(sxmc_group* g) {
     // only by monotone one-coefficient systematics, read by nothing): that one too is a per-granule constant,
     // worked out per evaluation from the granule's end values, except in the granules that straddle a bin edge.
     bool bucketed = false;
-    auto try_bucket = [&](int ordered) -> int {
+    // box_truth >= 0: `ordered` is a BOXED observable (fill_boxed_kernel) and box_truth the slot of its truth field
+    auto try_bucket = [&](int ordered, int box_truth = -1) -> int {
       unsigned touched = 0, read = 0;
       for (int q = 0; q < d.nsyst; q++) {
         touched |= 1u << d.syst[q].obs_slot;
@@ -593,18 +636,22 @@ int group_rebuild(sxmc_group* g) {
         fields.push_back(d.slot_col[ordered]);
       }
       // (beyond LDS the granule word has no room for the row count: something must be binned per sample)
-      const bool shape_ok = ordered >= 0 ? (nobs2 <= 5 && fields.size() <= 7 && (lds_hist || nobs2 >= 1))
-                                         : (mask && nobs2 >= 1 && sx_fill_has_specialization(nobs2, (int)fields.size()));
+      const bool shape_ok = box_truth >= 0 ? (nobs2 == 1 && fields.size() == 3 && lds_hist &&
+                                              fields[1] == d.slot_col[box_truth])
+                            : ordered >= 0 ? (nobs2 <= 5 && fields.size() <= 7 && (lds_hist || nobs2 >= 1))
+                                           : (mask && nobs2 >= 1 && sx_fill_has_specialization(nobs2, (int)fields.size()));
       if (!shape_ok) return SXMC_OK;
       SxSignalDesc cd;
       compact_desc(d, keep, nobs2, cd, ordered);
       const std::vector<unsigned> prog2 = prog_words(cd);
-      const int prew = ordered >= 0 ? 5 : 3;
-      const int sp = ordered >= 0 ? sx_fill_find_ordered_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data())
-                                  : sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
+      const int prew = box_truth >= 0 ? 6 : ordered >= 0 ? 5 : 3;
+      const int sp = box_truth >= 0 ? sx_fill_find_boxed_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data())
+                     : ordered >= 0 ? sx_fill_find_ordered_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data())
+                                    : sx_fill_find_static_program(cd.nobs, cd.nslot, (int)prog2.size(), prog2.data());
       if (!have_kernel(cd.nobs, cd.nslot, prew, 0, prog2, sp, &rtc_fill)) return SXMC_OK;
       const SampleStore::BucketSort* bs = nullptr;
-      int rc2 = get_bucket_sort(h, g->d_descs + i, mask, ordered, &bs);
+      int rc2 = get_bucket_sort(h, g->d_descs + i, mask, ordered, &bs,
+                                box_truth >= 0 ? d.slot_col[box_truth] : -1);
       if (rc2) return rc2;
       if (!bs) {
         rtc_fill = nullptr;
@@ -619,7 +666,7 @@ int group_rebuild(sxmc_group* g) {
       for (int k = 0; k < h->nobs; k++) {
         narrow = narrow && h->nbins[(size_t)k] < (1 << 23) && h->stride[(size_t)k] < (1 << 23);
       }
-      runs_mode = !lds_hist && narrow && h->has_points && h->d_table &&
+      runs_mode = !lds_hist && narrow && h->has_points && h->d_table && box_truth < 0 &&
                   have_kernel(cd.nobs, cd.nslot, prew, 1, prog2, sp, &rtc_sparse);
       if (!lds_hist && !narrow && h->has_points && h->d_table) {
         // (a regression on very large histograms must be visible: sxmc_group_launch_info prints this)
@@ -678,7 +725,60 @@ int group_rebuild(sxmc_group* g) {
           if ((double)h->nsamples / 256.0 < 2.0 * straddling) ordered = -1;
         }
       }
-      if (ordered >= 0) {
+      // The BOXED observable (fill_boxed_kernel): written by one-coefficient shift / scale / cos-theta scale and at least
+      // one resolution scale, all of those against ONE field that nothing writes, and read by nothing; beside it exactly one
+      // other written observable, with one-coefficient shift / scale / cos-theta scale only (one streamed field, as 16-bit
+      // codes).  Histogram in LDS, codes on.  Where the ordered form also applies this one streams half the bytes.
+      int boxed = -1, box_truth = -1;
+      if (g->cfg_box != 0 && !g->box_blocked && g->cfg_order && lds_hist && h->total_nbins < (1 << 22) && codes_enabled(g)) {
+        int nwritten = 0;
+        bool others_ok = true;
+        for (int k = 0; k < d.nobs; k++) {
+          bool written = false, ok = true, has_res = false;
+          int truth = -1;
+          for (int q = 0; q < d.nsyst; q++) {
+            const SxSystOp& op = d.syst[q];
+            if (op.obs_slot == k) {
+              written = true;
+              ok = ok && op.npars == 1;
+              if (op.type == SXMC_SYST_RESOLUTION_SCALE) {
+                has_res = true;
+                ok = ok && (truth < 0 || truth == op.extra_slot) && op.extra_slot != k;
+                truth = op.extra_slot;
+              }
+            }
+            if (op.type == SXMC_SYST_RESOLUTION_SCALE && op.extra_slot == k) ok = false;   // (read by a systematic)
+          }
+          if (!written) continue;
+          nwritten++;
+          if (has_res && ok && boxed < 0) {
+            boxed = k;
+            box_truth = truth;
+          } else {
+            others_ok = others_ok && ok && !has_res;
+          }
+        }
+        bool truth_written = false;
+        for (int q = 0; q < d.nsyst && box_truth >= 0; q++) truth_written = truth_written || d.syst[q].obs_slot == box_truth;
+        if (boxed < 0 || nwritten != 2 || !others_ok || truth_written || d.nsyst > 8) boxed = -1;
+        // Does it pay?  A box straddles an edge of the observable when it is not small against a bin: with fewer than a
+        // few granules per bin, stratum and bucket most do.  cfg_box == 1 (tests): wherever it applies.
+        if (boxed >= 0 && g->cfg_box < 0) {
+          double buckets = 1.0;
+          for (int k = 0; k < d.nobs; k++) {
+            bool written = false;
+            for (int q = 0; q < d.nsyst; q++) written = written || d.syst[q].obs_slot == k;
+            if (!written) buckets *= (double)h->nbins[(size_t)k];
+          }
+          const double per = (double)h->nsamples / 256.0 / (buckets * box_strata());
+          if (per < 4.0 * ((double)h->nbins[(size_t)boxed] + 1.0)) boxed = -1;
+        }
+      }
+      if (boxed >= 0) {
+        rc = try_bucket(boxed, box_truth);
+        if (rc) return rc;
+      }
+      if (!bucketed && ordered >= 0) {
         rc = try_bucket(ordered);
         if (rc) return rc;
         if (bucketed && !lds_hist && !runs_mode) {   // (no kernel for the runs: the unordered layout has the filter path)
@@ -786,8 +886,9 @@ int group_rebuild(sxmc_group* g) {
   if (n) SX_HIP(hipMemcpy(g->d_descs_sparse, sparse_descs.data(), sizeof(SxSignalDesc) * n, hipMemcpyHostToDevice));
 
   for (LaunchClass& c : g->classes) {
-    const bool bucketed = c.shape.pre_width == 3 || c.shape.pre_width == 5;
-    const bool ordered = c.shape.pre_width == 5;
+    const bool boxed = c.shape.pre_width == 6;
+    const bool bucketed = c.shape.pre_width == 3 || c.shape.pre_width == 5 || boxed;
+    const bool ordered = c.shape.pre_width == 5 || boxed;   // (the LDS layout, shapes and partition of the ordered form)
     // ---- threads per workgroup, LDS
     int cls_max_bins = 0, cls_nsyst = 0;
     for (int idx : c.member_idx) {
@@ -874,6 +975,7 @@ int group_rebuild(sxmc_group* g) {
         d.nvec = bk->ngranules * 64;
         d.pre = bk->d_gpre;
         d.edges = bk->d_gedge;
+        d.boxes = bk->d_gbox;
         g->member_bucket[(size_t)idx] = bk;
         // CODES: ordered table, histogram in LDS, 2 to 4 streamed fields, every systematic on them affine (one
         // coefficient) -- the conditions fill_ordered_body's kCodes states at compile time
@@ -882,7 +984,7 @@ int group_rebuild(sxmc_group* g) {
         // observable a code step is 1/220 of a bin, 0.8 % of the samples are ambiguous and 87 % of the 256-sample
         // units hold one; the fix-up then runs almost everywhere.  Codes pay where bins are coarse against 2^-16 of
         // the window: not offered there.)
-        bool affine = ordered && c.shape.lds_hist && c.shape.nobs >= 1 && c.shape.nslot - 1 >= 2 &&
+        bool affine = ordered && c.shape.lds_hist && c.shape.nobs >= 1 && (boxed || c.shape.nslot - 1 >= 2) &&
                       c.shape.nslot - 1 <= SXMC_MAX_QSLOTS && !c.runs_mode && codes_enabled(g);
         for (unsigned w : c.prog) affine = affine && ((int)((w >> 4) & 15u) == c.shape.nslot - 1 || ((w >> 12) & 15u) == 0u);
         if (affine) {
@@ -896,6 +998,11 @@ int group_rebuild(sxmc_group* g) {
             }
             c.codes = true;
           }
+        }
+        if (boxed && !d.qcol) {   // (no table of codes -- too many ambiguous rows, rows outside the window, no memory: the
+                                  //  boxed form has no float stream of its own.  Planned again without it.)
+          g->box_blocked = true;
+          return group_rebuild(g);
         }
       }
       d.vec_start = prefix;
@@ -963,8 +1070,12 @@ int group_rebuild(sxmc_group* g) {
           bool all = true;
           for (size_t q = 0; q < c.member_idx.size(); q++) {
             const sxmc_hist* h = g->members[(size_t)c.member_idx[q]];
-            const long long S = descs[q].bin_stride[0], nb = descs[q].nbins[0];   // (slot 0 of the compacted problem)
+            const long long nb = descs[q].nbins[0];   // (slot 0 of the compacted problem)
+            // (ordered form: the observable binned per sample must be the histogram's outermost dimension; the boxed
+            // form makes it the outermost dimension of the LDS copy wherever it sits)
+            const long long S = boxed ? (nb >= 1 ? (long long)h->total_nbins / nb : 0) : descs[q].bin_stride[0];
             all = all && S >= 1 && nb >= 1 && S * nb == (long long)h->total_nbins && S * (nb + 2) < (1ll << 22);
+            if (boxed) all = all && descs[q].bin_stride[0] >= 1 && (long long)h->total_nbins % ((long long)descs[q].bin_stride[0] * nb) == 0;
             if (all) rs = std::max(rs, ordered_rstride_padded(h->total_nbins, (int)nb));
           }
           if (all && rs) {
@@ -982,6 +1093,15 @@ int group_rebuild(sxmc_group* g) {
         c.shape.lds_layout |= qlog << 28;
         c.shape.lds_bytes += ordered_queue_bytes(qlog);
         if (!qlog) c.codes = false;   // (no room for queues: the kernel streams the float columns)
+        if (boxed && (!qlog || !c.padded_rstride)) {   // (the boxed form exists only in the padded form with queues)
+          for (LaunchClass& cc : g->classes) free_class(cc);   // (what this pass has allocated so far)
+          g->box_blocked = true;
+          return group_rebuild(g);
+        }
+      } else if (boxed) {
+        for (LaunchClass& cc : g->classes) free_class(cc);
+        g->box_blocked = true;
+        return group_rebuild(g);
       }
     }
     unsigned long long grid = (unsigned long long)props.cus * bpc;
@@ -1070,6 +1190,7 @@ int group_rebuild(sxmc_group* g) {
   g->cfg_seen_prebin = g->cfg_prebin;
   g->cfg_seen_bucket = g->cfg_bucket;
   g->cfg_seen_order = g->cfg_order;
+  g->cfg_seen_box = g->cfg_box;
   g->cfg_seen_rtc = g->cfg_rtc;
   g->cfg_seen_codes = g->cfg_codes;
   g->cfg_seen_queue_log = g->cfg_queue_log;
@@ -1110,7 +1231,7 @@ int group_refresh(sxmc_group* g) {
                g->cfg_seen_partition != g->cfg_partition || g->cfg_seen_teams != g->cfg_teams ||
                g->cfg_seen_prebin != g->cfg_prebin ||
                g->cfg_seen_bucket != g->cfg_bucket || g->cfg_seen_rtc != g->cfg_rtc ||
-               g->cfg_seen_order != g->cfg_order || g->cfg_seen_codes != g->cfg_codes ||
+               g->cfg_seen_order != g->cfg_order || g->cfg_seen_codes != g->cfg_codes || g->cfg_seen_box != g->cfg_box ||
                g->cfg_seen_queue_log != g->cfg_queue_log || g->cfg_seen_fused != g->cfg_fused;
   bool points = false;
   for (size_t i = 0; !stale && i < g->members.size(); i++) {

@@ -132,6 +132,7 @@ int sxmc_multigroup_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, const sxmc
                    a.d_v_proposed && a.d_accepted && a.d_counter && a.d_jump_buffer && a.d_jump_width &&
                    a.d_nexpected && a.d_n_mc && a.d_source_id && a.d_norms && a.nparameters > 0,
                "null argument");
+    g->cfg_box = 0;   // (several chains per pass: the ordered form; the boxed one has no such kernel)
     int rc = group_refresh(g);
     if (rc) return rc;
     if (!replan && mg->seen[c] != g->plan_generation) replan = true;
@@ -265,6 +266,7 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
   bool replan = mg->seen.size() != 2;
   for (size_t c = 0; c < 2; c++) {
     sxmc_group* g = mg->groups[c];
+    g->cfg_box = 0;   // (several chains per pass: the ordered form; the boxed one has no such kernel)
     int rc = group_refresh(g);
     if (rc) return rc;
     if (!replan && mg->seen[c] != g->plan_generation) replan = true;
@@ -371,6 +373,7 @@ int sxmc_multigroup_lookahead_step_async(sxmc_multigroup_t mg, sxmc_stream_t s, 
 int sxmc_group_lookahead_supported(sxmc_group_t g, int* ok) {
   SX_REQUIRE(g && ok, "null argument");
   *ok = 0;
+  g->cfg_box = 0;   // (the look-ahead pass runs over the ordered form: the question is asked of that plan)
   int rc = group_refresh(g);
   if (rc) return rc;
   if (!g->same_points || g->cfg_lut || (g->sparse_ready && g->cfg_sparse) || g->members.empty()) return SXMC_OK;

@@ -35,6 +35,13 @@ std::string kernel_source(const SxRtcSpec& k) {
   for (int i = 0; i < k.nops; i++) prog += (i ? ", " : "") + std::to_string(k.ops[i]) + "u";
   prog += ">";
   std::string s = "#include \"fill_kernels.inc.h\"\nusing namespace sxfill;\n";
+  if (k.pre_width == 6) {   // bucketed table with a boxed observable (fill_boxed_body)
+    s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(const SxSignalDesc* __restrict__ descs, "
+         "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";
+    s += "  fill_boxed_body<" + std::to_string(k.nobs) + ", " + std::to_string(k.nslot) + ", " + prog +
+         ">(descs, segs, blk_off, w, dbg);\n}\n";
+    return s;
+  }
   if (k.pre_width == 5 && k.sparse_runs) {   // ... its sparse counting over runs
     s += "extern \"C\" __global__ __launch_bounds__(1024) void sx_rtc_fill(const SxSignalDesc* __restrict__ descs, "
          "const SxSegment* __restrict__ segs, const unsigned* __restrict__ blk_off, unsigned w, unsigned dbg) {\n";

@@ -107,6 +107,12 @@ class EvalGroup:
         has enough granules per bin edge to pay; force: wherever it applies)."""
         capi.call("sxmc_group_set_ordering", self._g, 2 if (enable and force) else int(bool(enable)))
 
+    def SetBoxes(self, enable):
+        """Group each bucket's rows into small boxes of a resolution-scaled observable and its truth field: the observable
+        is then one constant per 256-sample granule wherever the box's image lands in one bin (None: where it pays, the
+        default; True: wherever it applies; False: never).  See include/sxmc_hip.h."""
+        capi.call("sxmc_group_set_boxes", self._g, -1 if enable is None else int(bool(enable)))
+
     def SetCodes(self, enable):
         """Stream an ordered table's fields as 16-bit codes with an exact recheck of the samples near a bin edge
         (default on where it applies; None: the library's default).  See include/sxmc_hip.h."""

@@ -141,6 +141,7 @@ def one_parameter_set(rng, params, nbackground, scales=True):
         ev.SetParameterBuffer(pbuf)
         group = nll.EvalGroup([ev])
         group.SetOrdering(True, force=True)
+        group.SetBoxes(False)     # (the two-field codes of the ordered form: where the bound's S term is largest)
         group.SetCodes(True)
         assert "ordered+codes" in group.LaunchInfo(), group.LaunchInfo()
         return ev, group, norm, pbuf

@@ -70,6 +70,7 @@ def test_codes_give_identical_histograms(name, nobs, nbins, systs, param_sets, n
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, nobs, nbins, systs, param_sets[0], nfields=nfields)
     group = nll.EvalGroup(evs)
     group.SetOrdering(True, force=True)
+    group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     group.SetCodes(True)
     assert "ordered+codes" in group.LaunchInfo(), group.LaunchInfo()
     members, rows, exact_rows, never_rows = group.CodesInfo()
@@ -120,6 +121,7 @@ def test_codes_samples_on_the_transformed_bin_edges():
     ev.SetParameterBuffer(pbuf)
     group = nll.EvalGroup([ev])
     group.SetOrdering(True, force=True)
+    group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     assert "ordered+codes" in group.LaunchInfo()
     for pv in ([0.0, p1, p2], [0.0, np.nextafter(p1, 1.0), p2], [0.0, p1, np.nextafter(p2, -1.0)], [0.0, 0.0, 0.0],
                [0.01, -p1, -p2]):
@@ -157,6 +159,7 @@ def test_codes_rows_outside_the_windows_and_values_that_are_not_finite():
     ev.SetParameterBuffer(pbuf)
     group = nll.EvalGroup([ev])
     group.SetOrdering(True, force=True)
+    group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     assert "ordered+codes" in group.LaunchInfo()
     members, rows, exact_rows, never_rows = group.CodesInfo()
     assert members == 1 and exact_rows > 0.002 * n and never_rows > 0.002 * n
@@ -186,6 +189,7 @@ def test_codes_with_large_and_wild_parameters():
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, nbins, C3, [0.0, 0.0, 0.0], nfields=5)
     group = nll.EvalGroup(evs)
     group.SetOrdering(True, force=True)
+    group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     assert "ordered+codes" in group.LaunchInfo()
     for params in ([0.0, 30.0, 0.0], [0.0, 0.0, 40.0], [0.0, -25.0, 12.0], [0.0, 150.0, 0.0], [0.0, 1e4, -1e4],
                    [0.0, 1e300, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [0.0, np.nan, 0.0], [0.0, 0.0, np.inf],
@@ -214,6 +218,7 @@ def test_codes_queue_overflow(queue_log):
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, nbins, C3, [0.0, 0.0, 0.0], nfields=5)
     group = nll.EvalGroup(evs)
     group.SetOrdering(True, force=True)
+    group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     group.SetCodesQueueLog(queue_log)
     assert "ordered+codes" in group.LaunchInfo()
     for params in ([0.0, 30.0, 0.0], [0.02, -0.01, 0.07], [0.0, -20.0, 15.0]):
@@ -235,6 +240,7 @@ def test_codes_lookup_and_tables_shared_between_groups():
     evs, tabs, lut, norms, pbuf = build_group(rng, sizes, 3, [20, 20, 20], C3, params, nfields=5, points=pts)
     group = nll.EvalGroup(evs)
     group.SetOrdering(True, force=True)
+    group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     assert "ordered+codes" in group.LaunchInfo()
     group.EvalAsync(True)
     group.EvalFinished()
@@ -250,6 +256,7 @@ def test_codes_lookup_and_tables_shared_between_groups():
         s.SetParameterBuffer(pbuf2, 0, 1)
     g2 = nll.EvalGroup(shared)
     g2.SetOrdering(True, force=True)
+    g2.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     assert "ordered+codes" in g2.LaunchInfo()
     g2.EvalAsync(False)
     g2.EvalFinished()
@@ -288,6 +295,7 @@ def test_codes_degenerate_columns():
         ev.SetParameterBuffer(pbuf)
         group = nll.EvalGroup([ev])
         group.SetOrdering(True, force=True)
+        group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
         for pv in ([0.0, 0.0, 0.0], [0.03, -0.02, 0.1], [-0.2, 0.4, -0.6], [0.0, 0.0, 1e-4]):
             pbuf.set(np.array(pv))
             bins, nrm = oracle.bin_samples(geom, tab, 5, C3, np.array(pv))
@@ -328,6 +336,7 @@ def test_codes_with_windows_far_from_zero(offset):
     ev.SetParameterBuffer(pbuf)
     group = nll.EvalGroup([ev])
     group.SetOrdering(True, force=True)
+    group.SetBoxes(False)      # (the ordered form: the boxed one has tests/test_gpu_boxed.py)
     group.SetCodes(True)
     assert "ordered+codes" in group.LaunchInfo(), group.LaunchInfo()
     base, step = group.CodesWindows(0)

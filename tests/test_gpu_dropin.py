@@ -330,7 +330,7 @@ def test_optimize_flag_of_the_evaluators_decides_the_batchs_trial_launches():
         assert (trials > 0) == flag, info
         if not flag:
             # the analytic default over codes: two workgroups of 512 lanes per CU (group_rebuild)
-            assert "threads=512" in info and "ordered+codes" in info, info
+            assert "threads=512" in info and "+codes" in info, info
             # Optimize() by hand: the trials run at the next lookup evaluation
             capi.call("sxmc_hist_optimize", pdfs[0].handle)
             for p in pdfs:

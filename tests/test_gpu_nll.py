@@ -272,15 +272,18 @@ def test_free_chain_runs_and_accepts_some():
 
 
 @pytest.mark.parametrize("make,scale,plan", [(workloads.config2, 1.0, "table=prebinned"),
-                                             (workloads.config3, 1.0, "table=ordered")])
+                                             (workloads.config3, 1.0, "table=boxed+codes"),
+                                             (workloads.config3, 1.0, "table=ordered+codes")])
 def test_baseline_configs_at_size_against_the_oracle(make, scale, plan):
     """BASELINE config 2 (10^7 samples) and config 3 (10^8 samples, 12 signals, shift + scale + resolution_scale), both
-    at their FULL size and through the kernels the bench measures (config 3: the bucketed table with the shifted
-    observable ordered, fill_ordered_kernel -- the headline kernel at the headline size): one whole MCMC step in the
+    at their FULL size and through the kernels the bench measures (config 3: the bucketed table with the energy
+    observable boxed and the radius streamed as codes, fill_boxed_kernel -- the headline kernel at the headline size): one whole MCMC step in the
     walk's default form (event classes, graph-recorded launches) against the oracle -- every bin, the norms, the
     lookup table bits and the NLL."""
     w = make(scale, nevents=100000)
     m = MCMC(w, seed=31, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
+    if plan == "table=ordered+codes":            # (rounds 4-5's headline kernel, fill_ordered_kernel over two-field codes)
+        m.group.SetBoxes(False)
     m.setup(sync_interval=8)
     capi.synchronize()                           # (the first proposal is drawn on the chain's non-blocking stream)
     assert plan in m.group.LaunchInfo(), m.group.LaunchInfo()
