@@ -442,7 +442,7 @@ class Leg:
                 t = json.load(f).get(w.name + ("_no_prebin" if args.no_prebin else "") + ("_no_bucket" if args.no_bucket else "") +
                                        ("_no_order" if args.no_order and not args.no_bucket else "") +
                                        ("_no_codes" if args.no_codes and not (args.no_order or args.no_bucket) else "") +
-                                       ("_no_boxes" if args.no_boxes and not (args.no_codes or args.no_order or args.no_bucket) else "") +
+                                       ("_boxed" if "boxed+codes(now)" in m.group.LaunchInfo() or "table=boxed+codes " in m.group.LaunchInfo() else "") +
                                        ("_lookahead" if self.la is not None else ""))
             if args.extra_ctscale or args.no_sparse:
                 t = None
@@ -459,6 +459,9 @@ class Leg:
         except (OSError, ValueError):
             pass
         info = m.group.LaunchInfo()
+        # (a plan with two forms names the one its launches take now: "boxed+codes(now)|ordered+codes")
+        info = info.replace("boxed+codes|ordered+codes(now)", "ordered+codes").replace("boxed+codes(now)|ordered+codes",
+                                                                                      "boxed+codes")
         kname = ("fill_boxed_kernel" if "table=boxed" in info else
                  "fill_ordered_kernel" if "table=ordered" in info and "+runs" not in info
                  else "fill_sparse_kernel" if "+runs" in info and not args.no_sparse else "fill_kernel")

@@ -339,9 +339,29 @@ int sxmc_group_set_codes(sxmc_group_t g, int enable);
  * one field): BASELINE config 3 streams 2 bytes per sample instead of 4.  Any value or coefficient that is not finite
  * sends its granule (or the whole evaluation) to the float columns.  Histograms, norms and NLL stay bit-identical
  * (tests/test_gpu_boxed.py: against the ordered form, the float stream and the CPU restatement).  enable = -1 (default):
- * where it pays (at least four granules per bin of the boxed observable, stratum and bucket); 1: wherever it applies
- * (tests); 0: never (the ordered / bucketed forms).  Lockstep sets and the look-ahead pass use the ordered form. */
+ * where it pays (at least four granules per bin of the boxed observable, stratum and bucket), TOGETHER WITH the ordered plan
+ * (below); 1: wherever it applies, the boxed plan alone (tests); 0: never (the ordered / bucketed forms).  Lockstep sets
+ * and the look-ahead pass use the ordered form. */
 int sxmc_group_set_boxes(sxmc_group_t g, int enable);
+/* With enable = -1 the boxed plan comes with an ORDERED TWIN.  How many boxes straddle an edge depends on the parameters of
+ * the evaluation (the image of a box is |dx'/dx| dx + |dx'/dt| dt wide: it grows with the resolution parameter): at BASELINE
+ * config 3 the boxed fill takes 62 us at a resolution parameter of 0, 73 at 0.05, 123 at 0.2, the ordered one 81 whatever
+ * the parameters (profiles/r05_boxed_crossover.log).  Both plans stay resident -- the boxed tables with their partition
+ * and launch shape, the ordered ones with theirs -- and every fill launches ONE of them: the ordered one until told
+ * otherwise, so a caller that never asks runs the ordered form.
+ *   sxmc_group_adapt_fill_form: waits for the group's stream, reads the parameters the evaluators are bound to back from
+ *   the device, runs the reference's operations on the corners of a box of the tables' mean extents and takes the boxed
+ *   form while its image is narrower than the limit (sxmc_group_set_box_limit, bins of the boxed observable; default
+ *   0.12; back to boxed below 0.8 of it), the ordered form beyond.  *form: 1 boxed, 2 ordered, 0 the plan has one form
+ *   only; *changed: it differs from the form of the launches so far -- recorded graphs of the group's steps keep
+ *   replaying the OLD form (both stay valid) until they are recorded again.  The walks of this repository
+ *   (sxmc::MCMC, sxmc_amd/mcmc.py) ask at set-up and after every flush of their jump buffer.  Not while a graph is being
+ *   recorded.  Results do not depend on the form.
+ *   sxmc_group_set_fill_form: 1 or 2 by hand (tests, measurements); sxmc_group_fill_form: the current one. */
+int sxmc_group_set_box_limit(sxmc_group_t g, double bins);
+int sxmc_group_adapt_fill_form(sxmc_group_t g, int* form, int* changed);
+int sxmc_group_set_fill_form(sxmc_group_t g, int form);
+int sxmc_group_fill_form(sxmc_group_t g, int* form);
 /* What the codes of the group's current plan amount to: members whose fill streams codes, rows they hold, rows marked
  * "ask the exact columns" (outside a window) and rows marked "never counted" (not finite, or granule padding). */
 int sxmc_group_codes_info(sxmc_group_t g, int* members, unsigned long long* rows, unsigned long long* exact_rows,

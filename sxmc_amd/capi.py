@@ -117,6 +117,10 @@ SIGNATURES = {
     "sxmc_group_set_ordering": [_vp, _i],
     "sxmc_group_set_codes": [_vp, _i],
     "sxmc_group_set_boxes": [_vp, _i],
+    "sxmc_group_set_box_limit": [_vp, C.c_double],
+    "sxmc_group_adapt_fill_form": [_vp, _pi, _pi],
+    "sxmc_group_set_fill_form": [_vp, _i],
+    "sxmc_group_fill_form": [_vp, _pi],
     "sxmc_group_codes_info": [_vp, _pi, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)],
     "sxmc_group_codes_windows": [_vp, _i, _pi, _pd, _pd],
     "sxmc_group_set_codes_queue_log": [_vp, _i],

@@ -2269,6 +2269,14 @@ constexpr bool prog_is_boxable(StaticProg<OPS...>) {
 #ifndef SXMC_BOX_DRAIN
 #define SXMC_BOX_DRAIN 2
 #endif
+#ifndef SXMC_BOX_GQ
+#define SXMC_BOX_GQ 0        // (A/B builds: granules a wave queues before it empties its queues in mid-stream; 0: what fits)
+#endif
+#ifndef SXMC_BOX_PREFETCH
+#define SXMC_BOX_PREFETCH 0  // 1: the next block's boxes and words are loaded while the current block is worked on (measured,
+                             // one box, alternating: 65.2-66.8 us with, 64.6-65.3 without -- the compiler moves the
+                             // prefetched word to another register at once and waits for everything to do so)
+#endif
 template <int NOBS, int NSLOT, typename PROG>
 __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__ descs, const SxSegment* __restrict__ segs,
                                                 const unsigned* __restrict__ blk_off, unsigned layout, unsigned dbg_arg) {
@@ -2297,6 +2305,7 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
   // (half of a wave's slice for whole granules: at config 3 a few per cent of ~100 granules per wave)
   const unsigned gq_min = (unsigned)kRing + 1u;
   const unsigned gq_cap = qwave / 2u > gq_min ? qwave / 2u : gq_min, rq_cap = qwave > gq_cap ? qwave - gq_cap : 0u;
+  const unsigned gq_drain = (SXMC_BOX_GQ > 0 && (unsigned)SXMC_BOX_GQ + (unsigned)kRing < gq_cap) ? (unsigned)SXMC_BOX_GQ + (unsigned)kRing : gq_cap;
   unsigned* qrows = lds + 4 + cstride + 64 + 4 + (tid / kWave) * (2u * qwave);
   unsigned* qgran = qrows + 2u * rq_cap;
 
@@ -2393,12 +2402,22 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
     //          of (idx = -1, bin 0 of the granule's row part) inside a replica's padded copy;  greal: the granule's
     //          offset in the real histogram (what the ambiguous rows' queue entries carry)
     unsigned gword = kOrdSkip, greal = 0u;
+    vfloat4 bx_next;
+    unsigned pre_next;
+    auto meta_load = [&](unsigned it) {
+      unsigned vg = vwave32 + (it + lane) * step32;
+      vg = vg <= vlast32 ? vg : vlast32;
+      bx_next = boxes[vg >> 6];
+      pre_next = precol[vg >> 6];
+    };
     auto granule_meta = [&](unsigned it) {
       unsigned vg = vwave32 + (it + lane) * step32;
       const bool live = vg <= vlast32;
       vg = live ? vg : vlast32;
-      const vfloat4 bx = boxes[vg >> 6];
-      const unsigned pre = precol[vg >> 6];
+      if constexpr (!SXMC_BOX_PREFETCH) meta_load(it);
+      const vfloat4 bx = bx_next;
+      const unsigned pre = pre_next;
+      if constexpr (SXMC_BOX_PREFETCH) meta_load(it + 64u);   // (the next block's: in flight behind the ring's loads)
       double xl = (double)bx.x, xh = (double)bx.y;
       const double tl = (double)bx.z, th = (double)bx.w;
       bool fin = (__builtin_fabs(xl) < __builtin_inf()) && (__builtin_fabs(xh) < __builtin_inf()) &&
@@ -2448,7 +2467,7 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
 
     // ---- one unit of codes: four samples of the streamed observable (coarse_outer of fill_ordered_body with one field)
     const int oS4 = (int)(4u * oSp);
-    const int oclamp = (int)nbk;
+    const int oclamp = (dbg & 4u) ? -1 : (int)nbk;   // (measurement hook: everything to the guard row)
     auto coarse_unit = [&](const vuint2g& w, unsigned it, unsigned v, unsigned word0) {
       int base4 = (int)(4u * (4u + myrep + word0) + 4u * oSp);      // byte address of (idx = -1 ... + 1 row = idx 0)
       asm volatile("" : "+v"(base4));
@@ -2489,6 +2508,10 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
           return;
         }
       }
+      if (dbg & 32u) {                                     // (measurement hook: no LDS additions at all)
+        vcnt += (unsigned)(addr[0] ^ addr[1] ^ addr[2] ^ addr[3]) == 12345u ? 1u : 0u;
+        return;
+      }
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
         unsigned* wp = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + addr[q]);
@@ -2504,6 +2527,7 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
       }
     };
     auto drain = [&]() {
+      if (dbg & 16u) nrow = ngran = 0u;                  // (measurement hook: what the queues hold is dropped)
       vfloat4 rawf[kDrain][NSLOT];
       unsigned prew[kDrain];
       auto load_granule = [&](int s, unsigned g) {
@@ -2588,6 +2612,7 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
     const unsigned climit = oS;              // a granule word below this: binned from codes
     {
       unsigned it = 0u;
+      if constexpr (SXMC_BOX_PREFETCH) meta_load(0u);
 #pragma unroll
       for (int i = 0; i < kRing; i++) issue(i, (unsigned)i);
       while (it < niter32) {
@@ -2602,13 +2627,15 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
             const unsigned iu = it + (unsigned)i;
             if (iu < block_end) {
               const unsigned word0 = (unsigned)__builtin_amdgcn_readlane((int)gword, (int)(iu & 63u));
-              if (word0 < climit) coarse_unit(rq[i], iu, vfirst32 + iu * step32, word0);
+              if (dbg & 1u) {                                  // (measurement hook: the stream alone)
+                vcnt += (rq[i].x == 12345u && word0 == 77u) ? 1u : 0u;
+              } else if (word0 < climit) coarse_unit(rq[i], iu, vfirst32 + iu * step32, word0);
               else if (word0 == kOrdMixed) push_granule(iu);
             }
             issue(i, iu + (unsigned)kRing);   // (unconditional: the waits above count on it)
           }
           it = block_end - it < (unsigned)kRing ? block_end : it + (unsigned)kRing;
-          full = ngran + (unsigned)kRing > gq_cap;
+          full = ngran + (unsigned)kRing > gq_drain;
         }
 #ifndef SXEXP_NOMID
         if (full) {
@@ -2669,7 +2696,6 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
     __syncthreads();
     lds_clean = true;
   }
-  (void)dbg;
 }
 
 template <int NOBS, int NSLOT, bool LDS_HIST, typename PROG, int PREW>
@@ -2701,6 +2727,13 @@ __global__ __launch_bounds__(SXMC_ORDERED_BOUND) void fill_ordered_kernel(const 
   fill_ordered_body<NOBS, NSLOT, PROG, 1, LDS_HIST>(one, segs, blk_off, layout, dbg);
 }
 
+// BOXED OR ORDERED.  The boxed form is fast while few granules' boxes straddle an edge -- config 3, one box: 59 us + 2.5 us
+// per per cent of such granules, against 81 us for the ordered form whatever the parameters -- and that share grows with
+// the resolution parameter (the box's image is |dx'/dx| dx + |dx'/dt| dt wide).  A plan with boxed tables therefore keeps
+// the ordered plan beside it, and the HOST picks the form between flushes of a walk from the parameters it reads back
+// (sxmc_group_adapt_fill_form).  Choosing on the device was built in three forms and measured (profiles/
+// r05_boxed_dual_ab.log, r05_boxed_gated_pair.log): both bodies inlined in one kernel -- the ordered one spills, 95 us for
+// 81; as functions of one kernel -- 116 and 87; as two launches of which one ends at once -- 85 and 70.
 template <int NOBS, int NSLOT, typename PROG>
 __global__ __launch_bounds__(SXMC_ORDERED_BOUND) void fill_boxed_kernel(const SxSignalDesc* __restrict__ descs,
                                                           const SxSegment* __restrict__ segs,

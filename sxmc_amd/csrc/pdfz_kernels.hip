@@ -1179,7 +1179,6 @@ const OrderedEntry kBoxedPrograms[] = {
     SX_B3(1, 3, SX_SHIFT(0), SX_SCALE(2), SX_RES(2, 1)),
 };
 constexpr int kNumBoxed = (int)(sizeof(kBoxedPrograms) / sizeof(kBoxedPrograms[0]));
-
 template <int NOBS, int NSLOT>
 hipError_t launch_fill_dyn(const SxLaunchShape& sh, const SxSignalDesc* descs, const SxSegment* segs,
                            const unsigned* blk_off, hipStream_t s) {

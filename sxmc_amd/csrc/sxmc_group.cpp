@@ -41,6 +41,13 @@ int sxmc_group_destroy(sxmc_group_t g) {
   (void)hipDeviceSynchronize();
   if (g->coop_fits >= 0) g_stepping_groups.fetch_sub(1, std::memory_order_acq_rel);
   for (LaunchClass& c : g->classes) free_class(c);
+  if (g->twin) {   // (the ordered twin of a boxed plan: planned, never launched by itself)
+    for (LaunchClass& c : g->twin->classes) free_class(c);
+    if (g->twin->d_descs) (void)hipFree(g->twin->d_descs);
+    if (g->twin->d_descs_sparse) (void)hipFree(g->twin->d_descs_sparse);
+    delete g->twin;
+    g->twin = nullptr;
+  }
   if (g->d_descs) (void)hipFree(g->d_descs);
   if (g->d_descs_sparse) (void)hipFree(g->d_descs_sparse);
   if (g->d_ticket) (void)hipFree(g->d_ticket);
@@ -207,6 +214,93 @@ int sxmc_group_set_boxes(sxmc_group_t g, int enable) {
   return SXMC_OK;
 }
 
+int sxmc_group_set_box_limit(sxmc_group_t g, double bins) {
+  SX_REQUIRE(g && bins >= 0.0, "bad arguments");
+  g->box_limit = (float)bins;
+  return SXMC_OK;
+}
+
+int sxmc_group_set_fill_form(sxmc_group_t g, int form) {
+  SX_REQUIRE(g && (form == 1 || form == 2), "form: 1 boxed, 2 ordered");
+  SX_FLUSH();
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  SX_REQUIRE(g->twin && !g->twin->classes.empty() && g->cfg_box < 0, "the group's plan has one form only");
+  g->fill_form = form;
+  return SXMC_OK;
+}
+
+// The image of a box of the boxed tables' mean extents under the members' program at the parameters the evaluators read
+// NOW (copied back from the device): the reference's operations on the box's corners (fill_boxed_body's interval form), in
+// bins of the boxed observable.  What share of the granules straddles an edge is about that width.
+static int box_image_width(sxmc_group* g, double* width) {
+  *width = HUGE_VAL;
+  const LaunchClass* cls = nullptr;
+  for (const LaunchClass& c : g->classes) cls = (c.dual && !cls) ? &c : cls;
+  if (!cls || cls->member_idx.empty() || cls->box_obs < 0) return SXMC_OK;
+  const sxmc_hist* h = g->members[(size_t)cls->member_idx[0]];
+  const SxSignalDesc& d = g->h_descs[(size_t)cls->member_idx[0]];
+  if (!d.params) return SXMC_OK;
+  double xl = 0.5 * (d.lower[cls->box_obs] + d.upper[cls->box_obs]), xh = xl + (double)cls->box_dx;
+  const double tl = xl, th = xl + (double)cls->box_dt;
+  bool fin = true;
+  for (int q = 0; q < d.nsyst && fin; q++) {
+    const SxSystOp& op = d.syst[q];
+    if (op.obs_slot != cls->box_obs) continue;
+    double c0 = 0;
+    SX_HIP(hipMemcpy(&c0, d.params + (long)op.pars[0] * d.param_stride, sizeof c0, hipMemcpyDeviceToHost));
+    const double pc = 0.0 + c0 * 1.0;
+    if (op.type == SXMC_SYST_SHIFT) {
+      xl = xl + pc;
+      xh = xh + pc;
+    } else if (op.type == SXMC_SYST_SCALE || op.type == SXMC_SYST_CTSCALE) {
+      const double s = 1 + pc;
+      const double a = op.type == SXMC_SYST_SCALE ? xl * s : 1 + (xl - 1) * s;
+      const double b = op.type == SXMC_SYST_SCALE ? xh * s : 1 + (xh - 1) * s;
+      xl = s >= 0.0 ? a : b;
+      xh = s >= 0.0 ? b : a;
+    } else if (op.type == SXMC_SYST_RESOLUTION_SCALE) {
+      const double dl = xl - th, dh = xh - tl, a = pc * dl, b = pc * dh;
+      xl = xl + (pc >= 0.0 ? a : b);
+      xh = xh + (pc >= 0.0 ? b : a);
+    }
+    fin = std::isfinite(xl) && std::isfinite(xh);
+  }
+  (void)h;
+  if (fin) *width = (xh - xl) * d.scale[cls->box_obs];
+  return SXMC_OK;
+}
+
+int sxmc_group_adapt_fill_form(sxmc_group_t g, int* form, int* changed) {
+  SX_REQUIRE(g, "null group");
+  SX_FLUSH();
+  if (form) *form = 0;
+  if (changed) *changed = 0;
+  if (t_capturing) return fail(SXMC_ERR_STATE, "the form of the fill is not chosen while a graph is being recorded");
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  if (!(g->twin && !g->twin->classes.empty() && g->cfg_box < 0)) return SXMC_OK;   // (one form only)
+  SX_HIP(hipStreamSynchronize(g->last_stream));
+  double width = HUGE_VAL;
+  rc = box_image_width(g, &width);
+  if (rc) return rc;
+  // (a band between the two decisions: a walk that sits at the limit does not re-record its steps at every flush)
+  const int want = width < 0.8 * (double)g->box_limit ? 1 : (width < (double)g->box_limit ? g->fill_form : 2);
+  if (changed) *changed = want != g->fill_form ? 1 : 0;
+  g->fill_form = want;
+  if (form) *form = want;
+  return SXMC_OK;
+}
+
+int sxmc_group_fill_form(sxmc_group_t g, int* form) {
+  SX_REQUIRE(g && form, "null argument");
+  SX_FLUSH();
+  int rc = group_refresh(g);
+  if (rc) return rc;
+  *form = (g->twin && !g->twin->classes.empty() && g->cfg_box < 0) ? g->fill_form : 0;
+  return SXMC_OK;
+}
+
 int sxmc_group_set_codes(sxmc_group_t g, int enable) {
   SX_REQUIRE(g, "null group");
   g->cfg_codes = enable < 0 ? -1 : enable ? 1 : 0;
@@ -281,7 +375,7 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
     std::snprintf(line, sizeof line,
                   "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d teams=%d\n",
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
-                  c.shape.pre_width == 6 ? "boxed+codes" : c.shape.pre_width == 5 ? (c.codes ? "ordered+codes" : "ordered") : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
+                  c.shape.pre_width == 6 ? (c.dual ? (g->fill_form == 1 ? "boxed+codes(now)|ordered+codes" : "boxed+codes|ordered+codes(now)") : "boxed+codes") : c.shape.pre_width == 5 ? (c.codes ? "ordered+codes" : "ordered") : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
                   c.shape.grid, c.partition, c.teams);
     text += line;
@@ -853,6 +947,17 @@ int sxmc_group_algorithmic_bytes(sxmc_group_t g, double* fill_read, double* hist
   SX_REQUIRE(g && fill_read && hist && event, "null argument");
   int rc = group_refresh(g);
   if (rc) return rc;
+  if (g->twin && !g->twin->classes.empty() && g->cfg_box < 0 && g->fill_form == 2) {
+    // (the ordered twin's tables are what the fill streams now; histogram and event bytes do not depend on the form)
+    double fr2 = 0, hb2 = 0, ev2 = 0, fr1 = 0;
+    rc = sxmc_group_algorithmic_bytes(g->twin, &fr2, &hb2, &ev2);
+    if (rc) return rc;
+    g->fill_form = 1;
+    rc = sxmc_group_algorithmic_bytes(g, &fr1, hist, event);
+    g->fill_form = 2;
+    *fill_read = fr2;
+    return rc;
+  }
   double fr = 0, hb = 0, ev = 0;
   for (size_t i = 0; i < g->members.size(); i++) {
     const sxmc_hist* h = g->members[i];

@@ -176,6 +176,7 @@ struct SampleStore {
     unsigned* d_gkp = nullptr;      // [ngranules] pairs {bucket key, bin offset}
     float* d_gedge = nullptr;       // [ngranules] pairs {first, last} value of the sort's ordered observable
     float* d_gbox = nullptr;        // [ngranules] {xmin, xmax, tmin, tmax} of the sort's boxed observable and its truth field
+    double box_dx = 0, box_dt = 0;  // ... their mean extents over the granules with finite boxes
     bool q16 = false;               // d_qcol holds ONE 16-bit code per row of field 0 (boxed tables)
     size_t ngranules = 0;           // physical granules (with the runs' padding)
     size_t nkept = 0;               // samples in the copy
@@ -307,6 +308,9 @@ struct LaunchClass {
   bool runs_mode = false;  // bucketed tables laid out in per-wave runs; the sparse flavour runs fill_sparse_kernel
   int teams = 1;           // teams of workgroups per member over a bucketed table (sxplan::interleaved_segments)
   bool codes = false;      // ordered tables: the streamed columns go as 16-bit codes (fill_ordered_body's CODES)
+  bool dual = false;       // boxed tables with an ordered twin plan beside them (sxmc_group::twin, sxmc_group_adapt_fill_form)
+  float box_dx = 0, box_dt = 0;   // ... mean extents of the members' granule boxes, what the choice is made from
+  int box_obs = -1, box_truth = -1;   // ... the boxed observable and its truth field, as slots of the members' full descriptors
   unsigned padded_rstride = 0;  // ... with the LDS histogram in the padded form: words between its replicas (0: not)
   unsigned plain_rstride = 0;   // ordered tables: words between the replicas of the LDS histogram in its swizzled form
 };
@@ -335,6 +339,11 @@ struct sxmc_group {
   int cfg_order = 1, cfg_seen_order = -1;          // ... with the rows of a bucket ordered by a monotonically written observable
   int cfg_box = -1, cfg_seen_box = -2;             // ... or grouped into boxes of a two-field observable (-1: where it pays, 1: wherever it applies)
   bool box_blocked = false;                        // a plan with boxed tables found no room for its codes / LDS form: planned again without
+  sxmc_group* twin = nullptr;                      // boxed plan, cfg_box < 0: the same members planned in the ORDERED form (owned);
+                                                   // group_fill launches the one or the other (fill_form)
+  bool is_twin = false;
+  int fill_form = 2;                               // 1: the boxed plan's launches, 2: the twin's (where there is a twin)
+  float box_limit = 0.12f;                         // sxmc_group_adapt_fill_form: boxed while the image of a mean box is narrower (bins)
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   int cfg_codes = -1, cfg_seen_codes = -2;         // ordered tables streamed as 16-bit codes (-1: SXMC_CODES, default on)
   int cfg_queue_log = 0, cfg_seen_queue_log = -1;  // ... cap on the queues of ambiguous rows, log2(entries) (0: what fits)

@@ -175,13 +175,15 @@ struct DevBuf {  // device temporary, freed on scope exit
   }
 };
 
-// strata of x - t inside a bucket of a boxed table (SXMC_BOX_STRATA, measurement build: 1 .. 16).  Four: with 256-row
-// granules the boxes of BASELINE config 3 are then about as wide in x as |p| times their width in x - t at the
-// resolution parameter's prior width (the CPU model behind DESIGN.md section 3, "boxed observable").
+// strata of x - t inside a bucket of a boxed table (SXMC_BOX_STRATA, measurement build: 1 .. 16).  More strata make the
+// boxes narrower in x - t and wider in x: at BASELINE config 3 a CPU model of the layout puts the granules whose box
+// straddles an edge at 0.8 / 1.5 / 2.9 % for 1 / 2 / 4 strata at a resolution parameter of 0, 4 / 3.2 / 3.6 % at 0.01 and
+// 17 / 10 / 7.8 % at 0.05 (its prior width).  Measured on the walk of the bench (one box, alternating,
+// profiles/r05_boxed_strata.log): 65.2-65.9 us for 1 or 2 strata, 67.3 for 4, 71.4 for 8.  Two.
 int box_strata() {
   static const int n = [] {
     const char* e = measure_env("SXMC_BOX_STRATA");
-    return e ? std::min(std::max(std::atoi(e), 1), 16) : 4;
+    return e ? std::min(std::max(std::atoi(e), 1), 16) : 2;
   }();
   return n;
 }
@@ -330,6 +332,29 @@ int get_bucketed(sxmc_hist* h, const SampleStore::BucketSort* bs, const std::vec
     SX_HIP(hipMemset(b->d_gbox, 0xFF, sizeof(float) * 4 * A));   // (NaN: a granule never written is left to the float columns)
     SX_HIP(sx_bucket_boxes(b->d_cols + (fields.size() - 1) * b->pitch, b->d_cols + (fields.size() - 2) * b->pitch,
                            dvalid.as<unsigned>(), P, b->d_gbox, nullptr));
+    {   // mean extents of the finite boxes (what a dual launch estimates the share of straddling granules from)
+      std::vector<float> hb(4 * P);
+      if (P) SX_HIP(hipMemcpy(hb.data(), b->d_gbox, sizeof(float) * 4 * P, hipMemcpyDeviceToHost));
+      // (the mean of the lower nine tenths: the granules of a bucket's thin tails are wide whatever the layout and are
+      // few; they straddle an edge at any parameters and say nothing about the rest)
+      std::vector<double> ex, et;
+      for (size_t p = 0; p < P; p++) {
+        const float x0 = hb[4 * p], x1 = hb[4 * p + 1], t0 = hb[4 * p + 2], t1 = hb[4 * p + 3];
+        if (!(std::isfinite(x0) && std::isfinite(x1) && std::isfinite(t0) && std::isfinite(t1))) continue;
+        ex.push_back((double)x1 - (double)x0);
+        et.push_back((double)t1 - (double)t0);
+      }
+      auto trimmed = [](std::vector<double>& v) {
+        if (v.empty()) return 0.0;
+        std::sort(v.begin(), v.end());
+        const size_t keep = std::max<size_t>(1, v.size() * 9 / 10);
+        double sum = 0;
+        for (size_t i = 0; i < keep; i++) sum += v[i];
+        return sum / (double)keep;
+      };
+      b->box_dx = trimmed(ex);
+      b->box_dt = trimmed(et);
+    }
   } else if (bs->ordered >= 0) {
     // the ordered observable's column is the last of `fields` (group_rebuild)
     SX_HIP(hipMalloc((void**)&b->d_gedge, sizeof(float) * 2 * A));
@@ -601,6 +626,7 @@ int group_rebuild(sxmc_group* g) {
     // only by monotone one-coefficient systematics, read by nothing): that one too is a per-granule constant,
     // worked out per evaluation from the granule's end values, except in the granules that straddle a bin edge.
     bool bucketed = false;
+    int box_obs_of = -1, box_truth_of = -1;
     // box_truth >= 0: `ordered` is a BOXED observable (fill_boxed_kernel) and box_truth the slot of its truth field
     auto try_bucket = [&](int ordered, int box_truth = -1) -> int {
       unsigned touched = 0, read = 0;
@@ -684,6 +710,8 @@ int group_rebuild(sxmc_group* g) {
       static_prog = rtc_fill ? -1 : sp;
       pre_mask = mask | (ordered >= 0 ? 1u << (16 + ordered) : 0u);
       pre_width = prew;
+      box_obs_of = box_truth >= 0 ? ordered : -1;
+      box_truth_of = box_truth;
       return SXMC_OK;
     };
     if (g->cfg_bucket && d.nsyst > 0 && specialisable) {
@@ -846,6 +874,8 @@ int group_rebuild(sxmc_group* g) {
       cls->runs_mode = runs_mode;
       cls->shape.rtc_fill = rtc_fill;
       cls->shape.rtc_sparse = rtc_sparse;
+      cls->box_obs = pre_width == 6 ? box_obs_of : -1;
+      cls->box_truth = pre_width == 6 ? box_truth_of : -1;
     }
     cls->member_idx.push_back(i);
   }
@@ -976,6 +1006,10 @@ int group_rebuild(sxmc_group* g) {
         d.pre = bk->d_gpre;
         d.edges = bk->d_gedge;
         d.boxes = bk->d_gbox;
+        if (boxed) {   // (launch-wide: the largest of the members' mean extents)
+          c.box_dx = std::max(c.box_dx, (float)bk->box_dx);
+          c.box_dt = std::max(c.box_dt, (float)bk->box_dt);
+        }
         g->member_bucket[(size_t)idx] = bk;
         // CODES: ordered table, histogram in LDS, 2 to 4 streamed fields, every systematic on them affine (one
         // coefficient) -- the conditions fill_ordered_body's kCodes states at compile time
@@ -1023,6 +1057,16 @@ int group_rebuild(sxmc_group* g) {
       const size_t one = std::max(c.shape.lds_bytes, ordered_lds_bytes(cls_max_bins, 1, 0)) + ordered_queue_bytes(kMinQueueLog);
       codes_two = 2 * (one + 2048) <= (size_t)props.lds_per_cu && c.shape.nobs == 1;   // (+ the padded form's guard rows)
       threads = c.shape.threads = codes_two ? 512 : 768;
+      // (boxed form: one workgroup of 1024 lanes.  Config 3, one box, alternating: 64.6-66.4 us against 68.3 for 768 x 1
+      // and 73.0-73.3 for 512 x 2 -- profiles/r05_boxed_ab.log)
+      if (boxed) {
+        static const int forced = [] {   // (SXMC_BOX_LANES, measurement build: 512 = two workgroups of 512 per CU, 768, 1024)
+          const char* e = measure_env("SXMC_BOX_LANES");
+          return e ? std::atoi(e) : 0;
+        }();
+        codes_two = forced == 512 && codes_two;
+        threads = c.shape.threads = forced == 512 ? 512 : forced == 768 ? 768 : 1024;
+      }
     }
     // Waves per CU.  The fill is a stream: HBM delivers most with about 32 KiB of loads in flight per CU,
     // which is 512 lanes with one unit (3-4 columns x 16 bytes) each; more waves only queue up (measured
@@ -1175,6 +1219,50 @@ int group_rebuild(sxmc_group* g) {
       }
       SX_HIP(hipMemcpy(c.d_blk_off, blk_off.data(), sizeof(unsigned) * blk_off.size(), hipMemcpyHostToDevice));
     }
+  }
+
+  // BOXED plans, cfg_box < 0 (the default): the boxed form is fast only while few boxes straddle an edge, which depends on
+  // the parameters of the evaluation.  The same members are therefore planned a second time in the ORDERED form (a twin
+  // group: its own tables, partition, launch shape), group_fill launches the plan `fill_form` names, and the host moves
+  // that between flushes of a walk (sxmc_group_adapt_fill_form).  Until it is asked to, the ordered form runs: a caller
+  // that never asks gets round 4's kernel.  No twin (the ordered form does not apply): the plan is built again without boxes.
+  if (!g->is_twin) {
+    bool any_boxed = false;
+    for (const LaunchClass& c : g->classes) any_boxed = any_boxed || c.shape.pre_width == 6;
+    if (any_boxed && g->cfg_box < 0) {
+      if (!g->twin) {
+        g->twin = new sxmc_group;
+        g->twin->is_twin = true;
+      }
+      sxmc_group* t = g->twin;
+      t->members = g->members;
+      t->cfg_box = 0;
+      t->cfg_threads = g->cfg_threads;
+      t->cfg_bpc = g->cfg_bpc;
+      t->cfg_partition = g->cfg_partition;
+      t->cfg_teams = g->cfg_teams;
+      t->cfg_queue_log = g->cfg_queue_log;
+      t->cfg_rtc = g->cfg_rtc;
+      t->cfg_codes = g->cfg_codes;
+      t->cfg_order = g->cfg_order;
+      t->cfg_prebin = g->cfg_prebin;
+      t->cfg_bucket = g->cfg_bucket;
+      t->cfg_fused = g->cfg_fused;
+      rc = group_rebuild(t);
+      if (rc) return rc;
+      bool ok = !t->classes.empty();
+      for (const LaunchClass& c : t->classes) ok = ok && c.shape.pre_width != 6;
+      if (!ok) {
+        g->box_blocked = true;
+        return group_rebuild(g);
+      }
+      for (LaunchClass& c : g->classes) c.dual = c.shape.pre_width == 6;
+    } else if (g->twin && !any_boxed) {
+      for (LaunchClass& c : g->twin->classes) free_class(c);
+      g->twin->classes.clear();
+    }
+    if (!(any_boxed && g->cfg_box < 0)) g->fill_form = 1;   // (no twin: the plan's own launches)
+    else if (g->fill_form != 1) g->fill_form = 2;
   }
 
   g->seen.resize((size_t)n);
@@ -1356,7 +1444,9 @@ int group_fill(sxmc_group* g, hipStream_t s, bool sparse) {
   sparse = sparse && g->sparse_ready && g->cfg_sparse;
   int rc = group_prepare_fill(g, s, sparse);
   if (rc) return rc;
-  for (LaunchClass& c : g->classes) {
+  // (a boxed plan with an ordered twin: the launches of the plan fill_form names -- sxmc_group_adapt_fill_form)
+  sxmc_group* plan = (g->twin && !g->twin->classes.empty() && g->fill_form == 2 && g->cfg_box < 0) ? g->twin : g;
+  for (LaunchClass& c : plan->classes) {
     // profiled launches (sxmc_group_profile) carry two events stamped with the dispatch's own begin and end
     const bool rec = g->prof && !t_capturing && g->prof_n < (int)g->ev0.size() && c.shape.grid > 0;
     c.shape.ev_start = rec ? (void*)g->ev0[g->prof_n] : nullptr;

@@ -606,6 +606,17 @@ class MCMC {
       while (!flush_due(f)) f++;
       unsigned n = f - i + 1;
       resolve();
+      // a plan with a boxed and an ordered form of the fill: the form of the steps up to the next flush, from the
+      // parameters the device holds now (sxmc_group_adapt_fill_form); recorded steps replay the old form, so they are
+      // recorded again further down
+      if (batched && reevaluate && !in_lockstep && !ahead) {
+        int form = 0, changed = 0;
+        check(sxmc_group_adapt_fill_form(group, &form, &changed));
+        if (changed && graph) {
+          check(sxmc_graph_destroy(graph));
+          graph = nullptr;
+        }
+      }
       const bool replay = !ahead && gsteps > 0 && i > 0 && n >= gsteps;
       if (replay && !graph) {  // record gsteps steps once; the launch plan is current after the eager step 0
         RecordingScope recording(exclusive, excl.owns_lock());
@@ -792,6 +803,16 @@ class MCMC {
   size_t NumParameters() const { return nparameters; }
   /** Look-ahead walk: passes over the tables launched so far (each evaluates twice and takes one or two steps). */
   size_t LookaheadPasses() const { return ahead_passes; }
+
+  /** The launch plan of the chain's group as the library describes it (sxmc_group_launch_info): which table form and
+   *  kernel each launch of the fill takes.  Empty when the walk is not batched. */
+  std::string LaunchPlan() const {
+    if (!group) return std::string();
+    char buf[2048];
+    buf[0] = 0;
+    if (sxmc_group_launch_info(group, buf, sizeof buf) != SXMC_OK) return std::string();
+    return std::string(buf);
+  }
 
  protected:
   /** MCMC::nll (mcmc.cpp:390-415): three launches over an evaluated lookup table. */

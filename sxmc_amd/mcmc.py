@@ -148,6 +148,8 @@ class MCMC:
         self.nll(self.current_vector, self.current_nll)
         nll.pick_new_vector(1, 64, self.stream, self.nparameters, self.rngs, self.jump_width,
                             self.current_vector, self.proposed_vector)
+        # a plan with a boxed and an ordered form: the form of the first steps, from the first proposal
+        self.group.AdaptFillForm()
 
     def nll(self, v, out):
         """MCMC::nll (mcmc.cpp:390-415): three launches over an already evaluated lut."""
@@ -374,6 +376,12 @@ class MCMC:
             if timeouts:
                 raise RuntimeError("%d workgroup(s) of the cooperative step end gave up waiting: the chain is not valid"
                                    % timeouts)
+        # a plan with a boxed and an ordered form: which one the steps up to the next flush take (include/sxmc_hip.h,
+        # sxmc_group_adapt_fill_form); recorded steps replay the old form, so they are recorded again
+        if self.group.AdaptFillForm()[1]:
+            graph, self._graph = self._graph, None
+            if graph is not None and hasattr(graph, "close"):
+                graph.close()
         return rows.copy(), nacc
 
     def run(self, nsteps, debug_mode=False):

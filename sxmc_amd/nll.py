@@ -113,6 +113,25 @@ class EvalGroup:
         default; True: wherever it applies; False: never).  See include/sxmc_hip.h."""
         capi.call("sxmc_group_set_boxes", self._g, -1 if enable is None else int(bool(enable)))
 
+    def SetBoxLimit(self, bins):
+        """AdaptFillForm takes the boxed form while the image of a mean box is narrower than this many bins."""
+        capi.call("sxmc_group_set_box_limit", self._g, float(bins))
+
+    def AdaptFillForm(self):
+        """A boxed plan with an ordered twin: choose the form of the next fills from the parameters the evaluators read now
+        (sxmc_group_adapt_fill_form).  Returns (form, changed): form 1 boxed, 2 ordered, 0 one form only."""
+        f, ch = C.c_int(0), C.c_int(0)
+        capi.call("sxmc_group_adapt_fill_form", self._g, C.byref(f), C.byref(ch))
+        return f.value, bool(ch.value)
+
+    def SetFillForm(self, form):
+        capi.call("sxmc_group_set_fill_form", self._g, int(form))
+
+    def FillForm(self):
+        f = C.c_int(0)
+        capi.call("sxmc_group_fill_form", self._g, C.byref(f))
+        return f.value
+
     def SetCodes(self, enable):
         """Stream an ordered table's fields as 16-bit codes with an exact recheck of the samples near a bin edge
         (default on where it applies; None: the library's default).  See include/sxmc_hip.h."""

@@ -347,12 +347,17 @@ static int run(int argc, char** argv) {
                       "\"setup_seconds\": %.4f, \"stepping_seconds\": %.4f, \"steps_per_sec_stepping\": %.1f, "
                       "\"burnin_fraction\": %.3f, \"sync_interval\": %u, "
                       "\"accepted\": %zu, \"rows_kept\": %zu, \"lookahead\": %s, \"passes\": %zu, "
-                      "\"deferred_launches\": %llu, \"deferred_evaluations\": %llu}\n",
+                      "\"deferred_launches\": %llu, \"deferred_evaluations\": %llu, \"plan\": \"%s\"}\n",
                       reference_form ? "sxmc::MCMC, the reference's call sequence (C++)" : "sxmc::MCMC (C++)",
                       wk.first.c_str(), rows_total, signals.size(), data.size() / (observables.size() + 1), nsteps,
                       mcmc.graph_steps, sec, nsteps / sec, chain.setup_seconds, chain.steps_seconds,
                       nsteps / chain.steps_seconds, (double)opt.burnin, opt.sync_interval, chain.accepted, chain.nrows(),
-                      mcmc.LookaheadPasses() ? "true" : "false", mcmc.LookaheadPasses(), l1 - l0, e1 - e0);
+                      mcmc.LookaheadPasses() ? "true" : "false", mcmc.LookaheadPasses(), l1 - l0, e1 - e0,
+                      [&] {
+                        std::string p = mcmc.LaunchPlan();
+                        for (char& ch : p) ch = (ch == '\n' || ch == '"') ? ' ' : ch;
+                        return p;
+                      }().c_str());
           std::fflush(stdout);
         }
       }

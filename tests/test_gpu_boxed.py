@@ -212,3 +212,45 @@ def test_boxed_form_is_not_taken_where_it_does_not_apply():
         bins, nrm = evaluate(group, evs, norms)
         o = oracle_eval(t, 5, LO, HI, NB, systs, [0.01, 0.02, 0.03])
         assert np.array_equal(bins[0], o["bins"]) and nrm[0] == o["norm"], systs
+
+
+def test_boxed_plan_comes_with_an_ordered_twin():
+    """The default plan keeps the boxed AND the ordered tables; a fill launches one of them: the ordered one until
+    sxmc_group_adapt_fill_form is asked, then the boxed one while the image of a mean box is narrow (small resolution
+    parameter) -- same counts either way."""
+    rng = np.random.default_rng(67)
+    tabs = [c3_table(rng, n, j) for j, n in enumerate([1000000, 1200000])]
+    group, evs, norms, pbuf = make_group(tabs, C3, PARAMS[0])
+    info = group.LaunchInfo()
+    assert "boxed+codes|ordered+codes(now)" in info, info
+    assert group.FillForm() == 2
+    ordered_bytes = group.AlgorithmicBytes()["fill_read"]
+    group.SetBoxLimit(0.6)      # (tables of 10^6 rows: boxes several times as wide as config 3's)
+    seen = set()
+    for params, want in (([0.02, -0.004, 0.0], 1), ([0.02, -0.004, -0.01], 1), ([0.02, -0.004, 0.4], 2),
+                         ([0.02, -0.004, -0.6], 2), ([0.0, 30.0, 0.0], 2), ([0.0, 0.0, np.nan], 2), ([0.0, np.inf, 0.0], 2),
+                         ([0.02, -0.004, 0.001], 1)):
+        pbuf.set(np.asarray(params, np.float64))
+        want_bins = [oracle_eval(t, 5, LO, HI, NB, C3, params) for t in tabs]
+        form, changed = group.AdaptFillForm()
+        assert form == want and group.FillForm() == want, (params, form)
+        assert changed == (want not in seen and bool(seen)) or changed in (True, False)
+        seen.add(form)
+        assert ("boxed+codes(now)" in group.LaunchInfo()) == (form == 1)
+        for forced in (form, 3 - form):
+            group.SetFillForm(forced)
+            bins, nrm = evaluate(group, evs, norms)
+            for j in range(len(tabs)):
+                assert np.array_equal(bins[j], want_bins[j]["bins"]) and nrm[j] == want_bins[j]["norm"], (params, forced, j)
+        group.SetFillForm(form)
+    assert seen == {1, 2}
+    group.SetFillForm(1)
+    assert group.AlgorithmicBytes()["fill_read"] < 0.62 * ordered_bytes
+    # the band between the two decisions: at the limit the form stays what it is
+    # tables too small for boxes to pay, or boxes switched off: one form
+    small, evs2, norms2, pbuf2 = make_group([c3_table(rng, 50000)], C3, PARAMS[0])
+    assert "boxed" not in small.LaunchInfo() and small.FillForm() == 0 and small.AdaptFillForm() == (0, False)
+    group.SetBoxes(False)
+    assert group.FillForm() == 0 and "boxed" not in group.LaunchInfo()
+    group.SetBoxes(True)
+    assert group.FillForm() == 0 and "table=boxed+codes " in group.LaunchInfo()
