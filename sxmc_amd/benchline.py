@@ -56,9 +56,11 @@ def compact_roofline(rf):
               "survey_bytes_per_launch", "avg_launch_ms", "launches_timed", "whole_step_frac", "evaluations_per_launch"):
         if k in rf:
             out[k] = _num(rf[k])
-    for k in ("traffic_source", "streams"):
+    for k in ("traffic_source", "streams", "fill_form", "ordered_form"):
         if isinstance(rf.get(k), str):
             out[k] = rf[k][:96]
+        elif isinstance(rf.get(k), dict):
+            out[k] = _pick(rf[k], ("evals_per_sec", "fill_kernel_us", "frac"))
     if isinstance(rf.get("f64_stream"), dict):      # the conservative, pure-f64 figure (also.c3_float_stream)
         out["f64_stream"] = _pick(rf["f64_stream"], ("evals_per_sec", "fill_kernel_us", "frac"))
     if isinstance(rf.get("sample"), str) and len(rf["sample"]) <= 48:

@@ -2637,17 +2637,16 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
           it = block_end - it < (unsigned)kRing ? block_end : it + (unsigned)kRing;
           full = ngran + (unsigned)kRing > gq_drain;
         }
-#ifndef SXEXP_NOMID
         if (full) {
           drain();
+          // (what the drain's loads leave in the compiler's model of outstanding loads would reach the loop header and add
+          // waits far below the ring's depth to every unit -- s_waitcnt vmcnt(2) where vmcnt(7) is meant.  An explicit
+          // full wait here clears that model: the loop's waits are then the counted ones and nothing else.)
           __builtin_amdgcn_s_waitcnt(0);
         }
-#endif
       }
     }
-#ifndef SXEXP_NOFINAL
     drain();
-#endif
 
     // in-domain counts: lane registers -> wave -> workgroup
     {

@@ -41,6 +41,7 @@ int sxmc_group_destroy(sxmc_group_t g) {
   (void)hipDeviceSynchronize();
   if (g->coop_fits >= 0) g_stepping_groups.fetch_sub(1, std::memory_order_acq_rel);
   for (LaunchClass& c : g->classes) free_class(c);
+  if (g->h_pin) (void)hipHostFree(g->h_pin);
   if (g->twin) {   // (the ordered twin of a boxed plan: planned, never launched by itself)
     for (LaunchClass& c : g->twin->classes) free_class(c);
     if (g->twin->d_descs) (void)hipFree(g->twin->d_descs);
@@ -241,14 +242,27 @@ static int box_image_width(sxmc_group* g, double* width) {
   const sxmc_hist* h = g->members[(size_t)cls->member_idx[0]];
   const SxSignalDesc& d = g->h_descs[(size_t)cls->member_idx[0]];
   if (!d.params) return SXMC_OK;
+  // the coefficients, in ONE asynchronous copy on the group's own stream into pinned memory: a copy through the legacy
+  // stream would wait for every blocking stream of the process -- and fail outright while another chain records a graph
+  int lo_idx = 1 << 30, hi_idx = -1;
+  for (int q = 0; q < d.nsyst; q++) {
+    if (d.syst[q].obs_slot != cls->box_obs) continue;
+    lo_idx = std::min(lo_idx, (int)d.syst[q].pars[0]);
+    hi_idx = std::max(hi_idx, (int)d.syst[q].pars[0]);
+  }
+  if (hi_idx < 0 || d.param_stride < 1 || (long)(hi_idx - lo_idx) * d.param_stride >= 256) return SXMC_OK;
+  if (!g->h_pin) SX_HIP(hipHostMalloc((void**)&g->h_pin, 256 * sizeof(double)));
+  const size_t span = (size_t)(hi_idx - lo_idx) * (size_t)d.param_stride + 1;
+  SX_HIP(hipMemcpyAsync(g->h_pin, d.params + (long)lo_idx * d.param_stride, span * sizeof(double), hipMemcpyDeviceToHost,
+                        g->last_stream));
+  SX_HIP(hipStreamSynchronize(g->last_stream));
   double xl = 0.5 * (d.lower[cls->box_obs] + d.upper[cls->box_obs]), xh = xl + (double)cls->box_dx;
   const double tl = xl, th = xl + (double)cls->box_dt;
   bool fin = true;
   for (int q = 0; q < d.nsyst && fin; q++) {
     const SxSystOp& op = d.syst[q];
     if (op.obs_slot != cls->box_obs) continue;
-    double c0 = 0;
-    SX_HIP(hipMemcpy(&c0, d.params + (long)op.pars[0] * d.param_stride, sizeof c0, hipMemcpyDeviceToHost));
+    const double c0 = g->h_pin[(size_t)((int)op.pars[0] - lo_idx) * (size_t)d.param_stride];
     const double pc = 0.0 + c0 * 1.0;
     if (op.type == SXMC_SYST_SHIFT) {
       xl = xl + pc;
@@ -368,14 +382,19 @@ int sxmc_group_launch_info(sxmc_group_t g, char* out, size_t n) {
   int rc = group_refresh(g);
   if (rc) return rc;
   std::string text;
-  for (size_t i = 0; i < g->classes.size(); i++) {
-    const LaunchClass& c = g->classes[i];
+  // (a plan with two forms: the launches of the form that runs now, its table named with the other form beside it)
+  const bool two = g->twin && !g->twin->classes.empty() && g->cfg_box < 0;
+  const sxmc_group* plan = (two && g->fill_form == 2) ? g->twin : g;
+  for (size_t i = 0; i < plan->classes.size(); i++) {
+    const LaunchClass& c = plan->classes[i];
     char line[512];
     const char* kind = c.shape.rtc_fill ? "runtime" : c.shape.static_prog >= 0 ? "builtin" : c.shape.nobs ? "decoded" : "generic";
     std::snprintf(line, sizeof line,
                   "launch %zu: members=%zu nobs=%d nslot=%d hist=%s program=%s table=%s%s threads=%d grid=%d partition=%d teams=%d\n",
                   i, c.member_idx.size(), c.shape.nobs, c.shape.nslot, c.shape.lds_hist ? "lds" : "global", kind,
-                  c.shape.pre_width == 6 ? (c.dual ? (g->fill_form == 1 ? "boxed+codes(now)|ordered+codes" : "boxed+codes|ordered+codes(now)") : "boxed+codes") : c.shape.pre_width == 5 ? (c.codes ? "ordered+codes" : "ordered") : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
+                  c.shape.pre_width == 6 ? (c.dual ? "boxed+codes(now)|ordered+codes" : "boxed+codes")
+                  : (two && plan == g->twin && c.shape.pre_width == 5) ? (c.codes ? "boxed+codes|ordered+codes(now)" : "boxed+codes|ordered(now)")
+                  : c.shape.pre_width == 5 ? (c.codes ? "ordered+codes" : "ordered") : c.shape.pre_width == 3 ? "bucketed" : c.shape.pre_width ? "prebinned" : "rows",
                   c.runs_mode ? (c.shape.rtc_sparse ? "+runs(runtime)" : "+runs(builtin)") : "", c.shape.threads,
                   c.shape.grid, c.partition, c.teams);
     text += line;

@@ -148,8 +148,7 @@ class MCMC:
         self.nll(self.current_vector, self.current_nll)
         nll.pick_new_vector(1, 64, self.stream, self.nparameters, self.rngs, self.jump_width,
                             self.current_vector, self.proposed_vector)
-        # a plan with a boxed and an ordered form: the form of the first steps, from the first proposal
-        self.group.AdaptFillForm()
+        self._adapt_pending = True               # (a plan with two forms of the fill: chosen at the first step)
 
     def nll(self, v, out):
         """MCMC::nll (mcmc.cpp:390-415): three launches over an already evaluated lut."""
@@ -165,6 +164,11 @@ class MCMC:
     def step(self, debug_mode=False):
         """One pass of the hot path = one NLL evaluation at the proposed vector + the fused
         accept/reject/propose (mcmc.cpp:264-271, 314-348).  Asynchronous."""
+        if getattr(self, "_adapt_pending", False) and not getattr(self, "_recording", False):
+            # a plan with a boxed and an ordered form: the form of the first steps, from the first proposal
+            # (sxmc_group_adapt_fill_form; flush() asks again)
+            self._adapt_pending = False
+            self.group.AdaptFillForm()
         self._launching(1)
         if self.fused == "step":
             self.group.McmcStepAsync(self.stream, self.parameter_means, self.parameter_sigma, self.rngs,

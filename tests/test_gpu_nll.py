@@ -289,6 +289,8 @@ def test_baseline_configs_at_size_against_the_oracle(make, scale, plan):
     assert plan in m.group.LaunchInfo(), m.group.LaunchInfo()
     proposal = m.proposed_vector.get()
     m.step(debug_mode=True)
+    if plan == "table=boxed+codes":              # (the walk asked at its first step: a small resolution parameter)
+        assert m.group.FillForm() == 1 and "boxed+codes(now)" in m.group.LaunchInfo()
     m.steps(4, graph_steps=2, debug_mode=True)
     rows, nacc = m.flush()
     assert nacc == 5
