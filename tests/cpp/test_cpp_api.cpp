@@ -536,6 +536,58 @@ TEST_F(SmallFit, LookaheadWalkIsTheSequentialChain) {
   }
 }
 
+TEST_F(SmallFit, BoxedFormOfTheFillGivesTheSameHistograms) {
+  // this fit has the shape the boxed form is for (one observable resolution-scaled against a truth field, one shifted):
+  // forced on (sxmc_group_set_boxes 1) and off, the same bins and norms for several parameter vectors; the plan of a
+  // table this small has ONE form (boxes do not pay), so sxmc_group_adapt_fill_form reports 0 and changes nothing
+  std::vector<sxmc_hist_t> handles;
+  pdfz::Array<double> params(2, true);
+  pdfz::Array<unsigned> norms(signals.size(), true);
+  for (size_t j = 0; j < signals.size(); j++) {
+    pdfz::EvalHist* h = dynamic_cast<pdfz::EvalHist*>(signals[j].histogram);
+    h->SetNormalizationBuffer(&norms, (int)j);
+    h->SetParameterBuffer(&params, 0);
+    h->Bind();
+    handles.push_back(h->Handle());
+  }
+  sxmc_group_t g = nullptr;
+  sxmc::check(sxmc_group_create(handles.data(), (int)handles.size(), &g));
+  int form = -1, changed = -1;
+  sxmc::check(sxmc_group_adapt_fill_form(g, &form, &changed));
+  EXPECT_EQ(form, 0);
+  EXPECT_EQ(changed, 0);
+  EXPECT_TRUE(sxmc_group_set_fill_form(g, 1) != SXMC_OK);
+  const double sets[4][2] = {{0.0, 0.0}, {0.03, 0.08}, {-0.2, -0.5}, {0.01, 2.5}};
+  for (const auto& p : sets) {
+    params.writeOnlyHostPtr()[0] = p[0];
+    params.writeOnlyHostPtr()[1] = p[1];
+    (void)params.readOnlyPtr();
+    std::vector<std::vector<unsigned>> got[2];
+    std::vector<unsigned> nrm[2];
+    for (int boxes = 1; boxes >= 0; boxes--) {
+      sxmc::check(sxmc_group_set_boxes(g, boxes));
+      char info[1024];
+      sxmc::check(sxmc_group_launch_info(g, info, sizeof info));
+      EXPECT_EQ(std::string(info).find("boxed+codes") != std::string::npos, boxes == 1);
+      sxmc::check(sxmc_group_eval_async(g, 0, nullptr));
+      sxmc::check(sxmc_group_synchronize(g));
+      for (sxmc_hist_t h : handles) {
+        int nb = 0;
+        sxmc::check(sxmc_hist_total_nbins(h, &nb));
+        std::vector<unsigned> bins((size_t)nb);
+        sxmc::check(sxmc_hist_get_bins(h, bins.data(), bins.size()));
+        got[boxes].push_back(bins);
+      }
+      const unsigned* n = norms.readOnlyHostPtr();
+      nrm[boxes].assign(n, n + signals.size());
+    }
+    EXPECT_TRUE(got[0] == got[1]);
+    EXPECT_TRUE(nrm[0] == nrm[1]);
+    EXPECT_TRUE(nrm[1][0] > 0u);
+  }
+  sxmc::check(sxmc_group_destroy(g));
+}
+
 TEST_F(SmallFit, AutoWalkTakesTheLookaheadPassOnlyWhereThePlanStreamsFloatColumns) {
   // MCMC::lookahead_auto: the walk decides -- the look-ahead pass where the fill streams float columns (this small
   // fit), one evaluation per step where it streams codes; the chain is the sequential one either way
