@@ -128,12 +128,21 @@ int flush_deferred() {
   // Here the trials are the BATCH's (sxmc_group_optimize: a few timed fills choose lanes per CU, teams and codes for
   // this box; only a long pure stream has anything to choose, it returns at once otherwise): at the batch's first
   // lookup evaluation, when every member asks for it.  The evaluation proper follows and zeroes what the trials counted.
+  // A plan with a boxed and an ordered form of the fill (sxmc_group_adapt_fill_form): the unchanged caller has no flush
+  // to ask at, so its batches ask themselves -- the first one and every 256th after it wait for the batch's stream and
+  // read the parameters back (a few hundred microseconds per 256 steps of ~100 us each).
+  if (m.size() >= 2 && g->cfg_box < 0 && (g->adapt_tick++ & 255u) == 0u) {
+    int form = 0, changed = 0;
+    g->last_stream = fl->stream;
+    rc = sxmc_group_adapt_fill_form(g, &form, &changed);
+  }
+  // (... before the trial launches, which then time the form that runs)
   bool want = do_eval_pdf != 0;
   for (sxmc_hist* h : m) want = want && h->want_optimize && h->has_points;
   if (m.size() == 1 || m[0]->cfg_threads > 0 || m[0]->cfg_bpc > 0) {
     g->cfg_threads = m[0]->cfg_threads;   // (a launch shape set by hand on the evaluators)
     g->cfg_bpc = m[0]->cfg_bpc;
-  } else if (m.size() >= 2 && !g->tuned && want) {
+  } else if (rc == SXMC_OK && m.size() >= 2 && !g->tuned && want) {
     g->tuned = true;
     rc = sxmc_group_optimize(g, fl->stream, nullptr);
   }

@@ -344,6 +344,7 @@ struct sxmc_group {
   bool is_twin = false;
   int fill_form = 2;                               // 1: the boxed plan's launches, 2: the twin's (where there is a twin)
   double* h_pin = nullptr;                         // pinned host words sxmc_group_adapt_fill_form reads the parameters into
+  unsigned adapt_tick = 0;                         // deferred batches launched for this group (every 256th asks for the form)
   float box_limit = 0.12f;                         // sxmc_group_adapt_fill_form: boxed while the image of a mean box is narrower (bins)
   int cfg_rtc = 1, cfg_seen_rtc = -1;              // specialise the fill kernel at run time for programs not built in
   int cfg_codes = -1, cfg_seen_codes = -2;         // ordered tables streamed as 16-bit codes (-1: SXMC_CODES, default on)

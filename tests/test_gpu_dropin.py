@@ -330,7 +330,9 @@ def test_optimize_flag_of_the_evaluators_decides_the_batchs_trial_launches():
         assert (trials > 0) == flag, info
         if not flag:
             # the analytic default over codes: two workgroups of 512 lanes per CU (group_rebuild)
-            assert "threads=512" in info and "+codes" in info, info
+            # (... or, where the batch's first look at its parameters chose the boxed form: one workgroup of 1024)
+            assert ("threads=512" in info and "ordered+codes" in info) or \
+                   ("threads=1024" in info and "boxed+codes(now)" in info), info
             # Optimize() by hand: the trials run at the next lookup evaluation
             capi.call("sxmc_hist_optimize", pdfs[0].handle)
             for p in pdfs:
