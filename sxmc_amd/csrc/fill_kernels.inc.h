@@ -2512,6 +2512,8 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
         vcnt += (unsigned)(addr[0] ^ addr[1] ^ addr[2] ^ addr[3]) == 12345u ? 1u : 0u;
         return;
       }
+      // (issuing the additions on their byte addresses by hand -- the pointer form costs one v_add of the LDS block's
+      // relocated base, 0, per sample -- was measured, one box, alternating: 63.2-64.5 us against 62.9-65.6: nothing)
 #pragma unroll
       for (int q = 0; q < SXMC_VEC; q++) {
         unsigned* wp = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + addr[q]);
@@ -2609,7 +2611,7 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
       rq[slot] = __builtin_nontemporal_load((gptr<const vuint2g>)((gptr<const char>)qcol + (unsigned long long)o));
       __builtin_amdgcn_sched_barrier(0);
     };
-    const unsigned climit = oS;              // a granule word below this: binned from codes
+    const unsigned climit = (unsigned)uniform_i((int)oS);   // a granule word below this: binned from codes (a scalar compare)
     {
       unsigned it = 0u;
       if constexpr (SXMC_BOX_PREFETCH) meta_load(0u);
