@@ -254,3 +254,38 @@ def test_boxed_plan_comes_with_an_ordered_twin():
     assert group.FillForm() == 0 and "boxed" not in group.LaunchInfo()
     group.SetBoxes(True)
     assert group.FillForm() == 0 and "table=boxed+codes " in group.LaunchInfo()
+
+
+def test_walks_are_the_same_chain_in_either_form():
+    """A walk over a plan with both forms: forced boxed, forced ordered, and left to sxmc_group_adapt_fill_form (asked at
+    the first step and at every flush, the recorded steps recorded again when the form changes) -- the fills are
+    bit-identical, so the chains are."""
+    from sxmc_amd import capi, workloads
+    from sxmc_amd.mcmc import MCMC
+    w = workloads.config3(0.25, nevents=5000)
+    chains = []
+    for mode in ("adaptive", "boxed", "ordered"):
+        m = MCMC(w, seed=11, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
+        m.setup(sync_interval=64)
+        capi.synchronize()
+        assert "boxed+codes|ordered+codes(now)" in m.group.LaunchInfo()
+        rows = []
+        for block in range(4):
+            if mode != "adaptive":
+                m._adapt_pending = False
+                m.group.SetFillForm(1 if mode == "boxed" else 2)
+            m.step()
+            m.steps(60, graph_steps=10)
+            if mode != "adaptive":
+                m.group.SetFillForm(1 if mode == "boxed" else 2)
+            r, _ = m.flush()
+            if mode != "adaptive":                      # (flush asked; put the forced form back for the next block)
+                m._graph = None
+                m.group.SetFillForm(1 if mode == "boxed" else 2)
+            rows.append(r)
+        if mode == "adaptive":
+            assert m.group.FillForm() in (1, 2)
+        chains.append(np.concatenate(rows, axis=0))
+    assert chains[0].shape[0] > 0
+    assert np.array_equal(chains[0].view(np.uint32), chains[1].view(np.uint32))
+    assert np.array_equal(chains[0].view(np.uint32), chains[2].view(np.uint32))
