@@ -481,6 +481,9 @@ class Leg:
             "traffic": traffic, "traffic_provenance": traffic_note,
             # (PMC counters cannot be read inside this run: separate rocprofv3 --pmc passes, tools/profile_on_gpu.sh)
             "traffic_source": ("profiles/traffic.json: " + str(traffic_note.get("from"))) if traffic_note else None,
+            # (... and where the chain was: the systematics' parameters of the evaluations around the timed region -- the
+            # boxed fill's time depends on the resolution parameter)
+            "systematics_at_timed_steps": [float(x) for x in m.proposed_vector.get()[w.nsources:]] if w.systematics else None,
             # (a plan with two forms of the fill: which one the timed launches took, and who chose)
             "fill_form": ("boxed: chosen by the walk from the first proposal's parameters (sxmc_group_adapt_fill_form)"
                           if "boxed+codes(now)" in m.group.LaunchInfo() else

@@ -61,6 +61,8 @@ def compact_roofline(rf):
             out[k] = rf[k][:96]
         elif isinstance(rf.get(k), dict):
             out[k] = _pick(rf[k], ("evals_per_sec", "fill_kernel_us", "frac"))
+    if isinstance(rf.get("systematics_at_timed_steps"), list):
+        out["systematics_at_timed_steps"] = [_num(x, 3) for x in rf["systematics_at_timed_steps"][:8]]
     if isinstance(rf.get("f64_stream"), dict):      # the conservative, pure-f64 figure (also.c3_float_stream)
         out["f64_stream"] = _pick(rf["f64_stream"], ("evals_per_sec", "fill_kernel_us", "frac"))
     if isinstance(rf.get("sample"), str) and len(rf["sample"]) <= 48:
