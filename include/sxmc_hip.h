@@ -345,8 +345,8 @@ int sxmc_group_set_codes(sxmc_group_t g, int enable);
 int sxmc_group_set_boxes(sxmc_group_t g, int enable);
 /* With enable = -1 the boxed plan comes with an ORDERED TWIN.  How many boxes straddle an edge depends on the parameters of
  * the evaluation (the image of a box is |dx'/dx| dx + |dx'/dt| dt wide: it grows with the resolution parameter): at BASELINE
- * config 3 the boxed fill takes 62 us at a resolution parameter of 0, 73 at 0.05, 123 at 0.2, the ordered one 81 whatever
- * the parameters (profiles/r05_boxed_crossover.log).  Both plans stay resident -- the boxed tables with their partition
+ * config 3 the boxed fill takes 65-67 us at a resolution parameter of 0, 76 at 0.05, 84 at 0.07, 131 at 0.2, the ordered
+ * one 82-85 whatever the parameters (one box, profiles/r05_boxed_crossover.log).  Both plans stay resident -- the boxed tables with their partition
  * and launch shape, the ordered ones with theirs -- and every fill launches ONE of them: the ordered one until told
  * otherwise, so a caller that never asks runs the ordered form.
  *   sxmc_group_adapt_fill_form: waits for the group's stream, reads the parameters the evaluators are bound to back from
