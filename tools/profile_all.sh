@@ -9,7 +9,8 @@ if [ "$2" = "c5" ]; then
   bash tools/profile_on_gpu.sh ${P}_c5 --workload c5 --steps 40 --also none --experiments 0 || exit 6
   exit 0
 fi
-bash tools/profile_on_gpu.sh ${P}_c3 --also none --experiments 0 || exit 1
+bash tools/profile_on_gpu.sh ${P}_c3_boxed --also none --experiments 0 || exit 8     # (the walk's choice at its first steps: the boxed form)
+bash tools/profile_on_gpu.sh ${P}_c3 --no-boxes --also none --experiments 0 || exit 1   # (the ordered form over codes)
 bash tools/profile_on_gpu.sh ${P}_c3_no_codes --no-codes --also none --experiments 0 || exit 7
 bash tools/profile_on_gpu.sh ${P}_c3_lookahead --lookahead --also none --experiments 0 || exit 2
 bash tools/profile_on_gpu.sh ${P}_c3_no_order --no-order --also none --experiments 0 || exit 3
