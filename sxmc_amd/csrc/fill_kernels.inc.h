@@ -1255,7 +1255,11 @@ __device__ __forceinline__ void fill_ordered_body(SxChainDescs chains, const SxS
   // CODES (see AffineForm above): the streamed slots as 16-bit codes, two to a word
   constexpr bool kCodes = LDS_HIST && NOBS >= 1 && NSTREAM >= 2 && NSTREAM <= SXMC_MAX_QSLOTS && prog_is_affine<ORD>(PROG{});
   constexpr int NQ = kCodes ? NSTREAM : 1, QW = (NQ + 1) / 2;
-  constexpr int kRing = 4;             // units of codes a lane holds: one being worked on, the others in flight
+#ifndef SXMC_ORD_RING
+#define SXMC_ORD_RING 4   // (8 with a launch bound of 768 lanes, 145 VGPRs, now that the waits are the counted ones: 82.3-83.3 us
+                          //  against 80.1-80.4 at the same shape -- profiles/r05_ring_depth_ab.log: not what is in flight)
+#endif
+  constexpr int kRing = SXMC_ORD_RING;   // units of codes a lane holds: one being worked on, the others in flight
 #ifndef SXMC_DRAIN_BATCH
 #define SXMC_DRAIN_BATCH 1
 #endif
@@ -2285,7 +2289,10 @@ __device__ __forceinline__ void fill_boxed_body(const SxSignalDesc* __restrict__
   constexpr int BX = 2, XT = 1;        // the boxed observable's slot, its truth field's
   static_assert(prog_is_boxable<BX, XT>(PROG{}), "not a program the boxed form can run");
   constexpr int NC = PROG::ncoef > 0 ? PROG::ncoef : 1;
-  constexpr int kRing = 8;             // units of codes (8 bytes each) a lane holds: one worked on, seven in flight
+#ifndef SXMC_BOX_RING
+#define SXMC_BOX_RING 8   // (16, 125 VGPRs: 65.9-66.2 us against 64.1-64.2, one box alternating -- profiles/r05_ring_depth_ab.log)
+#endif
+  constexpr int kRing = SXMC_BOX_RING;   // units of codes (8 bytes each) a lane holds: one worked on, the others in flight
   constexpr int kDrain = SXMC_BOX_DRAIN;   // queued granules whose float columns the drain loads together
   static_assert(64 % kRing == 0, "a block of 64 units is a whole number of rounds of the ring");
   typedef typename MakeISeq<PROG::n>::type Seq;
