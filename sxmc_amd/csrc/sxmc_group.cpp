@@ -239,7 +239,6 @@ static int box_image_width(sxmc_group* g, double* width) {
   const LaunchClass* cls = nullptr;
   for (const LaunchClass& c : g->classes) cls = (c.dual && !cls) ? &c : cls;
   if (!cls || cls->member_idx.empty() || cls->box_obs < 0) return SXMC_OK;
-  const sxmc_hist* h = g->members[(size_t)cls->member_idx[0]];
   const SxSignalDesc& d = g->h_descs[(size_t)cls->member_idx[0]];
   if (!d.params) return SXMC_OK;
   // the coefficients, in ONE asynchronous copy on the group's own stream into pinned memory: a copy through the legacy
@@ -280,7 +279,6 @@ static int box_image_width(sxmc_group* g, double* width) {
     }
     fin = std::isfinite(xl) && std::isfinite(xh);
   }
-  (void)h;
   if (fin) *width = (xh - xl) * d.scale[cls->box_obs];
   return SXMC_OK;
 }
