@@ -257,6 +257,8 @@ class MCMC {
                                 //!< per second where the fill streams float columns (it is bound by the stream, and the
                                 //!< pass streams once for two evaluations), SLOWER where it streams 16-bit codes (the
                                 //!< pass is then bound by its arithmetic: BASELINE config 3, 9 380 against 10 290).
+  unsigned adapt_interval = 1000;  //!< a plan with two forms of the fill: steps between the flushes at which the walk asks
+                                   //!< which one to take (sxmc_group_adapt_fill_form); 0: only at the reference's flushes
   bool lookahead_auto = false;  //!< let the walk decide: the look-ahead pass where the launch plan streams float columns,
                                 //!< one evaluation per step where it streams codes (what the measurements above say)
   /** Hooks for a driver that runs several walks side by side (sxmc::ensemble_concurrent): called once the walk's
@@ -581,8 +583,13 @@ class MCMC {
                          (int)nparameters, d.jump_width, d.nexpected, d.n_mc, d.source_id, d.norms, debug_mode);
     };
     // Steps after which the jump buffer is read back (mcmc.cpp:351-377)
+    // (a plan with a boxed and an ordered form of the fill is asked for its form at every flush, from the parameters at
+    // that moment, and a chain moves -- config 3's resolution parameter by ~0.05 in 5 000 steps: flushes every
+    // adapt_interval steps bound how stale the choice gets; the chain does not depend on where the flushes fall)
+    bool two_forms = false;
     auto flush_due = [&](unsigned i) {
-      return i % sync_interval == 0 || i == nsteps - 1 || i == burnin_steps - 1 || i == 2 * burnin_steps - 1;
+      return i % sync_interval == 0 || i == nsteps - 1 || i == burnin_steps - 1 || i == 2 * burnin_steps - 1 ||
+             (two_forms && adapt_interval > 0 && i % adapt_interval == adapt_interval - 1);
     };
 
     unsigned i = 0;
@@ -612,6 +619,7 @@ class MCMC {
       if (batched && reevaluate && !in_lockstep && !ahead) {
         int form = 0, changed = 0;
         check(sxmc_group_adapt_fill_form(group, &form, &changed));
+        two_forms = form != 0 && adapt_interval < sync_interval;
         if (changed && graph) {
           check(sxmc_graph_destroy(graph));
           graph = nullptr;

@@ -37,6 +37,11 @@ def make_systematic(desc):
     raise ValueError(t)
 
 
+# Steps between the flushes at which a walk over a plan with two forms of the fill asks which one to take
+# (sxmc_group_adapt_fill_form): config 3's chain moves its resolution parameter by ~0.05 in 5 000 steps.
+ADAPT_INTERVAL = 1000
+
+
 class MCMC:
     def __init__(self, workload, seed=1234, stream=None, fused=True, samples_on_device=None, share_with=None,
                  lut_output=True, consume=False):
@@ -149,6 +154,7 @@ class MCMC:
         nll.pick_new_vector(1, 64, self.stream, self.nparameters, self.rngs, self.jump_width,
                             self.current_vector, self.proposed_vector)
         self._adapt_pending = True               # (a plan with two forms of the fill: chosen at the first step)
+        self._two_forms_cached = None
 
     def nll(self, v, out):
         """MCMC::nll (mcmc.cpp:390-415): three launches over an already evaluated lut."""
@@ -276,7 +282,12 @@ class MCMC:
         """Indices of the steps after which the jump buffer is read back (mcmc.cpp:351-377), ascending.  The
         re-tuning points (burnin_steps, 2 * burnin_steps) each directly follow one of them."""
         n, b = self._nsteps, self._burnin
-        return sorted({k for k in range(0, n, self.sync_interval)} | {k for k in (n - 1, b - 1, 2 * b - 1) if 0 <= k < n})
+        due = {k for k in range(0, n, self.sync_interval)} | {k for k in (n - 1, b - 1, 2 * b - 1) if 0 <= k < n}
+        # a plan with two forms of the fill (sxmc_group_adapt_fill_form is asked at every flush): the choice is made from
+        # the parameters at the flush, and a chain moves -- flushes every ADAPT_INTERVAL steps bound how stale it gets
+        if self._two_forms():
+            due |= {k for k in range(ADAPT_INTERVAL - 1, n, ADAPT_INTERVAL)}
+        return sorted(due)
 
     def capture_steps(self, k, debug_mode=False):
         """Records k steps on this chain's stream as one HIP graph.  One step must have
@@ -348,10 +359,17 @@ class MCMC:
 
     def _flush_if_due(self, i):
         b = self._burnin
-        if i % self.sync_interval == 0 or i == self._nsteps - 1 or i == b - 1 or i == 2 * b - 1:
+        if i % self.sync_interval == 0 or i == self._nsteps - 1 or i == b - 1 or i == 2 * b - 1 or \
+                (i % ADAPT_INTERVAL == ADAPT_INTERVAL - 1 and self._two_forms()):
             r, nacc = self.flush(device_wide=False)                # mcmc.cpp:351-377
             self._rows.append(r)
             self._accepted += nacc
+
+    def _two_forms(self):
+        """Does the chain's plan hold a boxed and an ordered form of the fill (decided once per walk)?"""
+        if getattr(self, "_two_forms_cached", None) is None:
+            self._two_forms_cached = self.group.FillForm() != 0
+        return self._two_forms_cached
 
     def walk_advance(self, i):
         self._retune_if_due(i)

@@ -289,3 +289,34 @@ def test_walks_are_the_same_chain_in_either_form():
     assert chains[0].shape[0] > 0
     assert np.array_equal(chains[0].view(np.uint32), chains[1].view(np.uint32))
     assert np.array_equal(chains[0].view(np.uint32), chains[2].view(np.uint32))
+
+
+def test_whole_walk_with_burn_in_is_the_same_chain_whatever_chooses_the_form():
+    """MCMC.walk (burn-in re-tuning, flushes, graph replay) over a plan with two forms: flushing -- and asking for the form
+    -- every ADAPT_INTERVAL steps gives the chain of a walk pinned to the ordered form."""
+    from sxmc_amd import capi, workloads
+    from sxmc_amd import mcmc as mcmc_mod
+    w = workloads.config3(0.25, nevents=5000)
+    chains = []
+    for pinned in (False, True):
+        m = mcmc_mod.MCMC(w, seed=13, fused=True, lut_output=False, consume=True, stream=capi.new_stream())
+        if pinned:
+            class Pinned:                              # (the group, with the question answered "ordered, unchanged")
+                def __init__(self, g):
+                    self._grp = g
+
+                def __getattr__(self, name):
+                    return getattr(self._grp, name)
+
+                def AdaptFillForm(self):
+                    return 2, False
+
+                def FillForm(self):
+                    return 0
+            m.group = Pinned(m.group)
+        chain, acc = m.walk(w.events, 2300, 0.2, sync_interval=10000, graph_steps=10)
+        chains.append((chain, acc))
+        if not pinned:
+            assert m.group.FillForm() in (1, 2) and mcmc_mod.ADAPT_INTERVAL - 1 in m.flush_schedule()
+    assert chains[0][1] == chains[1][1]
+    assert np.array_equal(chains[0][0].view(np.uint32), chains[1][0].view(np.uint32))
