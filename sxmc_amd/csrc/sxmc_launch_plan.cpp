@@ -1206,8 +1206,11 @@ int group_rebuild(sxmc_group* g) {
           const char* e = measure_env("SXMC_PART_GROUPS");
           return e ? std::atoi(e) : 0;
         }();
+        // (the boxed form, where nothing was asked for: 20 teams -- a workgroup then sees a twentieth of the sorted order,
+        // its bucket or two, and flushes as few bins.  One box, alternating, two rounds (profiles/r05_boxed_teams_ab.log):
+        // fill 63.4-63.5 us and step 77.9 against 65.0-65.1 and 79.9-80.0 for one team; 3-10 teams in between.)
         const int groups = (bucketed && c.shape.lds_hist)
-                               ? (forced_groups > 0 ? forced_groups : std::max(1, g->cfg_teams)) : 1;
+                               ? (forced_groups > 0 ? forced_groups : g->cfg_teams > 0 ? g->cfg_teams : boxed ? 20 : 1) : 1;
         c.teams = groups;
         build_partition(descs, c.shape.grid, threads, g->cfg_partition, segs, blk_off, c.partition, bucketed ? 64 : 1,
                         groups);
