@@ -26,6 +26,8 @@ def op(type_, obs_slot, extra_slot=0, npars=0):
     (2, 4, 1, 5, 0, [op(CTSCALE, 3), op(SCALE, 3), op(SCALE, 0), op(RES, 1, 2)]),      # two ops on the ordered observable
     (1, 3, 0, 5, 1, [op(SHIFT, 2), op(SCALE, 0), op(RES, 0, 1)]),                      # C5, r ordered: sparse counting over runs
     (1, 3, 0, 5, 0, [op(SHIFT, 2), op(SCALE, 0), op(RES, 0, 1)]),                      # ... and its dense evaluation
+    (1, 3, 1, 6, 0, [op(SHIFT, 0), op(SCALE, 2), op(RES, 2, 1)]),                      # C3 bucketed, e BOXED, r streamed
+    (1, 3, 1, 6, 0, [op(RES, 2, 1), op(CTSCALE, 0), op(SHIFT, 2), op(RES, 2, 1)]),     # two resolution scales on the boxed one
 ])
 def test_runtime_specialisation_compiles_without_a_gpu(nobs, nslot, lds, prew, runs, ops):
     lib = capi.load()
@@ -41,6 +43,18 @@ def test_ordered_kernel_refuses_a_systematic_that_is_not_monotone():
     arr = np.asarray([op(SHIFT, 1, 0, 2)], dtype=np.uint32)   # a 2-coefficient (polynomial) shift on the ordered slot
     rc = lib.sxmc_rtc_compile_check(1, 2, 1, 5, 0, capi.ptr(arr), 1, None)
     assert rc != 0 and "not a monotone systematic" in capi.last_error()
+
+
+def test_boxed_kernel_refuses_programs_it_cannot_box():
+    lib = capi.load()
+    # a resolution scale on the STREAMED observable (its truth field would have to be streamed too)
+    arr = np.asarray([op(RES, 0, 1), op(SCALE, 2)], dtype=np.uint32)
+    rc = lib.sxmc_rtc_compile_check(1, 3, 1, 6, 0, capi.ptr(arr), 2, None)
+    assert rc != 0 and "not a program the boxed form can run" in capi.last_error()
+    # a polynomial on the boxed observable
+    arr = np.asarray([op(SHIFT, 0), op(SCALE, 2, 0, 2), op(RES, 2, 1)], dtype=np.uint32)
+    rc = lib.sxmc_rtc_compile_check(1, 3, 1, 6, 0, capi.ptr(arr), 3, None)
+    assert rc != 0
 
 
 def test_runtime_specialisation_reports_a_bad_shape():
