@@ -481,6 +481,10 @@ class Leg:
             "traffic": traffic, "traffic_provenance": traffic_note,
             # (PMC counters cannot be read inside this run: separate rocprofv3 --pmc passes, tools/profile_on_gpu.sh)
             "traffic_source": ("profiles/traffic.json: " + str(traffic_note.get("from"))) if traffic_note else None,
+            # (the boxed fill is not bound by its stream: say so where `bound` is read)
+            "bound_note": ("boxed fill: vector issue, LDS additions and the float-column drain, not the stream "
+                           "(the stream alone takes 41 of its 63-65 us: profiles/r05_boxed_parts.log)"
+                           if "boxed+codes(now)" in m.group.LaunchInfo() or "table=boxed+codes " in m.group.LaunchInfo() else None),
             # (... and where the chain was: the systematics' parameters of the evaluations around the timed region -- the
             # boxed fill's time depends on the resolution parameter)
             "systematics_at_timed_steps": [float(x) for x in m.proposed_vector.get()[w.nsources:]] if w.systematics else None,

@@ -56,9 +56,9 @@ def compact_roofline(rf):
               "survey_bytes_per_launch", "avg_launch_ms", "launches_timed", "whole_step_frac", "evaluations_per_launch"):
         if k in rf:
             out[k] = _num(rf[k])
-    for k in ("traffic_source", "streams", "fill_form", "ordered_form"):
+    for k in ("traffic_source", "streams", "fill_form", "ordered_form", "bound_note"):
         if isinstance(rf.get(k), str):
-            out[k] = rf[k][:96]
+            out[k] = rf[k][:160 if k == "bound_note" else 96]
         elif isinstance(rf.get(k), dict):
             out[k] = _pick(rf[k], ("evals_per_sec", "fill_kernel_us", "frac"))
     if isinstance(rf.get("systematics_at_timed_steps"), list):
